@@ -1,0 +1,317 @@
+"""ctypes front end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg
+import this module.  It wraps ``libptmcmc_oracle.so`` (built from
+``ptmcmc_oracle.c`` by ``make -C oracle``) and composes the per-operation C
+functions into the sampler loop of the reference
+(``PTMCMCSampler.py:495-528`` driving ``PTMCMCOneStep`` ``:530-629``) for all
+temperatures of ``nwalkers`` independent replicas in one process.
+
+Draw sources: ``replay`` (the reference's recorded draws, one stream per rank;
+pins the oracle to the reference) or Philox (what the HIP kernels use).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libptmcmc_oracle.so")
+
+LOGL = {"iso": 0, "dense": 1, "curved": 2}
+LOGP = {"flat": 0, "box": 1}
+J_SCAM, J_AM, J_DE, J_NTYPES = 0, 1, 2, 3
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint64)
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "ndim", "ntemps", "nwalkers", "lanes", "logl_kind", "logp_kind", "w_scam", "w_am", "w_de",
+        "de_on", "de_size", "cov_update", "tskip", "cov_per_walker", "ntemps_global", "temp0", "walker0", "pad_")] + [
+        ("seed", C.c_uint64), ("logl_par", _dp), ("logp_par", _dp), ("temps_mh", _dp), ("beta", _dp)]
+
+
+class State(C.Structure):
+    _fields_ = [("X", _dp), ("lnL", _dp), ("lp", _dp), ("temp_of", _ip), ("slot_of", _ip), ("Ut", _dp), ("S", _dp),
+                ("DE", _dp), ("AM", _dp), ("nacc", _up), ("jstat", _up)]
+
+
+class Replay(C.Structure):
+    _fields_ = [("kinds", C.POINTER(C.c_uint8)), ("vals", _dp), ("bounds", C.POINTER(C.c_int64)),
+                ("n", C.c_int64), ("pos", C.c_int64), ("err", C.c_int64)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ptmcmc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_log.restype = L.orc_exp.restype = L.orc_cos2pi.restype = C.c_double
+        L.orc_log.argtypes = L.orc_exp.argtypes = L.orc_cos2pi.argtypes = [C.c_double]
+        L.orc_normal.restype = C.c_double
+        L.orc_normal.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_uniform.restype = C.c_double
+        L.orc_uniform.argtypes = [C.c_uint64]
+        L.orc_index.restype = C.c_uint64
+        L.orc_index.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_mh_steps.argtypes = [C.POINTER(Cfg), C.POINTER(State), C.c_int64, C.c_int, C.POINTER(Replay)]
+        L.orc_swap_sweep.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int64, C.c_uint64, C.c_int, _ip, _up,
+                                     C.POINTER(Replay)]
+        L.orc_swap_apply.argtypes = [C.POINTER(Cfg), C.POINTER(State), _ip, C.c_int64]
+        L.orc_welford.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]
+        L.orc_pool_cov.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]
+        L.orc_de_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
+        L.orc_de_update_pooled.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]
+        L.orc_eval_state.argtypes = [C.POINTER(Cfg), C.POINTER(State)]
+        L.orc_logl.restype = C.c_double
+        L.orc_logl.argtypes = [C.POINTER(Cfg), _dp]
+        assert L.orc_sizeof_cfg() == C.sizeof(Cfg)
+        _lib = L
+    return _lib
+
+
+def _p(a, t=_dp):
+    return a.ctypes.data_as(t)
+
+
+def lanes_for(ndim):
+    """Lanes that share one chain in the HIP kernels (fixes the summation order)."""
+    return 4 if ndim <= 32 else (16 if ndim <= 256 else 64)
+
+
+def philox(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    return [int(v) for v in out]
+
+
+def temperature_ladder(nchain, ndim, Tmin=1, Tmax=None):
+    """PTMCMCSampler.py:699-720 (host-side; same numpy expressions)."""
+    if nchain > 1:
+        if Tmax is None:
+            tstep = 1 + np.sqrt(2 / ndim)
+        else:
+            tstep = np.exp(np.log(Tmax / Tmin) / (nchain - 1))
+        ladder = np.zeros(nchain)
+        for ii in range(nchain):
+            ladder[ii] = Tmin * tstep**ii
+        return ladder
+    return np.array([1])
+
+
+def welford(AM, mu, M2, it):
+    """In-place PTMCMCSampler.py:769-794; returns cov."""
+    mem, d = AM.shape
+    cov = np.empty((d, d))
+    AMc = np.ascontiguousarray(AM)
+    lib().orc_welford(d, mem, it, _p(AMc), _p(mu), _p(M2), _p(cov))
+    return cov
+
+
+def de_update(DE, AM):
+    AMc = np.ascontiguousarray(AM)
+    lib().orc_de_update(DE.shape[1], DE.shape[0], AMc.shape[0], _p(DE), _p(AMc))
+
+
+def swap_sweep(ladder, lnL_pos, it=0, seed=0, walker0=0, uniforms=None):
+    """Returns (map[W][n], acc[W][n]) for PTMCMCSampler.py:672-681."""
+    lnL_pos = np.ascontiguousarray(np.atleast_2d(lnL_pos), dtype=np.float64)
+    W, n = lnL_pos.shape
+    ladder = np.ascontiguousarray(ladder, dtype=np.float64)
+    m = np.zeros((W, n), dtype=np.int32)
+    acc = np.zeros((W, n), dtype=np.uint64)
+    rp = None
+    if uniforms is not None:
+        rp = make_replay(np.ones(len(uniforms), np.uint8), np.asarray(uniforms, float), np.zeros(len(uniforms), np.int64))
+    err = lib().orc_swap_sweep(W, n, _p(ladder), _p(lnL_pos), it, seed, walker0, _p(m, _ip), _p(acc, _up),
+                               C.byref(rp[0]) if rp else None)
+    assert err == 0, "replay error %d" % err
+    return m, acc
+
+
+def make_replay(kinds, vals, bounds):
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    bounds = np.ascontiguousarray(bounds, dtype=np.int64)
+    r = Replay(_p(kinds, C.POINTER(C.c_uint8)), _p(vals), _p(bounds, C.POINTER(C.c_int64)), len(kinds), 0, 0)
+    return r, (kinds, vals, bounds)
+
+
+class OracleEngine(object):
+    """All temperatures x walkers of the reference's sampler loop, on the CPU.
+
+    Walker = an independent replica of the whole reference run (own ladder copy,
+    own RNG streams; own cov/U/S/DE history when ``cov_mode='per_walker'``).
+    """
+
+    def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
+                 weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
+                 cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
+                 ntemps_global=None, temp0=0, walker0=0):
+        self.d, self.nt, self.W = ndim, ntemps, nwalkers
+        self.ntg = ntemps if ntemps_global is None else ntemps_global
+        self.temp0, self.walker0 = temp0, walker0
+        self.ladder = np.asarray(temperature_ladder(self.ntg, ndim, Tmin, Tmax) if ladder is None else ladder,
+                                 dtype=np.float64)
+        self.temps_mh = self.ladder[temp0:temp0 + ntemps].copy()
+        if hot_chain and temp0 + ntemps == self.ntg:
+            self.temps_mh[-1] = 1e80                       # PTMCMCSampler.py:281-282
+        self.beta = 1 / self.temps_mh
+        self.cov_update, self.burn, self.tskip, self.seed = cov_update, burn, tskip, seed
+        self.per_walker = cov_mode == "per_walker"
+        self.Wc = nwalkers if self.per_walker else 1
+        self.lanes = lanes_for(ndim) if lanes is None else lanes
+        d, nt, W = ndim, ntemps, nwalkers
+        self.X = np.zeros((W, nt, d))
+        self.lnL = np.zeros((W, nt))
+        self.lp = np.zeros((W, nt))
+        self.temp_of = np.tile(np.arange(nt, dtype=np.int32), (W, 1))
+        self.slot_of = self.temp_of.copy()
+        self.cov = np.tile(np.asarray(cov0, dtype=np.float64), (self.Wc, 1, 1))
+        self.Ut = np.zeros((self.Wc, d, d))
+        self.S = np.zeros((self.Wc, d))
+        for w in range(self.Wc):
+            self._svd(w)
+        self.mu = np.zeros((W, d))
+        self.M2 = np.zeros((W, d, d))
+        self.DE = np.zeros((self.Wc, burn, d))
+        self.AM = np.zeros((W, cov_update, d))
+        self.nacc = np.zeros((W, nt), dtype=np.uint64)
+        self.jstat = np.zeros((W, nt, J_NTYPES, 2), dtype=np.uint64)
+        self.nswap = np.zeros((W, self.ntg), dtype=np.uint64)
+        self.swap_proposed = 0
+        self._par_l = np.zeros(1)
+        self._par_p = np.zeros(1)
+        if logl[0] == "dense":
+            mu, P = np.asarray(logl[1], float), np.asarray(logl[2], float)
+            self._par_l = np.concatenate([mu, np.ascontiguousarray(P.T).ravel()])
+        if logp[0] == "box":
+            self._par_p = np.concatenate([np.asarray(logp[1], float), np.asarray(logp[2], float)])
+        self.cfg = Cfg(ndim=d, ntemps=nt, nwalkers=W, lanes=self.lanes, logl_kind=LOGL[logl[0]],
+                       logp_kind=LOGP[logp[0]], w_scam=weights[0], w_am=weights[1], w_de=weights[2], de_on=0,
+                       de_size=burn, cov_update=cov_update, tskip=tskip, cov_per_walker=int(self.per_walker),
+                       ntemps_global=self.ntg, temp0=temp0, walker0=walker0, seed=seed,
+                       logl_par=_p(self._par_l), logp_par=_p(self._par_p), temps_mh=_p(self.temps_mh),
+                       beta=_p(self.beta))
+        self.iter = 0
+
+    # -- helpers
+    def _state(self):
+        return State(_p(self.X), _p(self.lnL), _p(self.lp), _p(self.temp_of, _ip), _p(self.slot_of, _ip), _p(self.Ut),
+                     _p(self.S), _p(self.DE), _p(self.AM) if self.temp0 == 0 else None, _p(self.nacc, _up),
+                     _p(self.jstat, _up))
+
+    def _svd(self, w):
+        U, S, _ = np.linalg.svd(self.cov[w])               # PTMCMCSampler.py:145,803 (host LAPACK)
+        self.Ut[w] = np.ascontiguousarray(U.T)
+        self.S[w] = S
+
+    def set_eig(self, U, S, w=0):
+        self.Ut[w] = np.ascontiguousarray(np.asarray(U).T)
+        self.S[w] = S
+
+    def init_state(self, p0):
+        p0 = np.asarray(p0, dtype=np.float64)
+        self.X[...] = p0 if p0.ndim == 3 else np.broadcast_to(p0, self.X.shape)
+        lib().orc_eval_state(C.byref(self.cfg), C.byref(self._state()))
+        if self.temp0 == 0:
+            self.AM[:, 0, :] = self.X[np.arange(self.W), self.slot_of[:, 0]]   # updateChains(p0, ..., 0), :491
+
+    def by_temp(self, a):
+        """Reorder a per-slot array [W][nt][...] into temperature order."""
+        return np.take_along_axis(a, self.slot_of.reshape(self.slot_of.shape + (1,) * (a.ndim - 2)).astype(np.int64), 1)
+
+    def lnprob(self):
+        return self.beta[self.temp_of] * self.lnL + self.lp
+
+    # -- epochs (PTMCMCSampler.py:545-585)
+    def _epochs(self, it):
+        cu, burn = self.cov_update, self.burn
+        if self.temp0 == 0:
+            if (it - 1) % cu == 0 and it - 1 != 0:
+                for w in range(self.W):
+                    c = welford(self.AM[w], self.mu[w], self.M2[w], it - 1)
+                    if self.per_walker:
+                        self.cov[w] = c
+                if not self.per_walker:
+                    mu_o, cov_o = np.zeros(self.d), np.zeros((self.d, self.d))
+                    lib().orc_pool_cov(self.d, self.W, it - 1, _p(self.mu), _p(self.M2), _p(mu_o), _p(cov_o))
+                    self.cov[0] = cov_o
+                for w in range(self.Wc):
+                    self._svd(w)
+            if (it - 1) % burn == 0 and it - 1 != 0:
+                if self.per_walker:
+                    for w in range(self.W):
+                        de_update(self.DE[w], self.AM[w])
+                else:
+                    lib().orc_de_update_pooled(self.d, burn, cu, self.W, _p(self.DE), _p(self.AM))
+        if it - 1 == burn:
+            self.cfg.de_on = 1
+
+    def _next_event(self, it, niter):
+        """Last iteration of the segment that starts at ``it`` (no epoch inside, swap only at its end)."""
+        end = niter
+        for per in (self.cov_update, self.burn) + ((self.tskip,) if self.tskip > 0 and self.ntg > 1 else ()):
+            end = min(end, ((it - 1) // per + 1) * per)
+        return end
+
+    def swap(self, it, replay0=None):
+        """Single-process PT swap over the local ranks (requires the whole ladder local)."""
+        assert self.nt == self.ntg
+        lnL_pos = np.ascontiguousarray(self.by_temp(self.lnL))
+        m = np.zeros((self.W, self.nt), dtype=np.int32)
+        err = lib().orc_swap_sweep(self.W, self.nt, _p(self.ladder), _p(lnL_pos), it, self.seed, self.walker0,
+                                   _p(m, _ip), _p(self.nswap, _up), replay0)
+        assert err == 0, "replay error %d" % err
+        lib().orc_swap_apply(C.byref(self.cfg), C.byref(self._state()), _p(m, _ip), it)
+        self.swap_proposed += 1
+        return m
+
+    def run(self, niter, replay=None, record=False):
+        """Advance ``niter`` iterations. ``replay``: list (one per rank) of (kinds, vals, bounds)."""
+        rp_arr, keep = None, []
+        if replay is not None:
+            assert self.W == 1
+            rp_arr = (Replay * self.nt)()
+            for t, (k, v, b) in enumerate(replay):
+                r, ka = make_replay(k, v, b)
+                keep.append(ka)
+                rp_arr[t] = r
+        rec = None
+        if record:
+            rec = dict(X=[self.by_temp(self.X).copy()], lnL=[self.by_temp(self.lnL).copy()],
+                       lnprob=[self.by_temp(self.lnprob()).copy()])
+        last = self.iter + niter
+        it = self.iter + 1
+        while it <= last:
+            self._epochs(it)
+            end = it if record else self._next_event(it, last)
+            err = lib().orc_mh_steps(C.byref(self.cfg), C.byref(self._state()), it, end - it + 1, rp_arr)
+            assert err == 0, "replay error %d at iter %d" % (err, it)
+            if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
+                self.swap(end, C.byref(rp_arr[0]) if rp_arr is not None else None)
+            if record:
+                rec["X"].append(self.by_temp(self.X).copy())
+                rec["lnL"].append(self.by_temp(self.lnL).copy())
+                rec["lnprob"].append(self.by_temp(self.lnprob()).copy())
+            it = end + 1
+        self.iter = last
+        if rp_arr is not None:
+            self.replay_left = [int(rp_arr[t].n - rp_arr[t].pos) for t in range(self.nt)]
+        if record:
+            return {k: np.asarray(v) for k, v in rec.items()}
+        return None
