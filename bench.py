@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- MH updates/sec of the fused Metropolis-Hastings hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 100-d isotropic Gaussian logl,
+flat prior, 64 temperatures x 4096 walkers per GPU, p0 = 0, cov0 = 0.01 I, SCAM proposal
+cycle ("SCAM + accept kernel"), Tskip = 100, covUpdate = 1000, burn = 10000, seed 1234,
+pooled covariance.  One "step" = one MH iteration of every chain (swap and covariance
+epochs included in the wall time).  With --gpus N the ladder is sharded by temperature
+block (64 ranks per GPU, 64*N in the ladder) and rows cross block edges over RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = whole-job MH updates per second with the state
+resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--ndim", type=int, default=100)
+    ap.add_argument("--ntemps", type=int, default=64, help="temperature ranks per GPU")
+    ap.add_argument("--nwalkers", type=int, default=4096)
+    ap.add_argument("--mix", default="scam", choices=["scam", "default"], help="scam: SCAM-only; default: SCAM/AM/DE 20/20/20")
+    ap.add_argument("--logl", default="iso", choices=["iso", "dense"])
+    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=4000)
+    ap.add_argument("--ess-walkers", type=int, default=32)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    d, nt, W = a.ndim, a.ntemps, a.nwalkers
+    weights = (20, 0, 0) if a.mix == "scam" else (20, 20, 20)
+    logl = ("iso",)
+    if a.logl == "dense":
+        A = np.random.default_rng(0).standard_normal((d, d))
+        logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
+    kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=100, seed=1234, cov_mode=a.cov_mode, logl=logl,
+              device=local)
+    if world == 1:
+        from ptmcmcsampler_amd.engine import PTEngine
+        eng = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    else:
+        from ptmcmcsampler_amd.sharded import ShardedPTEngine
+        eng = ShardedPTEngine(d, nt * world, W, np.eye(d) * 0.01, group=dist.group.WORLD, **kw)
+    eng.init_state(np.zeros(d))
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.run(a.warmup)
+    fence()
+    # timed region: exactly --steps iterations; each fused-MH launch is bracketed by HIP events on the
+    # engine's stream (= torch's current stream, the one the kernels are launched on)
+    events = []
+    orig = eng.mh_steps
+
+    def timed_mh(iter0, nsteps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(eng.stream)
+        orig(iter0, nsteps)
+        e1.record(eng.stream)
+        events.append((e0, e1, nsteps))
+
+    eng.mh_steps = timed_mh
+    ess_keep = []
+    nw_ess = min(a.ess_walkers, W) if eng.owns_cold else 0
+    orig_cov = eng.update_cov
+
+    def cov_and_keep(it_done):
+        if nw_ess:
+            ess_keep.append(eng.t["AM"][:nw_ess].clone())       # device-side copy of the cold samples of a few walkers
+        orig_cov(it_done)
+
+    eng.update_cov = cov_and_keep
+    t0 = time.perf_counter()
+    eng.run(a.steps)
+    fence()
+    wall = time.perf_counter() - t0
+    eng.mh_steps, eng.update_cov = orig, orig_cov
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    nchains_total = nt * world * W
+    value = nchains_total * a.steps / wall
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    kern_steps = sum(n for _, _, n in events)
+    bytes_per_update = 16 * d + 32
+    avg_launch_ms = kern_ms / max(1, len(events))
+    avg_steps = kern_steps / max(1, len(events))
+    achieved = bytes_per_update * nt * W * avg_steps / (avg_launch_ms * 1e-3) / 1e9
+    out = {
+        "metric": "MH updates/sec (whole node), 100-d Gaussian, 64 temps x 4096 walkers per GPU",
+        "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d-d %s Gaussian logl, %d temps x %d walkers per GPU, %s cycle, "
+                               "Tskip=100, covUpdate=1000, cov_mode=%s" % (d, a.logl, nt, W, a.mix, a.cov_mode),
+                   "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "parallelism": "temperature blocks x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "mh_steps_kernel", "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,
+                     "algorithmic_bytes_per_update": bytes_per_update, "kernel_time_share_of_wall": kern_ms * 1e-3 / wall},
+    }
+    if rank == 0:
+        acc = eng.get("nacc").astype(np.float64)
+        out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / (a.steps + a.warmup))
+        out["swap_accept_rate_pair0"] = float(eng.get("nswap")[:, 0].mean() / max(1, eng.swap_proposed))
+        if ess_keep:
+            from ptmcmcsampler_amd.ess import ess
+            blocks = [b.cpu().numpy() for b in ess_keep]
+            cu = blocks[0].shape[1]
+            # AM rows are in ring order (row 0 = newest); restore time order before concatenating
+            chain = np.concatenate([np.concatenate([b[:, 1:], b[:, :1]], axis=1) for b in blocks], axis=1)
+            per_walker = [ess(chain[w]) for w in range(chain.shape[0])]
+            covered = cu * len(blocks)
+            out["ess_per_sec"] = float(np.mean(per_walker) / covered * a.steps * W / wall)
+            out["ess_note"] = "Sokal-window ESS (min over dims) of the T=1 chain, mean over %d walkers x %d samples, scaled to %d walkers" % (
+                len(per_walker), covered, W)
+        if not a.no_cpu_baseline:
+            from oracle import numpy_port
+            v, cores, what = numpy_port.time_baseline(ndim=d, niter=a.cpu_iters, covUpdate=1000, burn=10000, weights=weights)
+            out["cpu_baseline"] = {"value": v, "unit": "updates/s", "cores": cores, "kind": "port",
+                                   "sample": "reference-equivalent NumPy port (oracle/numpy_port.py), " + what}
+            # the C oracle on one core, for scale (a compiled scalar port; not what a reference user gets)
+            from oracle import oracle as orc
+            o = orc.OracleEngine(d, 8, 8, np.eye(d) * 0.01, weights=weights, cov_update=1000, burn=10000, tskip=100,
+                                 seed=1234, cov_mode=a.cov_mode)
+            o.init_state(np.zeros(d))
+            t1 = time.perf_counter()
+            o.run(1000)
+            out["cpu_c_oracle"] = {"value": 64 * 1000 / (time.perf_counter() - t1), "unit": "updates/s", "cores": 1,
+                                   "sample": "oracle/ptmcmc_oracle.c, 8 temps x 8 walkers x 1000 iterations"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

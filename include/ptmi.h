@@ -1,0 +1,177 @@
+/*
+ * ptmi.h -- C ABI of libptmi.so, the MI355X (gfx950) engine behind the
+ * Metropolis-Hastings inner loop of a PTSampler-compatible parallel-tempering
+ * sampler.
+ *
+ * The reference (nanograv/PTMCMCSampler) has no FFI: its hot path is the Python
+ * method PTSampler.PTMCMCOneStep (PTMCMCSampler/PTMCMCSampler.py:530-629) plus
+ * PTswap (:631-697), _updateRecursive (:769-803) and _updateDEbuffer (:806-817),
+ * one chain per MPI rank.  Each entry point below names the reference code it
+ * replaces.  The binding a maintainer would add is a ctypes stub: see
+ * INTEGRATION.md and ptmcmcsampler_amd/_lib.py.
+ *
+ * Conventions
+ *   - every call returns 0 on success, a negative PTMI_E* code otherwise; the
+ *     message is available from ptmi_last_error() (thread-local);
+ *   - no C++ exception crosses this boundary;
+ *   - every pointer in ptmi_buffers is DEVICE memory owned by the caller (e.g. a
+ *     torch-ROCm tensor's data_ptr(), or ptmi_malloc); pointers in ptmi_config
+ *     are HOST memory, copied at create time;
+ *   - all arrays are C-contiguous; state rows are float64;
+ *   - kernels run asynchronously on the stream given at create time; a handle is
+ *     not thread-safe, different handles are independent.
+ *
+ * Layout ("slots and ranks"): a walker is an independent replica of the whole
+ * reference run; it has `ntemps` chains.  State rows never move inside a GPU:
+ * row (w, s) -- walker w, SLOT s -- holds whichever state currently sits at
+ * temperature RANK temp_of[w][s]; slot_of is the inverse table.  A PT swap only
+ * rewrites the two tables.  Per-rank quantities (RNG stream, counters) are
+ * indexed by rank, exactly as they belong to an MPI rank in the reference.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_VERSION 1
+
+enum { PTMI_OK = 0, PTMI_EINVAL = -1, PTMI_EHIP = -2, PTMI_EUNSUPPORTED = -3, PTMI_ENODEVICE = -4 };
+
+/* built-in device likelihoods / priors (a Python callback cannot run in a kernel;
+ * user callbacks go through ptmi_propose / ptmi_accept instead) */
+enum { PTMI_LOGL_ISO = 0,      /* -1/2 sum x^2 */
+       PTMI_LOGL_DENSE = 1,    /* -(x-mu)^T P (x-mu) / 2 ; par = mu[d], Pt[d*d] (Pt[j*d+i] = P[i][j]) */
+       PTMI_LOGL_CURVED = 2 }; /* d/2 copies of examples/curved_likelihood.ipynb's 2-d likelihood */
+enum { PTMI_LOGP_FLAT = 0,     /* 0 everywhere */
+       PTMI_LOGP_BOX = 1 };    /* 0 inside [lo,hi], -inf outside ; par = lo[d], hi[d] */
+
+/* proposal types; also the index into jstat */
+enum { PTMI_J_SCAM = 0, PTMI_J_AM = 1, PTMI_J_DE = 2, PTMI_J_NTYPES = 3 };
+
+typedef struct ptmi_config {
+    int32_t ndim;            /* parameters per chain */
+    int32_t ntemps;          /* temperature ranks held by THIS handle (a contiguous block) */
+    int32_t nwalkers;        /* walkers held by this handle */
+    int32_t ntemps_global;   /* ranks in the whole ladder (== ntemps on one GPU) */
+    int32_t temp0;           /* first global rank of this block */
+    int32_t walker0;         /* first global walker index (RNG stream ids are global) */
+    int32_t logl_kind, logp_kind;
+    int32_t w_scam, w_am, w_de;   /* proposal-cycle weights, PTMCMCSampler.py:261-264, 579-585 */
+    int32_t de_size;         /* rows of a DE buffer (= burn, :221) */
+    int32_t cov_update;      /* rows of an AM buffer (= covUpdate, :220) */
+    int32_t tskip;           /* swap period (:624); 0 = never */
+    int32_t cov_per_walker;  /* 1: Ut/S/DE/cov per walker (faithful replicas); 0: one pooled set */
+    int32_t device;          /* HIP device ordinal */
+    uint64_t seed;
+    void *stream;            /* hipStream_t to launch on; NULL = the null stream */
+    const double *ladder;    /* host [ntemps_global]  temperatures used by the swap (:658) */
+    const double *temps_mh;  /* host [ntemps] temperature each local rank samples at (:278-282; hot chain = 1e80) */
+    const double *logl_par;  /* host, per logl_kind */
+    int64_t logl_par_len;
+    const double *logp_par;  /* host, per logp_kind */
+    int64_t logp_par_len;
+} ptmi_config;
+
+/* Device buffers, caller-owned.  W = nwalkers, T = ntemps, d = ndim,
+ * Wc = cov_per_walker ? W : 1.  Optional ones may be NULL when unused. */
+typedef struct ptmi_buffers {
+    double *X;          /* [W][T][d]   state rows by slot */
+    double *lnL;        /* [W][T]      log-likelihood of the row in a slot */
+    double *lp;         /* [W][T]      log-prior of the row in a slot */
+    int32_t *temp_of;   /* [W][T]      local rank held by a slot */
+    int32_t *slot_of;   /* [W][T]      slot holding a local rank */
+    double *Ut;         /* [Wc][d][d]  eigenvectors, one per ROW (Ut[k][i] = U[i][k] of :145,803) */
+    double *S;          /* [Wc][d]     eigenvalues */
+    double *DE;         /* [Wc][de_size][d]  DE history ring (optional) */
+    double *AM;         /* [W][cov_update][d] samples of the rank-0 chain (:327-328); only where temp0 == 0 */
+    uint64_t *nacc;     /* [W][T]      accepted MH updates per rank (:621) */
+    uint64_t *jstat;    /* [W][T][PTMI_J_NTYPES][2]  proposed, accepted per jump type (:602,622) */
+    uint64_t *nswap;    /* [W][ntemps_global]  accepted swaps credited to the lower rank (:681) */
+    double *mu;         /* [W][d]      running mean of the rank-0 chain (:148) */
+    double *M2;         /* [W][d][d]   running sum of outer products (:147) */
+    double *cov;        /* [Wc][d][d]  published covariance (:794) */
+    double *Q;          /* [W][T][d]   proposals, split path only (optional) */
+    double *qaux;       /* [W][T][4]   split path: qxy, jump type, accept uniform, spare (optional) */
+} ptmi_buffers;
+
+typedef struct ptmi_engine *ptmi_handle;
+
+const char *ptmi_last_error(void);
+int ptmi_version(void);
+int ptmi_device_count(int *count);
+/* lanes of a wavefront that share one chain for a given ndim (fixes the summation order) */
+int ptmi_lanes_for(int ndim);
+
+int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out);
+int ptmi_destroy(ptmi_handle h);
+int ptmi_sync(ptmi_handle h);
+
+/* lnL and lp of every row from X: the initial evaluation of sample(), PTMCMCSampler.py:479-487 */
+int ptmi_eval_state(ptmi_handle h);
+
+/* DE enters the proposal cycle after burn (PTMCMCSampler.py:574-585) */
+int ptmi_set_de_active(ptmi_handle h, int on);
+
+/* `nsteps` fused Metropolis-Hastings updates of every chain for iterations
+ * iter0 .. iter0+nsteps-1: _jump + SCAM/AM/DE (:1048-1067, :820-985), logp/logl +
+ * tempering (:605-612), the Hastings test (:615-622) and the AM-buffer write of
+ * updateChains (:327-328).  The caller splits the run at swap / covariance / DE
+ * epochs (none may fall strictly inside the range). */
+int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps);
+
+/* PTswap (:631-697) for iteration `iter` when the whole ladder is on this GPU. */
+int ptmi_swap(ptmi_handle h, int64_t iter);
+
+/* The same in three pieces for a ladder sharded over GPUs (the caller all-gathers
+ * lnL between 1 and 2 and exchanges the rows that cross a block edge after 2):
+ *  1. lnL by local rank:  lnL_pos[w][t] = lnL[w][slot_of[w][t]]
+ *  2. the sweep over the global ladder -> map[w][j] = position whose state moves to j
+ *     (every GPU computes the identical map; credits go to nswap for local ranks only)
+ *  3. rewrite of the local tables for positions whose source is local; sources on
+ *     other GPUs are reported in `incoming` for the caller's exchange. */
+int ptmi_swap_gather_lnl(ptmi_handle h, double *lnL_pos_local /* dev [W][T] */);
+int ptmi_swap_sweep(ptmi_handle h, int64_t iter, const double *lnL_pos_global /* dev [W][ntemps_global] */,
+                    int32_t *map /* dev [W][ntemps_global] */);
+int ptmi_swap_write_am(ptmi_handle h, int64_t iter);
+
+/* _updateRecursive (:769-794) for every walker at iteration `iter` (= the multiple of
+ * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 the
+ * walkers' statistics are pooled into cov[0].  The eigendecomposition (:797-803) is a
+ * separate step: the host (LAPACK, as the reference) or ptmi_eig_jacobi. */
+int ptmi_update_cov(ptmi_handle h, int64_t iter);
+
+/* _updateDEbuffer (:806-817): drop the oldest cov_update rows of each DE history and
+ * append the AM buffer (pooled mode: row r comes from walker r mod W). */
+int ptmi_update_de(ptmi_handle h);
+
+/* Split path for host (Python) likelihood callbacks, one iteration per call:
+ * propose writes Q and qaux for every chain; the caller evaluates logp/logl on Q;
+ * accept applies the Hastings test with the caller's values (NaN-safe, -inf prior). */
+int ptmi_propose(ptmi_handle h, int64_t iter);
+int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL /* dev [W][T] */, const double *newlp /* dev [W][T] */);
+
+/* Self-test hooks used by the parity tests: evaluate the device's deterministic math on
+ * n inputs (op: 0 log, 1 exp, 2 cos2pi, 3 sqrt, 4 reciprocal-free divide a/b with b=in2). */
+int ptmi_selftest_math(int device, int op, const double *in, const double *in2, double *out, int64_t n);
+int ptmi_selftest_philox(int device, const uint32_t *ctr_key /* [n][6] */, uint32_t *out /* [n][4] */, int64_t n);
+
+/* plain device memory helpers, so that a C caller needs nothing but this library */
+int ptmi_malloc(void **p, size_t bytes);
+int ptmi_free(void *p);
+int ptmi_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int ptmi_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int ptmi_memset(void *dst, int value, size_t bytes);
+
+/* HIP-event stopwatch on the handle's stream (bench.py's kernel timing) */
+int ptmi_timer_start(ptmi_handle h);
+int ptmi_timer_stop_ms(ptmi_handle h, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

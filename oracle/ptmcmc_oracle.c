@@ -61,7 +61,10 @@ static void philox_words(uint64_t seed, uint64_t iter, uint32_t stream, uint32_t
     w[1] = ((uint64_t)o[3] << 32) | o[2];
 }
 
-/* slot numbers of the counter-based schedule (DESIGN.md "RNG schedule") */
+/* slot numbers of the counter-based schedule (DESIGN.md "RNG schedule"):
+ *   A: w0 cycle pick, w1 scale-branch uniform     B: w0 accept uniform, w1 SCAM direction / DE row mm
+ *   C: w0 DE row nn offset, w1 DE scale uniform    D: (w0,w1) SCAM normal
+ *   SWAP+k: w0 uniform of pair (k,k+1), stream of rank 0   AM+k: (w0,w1) normal of eigen-direction k */
 enum { SLOT_A = 0, SLOT_B = 1, SLOT_C = 2, SLOT_D = 3, SLOT_SWAP = 0x10000, SLOT_AM = 0x1000000 };
 
 static inline double w2uniform(uint64_t w) { return (double)(w >> 11) * 0x1.0p-53; }        /* [0,1) */
@@ -300,9 +303,8 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             double z;
             if (r) { k = (int)rp_next(r, K_INT, d); z = rp_next(r, K_NRM, 0); }
             else {
-                philox_words(c->seed, (uint64_t)it, sid, SLOT_C, C);
                 philox_words(c->seed, (uint64_t)it, sid, SLOT_D, D);
-                k = (int)w2index(C[0], (uint64_t)d);
+                k = (int)w2index(B[1], (uint64_t)d);
                 z = orc_normal(D[0], D[1]);
             }
             const double cd = 2.4 / sqrt(2.0 * 1.0) * scale;            /* PT:870, neff = 1 */
@@ -332,15 +334,15 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             prob = rp_next(r, K_UNI, 0);
         } else {
             philox_words(c->seed, (uint64_t)it, sid, SLOT_C, C);
-            mm = (int)w2index(C[0], (uint64_t)Bn);
-            nn = (int)(((uint64_t)mm + 1 + w2index(C[1], (uint64_t)(Bn - 1))) % (uint64_t)Bn);
+            mm = (int)w2index(B[1], (uint64_t)Bn);
+            nn = (int)(((uint64_t)mm + 1 + w2index(C[0], (uint64_t)(Bn - 1))) % (uint64_t)Bn);
             prob = w2uniform(A[1]);
         }
         if (prob > 0.5) scale = 1.0;
         else {
             double rr;
             if (r) rr = rp_next(r, K_UNI, 0);
-            else { philox_words(c->seed, (uint64_t)it, sid, SLOT_D, D); rr = w2uniform(D[0]); }
+            else rr = w2uniform(C[1]);
             scale = rr * 2.4 / sqrt(2.0 * (double)d) * sqrt(1.0 / beta); /* PT:976 */
         }
         const double *DE = st->DE + wc * (size_t)Bn * d;

@@ -1,0 +1,100 @@
+"""ctypes binding of libptmi.so (the C ABI in include/ptmi.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is visible the
+engine raises instead of computing anything on the host."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libptmi.so")
+
+LOGL = {"iso": 0, "dense": 1, "curved": 2}
+LOGP = {"flat": 0, "box": 1}
+J_SCAM, J_AM, J_DE, J_NTYPES = 0, 1, 2, 3
+JUMP_NAMES = ("covarianceJumpProposalSCAM", "covarianceJumpProposalAM", "DEJump")
+
+_dp = C.POINTER(C.c_double)
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "ndim", "ntemps", "nwalkers", "ntemps_global", "temp0", "walker0", "logl_kind", "logp_kind",
+        "w_scam", "w_am", "w_de", "de_size", "cov_update", "tskip", "cov_per_walker", "device")] + [
+        ("seed", C.c_uint64), ("stream", C.c_void_p), ("ladder", _dp), ("temps_mh", _dp),
+        ("logl_par", _dp), ("logl_par_len", C.c_int64), ("logp_par", _dp), ("logp_par_len", C.c_int64)]
+
+
+BUFFER_FIELDS = ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "DE", "AM", "nacc", "jstat", "nswap",
+                 "mu", "M2", "cov", "Q", "qaux")
+
+
+class Buffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in BUFFER_FIELDS]
+
+
+# every symbol include/ptmi.h declares
+SYMBOLS = (
+    "ptmi_last_error", "ptmi_version", "ptmi_device_count", "ptmi_lanes_for", "ptmi_create", "ptmi_destroy",
+    "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_swap", "ptmi_swap_gather_lnl",
+    "ptmi_swap_sweep", "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_update_de", "ptmi_propose", "ptmi_accept",
+    "ptmi_selftest_math", "ptmi_selftest_philox", "ptmi_malloc", "ptmi_free", "ptmi_memcpy_h2d", "ptmi_memcpy_d2h",
+    "ptmi_memset", "ptmi_timer_start", "ptmi_timer_stop_ms",
+)
+
+_lib = None
+
+
+class PtmiError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libptmi.so; raises PtmiError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise PtmiError("libptmi.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `python -m ptmcmcsampler_amd._build`; there is no CPU fallback." % SO)
+    L = C.CDLL(SO)
+    H = C.c_void_p
+    L.ptmi_last_error.restype = C.c_char_p
+    L.ptmi_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.ptmi_lanes_for.argtypes = [C.c_int]
+    L.ptmi_create.argtypes = [C.POINTER(Config), C.POINTER(Buffers), C.POINTER(H)]
+    for n in ("ptmi_destroy", "ptmi_sync", "ptmi_eval_state", "ptmi_update_de", "ptmi_timer_start"):
+        getattr(L, n).argtypes = [H]
+    L.ptmi_set_de_active.argtypes = [H, C.c_int]
+    L.ptmi_mh_steps.argtypes = [H, C.c_int64, C.c_int32]
+    L.ptmi_swap.argtypes = [H, C.c_int64]
+    L.ptmi_swap_gather_lnl.argtypes = [H, C.c_void_p]
+    L.ptmi_swap_sweep.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]
+    L.ptmi_swap_write_am.argtypes = [H, C.c_int64]
+    L.ptmi_update_cov.argtypes = [H, C.c_int64]
+    L.ptmi_propose.argtypes = [H, C.c_int64]
+    L.ptmi_accept.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]
+    L.ptmi_selftest_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.ptmi_selftest_philox.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+    L.ptmi_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.ptmi_free.argtypes = [C.c_void_p]
+    L.ptmi_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ptmi_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ptmi_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.ptmi_timer_stop_ms.argtypes = [H, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise PtmiError("libptmi error %d: %s" % (rc, load().ptmi_last_error().decode()))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().ptmi_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def lanes_for(ndim):
+    return 4 if ndim <= 32 else (16 if ndim <= 256 else 64)

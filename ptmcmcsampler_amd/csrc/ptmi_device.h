@@ -1,0 +1,172 @@
+// ptmi_device.h -- device-side building blocks of libptmi (gfx950 only).
+//
+// Everything a parity decision depends on is spelled with IEEE-exact operations
+// (+ - * / sqrt, explicit fma) in a fixed order, so the kernels agree bit for bit
+// with the CPU oracle used by the tests.  Compile with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptmi {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---------------------------------------------------------------- cross-lane
+// DPP moves: full-rate lane permutations inside a row of 16 lanes (no LDS traffic).
+template <int CTRL>
+__device__ __forceinline__ u32 dpp32(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ u64 dpp64(u64 v)
+{
+    u32 lo = dpp32<CTRL>((u32)v), hi = dpp32<CTRL>((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ double dppf64(double v)
+{
+    return __longlong_as_double((long long)dpp64<CTRL>((u64)__double_as_longlong(v)));
+}
+// broadcast lane J of every quad to the quad
+template <int J>
+__device__ __forceinline__ u64 quad_bcast(u64 v) { return dpp64<J * 0x55>(v); }
+template <int J>
+__device__ __forceinline__ double quad_bcastf(double v) { return dppf64<J * 0x55>(v); }
+
+// All-reduce (sum) over the G lanes that share a chain.  Pairing order is the xor
+// butterfly m = G/2 .. 1; after the m = 8 step the data has period 8, so a row rotate
+// by 4 pairs exactly the lanes l and l^4.
+template <int G>
+__device__ __forceinline__ double group_sum(double p)
+{
+    if (G >= 64) p = p + __shfl_xor(p, 32, 64);
+    if (G >= 32) p = p + __shfl_xor(p, 16, 64);
+    if (G >= 16) p = p + dppf64<0x128>(p);   // row_ror:8  == xor 8
+    if (G >= 8) p = p + dppf64<0x124>(p);    // row_ror:4  == xor 4 on period-8 data
+    if (G >= 4) p = p + dppf64<0x4E>(p);     // quad_perm [2,3,0,1] == xor 2
+    if (G >= 2) p = p + dppf64<0xB1>(p);     // quad_perm [1,0,3,2] == xor 1
+    return p;
+}
+// true iff `ok` holds on all G lanes of the caller's group
+template <int G>
+__device__ __forceinline__ bool group_all(bool ok)
+{
+    const u64 m = __ballot(ok);
+    const int lane = (int)(threadIdx.x & 63);
+    const u64 full = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    return ((m >> (lane & ~(G - 1))) & full) == full;
+}
+
+// --------------------------------------------------------------------- Philox
+// Philox4x32-10 (Salmon et al., SC'11).  ctr = (iter_lo, iter_hi, stream, slot), key = seed.
+__device__ __forceinline__ void philox_words(u64 seed, u64 iter, u32 stream, u32 slot, u64 &w0, u64 &w1)
+{
+    u32 c0 = (u32)iter, c1 = (u32)(iter >> 32), c2 = stream, c3 = slot;
+    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const u32 h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const u32 h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const u32 n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    w0 = ((u64)c1 << 32) | c0;
+    w1 = ((u64)c3 << 32) | c2;
+}
+enum : u32 { SLOT_A = 0, SLOT_B = 1, SLOT_C = 2, SLOT_D = 3, SLOT_SWAP = 0x10000u, SLOT_AM = 0x1000000u };
+
+__device__ __forceinline__ double w2uniform(u64 w) { return (double)(w >> 11) * 0x1.0p-53; }            // [0,1)
+__device__ __forceinline__ double w2uniform_open(u64 w) { return (double)((w >> 11) + 1ull) * 0x1.0p-53; } // (0,1]
+__device__ __forceinline__ u64 w2index(u64 w, u64 n) { return __umul64hi(w, n); }
+
+// ------------------------------------------------------- deterministic libm
+__device__ __forceinline__ double det_log(double x)
+{
+    if (x != x) return x;
+    if (x <= 0.0) return x == 0.0 ? -__builtin_inf() : __builtin_nan("");
+    if (x == __builtin_inf()) return x;
+    u64 u = (u64)__double_as_longlong(x);
+    int k = 0;
+    if ((u >> 52) == 0) { x *= 0x1.0p54; u = (u64)__double_as_longlong(x); k = -54; }
+    k += (int)(u >> 52) - 1023;
+    const u64 man = u & 0x000FFFFFFFFFFFFFull;
+    if (man >= 0x6A09E667F3BCDull) { k += 1; u = man | 0x3FE0000000000000ull; }
+    else u = man | 0x3FF0000000000000ull;
+    const double f = __longlong_as_double((long long)u) - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+__device__ __forceinline__ double det_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return __builtin_inf();
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    const int k = (int)(1.44269504088896338700e+00 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double dk = (double)k;
+    const double hi = x - dk * 6.93147180369123816490e-01;
+    const double lo = dk * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 +
+                     t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    if (k == 0) return y;
+    if (k == 1024) return y * 2.0 * 0x1.0p1023;
+    const u64 yb = (u64)__double_as_longlong(y);
+    if (k >= -1021) return __longlong_as_double((long long)(yb + ((u64)(long long)k << 52)));
+    return __longlong_as_double((long long)(yb + ((u64)(long long)(k + 1000) << 52))) * 0x1.0p-1000;
+}
+
+__device__ __forceinline__ double det_cos2pi(double u)
+{
+    const double a = 4.0 * u;
+    const double q = __builtin_floor(a + 0.5);
+    const double r = a - q;
+    const double z = r * r;
+    const int qi = (int)q & 3;
+    double ps = -0x1.8a404211f9547p-45;
+    ps = __builtin_fma(ps, z, 0x1.aaec32af93359p-38);
+    ps = __builtin_fma(ps, z, -0x1.6fadb9f155744p-31);
+    ps = __builtin_fma(ps, z, 0x1.e8f434d018d63p-25);
+    ps = __builtin_fma(ps, z, -0x1.e3074fde8871fp-19);
+    ps = __builtin_fma(ps, z, 0x1.50783487ee782p-13);
+    ps = __builtin_fma(ps, z, -0x1.32d2cce62bd86p-8);
+    ps = __builtin_fma(ps, z, 0x1.466bc6775aae2p-4);
+    ps = __builtin_fma(ps, z, -0x1.4abbce625be53p-1);
+    ps = __builtin_fma(ps, z, 0x1.921fb54442d18p+0);
+    const double sn = ps * r;
+    double pc = 0x1.ef6e308d6d1c4p-49;
+    pc = __builtin_fma(pc, z, -0x1.2a0c591af8314p-41);
+    pc = __builtin_fma(pc, z, 0x1.20c62c2f2d7f5p-34);
+    pc = __builtin_fma(pc, z, -0x1.b6e24f44b128fp-28);
+    pc = __builtin_fma(pc, z, 0x1.f9d38a3763cc3p-22);
+    pc = __builtin_fma(pc, z, -0x1.a6d1f2a204a8cp-16);
+    pc = __builtin_fma(pc, z, 0x1.e1f506891babbp-11);
+    pc = __builtin_fma(pc, z, -0x1.55d3c7e3cbffap-6);
+    pc = __builtin_fma(pc, z, 0x1.03c1f081b5ac4p-2);
+    pc = __builtin_fma(pc, z, -0x1.3bd3cc9be45dep+0);
+    pc = __builtin_fma(pc, z, 1.0);
+    const double v = (qi & 1) ? sn : pc;
+    return (qi == 1 || qi == 2) ? -v : v;
+}
+
+__device__ __forceinline__ double det_sqrt(double x) { return __dsqrt_rn(x); }
+
+// Box-Muller, cos branch
+__device__ __forceinline__ double det_normal(u64 w0, u64 w1)
+{
+    return det_sqrt(-2.0 * det_log(w2uniform_open(w0))) * det_cos2pi(w2uniform(w1));
+}
+
+}  // namespace ptmi

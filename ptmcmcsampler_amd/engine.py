@@ -1,0 +1,227 @@
+"""Batched parallel-tempering engine: host-side driver of libptmi.so.
+
+One ``PTEngine`` owns the chains of ``nwalkers`` independent replicas x ``ntemps``
+temperature ranks on one MI355X and advances them with the fused HIP kernels.  The
+host part below is the epoch logic of the reference's ``PTMCMCOneStep``
+(PTMCMCSampler/PTMCMCSampler.py:545-585: covariance epoch, DE epoch, DE activation)
+and the iteration loop of ``sample()`` (:495-528), restated for a batch; everything
+per-chain runs on the device.  Device memory is held in torch tensors (plumbing only:
+allocation, host<->device copies, and RCCL in ``sharded.py``).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .ladder import temperature_ladder
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class PTEngine(object):
+    """Chains of ``nwalkers`` x ``ntemps`` on one GPU.
+
+    Parameters mirror the reference's sampler: ``cov0`` is the initial jump covariance
+    (``PTSampler.__init__`` ``cov``), ``weights`` = (SCAMweight, AMweight, DEweight),
+    ``cov_update`` = covUpdate, ``burn`` = burn (also the DE-buffer length), ``tskip`` =
+    Tskip.  ``cov_mode``: ``"per_walker"`` makes every walker a faithful replica of a
+    reference run (own covariance, eigenvectors and DE history); ``"pooled"`` adapts one
+    covariance from all walkers' rank-0 samples.  ``logl`` / ``logp`` select the built-in
+    device likelihood / prior: ("iso",), ("dense", mu, P), ("curved",); ("flat",),
+    ("box", lo, hi).
+    """
+
+    def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
+                 weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
+                 cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
+                 ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not torch.cuda.is_available() or _lib.device_count() < 1:
+            raise _lib.PtmiError("no MI355X visible: the engine has no CPU fallback")
+        self.d, self.nt, self.W = int(ndim), int(ntemps), int(nwalkers)
+        self.ntg = self.nt if ntemps_global is None else int(ntemps_global)
+        self.temp0, self.walker0 = int(temp0), int(walker0)
+        self.ladder = np.ascontiguousarray(
+            temperature_ladder(self.ntg, ndim, Tmin, Tmax) if ladder is None else ladder, dtype=np.float64)
+        if len(self.ladder) != self.ntg:
+            raise ValueError("ladder has %d entries for %d temperatures" % (len(self.ladder), self.ntg))
+        self.temps_mh = self.ladder[self.temp0:self.temp0 + self.nt].copy()
+        if hot_chain and self.temp0 + self.nt == self.ntg:
+            self.temps_mh[-1] = 1e80                                  # PTMCMCSampler.py:281-282
+        self.cov_update, self.burn, self.tskip, self.seed = int(cov_update), int(burn), int(tskip), int(seed)
+        self.weights = tuple(int(w) for w in weights)
+        self.per_walker = cov_mode == "per_walker"
+        if cov_mode not in ("per_walker", "pooled"):
+            raise ValueError("cov_mode must be 'per_walker' or 'pooled'")
+        self.Wc = self.W if self.per_walker else 1
+        self.device = torch.device("cuda", device)
+        self.dev_index = device
+        d, nt, W, Wc = self.d, self.nt, self.W, self.Wc
+        f64, i32, i64 = torch.float64, torch.int32, torch.int64
+        z = lambda shape, dt=f64: torch.zeros(shape, dtype=dt, device=self.device)  # noqa: E731
+        has_de = self.weights[2] > 0 if use_de_buffer is None else use_de_buffer
+        self.owns_cold = self.temp0 == 0
+        self.t = dict(
+            X=z((W, nt, d)), lnL=z((W, nt)), lp=z((W, nt)),
+            temp_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
+            slot_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
+            Ut=z((Wc, d, d)), S=z((Wc, d)),
+            DE=z((Wc, self.burn, d)) if has_de else None,
+            AM=z((W, self.cov_update, d)) if self.owns_cold else None,
+            nacc=z((W, nt), i64), jstat=z((W, nt, _lib.J_NTYPES, 2), i64), nswap=z((W, self.ntg), i64),
+            mu=z((W, d)) if self.owns_cold else None, M2=z((W, d, d)) if self.owns_cold else None,
+            cov=z((Wc, d, d)),
+            Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
+        )
+        cov0 = np.asarray(cov0, dtype=np.float64)
+        self.t["cov"].copy_(torch.from_numpy(np.broadcast_to(cov0, (Wc, d, d)).copy()))
+        # likelihood / prior parameters
+        self._par_l = np.zeros(0)
+        self._par_p = np.zeros(0)
+        if logl[0] == "dense":
+            mu, P = np.asarray(logl[1], np.float64), np.asarray(logl[2], np.float64)
+            self._par_l = np.concatenate([mu, np.ascontiguousarray(P.T).ravel()])
+        if logp[0] == "box":
+            self._par_p = np.concatenate([np.asarray(logp[1], np.float64), np.asarray(logp[2], np.float64)])
+        self.stream = torch.cuda.current_stream(self.device)
+        cfg = _lib.Config(
+            ndim=d, ntemps=nt, nwalkers=W, ntemps_global=self.ntg, temp0=self.temp0, walker0=self.walker0,
+            logl_kind=_lib.LOGL[logl[0]], logp_kind=_lib.LOGP[logp[0]], w_scam=self.weights[0], w_am=self.weights[1],
+            w_de=self.weights[2] if has_de else 0, de_size=self.burn, cov_update=self.cov_update, tskip=self.tskip,
+            cov_per_walker=int(self.per_walker), device=device, seed=self.seed,
+            stream=C.c_void_p(self.stream.cuda_stream),
+            ladder=self.ladder.ctypes.data_as(_lib._dp), temps_mh=self.temps_mh.ctypes.data_as(_lib._dp),
+            logl_par=self._par_l.ctypes.data_as(_lib._dp) if len(self._par_l) else None, logl_par_len=len(self._par_l),
+            logp_par=self._par_p.ctypes.data_as(_lib._dp) if len(self._par_p) else None, logp_par_len=len(self._par_p))
+        buf = _lib.Buffers(**{k: (C.c_void_p(v.data_ptr()) if v is not None else None) for k, v in self.t.items()})
+        self.h = C.c_void_p()
+        _lib.check(self.lib.ptmi_create(C.byref(cfg), C.byref(buf), C.byref(self.h)))
+        self.de_on = False
+        self.iter = 0
+        self.swap_proposed = 0
+        self.eig_epochs = 0
+        for w in range(Wc):
+            self._eig_host(w, cov0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None and self.h:
+                self.lib.ptmi_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ data access
+    def get(self, name):
+        """Device array -> numpy (counters as uint64)."""
+        a = self.t[name].cpu().numpy()
+        return a.view(np.uint64) if name in ("nacc", "jstat", "nswap") else a
+
+    def put(self, name, value):
+        torch = _torch()
+        self.t[name].copy_(torch.from_numpy(np.ascontiguousarray(value)).to(self.t[name].dtype))
+
+    def by_temp(self, name):
+        """A per-slot array ([W][nt][...]) reordered by temperature rank."""
+        a, so = self.get(name), self.get("slot_of").astype(np.int64)
+        return np.take_along_axis(a, so.reshape(so.shape + (1,) * (a.ndim - 2)), 1)
+
+    def sync(self):
+        _lib.check(self.lib.ptmi_sync(self.h))
+
+    # ------------------------------------------------------------------ set-up
+    def _eig_host(self, w, cov):
+        """U, S of the jump covariance by LAPACK, as the reference (:145, :803)."""
+        U, S, _ = np.linalg.svd(cov)
+        self.put_eig(U, S, w)
+
+    def put_eig(self, U, S, w=0):
+        torch = _torch()
+        self.t["Ut"][w].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(U).T)))
+        self.t["S"][w].copy_(torch.from_numpy(np.ascontiguousarray(S)))
+
+    def init_state(self, p0):
+        """Initial point(s): ``p0`` of shape [d] (broadcast) or [W][nt][d] (by slot)."""
+        torch = _torch()
+        p0 = np.asarray(p0, dtype=np.float64)
+        full = p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d))
+        self.t["X"].copy_(torch.from_numpy(np.ascontiguousarray(full)))
+        _lib.check(self.lib.ptmi_eval_state(self.h))                 # :479-487
+        if self.owns_cold:                                            # updateChains(p0, ..., i0=0), :491
+            idx = self.t["slot_of"][:, 0].long()
+            self.t["AM"][:, 0, :] = self.t["X"][torch.arange(self.W, device=self.device), idx]
+
+    # ------------------------------------------------------------------ epochs
+    def update_cov(self, it_done):
+        """Covariance epoch after iteration ``it_done`` (:545-560): device Welford, host SVD."""
+        if not self.owns_cold:
+            return
+        _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
+        cov = self.get("cov")
+        for w in range(self.Wc):
+            self._eig_host(w, cov[w])
+        self.eig_epochs += 1
+
+    def update_de(self):
+        if self.owns_cold and self.t["DE"] is not None:
+            _lib.check(self.lib.ptmi_update_de(self.h))
+
+    def _epochs(self, it):
+        cu, burn = self.cov_update, self.burn
+        if (it - 1) % cu == 0 and it - 1 != 0:
+            self.update_cov(it - 1)
+        if (it - 1) % burn == 0 and it - 1 != 0:
+            self.update_de()                                          # :563-571
+        if it - 1 == burn and self.weights[2] > 0 and self.t["DE"] is not None:
+            _lib.check(self.lib.ptmi_set_de_active(self.h, 1))        # :574-585
+            self.de_on = True
+
+    def _segment_end(self, it, last):
+        """Last iteration of the launch that starts at ``it``: no epoch inside, swap only at its end."""
+        end = last
+        pers = [self.cov_update, self.burn]
+        if self.tskip > 0 and self.ntg > 1:
+            pers.append(self.tskip)
+        for per in pers:
+            end = min(end, ((it - 1) // per + 1) * per)
+        return end
+
+    # ------------------------------------------------------------------ stepping
+    def mh_steps(self, iter0, nsteps):
+        _lib.check(self.lib.ptmi_mh_steps(self.h, iter0, nsteps))
+
+    def swap(self, it):
+        """PT swap of iteration ``it`` with the whole ladder on this GPU (:631-697)."""
+        _lib.check(self.lib.ptmi_swap(self.h, it))
+        self.swap_proposed += 1
+
+    def run(self, niter):
+        """Advance ``niter`` iterations (:499-503 for every chain)."""
+        last = self.iter + niter
+        it = self.iter + 1
+        while it <= last:
+            self._epochs(it)
+            end = self._segment_end(it, last)
+            self.mh_steps(it, end - it + 1)
+            if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
+                self.swap(end)
+            it = end + 1
+        self.iter = last
+
+    # ------------------------------------------------------------------ timing
+    def timer_start(self):
+        _lib.check(self.lib.ptmi_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_double(0)
+        _lib.check(self.lib.ptmi_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def lnprob(self):
+        """beta * lnL + lp of every slot (the reference's lnprob0)."""
+        beta = (1 / self.temps_mh)[self.get("temp_of")]
+        return beta * self.get("lnL") + self.get("lp")

@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/ptmi.h declares (no GPU needed)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from ptmcmcsampler_amd import _lib
+    if not os.path.exists(_lib.SO):
+        ge.build()
+    return _lib
+
+
+def test_header_and_binding_list_the_same_symbols(lib):
+    hdr = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ptmi_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.SYMBOLS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    L = lib.load()
+    for s in lib.SYMBOLS:
+        assert hasattr(L, s), s
+    assert L.ptmi_version() == 1
+
+
+def test_struct_layouts_match_the_header(lib):
+    import ctypes as C
+    # 16 int32 + u64 + ptr + 2 ptr + (ptr, i64) x 2
+    assert C.sizeof(lib.Config) == 16 * 4 + 8 + 8 + 2 * 8 + 4 * 8
+    assert C.sizeof(lib.Buffers) == 17 * 8
+    assert [lib.lanes_for(d) for d in (2, 32, 33, 100, 256, 257, 2048)] == [lib.load().ptmi_lanes_for(d) for d in (2, 32, 33, 100, 256, 257, 2048)]
+
+
+def test_no_cpu_fallback(lib):
+    """Without a device the product path refuses to run instead of computing on the host."""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ptmcmcsampler_amd.engine import PTEngine
+    with pytest.raises(lib.PtmiError):
+        PTEngine(4, 2, 2, np.eye(4))
+    assert lib.device_count() == 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ptmcmcsampler_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("oracle/", "").lower() or f == "_lib.py" or "import oracle" not in src, f
+                assert "from oracle" not in src and "import oracle" not in src, f

@@ -1,0 +1,281 @@
+"""HIP path (through the C ABI) against the CPU oracle, same Philox seeds: bit-exact.
+
+Run on the GPU box: ``python -m pytest tests -m gpu``.  Nothing here reads /root/reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd import _lib
+    from ptmcmcsampler_amd.engine import PTEngine
+    _lib.load()
+    assert _lib.device_count() >= 1, "no MI355X visible"
+    return orc, _lib, PTEngine
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_same(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    if a.dtype.kind == "f":
+        bad = _bits(a) != _bits(b)
+        # all NaNs are one value for this purpose
+        bad &= ~(np.isnan(a) & np.isnan(b))
+        assert not bad.any(), "%s: %d of %d differ, first at %s: %r vs %r" % (
+            what, bad.sum(), bad.size, np.argwhere(bad)[0], a[tuple(np.argwhere(bad)[0])], b[tuple(np.argwhere(bad)[0])])
+    else:
+        assert np.array_equal(a.astype(np.int64), b.astype(np.int64)), what
+
+
+def test_device_math_is_bit_identical_to_oracle(mods):
+    orc, _lib, _ = mods
+    L, O = _lib.load(), orc.lib()
+    rs = np.random.RandomState(3)
+
+    def dev(op, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = x if y is None else np.ascontiguousarray(y, dtype=np.float64)
+        out = np.empty_like(x)
+        _lib.check(L.ptmi_selftest_math(0, op, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
+        return out
+
+    xs = np.concatenate([rs.rand(20000), 2.0 ** rs.uniform(-1000, 1000, 5000), [0.0, 1.0, 2.0 ** -53, np.inf, 5e-324, 3e-310]])
+    assert_same(dev(0, xs), [O.orc_log(float(v)) for v in xs], "log")
+    es = np.concatenate([rs.uniform(-750, 710, 20000), rs.uniform(-3, 3, 5000), [0.0, -745.2, 709.9, -np.inf, np.inf, np.nan]])
+    assert_same(dev(1, es), [O.orc_exp(float(v)) for v in es], "exp")
+    us = np.concatenate([rs.rand(20000), [0.0, 0.25, 0.5, 0.75, 1 - 2.0 ** -53]])
+    assert_same(dev(2, us), [O.orc_cos2pi(float(v)) for v in us], "cos2pi")
+    ps = np.concatenate([rs.rand(10000) * 1e3, 2.0 ** rs.uniform(-1000, 1000, 5000)])
+    assert_same(dev(3, ps), np.sqrt(ps), "sqrt is correctly rounded")
+    a, b = rs.randn(20000) * 10 ** rs.uniform(-5, 5, 20000), rs.randn(20000) * 10 ** rs.uniform(-5, 5, 20000)
+    assert_same(dev(4, a, b), a / b, "division is correctly rounded")
+    w = rs.randint(0, 2 ** 62, size=(5000, 2)).astype(np.uint64) * np.uint64(4) + np.uint64(3)
+    got = dev(5, w[:, 0].view(np.float64), w[:, 1].view(np.float64))
+    assert_same(got, [O.orc_normal(int(p), int(q)) for p, q in w], "normal")
+    # the 16-lane butterfly: every lane of a row gets the oracle's tree sum
+    v = rs.randn(64 * 8)
+    got = dev(6, v)
+    for r in range(len(v) // 16):
+        p = v[r * 16:(r + 1) * 16].copy()
+        m = 8
+        while m >= 1:
+            p = p + p[np.arange(16) ^ m]
+            m >>= 1
+        assert_same(got[r * 16:(r + 1) * 16], p, "group_sum")
+
+
+def test_device_philox_matches_oracle(mods):
+    orc, _lib, _ = mods
+    L = _lib.load()
+    rs = np.random.RandomState(4)
+    ck = rs.randint(0, 2 ** 32, size=(4096, 6), dtype=np.uint64).astype(np.uint32)
+    ck[0] = 0
+    ck[1] = 0xFFFFFFFF
+    out = np.zeros((len(ck), 4), dtype=np.uint32)
+    _lib.check(L.ptmi_selftest_philox(0, ck.ctypes.data, out.ctypes.data, len(ck)))
+    for i in range(0, len(ck), 37):
+        assert list(out[i]) == orc.philox([int(v) for v in ck[i, :4]], [int(ck[i, 4]), int(ck[i, 5])])
+    assert list(out[0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+
+
+def _pair(mods, d, nt, W, **kw):
+    orc, _lib, PTEngine = mods
+    rs = np.random.RandomState(kw.pop("rs", 0))
+    cov0 = kw.pop("cov0", None)
+    if cov0 is None:
+        A = rs.randn(d, d)
+        cov0 = (A @ A.T / d + 0.5 * np.eye(d)) * 0.01
+    p0 = kw.pop("p0", None)
+    if p0 is None:
+        p0 = rs.randn(W, nt, d) * 0.3
+    g = PTEngine(d, nt, W, cov0, **kw)
+    okw = {k: v for k, v in kw.items() if k not in ("split", "use_de_buffer")}
+    o = orc.OracleEngine(d, nt, W, cov0, **okw)
+    assert o.lanes == _lib.lanes_for(d)
+    g.init_state(p0)
+    o.init_state(p0)
+    return g, o
+
+
+def _compare(g, o, what=""):
+    g.sync()
+    for name in ("X", "lnL", "lp", "temp_of", "slot_of", "nacc", "jstat"):
+        assert_same(g.get(name), getattr(o, name), what + name)
+    assert_same(g.get("nswap"), o.nswap, what + "nswap")
+    if g.owns_cold:
+        assert_same(g.get("AM"), o.AM, what + "AM")
+
+
+def test_initial_evaluation(mods):
+    for d, logl in ((100, ("iso",)), (20, ("iso",)), (1000, ("iso",)), (6, ("curved",))):
+        g, o = _pair(mods, d, 3, 5, logl=logl, tskip=0)
+        _compare(g, o, "init d=%d " % d)
+
+
+def test_scam_iso_fused_steps_bit_exact(mods):
+    """The bench slice: SCAM + iso-Gaussian + accept, K fused steps (config 2 shape, small batch)."""
+    g, o = _pair(mods, 100, 8, 16, weights=(20, 0, 0), tskip=0, cov_update=64, seed=1234)
+    g.mh_steps(1, 40)
+    o.run(40)
+    _compare(g, o, "scam ")
+    assert o.nacc.sum() > 0 and o.jstat[..., 0, 0].sum() == 8 * 16 * 40
+
+
+@pytest.mark.parametrize("d,nt,W", [(5, 4, 6), (20, 3, 7), (100, 4, 5), (300, 2, 3), (1000, 2, 2)])
+def test_full_cycle_with_adaptation_and_swaps(mods, d, nt, W):
+    """SCAM+AM+DE, covariance epochs, DE epochs and activation, PT swaps: every array bit-exact."""
+    n = 330 if d <= 100 else 130
+    g, o = _pair(mods, d, nt, W, weights=(20, 20, 20), cov_update=50, burn=100, tskip=10, seed=77, rs=d)
+    g.run(n)
+    o.run(n)
+    _compare(g, o, "full d=%d " % d)
+    assert_same(g.get("mu"), o.mu, "mu")
+    assert_same(g.get("M2"), o.M2, "M2")
+    assert_same(g.get("cov"), o.cov, "cov")
+    assert_same(g.get("Ut"), o.Ut, "Ut")
+    assert g.swap_proposed == o.swap_proposed and o.nswap.sum() > 0
+    if n > 200:
+        assert o.jstat[..., 2, 0].sum() > 0     # DE was proposed after burn
+
+
+def test_dense_gaussian_box_prior_hot_chain(mods):
+    d = 8
+    rs = np.random.RandomState(5)
+    mu = rs.uniform(0, 10, d)
+    A = rs.randn(d, d)
+    P = np.linalg.inv(A @ A.T + np.eye(d))
+    g, o = _pair(mods, d, 3, 6, logl=("dense", mu, P), logp=("box", np.zeros(d), 10 * np.ones(d)),
+                 p0=rs.uniform(0, 10, (6, 3, d)), cov0=np.eye(d) * 0.5, weights=(20, 20, 20), cov_update=40,
+                 burn=80, tskip=8, hot_chain=True, seed=5)
+    g.run(250)
+    o.run(250)
+    _compare(g, o, "dense ")
+    assert (o.jstat[..., 0].sum(-1) > o.jstat[..., 1].sum(-1)).all()      # prior rejections happened
+
+
+def test_dense_d100(mods):
+    d = 100
+    rs = np.random.RandomState(0)
+    A = rs.standard_normal((d, d))
+    P = np.linalg.inv(A @ A.T / d + np.eye(d))
+    g, o = _pair(mods, d, 4, 3, logl=("dense", np.zeros(d), P), cov0=np.eye(d) * 0.01, weights=(20, 20, 0),
+                 cov_update=30, burn=1000, tskip=10, seed=9)
+    g.run(70)
+    o.run(70)
+    _compare(g, o, "dense100 ")
+
+
+def test_curved_likelihood(mods):
+    g, o = _pair(mods, 20, 4, 5, logl=("curved",), logp=("box", -10 * np.ones(20), 10 * np.ones(20)),
+                 cov0=np.eye(20), weights=(10, 0, 10), cov_update=50, burn=100, tskip=10, seed=3)
+    g.run(260)
+    o.run(260)
+    _compare(g, o, "curved ")
+
+
+def test_pooled_covariance_mode(mods):
+    g, o = _pair(mods, 12, 3, 9, cov_mode="pooled", weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=21)
+    g.run(250)
+    o.run(250)
+    _compare(g, o, "pooled ")
+    assert_same(g.get("cov"), o.cov, "pooled cov")
+    assert_same(g.get("Ut"), o.Ut, "pooled Ut")
+
+
+def test_welford_kernel_against_reference_fixture(mods, golden):
+    """_updateRecursive (PTMCMCSampler.py:769-794): the device kernel reproduces the reference's mu, M2, cov bit for bit."""
+    orc, _lib, PTEngine = mods
+    gld = golden("welford")
+    for d in (5, 100):
+        mem = gld["am_d%d_e0" % d].shape[0]
+        g = PTEngine(d, 1, 2, np.eye(d), weights=(1, 0, 0), cov_update=mem, burn=mem, tskip=0)
+        for ep in range(3):
+            tag = "d%d_e%d" % (d, ep)
+            am = gld["am_" + tag]
+            g.put("AM", np.stack([am, am[::-1]]))        # walker 1 sees the rows reversed: must differ
+            _lib.check(g.lib.ptmi_update_cov(g.h, (ep + 1) * mem))
+            assert_same(g.get("mu")[0], gld["mu_" + tag], "mu")
+            assert_same(g.get("M2")[0], gld["M2_" + tag], "M2")
+            assert_same(g.get("cov")[0], gld["cov_" + tag], "cov")
+        assert not np.array_equal(g.get("M2")[1], g.get("M2")[0])
+
+
+def test_de_ring_against_reference_fixture(mods, golden):
+    """_updateDEbuffer (PTMCMCSampler.py:806-817) as a ring: logical row r == reference row r."""
+    orc, _lib, PTEngine = mods
+    gld = golden("debuffer")
+    d, mem, burn = [int(v) for v in gld["shape"]]
+    g = PTEngine(d, 1, 1, np.eye(d), weights=(1, 0, 1), cov_update=mem, burn=burn, tskip=0)
+    head = 0
+    for ep in range(5):
+        g.put("AM", gld["am_%d" % ep][None])
+        g.update_de()
+        head = (head + mem) % burn
+        ring = g.get("DE")[0]
+        logical = np.roll(ring, -head, axis=0)
+        assert_same(logical, gld["de_%d" % ep], "DE epoch %d" % ep)
+
+
+def test_split_path_equals_fused(mods):
+    """propose -> (host evaluates logl/logp) -> accept gives the fused kernel's result."""
+    orc, _lib, PTEngine = mods
+    import torch
+    d, nt, W = 10, 3, 4
+    g, o = _pair(mods, d, nt, W, weights=(20, 20, 0), cov_update=500, burn=1000, tskip=0, seed=8, split=True)
+    for it in range(1, 31):
+        _lib.check(g.lib.ptmi_propose(g.h, it))
+        Q = g.t["Q"]
+        newl = (-0.5 * (Q * Q).sum(-1))
+        # the host's summation order differs in the last bits; take the oracle's value so decisions match
+        qn = Q.cpu().numpy()
+        newl = torch.from_numpy(np.array([[orc.lib().orc_logl(C.byref(o.cfg), qn[w, s].ctypes.data_as(orc._dp))
+                                           for s in range(nt)] for w in range(W)])).to(g.device)
+        newp = torch.zeros_like(newl)
+        _lib.check(g.lib.ptmi_accept(g.h, it, newl.data_ptr(), newp.data_ptr()))
+    o.run(30)
+    _compare(g, o, "split ")
+
+
+def test_full_size_properties_and_subset_parity(mods):
+    """BASELINE config 2 shape (64 temps x 4096 walkers x 100-d): invariants on the whole batch and
+    bit parity on a few walkers (walkers are independent and the RNG is keyed by global walker id)."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    cov0 = np.eye(d) * 0.01
+    g = PTEngine(d, nt, W, cov0, weights=(20, 0, 0), cov_update=1000, burn=10000, tskip=100, seed=1234,
+                 cov_mode="pooled", use_de_buffer=False)
+    g.init_state(np.zeros(d))
+    n = 200
+    g.run(n)
+    g.sync()
+    so, to = g.get("slot_of"), g.get("temp_of")
+    assert (np.sort(so, axis=1) == np.arange(nt)).all()                       # tables stay permutations
+    assert (np.take_along_axis(to, so.astype(np.int64), 1) == np.arange(nt)).all()
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., 0].sum(-1) == n).all()                                     # every chain proposed n times
+    assert (js[..., 1].sum(-1) == g.get("nacc").astype(np.int64)).all()
+    X, lnL = g.get("X"), g.get("lnL")
+    assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12)
+    acc = g.get("nacc").astype(float).mean(0) / n
+    assert 0.05 < acc.min() and acc.max() < 0.99
+    assert g.get("nswap").sum() > 0
+    # idempotence: re-evaluating the state changes nothing
+    _lib.check(g.lib.ptmi_eval_state(g.h))
+    assert_same(g.get("lnL"), lnL, "eval_state idempotent")
+    for w0 in (0, 1777, 4095):
+        o = orc.OracleEngine(d, nt, 1, cov0, weights=(20, 0, 0), cov_update=1000, burn=10000, tskip=100, seed=1234,
+                             cov_mode="pooled", walker0=w0)
+        o.init_state(np.zeros(d))
+        o.run(n)
+        assert_same(X[w0], o.X[0], "walker %d X" % w0)
+        assert_same(so[w0], o.slot_of[0], "walker %d slot_of" % w0)
+        assert_same(g.get("nswap")[w0], o.nswap[0], "walker %d nswap" % w0)
