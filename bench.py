@@ -35,16 +35,44 @@ def parse():
     ap.add_argument("--logl", default="iso", choices=["iso", "dense"])
     ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=4000)
+    ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations per host core of the CPU baseline (about 6 s)")
     ap.add_argument("--ess-walkers", type=int, default=32)
     return ap.parse_args()
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
+def cpu_baseline(a, weights):
+    """Timed in a fresh interpreter BEFORE this process touches the GPU (no fork after HIP init)."""
+    import subprocess
+    code = ("import json,sys; sys.path.insert(0, %r); from oracle import numpy_port as p; "
+            "v,c,w = p.time_baseline(ndim=%d, niter=%d, covUpdate=1000, burn=10000, weights=%r); "
+            "print(json.dumps([v,c,w]))" % (ROOT, a.ndim, a.cpu_iters, tuple(weights)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")   # one core per chain
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline failed: " + r.stderr[-500:])
+    v, cores, what = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": v, "unit": "updates/s", "cores": cores, "kind": "port",
+            "sample": "reference-equivalent NumPy port (oracle/numpy_port.py), " + what}
+
+
 def main():
     a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    weights = (20, 0, 0) if a.mix == "scam" else (20, 20, 20)
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a, weights)
+        log("cpu baseline %.3g updates/s on %d cores" % (cpu["value"], cpu["cores"]))
     import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
@@ -57,7 +85,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     d, nt, W = a.ndim, a.ntemps, a.nwalkers
-    weights = (20, 0, 0) if a.mix == "scam" else (20, 20, 20)
     logl = ("iso",)
     if a.logl == "dense":
         A = np.random.default_rng(0).standard_normal((d, d))
@@ -71,6 +98,7 @@ def main():
         from ptmcmcsampler_amd.sharded import ShardedPTEngine
         eng = ShardedPTEngine(d, nt * world, W, np.eye(d) * 0.01, group=dist.group.WORLD, **kw)
     eng.init_state(np.zeros(d))
+    log("engine ready")
 
     def fence():
         torch.cuda.synchronize()
@@ -80,6 +108,7 @@ def main():
 
     eng.run(a.warmup)
     fence()
+    log("warmup done")
     # timed region: exactly --steps iterations; each fused-MH launch is bracketed by HIP events on the
     # engine's stream (= torch's current stream, the one the kernels are launched on)
     events = []
@@ -112,6 +141,7 @@ def main():
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
+    log("timed region %.3f s" % wall)
 
     nchains_total = nt * world * W
     value = nchains_total * a.steps / wall
@@ -149,11 +179,8 @@ def main():
             out["ess_per_sec"] = float(np.mean(per_walker) / covered * a.steps * W / wall)
             out["ess_note"] = "Sokal-window ESS (min over dims) of the T=1 chain, mean over %d walkers x %d samples, scaled to %d walkers" % (
                 len(per_walker), covered, W)
-        if not a.no_cpu_baseline:
-            from oracle import numpy_port
-            v, cores, what = numpy_port.time_baseline(ndim=d, niter=a.cpu_iters, covUpdate=1000, burn=10000, weights=weights)
-            out["cpu_baseline"] = {"value": v, "unit": "updates/s", "cores": cores, "kind": "port",
-                                   "sample": "reference-equivalent NumPy port (oracle/numpy_port.py), " + what}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
             # the C oracle on one core, for scale (a compiled scalar port; not what a reference user gets)
             from oracle import oracle as orc
             o = orc.OracleEngine(d, 8, 8, np.eye(d) * 0.01, weights=weights, cov_update=1000, burn=10000, tskip=100,

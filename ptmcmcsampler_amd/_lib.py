@@ -56,6 +56,14 @@ def load():
     if not os.path.exists(SO):
         raise PtmiError("libptmi.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "or `python -m ptmcmcsampler_amd._build`; there is no CPU fallback." % SO)
+    # torch bundles its own libamdhip64 (same soname as /opt/rocm's): it must be the first HIP
+    # runtime in the process, otherwise two copies get loaded and torch loses the GPU
+    try:
+        import torch  # noqa: F401
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = C.CDLL(SO)
     H = C.c_void_p
     L.ptmi_last_error.restype = C.c_char_p

@@ -266,7 +266,7 @@ def test_full_size_properties_and_subset_parity(mods):
     X, lnL = g.get("X"), g.get("lnL")
     assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12)
     acc = g.get("nacc").astype(float).mean(0) / n
-    assert 0.05 < acc.min() and acc.max() < 0.99
+    assert 0.5 < acc.min() and acc.max() <= 1.0 and acc[0] < acc[-1]        # small cov0: high, and hotter accepts more
     assert g.get("nswap").sum() > 0
     # idempotence: re-evaluating the state changes nothing
     _lib.check(g.lib.ptmi_eval_state(g.h))

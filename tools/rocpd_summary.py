@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd (.db) file: per-kernel duration statistics and, when the run
+collected counters, per-kernel PMC means.  Usage: rocpd_summary.py <results.db> [out.txt]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sys.argv[1]
+    c = sqlite3.connect(db)
+    out = []
+    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                     "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    out.append("# kernel-trace summary of %s" % db.split("/")[-1])
+    out.append("%-86s %7s %14s %14s %12s %12s %6s" % ("Name", "Calls", "TotalNs", "AvgNs", "MinNs", "MaxNs", "Pct"))
+    for n, k, t, a, mn, mx in rows:
+        out.append("%-86s %7d %14d %14.0f %12d %12d %6.2f" % (n[:86], k, t, a, mn, mx, 100.0 * t / tot))
+    try:
+        meta = c.execute("select name, max(grid_x), max(workgroup_x), max(lds_size), max(scratch_size), max(vgpr_count), "
+                         "max(accum_vgpr_count), max(sgpr_count) from kernels where name not like '%at::native%' group by name").fetchall()
+    except sqlite3.Error:
+        meta = []
+    if meta:
+        out.append("")
+        out.append("%-86s %10s %6s %8s %8s %6s %6s %6s" % ("Name", "grid_x", "wg_x", "lds", "scratch", "vgpr", "agpr", "sgpr"))
+        for m in meta:
+            out.append("%-86s %10s %6s %8s %8s %6s %6s %6s" % ((m[0][:86],) + tuple(m[1:])))
+    pm = []
+    try:
+        ccols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+        if ccols:
+            kcol = "kernel_name" if "kernel_name" in ccols else "name"
+            pm = c.execute("select %s, counter_name, avg(value), count(*) from counters_collection group by 1,2" % kcol).fetchall()
+    except sqlite3.Error as e:
+        out.append("# counters: %s" % e)
+    if pm:
+        out.append("")
+        out.append("%-86s %-24s %20s %8s" % ("Name", "Counter", "MeanPerDispatch", "N"))
+        for n, p, v, k in pm:
+            out.append("%-86s %-24s %20.1f %8d" % (n[:86], p, v, k))
+    text = "\n".join(out) + "\n"
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
