@@ -149,6 +149,10 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter);
  * append the AM buffer (pooled mode: row r comes from walker r mod W). */
 int ptmi_update_de(ptmi_handle h);
 
+/* Position of the logical row 0 inside the DE ring; a GPU that does not hold rank 0 receives
+ * the new rows from the one that does and then advances its ring by hand. */
+int ptmi_set_de_head(ptmi_handle h, int32_t head);
+
 /* Split path for host (Python) likelihood callbacks, one iteration per call:
  * propose writes Q and qaux for every chain; the caller evaluates logp/logl on Q;
  * accept applies the Hastings test with the caller's values (NaN-safe, -inf prior). */

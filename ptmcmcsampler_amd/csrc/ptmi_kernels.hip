@@ -983,6 +983,14 @@ int ptmi_update_de(ptmi_handle h)
     return PTMI_OK;
 }
 
+int ptmi_set_de_head(ptmi_handle h, int32_t head)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    if (head < 0 || head >= h->cfg.de_size) return fail(PTMI_EINVAL, "head %d outside the ring of %d rows", head, h->cfg.de_size);
+    h->de_head = head;
+    return PTMI_OK;
+}
+
 int ptmi_selftest_math(int device, int op, const double *in, const double *in2, double *out, int64_t n)
 {
     if (!in || !out || n < 0) return fail(PTMI_EINVAL, "bad argument");

@@ -170,6 +170,23 @@ class PTEngine(object):
         if self.owns_cold and self.t["DE"] is not None:
             _lib.check(self.lib.ptmi_update_de(self.h))
 
+    def set_de_active(self, on=True):
+        _lib.check(self.lib.ptmi_set_de_active(self.h, int(on)))
+        self.de_on = bool(on)
+
+    def set_de_head(self, head):
+        _lib.check(self.lib.ptmi_set_de_head(self.h, int(head)))
+
+    # pieces of the swap for a ladder sharded over GPUs (see sharded.py)
+    def gather_lnl(self, out):
+        _lib.check(self.lib.ptmi_swap_gather_lnl(self.h, out.data_ptr()))
+
+    def sweep(self, it, lnl_glob, map_out):
+        _lib.check(self.lib.ptmi_swap_sweep(self.h, it, lnl_glob.data_ptr(), map_out.data_ptr()))
+
+    def write_am(self, it):
+        _lib.check(self.lib.ptmi_swap_write_am(self.h, it))
+
     def _epochs(self, it):
         cu, burn = self.cov_update, self.burn
         if (it - 1) % cu == 0 and it - 1 != 0:
@@ -177,8 +194,7 @@ class PTEngine(object):
         if (it - 1) % burn == 0 and it - 1 != 0:
             self.update_de()                                          # :563-571
         if it - 1 == burn and self.weights[2] > 0 and self.t["DE"] is not None:
-            _lib.check(self.lib.ptmi_set_de_active(self.h, 1))        # :574-585
-            self.de_on = True
+            self.set_de_active(True)                                  # :574-585
 
     def _segment_end(self, it, last):
         """Last iteration of the launch that starts at ``it``: no epoch inside, swap only at its end."""

@@ -1,0 +1,200 @@
+"""Temperature-block sharding of one ladder over the GPUs of a node.
+
+Rank g of the process group owns the temperature ranks ``[g*nt, (g+1)*nt)`` of every
+walker (state ``[W][nt][d]`` on its GPU).  Chains only interact at
+
+* swap epochs (every Tskip, PTMCMCSampler/PTMCMCSampler.py:631-697): lnL is
+  all-gathered (``W * ntemps * 8`` bytes), every GPU runs the identical hot->cold sweep
+  (same Philox uniforms, same data -> same map), and only rows whose new position is in
+  another block travel, by one all-to-all over RCCL/xGMI;
+* covariance / DE epochs (:545-576): the GPU holding rank 0 adapts and broadcasts
+  ``cov, Ut, S`` and the new DE rows.
+
+The exchange below is written with torch tensor ops so it runs unchanged on CUDA tensors
+over RCCL ("nccl") and on CPU tensors over gloo (the CPU tests drive it with an
+oracle-backed stand-in for the per-GPU kernels).
+"""
+import numpy as np
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def plan_exchange(map_glob, slot_of, temp0, nt, rank, world):
+    """Who sends which row where, from the sweep's global map.
+
+    ``map_glob[w][j]`` = position whose state moves to position j (all ranks of the
+    ladder).  Returns a dict of tensors describing this rank's part; every index list is
+    in row-major (walker, position) order, which is what makes sender and receiver agree
+    without exchanging any metadata.
+    """
+    torch = _torch()
+    W, ntg = map_glob.shape
+    dev = map_glob.device
+    m = map_glob.long()
+    inv = torch.empty_like(m)
+    inv.scatter_(1, m, torch.arange(ntg, device=dev).expand(W, ntg))        # inv[w][map[w][j]] = j
+    src_pos = m[:, temp0:temp0 + nt]                                         # source of each local destination
+    dst_pos = inv[:, temp0:temp0 + nt]                                       # destination of each local source
+    src_rank = torch.div(src_pos, nt, rounding_mode="floor")
+    dst_rank = torch.div(dst_pos, nt, rounding_mode="floor")
+    so = slot_of.long()
+    # local moves: new_slot[w][j] = old slot of the local source
+    local_dst = src_rank == rank
+    new_slot = torch.zeros_like(so)
+    loc_src = (src_pos - temp0).clamp(0, nt - 1)
+    new_slot[local_dst] = torch.gather(so, 1, loc_src)[local_dst]
+    # rows that leave: ordered by (destination rank, walker, destination position)
+    leaving = dst_rank != rank
+    lw, lp_ = torch.nonzero(leaving, as_tuple=True)                          # row-major (w, local source position)
+    free_slots = so[lw, lp_]                                                 # k-th leaving row of a walker frees the k-th slot
+    arriving = ~local_dst
+    aw, aj = torch.nonzero(arriving, as_tuple=True)                          # row-major (w, local destination)
+    assert free_slots.numel() == aw.numel()
+    new_slot[aw, aj] = free_slots                                            # per walker the counts match, so the lists align
+    send_idx, send_counts, recv_w, recv_j, recv_counts = [], [], [], [], []
+    for q in range(world):
+        if q == rank:
+            send_counts.append(0)
+            recv_counts.append(0)
+            continue
+        sel = dst_rank[lw, lp_] == q
+        sw, sp, sd = lw[sel], lp_[sel], dst_pos[lw, lp_][sel]
+        order = torch.argsort(sw * ntg + sd)                                 # receiver's order: (walker, destination position)
+        send_idx.append(torch.stack([sw[order], so[sw, sp][order]], 1))
+        send_counts.append(int(sel.sum()))
+        rsel = src_rank[aw, aj] == q
+        recv_w.append(aw[rsel])
+        recv_j.append(aj[rsel])
+        recv_counts.append(int(rsel.sum()))
+    cat = lambda xs, width=None: (torch.cat(xs) if xs else torch.zeros((0,) if width is None else (0, width), dtype=torch.long, device=dev))  # noqa: E731
+    return dict(new_slot=new_slot, send_idx=cat(send_idx, 2), send_counts=send_counts,
+                recv_w=cat(recv_w), recv_j=cat(recv_j), recv_counts=recv_counts)
+
+
+class ShardedPTEngine(object):
+    """One ladder of ``ntemps_global`` ranks sharded over ``group``; same interface as PTEngine."""
+
+    def __init__(self, ndim, ntemps_global, nwalkers, cov0, group=None, local_factory=None, **kw):
+        torch = _torch()
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if ntemps_global % self.world:
+            raise ValueError("ntemps_global=%d is not a multiple of the %d ranks" % (ntemps_global, self.world))
+        self.ntg, self.nt = ntemps_global, ntemps_global // self.world
+        self.temp0 = self.rank * self.nt
+        self.d, self.W = ndim, nwalkers
+        if local_factory is None:
+            from .engine import PTEngine
+            local_factory = PTEngine
+        self.local = local_factory(ndim, self.nt, nwalkers, cov0, ntemps_global=ntemps_global, temp0=self.temp0, **kw)
+        L = self.local
+        self.t, self.owns_cold, self.device = L.t, L.owns_cold, L.device
+        self.cov_update, self.burn, self.tskip, self.weights = L.cov_update, L.burn, L.tskip, L.weights
+        self.stream = getattr(L, "stream", None)
+        self.iter, self.swap_proposed = 0, 0
+        self.de_head = 0
+        self._lnl_loc = torch.zeros((self.W, self.nt), dtype=torch.float64, device=self.device)
+        self._map = torch.zeros((self.W, self.ntg), dtype=torch.int32, device=self.device)
+        self.rows_moved = 0
+
+    # delegation
+    def get(self, name):
+        return self.local.get(name)
+
+    def init_state(self, p0):
+        p0 = np.asarray(p0, dtype=np.float64)
+        if p0.ndim == 3:                                                      # [W][ntemps_global][d] -> my block
+            p0 = p0[:, self.temp0:self.temp0 + self.nt]
+        self.local.init_state(p0)
+
+    def mh_steps(self, iter0, nsteps):
+        self.local.mh_steps(iter0, nsteps)
+
+    def sync(self):
+        self.local.sync()
+
+    # ---- swap epoch ----------------------------------------------------------------------
+    def swap(self, it):
+        torch, dist, L = _torch(), self.dist, self.local
+        W, nt, ntg, d = self.W, self.nt, self.ntg, self.d
+        L.gather_lnl(self._lnl_loc)
+        parts = torch.empty((self.world * W, nt), dtype=torch.float64, device=self.device)
+        dist.all_gather_into_tensor(parts, self._lnl_loc, group=self.group)
+        lnl_glob = parts.view(self.world, W, nt).permute(1, 0, 2).reshape(W, ntg).contiguous()
+        L.sweep(it, lnl_glob, self._map)                                      # identical on every rank
+        plan = plan_exchange(self._map, L.t["slot_of"], self.temp0, nt, self.rank, self.world)
+        X, lnL, lp = L.t["X"], L.t["lnL"], L.t["lp"]
+        si = plan["send_idx"]
+        send = torch.cat([X[si[:, 0], si[:, 1]], lnL[si[:, 0], si[:, 1]].unsqueeze(1), lp[si[:, 0], si[:, 1]].unsqueeze(1)], 1) \
+            if si.numel() else torch.zeros((0, d + 2), dtype=torch.float64, device=self.device)
+        nrecv = int(sum(plan["recv_counts"]))
+        recv = torch.empty((nrecv, d + 2), dtype=torch.float64, device=self.device)
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=plan["recv_counts"],
+                               input_split_sizes=plan["send_counts"], group=self.group)
+        new_slot = plan["new_slot"]
+        if nrecv:
+            rw, rj = plan["recv_w"], plan["recv_j"]
+            rs = new_slot[rw, rj]
+            X[rw, rs] = recv[:, :d]
+            lnL[rw, rs] = recv[:, d]
+            lp[rw, rs] = recv[:, d + 1]
+        L.t["slot_of"].copy_(new_slot.to(L.t["slot_of"].dtype))
+        pos = torch.arange(nt, device=self.device, dtype=L.t["temp_of"].dtype).expand(W, nt).contiguous()
+        L.t["temp_of"].scatter_(1, new_slot, pos)
+        L.write_am(it)
+        self.swap_proposed += 1
+        self.rows_moved += nrecv
+
+    # ---- covariance / DE epochs (PTMCMCSampler.py:545-576) ----------------------------------
+    def update_cov(self, it_done):
+        L = self.local
+        if self.owns_cold:
+            L.update_cov(it_done)
+        for name in ("cov", "Ut", "S"):
+            self.dist.broadcast(L.t[name], src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                group=self.group)
+
+    def update_de(self):
+        torch, L = _torch(), self.local
+        if L.t.get("DE") is None:
+            return
+        size, mem = self.burn, min(self.cov_update, self.burn)
+        idx = (self.de_head + torch.arange(mem, device=self.device)) % size
+        if self.owns_cold:
+            L.update_de()
+            rows = L.t["DE"][:, idx].contiguous()
+        else:
+            rows = torch.empty((L.t["DE"].shape[0], mem, self.d), dtype=torch.float64, device=self.device)
+        self.dist.broadcast(rows, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        if not self.owns_cold:
+            L.t["DE"][:, idx] = rows
+            L.set_de_head((self.de_head + mem) % size)
+        self.de_head = (self.de_head + mem) % size
+
+    def _epochs(self, it):
+        cu, burn = self.cov_update, self.burn
+        if (it - 1) % cu == 0 and it - 1 != 0:
+            self.update_cov(it - 1)
+        if (it - 1) % burn == 0 and it - 1 != 0:
+            self.update_de()
+        if it - 1 == burn and self.weights[2] > 0 and self.local.t.get("DE") is not None:
+            self.local.set_de_active(True)
+
+    def run(self, niter):
+        last = self.iter + niter
+        it = self.iter + 1
+        while it <= last:
+            self._epochs(it)
+            end = last
+            for per in (self.cov_update, self.burn) + ((self.tskip,) if self.tskip > 0 and self.ntg > 1 else ()):
+                end = min(end, ((it - 1) // per + 1) * per)
+            self.mh_steps(it, end - it + 1)
+            if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
+                self.swap(end)
+            it = end + 1
+        self.iter = last
+        self.local.iter = last
