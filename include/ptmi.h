@@ -61,6 +61,8 @@ typedef struct ptmi_config {
     int32_t temp0;           /* first global rank of this block */
     int32_t walker0;         /* first global walker index (RNG stream ids are global) */
     int32_t logl_kind, logp_kind;
+    int32_t w_host;          /* cycle entries served by host callbacks (custom / gradient jumps added with
+                              * addProposalToCycle before SCAM/AM, :988-1014); split path only, 0 for the fused kernel */
     int32_t w_scam, w_am, w_de;   /* proposal-cycle weights, PTMCMCSampler.py:261-264, 579-585 */
     int32_t de_size;         /* rows of a DE buffer (= burn, :221) */
     int32_t cov_update;      /* rows of an AM buffer (= covUpdate, :220) */
@@ -96,7 +98,10 @@ typedef struct ptmi_buffers {
     double *M2;         /* [W][d][d]   running sum of outer products (:147) */
     double *cov;        /* [Wc][d][d]  published covariance (:794) */
     double *Q;          /* [W][T][d]   proposals, split path only (optional) */
-    double *qaux;       /* [W][T][4]   split path: qxy, jump type, accept uniform, spare (optional) */
+    double *qaux;       /* [W][T][4]   split path: qxy, jump type (>= PTMI_J_NTYPES: host entry index + PTMI_J_NTYPES),
+                         *              accept uniform, log(accept uniform) (optional) */
+    double *AMaux;      /* [W][cov_update][2]  lnL and lp of the rank-0 chain beside each AM row: the
+                         *              _lnlike/_lnprob columns of updateChains (:331-335) (optional) */
 } ptmi_buffers;
 
 typedef struct ptmi_engine *ptmi_handle;
@@ -132,8 +137,9 @@ int ptmi_swap(ptmi_handle h, int64_t iter);
  *  1. lnL by local rank:  lnL_pos[w][t] = lnL[w][slot_of[w][t]]
  *  2. the sweep over the global ladder -> map[w][j] = position whose state moves to j
  *     (every GPU computes the identical map; credits go to nswap for local ranks only)
- *  3. rewrite of the local tables for positions whose source is local; sources on
- *     other GPUs are reported in `incoming` for the caller's exchange. */
+ *  3. the caller rewrites the tables and exchanges the rows that cross a block edge
+ *     (ptmcmcsampler_amd/sharded.py: plan_exchange + one all-to-all), then
+ *     ptmi_swap_write_am stores the AM row of the state that now sits at rank 0. */
 int ptmi_swap_gather_lnl(ptmi_handle h, double *lnL_pos_local /* dev [W][T] */);
 int ptmi_swap_sweep(ptmi_handle h, int64_t iter, const double *lnL_pos_global /* dev [W][ntemps_global] */,
                     int32_t *map /* dev [W][ntemps_global] */);

@@ -39,7 +39,7 @@ struct KArgs {
     double *X, *lnL, *lp;
     int32_t *temp_of, *slot_of;
     const double *Ut, *S, *DE;
-    double *AM;
+    double *AM, *AMaux;
     u64 *nacc, *jstat;
     // small device tables owned by the engine
     const double *temps_mh, *beta, *logl_par, *logp_par;
@@ -51,7 +51,7 @@ struct KArgs {
     long long iter0;
     int nsteps;
     int d, nt, W, ntg, temp0, walker0;
-    int w_scam, w_am, w_de, de_on, de_size, de_head;
+    int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
     int cov_update, tskip, per_walker, logp_kind;
 };
 
@@ -159,10 +159,16 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
     log_u = quad_bcastf<1>(lg);
     u_acc = w2uniform(B0);
 
-    const int L = a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
-    const int ind = (int)w2index(A0, (u64)L);
+    const int L = a.w_host + a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
+    const int pick = (int)w2index(A0, (u64)L);
+    const int ind = pick - a.w_host;
     int jt = ind < a.w_scam ? PTMI_J_SCAM : (ind < a.w_scam + a.w_am ? PTMI_J_AM : PTMI_J_DE);
     if (!FULL) jt = PTMI_J_SCAM;
+    if (FULL && ind < 0) {                      // a host-served cycle entry: hand the state back unchanged
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[e] = x[e];
+        return PTMI_J_NTYPES + pick;
+    }
     const double prob = w2uniform(A1);
 
     if (jt == PTMI_J_SCAM || jt == PTMI_J_AM) {
@@ -311,6 +317,11 @@ __global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
                     const int i = gl + G * e;
                     if (i < d) am[i] = x[e];
                 }
+                if (a.AMaux && gl == 0) {
+                    double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)(it % a.cov_update)) * 2;
+                    ax[0] = lnL;
+                    ax[1] = lp;
+                }
             }
         }
     }
@@ -415,6 +426,12 @@ __global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
             a.nacc[r] += 1;
             if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 1] += 1;
         }
+        a.qaux[ch * 4 + 2] = acc ? 1.0 : 0.0;   // decision, for the host's per-name jump statistics
+        if (am && a.AMaux) {
+            double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)(a.iter0 % a.cov_update)) * 2;
+            ax[0] = acc ? nlnL : a.lnL[ch];
+            ax[1] = acc ? nlp : a.lp[ch];
+        }
     }
 }
 
@@ -506,13 +523,19 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
 }
 
 // AM-buffer row of a swap iteration: the state that now sits at rank 0 (PT:624-627, 327-328)
-__global__ void am_write_kernel(const double *X, const int32_t *slot_of, double *AM, int W, int nt, int d, int cov_update,
-                                long long iter)
+__global__ void am_write_kernel(const double *X, const double *lnL, const double *lp, const int32_t *slot_of, double *AM,
+                                double *AMaux, int W, int nt, int d, int cov_update, long long iter)
 {
     const int w = (int)blockIdx.x;
-    const double *row = X + ((size_t)w * nt + slot_of[(size_t)w * nt]) * d;
+    const size_t r = (size_t)w * nt + slot_of[(size_t)w * nt];
+    const double *row = X + r * d;
     double *am = AM + ((size_t)w * cov_update + (size_t)(iter % cov_update)) * d;
     for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) am[i] = row[i];
+    if (AMaux && threadIdx.x == 0) {
+        double *ax = AMaux + ((size_t)w * cov_update + (size_t)(iter % cov_update)) * 2;
+        ax[0] = lnL[r];
+        ax[1] = lp[r];
+    }
 }
 
 // ------------------------------------------------------------------ Welford
@@ -695,13 +718,13 @@ static KArgs make_args(ptmi_engine *h)
     const ptmi_config &c = h->cfg;
     const ptmi_buffers &b = h->buf;
     a.X = b.X; a.lnL = b.lnL; a.lp = b.lp; a.temp_of = b.temp_of; a.slot_of = b.slot_of;
-    a.Ut = b.Ut; a.S = b.S; a.DE = b.DE; a.AM = c.temp0 == 0 ? b.AM : nullptr;
+    a.Ut = b.Ut; a.S = b.S; a.DE = b.DE; a.AM = c.temp0 == 0 ? b.AM : nullptr; a.AMaux = c.temp0 == 0 ? b.AMaux : nullptr;
     a.nacc = (u64 *)b.nacc; a.jstat = (u64 *)b.jstat;
     a.temps_mh = h->d_temps; a.beta = h->d_beta; a.logl_par = h->d_loglpar; a.logp_par = h->d_logppar;
     a.Q = b.Q; a.qaux = b.qaux;
     a.seed = c.seed;
     a.d = c.ndim; a.nt = c.ntemps; a.W = c.nwalkers; a.ntg = c.ntemps_global; a.temp0 = c.temp0; a.walker0 = c.walker0;
-    a.w_scam = c.w_scam; a.w_am = c.w_am; a.w_de = c.w_de; a.de_on = h->de_on; a.de_size = c.de_size; a.de_head = h->de_head;
+    a.w_host = c.w_host; a.w_scam = c.w_scam; a.w_am = c.w_am; a.w_de = c.w_de; a.de_on = h->de_on; a.de_size = c.de_size; a.de_head = h->de_head;
     a.cov_update = c.cov_update; a.tskip = c.tskip; a.per_walker = c.cov_per_walker; a.logp_kind = c.logp_kind;
     return a;
 }
@@ -777,8 +800,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (c.ndim < 1 || c.ntemps < 1 || c.nwalkers < 1) return fail(PTMI_EINVAL, "ndim/ntemps/nwalkers must be >= 1");
     if (c.ntemps_global < c.ntemps || c.temp0 < 0 || c.temp0 + c.ntemps > c.ntemps_global)
         return fail(PTMI_EINVAL, "temperature block [%d,%d) outside ladder of %d", c.temp0, c.temp0 + c.ntemps, c.ntemps_global);
-    if (c.w_scam < 0 || c.w_am < 0 || c.w_de < 0 || c.w_scam + c.w_am <= 0)
-        return fail(PTMI_EINVAL, "proposal weights: SCAM+AM must be positive before burn (PTMCMCSampler.py:267)");
+    if (c.w_host < 0 || c.w_scam < 0 || c.w_am < 0 || c.w_de < 0 || c.w_host + c.w_scam + c.w_am <= 0)
+        return fail(PTMI_EINVAL, "No jump proposals specified! (PTMCMCSampler.py:267)");
     if (c.cov_update < 1) return fail(PTMI_EINVAL, "cov_update must be >= 1");
     if (c.w_de > 0 && c.de_size < 2) return fail(PTMI_EINVAL, "de_size must be >= 2 when DE is used");
     if (c.logl_kind < 0 || c.logl_kind > PTMI_LOGL_CURVED || c.logp_kind < 0 || c.logp_kind > PTMI_LOGP_BOX)
@@ -865,6 +888,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     if (nsteps == 0) return PTMI_OK;
     KArgs a = make_args(h);
     a.iter0 = iter0; a.nsteps = nsteps;
+    if (h->cfg.w_host > 0) return fail(PTMI_EINVAL, "host-served jumps need the split path (ptmi_propose / ptmi_accept)");
     const bool full = h->cfg.w_am > 0 || (h->de_on && h->cfg.w_de > 0);
     if (!full && h->cfg.w_scam <= 0) return fail(PTMI_EINVAL, "empty proposal cycle");
     const int grid = chains_grid(h);
@@ -904,8 +928,9 @@ int ptmi_swap_write_am(ptmi_handle h, int64_t iter)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
     if (h->cfg.temp0 != 0 || !h->buf.AM) return PTMI_OK;
-    hipLaunchKernelGGL(am_write_kernel, dim3(h->cfg.nwalkers), dim3(64), 0, h->stream, h->buf.X, h->buf.slot_of, h->buf.AM,
-                       h->cfg.nwalkers, h->cfg.ntemps, h->cfg.ndim, h->cfg.cov_update, (long long)iter);
+    hipLaunchKernelGGL(am_write_kernel, dim3(h->cfg.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.X,
+                       (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)h->buf.slot_of, h->buf.AM,
+                       h->buf.AMaux, h->cfg.nwalkers, h->cfg.ntemps, h->cfg.ndim, h->cfg.cov_update, (long long)iter);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

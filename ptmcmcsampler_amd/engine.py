@@ -37,7 +37,8 @@ class PTEngine(object):
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
-                 ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None):
+                 ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
+                 w_host=0, keep_lnl=False):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -76,6 +77,7 @@ class PTEngine(object):
             mu=z((W, d)) if self.owns_cold else None, M2=z((W, d, d)) if self.owns_cold else None,
             cov=z((Wc, d, d)),
             Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
+            AMaux=z((W, self.cov_update, 2)) if (keep_lnl and self.owns_cold) else None,
         )
         cov0 = np.asarray(cov0, dtype=np.float64)
         self.t["cov"].copy_(torch.from_numpy(np.broadcast_to(cov0, (Wc, d, d)).copy()))
@@ -90,7 +92,7 @@ class PTEngine(object):
         self.stream = torch.cuda.current_stream(self.device)
         cfg = _lib.Config(
             ndim=d, ntemps=nt, nwalkers=W, ntemps_global=self.ntg, temp0=self.temp0, walker0=self.walker0,
-            logl_kind=_lib.LOGL[logl[0]], logp_kind=_lib.LOGP[logp[0]], w_scam=self.weights[0], w_am=self.weights[1],
+            logl_kind=_lib.LOGL[logl[0]], logp_kind=_lib.LOGP[logp[0]], w_host=int(w_host), w_scam=self.weights[0], w_am=self.weights[1],
             w_de=self.weights[2] if has_de else 0, de_size=self.burn, cov_update=self.cov_update, tskip=self.tskip,
             cov_per_walker=int(self.per_walker), device=device, seed=self.seed,
             stream=C.c_void_p(self.stream.cuda_stream),
@@ -151,9 +153,18 @@ class PTEngine(object):
         full = p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d))
         self.t["X"].copy_(torch.from_numpy(np.ascontiguousarray(full)))
         _lib.check(self.lib.ptmi_eval_state(self.h))                 # :479-487
-        if self.owns_cold:                                            # updateChains(p0, ..., i0=0), :491
+        self._store_initial()
+
+    def _store_initial(self):
+        """updateChains(p0, lnlike0, lnprob0, i0=0), :491: row 0 of the AM ring holds the start point."""
+        torch = _torch()
+        if self.owns_cold:
+            ar = torch.arange(self.W, device=self.device)
             idx = self.t["slot_of"][:, 0].long()
-            self.t["AM"][:, 0, :] = self.t["X"][torch.arange(self.W, device=self.device), idx]
+            self.t["AM"][:, 0, :] = self.t["X"][ar, idx]
+            if self.t["AMaux"] is not None:
+                self.t["AMaux"][:, 0, 0] = self.t["lnL"][ar, idx]
+                self.t["AMaux"][:, 0, 1] = self.t["lp"][ar, idx]
 
     # ------------------------------------------------------------------ epochs
     def update_cov(self, it_done):

@@ -1,0 +1,396 @@
+"""``PTSampler``: the reference's class surface on top of the MI355X engine.
+
+Same constructor, ``sample()`` keywords and defaults, ``addProposalToCycle()`` /
+``addAuxilaryJump()``, callback signatures, public attributes and output files as
+``PTMCMCSampler.PTSampler`` (PTMCMCSampler/PTMCMCSampler.py:40-1067), so a script written for
+the reference runs unchanged as ONE process driving one GPU.  Differences, all additive:
+
+* the reference runs one temperature per MPI rank; here one process owns every temperature
+  (``ntemps=``) of ``nwalkers=`` independent replicas, and user code sees ``nchain == 1``
+  semantics for its callbacks (``comm`` may be the size-1 dummy or ``None``);
+* ``logl`` may be a Python callable (evaluated on the host between the propose and accept
+  kernels, one launch pair per iteration) **or** a tuple naming a device likelihood --
+  ``("iso",)``, ``("dense", mu, P)``, ``("curved",)`` -- and ``logp`` a callable or
+  ``("flat",)`` / ``("box", lo, hi)``; with device likelihoods and no host-side jumps the
+  fused K-step kernel runs.
+
+Attributes ``_chain, _lnlike, _lnprob, naccepted, nswap_accepted, swapProposed, jumpDict, cov,
+U, S, ladder, temp`` describe walker 0's T = 1 chain, as rank 0's do in the reference.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import _lib
+from .ladder import temperature_ladder
+
+
+class _DummyComm(object):
+    """Size-1 communicator with the duck type of PTMCMCSampler/nompi4py.py:1-37."""
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 1
+
+    def barrier(self):
+        pass
+
+    def send(self, obj, dest=1, tag=55):
+        pass
+
+    def recv(self, source=1, tag=55):
+        pass
+
+    def scatter(self, sendobj, **kwargs):
+        return sendobj[0] if sendobj is not None else None
+
+    def bcast(self, obj, **kwargs):
+        return obj
+
+    def gather(self, sendobj, **kwargs):
+        return [sendobj]
+
+
+class _function_wrapper(object):
+    """Binds args/kwargs so that logl(x) is unary (PTMCMCSampler.py:1072-1086)."""
+
+    def __init__(self, f, args, kwargs):
+        self.f, self.args, self.kwargs = f, args, kwargs
+
+    def __call__(self, x):
+        return self.f(x, *self.args, **self.kwargs)
+
+
+class PTSampler(object):
+    def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
+                 logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
+                 nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1):
+        self.comm = comm if comm is not None else _DummyComm()
+        if self.comm.Get_size() != 1:
+            raise NotImplementedError(
+                "one process drives all temperatures here: run without mpirun and pass ntemps=%d" % self.comm.Get_size())
+        self.MPIrank, self.nchain = 0, int(ntemps) if ntemps else 1
+        self.nwalkers, self.device_index, self.cov_mode = int(nwalkers), device, cov_mode
+        self.keep_walkers = max(1, min(int(keep_walkers), self.nwalkers))
+        self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+        self.stream = np.random.default_rng(self.seed)      # for host-side custom jumps that want a generator
+        self.ndim = ndim
+        self.logl_spec = logl if isinstance(logl, tuple) else None
+        self.logp_spec = logp if isinstance(logp, tuple) else None
+        self.logl = None if self.logl_spec else _function_wrapper(logl, loglargs, loglkwargs)
+        self.logp = None if self.logp_spec else _function_wrapper(logp, logpargs, logpkwargs)
+        if (self.logl_spec is None) != (self.logp_spec is None):
+            raise ValueError("logl and logp must both be callables or both be device specifications")
+        self.logl_grad = self.logp_grad = None
+        if logl_grad is not None and logp_grad is not None:
+            self.logl_grad = _function_wrapper(logl_grad, loglargs, loglkwargs)
+            self.logp_grad = _function_wrapper(logp_grad, logpargs, logpkwargs)
+        self.outDir, self.verbose, self.resume = outDir, verbose, resume
+        if not os.path.exists(self.outDir):
+            try:
+                os.makedirs(self.outDir)
+            except OSError:
+                pass
+        self.groups = groups
+        if groups is None:
+            self.groups = [np.arange(0, self.ndim)]
+        elif len(groups) != 1 or len(groups[0]) != ndim or not np.array_equal(np.sort(groups[0]), np.arange(ndim)):
+            raise NotImplementedError("parameter groups (PTMCMCSampler.py:139-145) are not supported yet")
+        self.cov = cov                                       # kept by reference and updated in place (:134, :794)
+        self.U, self.S = [[]], [[]]
+        self.U[0], self.S[0], _ = np.linalg.svd(np.asarray(self.cov, dtype=np.float64))   # :145
+        self.M2 = np.zeros((ndim, ndim))
+        self.mu = np.zeros(ndim)
+        self.propCycle, self.jumpDict, self.aux = [], {}, []
+        self.engine = None
+
+    # ------------------------------------------------------------------ proposal cycle API
+    def addProposalToCycle(self, func, weight):
+        """PTMCMCSampler.py:988-1014: ``weight`` copies of ``func`` join the cycle; weight 0 is ignored."""
+        if weight == 0:
+            return
+        for _ in range(weight):
+            self.propCycle.append(func)
+        if func.__name__ not in self.jumpDict:
+            self.jumpDict[func.__name__] = [0, 0]
+            open(self.outDir + "/" + func.__name__ + "_jump.txt", "w").close()
+
+    def addAuxilaryJump(self, func):
+        """PTMCMCSampler.py:1017-1028."""
+        self.aux.append(func)
+
+    def randomizeProposalCycle(self):
+        """PTMCMCSampler.py:1031-1045 (the shuffled copy is dead state there too)."""
+        index = np.arange(len(self.propCycle))
+        self.stream.shuffle(index)
+        self.randomizedPropCycle = [self.propCycle[ind] for ind in index]
+
+    # the three built-in jumps exist as named cycle entries; their arithmetic runs on the device
+    def covarianceJumpProposalSCAM(self, x, iter, beta):
+        raise RuntimeError("built-in jump: evaluated inside the HIP kernels")
+
+    def covarianceJumpProposalAM(self, x, iter, beta):
+        raise RuntimeError("built-in jump: evaluated inside the HIP kernels")
+
+    def DEJump(self, x, iter, beta):
+        raise RuntimeError("built-in jump: evaluated inside the HIP kernels")
+
+    def _builtin(self, f):
+        for k, b in enumerate((self.covarianceJumpProposalSCAM, self.covarianceJumpProposalAM, self.DEJump)):
+            if f == b:
+                return k
+        return -1
+
+    def temperatureLadder(self, Tmin, Tmax=None, tstep=None):
+        return temperature_ladder(self.nchain, self.ndim, Tmin, Tmax, tstep)
+
+    # ------------------------------------------------------------------ initialize (:157-319)
+    def initialize(self, Niter, ladder=None, Tmin=1, Tmax=None, Tskip=100, isave=1000, covUpdate=1000, SCAMweight=30,
+                   AMweight=20, DEweight=50, NUTSweight=20, HMCweight=20, MALAweight=0, burn=50000, HMCstepsize=0.1,
+                   HMCsteps=300, maxIter=None, thin=10, i0=0, neff=None, writeHotChains=False, hotChain=False):
+        from .engine import PTEngine
+        if maxIter is None:
+            maxIter = Niter
+        self.ladder, self.covUpdate, self.burn, self.Tskip = ladder, covUpdate, burn, Tskip
+        self.SCAMweight, self.AMweight, self.DEweight = SCAMweight, AMweight, DEweight
+        self.thin, self.isave, self.Niter, self.neff, self.tstart = thin, isave, Niter, neff, 0
+        N = int(maxIter / thin) + 1
+        kw = self.keep_walkers
+        self._chains = np.zeros((kw, N, self.ndim))
+        self._lnlikes, self._lnprobs = np.zeros((kw, N)), np.zeros((kw, N))
+        self._chain, self._lnlike, self._lnprob = self._chains[0], self._lnlikes[0], self._lnprobs[0]
+        self.ind_next_write = 0
+        self.naccepted = self.swapProposed = self.nswap_accepted = 0
+        if self.logl_grad is not None and self.logp_grad is not None and (NUTSweight or HMCweight or MALAweight):
+            raise NotImplementedError("gradient jumps (nutsjump.py) are not built yet; pass NUTSweight=HMCweight=MALAweight=0")
+        self.addProposalToCycle(self.covarianceJumpProposalSCAM, self.SCAMweight)     # :261
+        self.addProposalToCycle(self.covarianceJumpProposalAM, self.AMweight)         # :264
+        if len(self.propCycle) == 0:
+            raise ValueError("No jump proposals specified!")
+        self.randomizeProposalCycle()
+        if self.ladder is None:
+            self.ladder = self.temperatureLadder(Tmin, Tmax=Tmax)
+        self.temp = self.ladder[0]
+        self.fname = self.outDir + "/chain_{0}.txt".format(self.temp)                # :285
+        self.writeHotChains, self.hotChain = writeHotChains, hotChain
+        self.resumeLength = 0
+        if self.resume:
+            raise NotImplementedError("resume (PTMCMCSampler.py:290-319) is not built yet")
+        open(self.fname, "w").close()
+        # ---- engine
+        self.host_jumps = [f for f in self.propCycle if self._builtin(f) < 0]
+        self.split = self.logl is not None or bool(self.host_jumps) or bool(self.aux)
+        if self.split and self.logl is None:
+            raise NotImplementedError("host-side jumps need Python logl/logp callbacks")
+        self.engine = PTEngine(
+            self.ndim, self.nchain, self.nwalkers, np.asarray(self.cov, dtype=np.float64), ladder=self.ladder,
+            logl=self.logl_spec or ("iso",), logp=self.logp_spec or ("flat",),
+            weights=(self.SCAMweight, self.AMweight, self.DEweight), cov_update=covUpdate, burn=burn, tskip=Tskip,
+            seed=self.seed, cov_mode=self.cov_mode, hot_chain=hotChain, device=self.device_index, split=self.split,
+            w_host=len(self.host_jumps), keep_lnl=True)
+
+    # ------------------------------------------------------------------ sample (:374-528)
+    def sample(self, p0, Niter, ladder=None, Tmin=1, Tmax=None, Tskip=100, isave=1000, covUpdate=1000, SCAMweight=20,
+               AMweight=20, DEweight=20, NUTSweight=20, MALAweight=20, HMCweight=20, burn=10000, HMCstepsize=0.1,
+               HMCsteps=300, maxIter=None, thin=10, i0=0, neff=None, writeHotChains=False, hotChain=False):
+        if maxIter is None:
+            maxIter = Niter
+        if isave % thin != 0:
+            raise ValueError("isave = %d is not a multiple of thin =  %d" % (isave, thin))
+        if Niter % thin != 0:
+            print("Niter = %d is not a multiple of thin = %d.  The last %d samples will be lost" % (Niter, thin, Niter % thin))
+        if self.logl_grad is None:
+            NUTSweight = MALAweight = HMCweight = 0
+        if i0 == 0:
+            self.initialize(Niter, ladder=ladder, Tmin=Tmin, Tmax=Tmax, Tskip=Tskip, isave=isave, covUpdate=covUpdate,
+                            SCAMweight=SCAMweight, AMweight=AMweight, DEweight=DEweight, NUTSweight=NUTSweight,
+                            MALAweight=MALAweight, HMCweight=HMCweight, burn=burn, HMCstepsize=HMCstepsize,
+                            HMCsteps=HMCsteps, maxIter=maxIter, thin=thin, i0=i0, neff=neff,
+                            writeHotChains=writeHotChains, hotChain=hotChain)
+        eng = self.engine
+        p0 = np.asarray(p0, dtype=np.float64)
+        if self.split:
+            self._init_split(p0)
+        else:
+            eng.init_state(p0)
+        self.tstart = time.time()
+        self._harvest([i0])
+        if i0 % self.isave == 0:
+            self.writeOutput(i0)
+        it = i0 + 1
+        message = "\nRun Complete"
+        while it <= self.Niter:
+            before = eng.eig_epochs
+            eng._epochs(it)
+            if eng.eig_epochs != before:
+                self._mirror_cov()
+            if (it - 1) == self.burn and self.DEweight and self.DEJump not in self.propCycle:     # :579-585
+                if self.verbose:
+                    print("Adding DE jump with weight {0}".format(self.DEweight))
+                self.addProposalToCycle(self.DEJump, self.DEweight)
+                self.randomizeProposalCycle()
+            if self.split:
+                end = it
+                self._split_step(it)
+            else:
+                end = min(eng._segment_end(it, self.Niter), ((it - 1) // self.isave + 1) * self.isave)
+                eng.mh_steps(it, end - it + 1)
+            if self.Tskip > 0 and self.nchain > 1 and end % self.Tskip == 0:
+                eng.swap(end)
+            self._harvest([i for i in range(it, end + 1) if i % self.thin == 0])
+            if end % self.isave == 0:
+                self.writeOutput(end)
+            if self.neff and end % 1000 == 0 and end > 2 * self.burn:                               # :510-521
+                from .ess import integrated_time
+                lo = self.burn // self.thin
+                tau = max(1.0, np.nanmax([integrated_time(self._chain[lo:end // self.thin, ii]) for ii in range(self.ndim)]))
+                Neff = (end - self.burn) / self.thin / tau
+                if int(Neff) >= self.neff:
+                    message = "\nRun Complete with {0} effective samples".format(int(Neff))
+                    self.Niter = end
+            it = end + 1
+        eng.iter = self.Niter
+        self.writeOutput(self.Niter)
+        if self.verbose:
+            print(message)
+
+    # ------------------------------------------------------------------ bookkeeping
+    def _mirror_cov(self):
+        cov = self.engine.get("cov")[0]
+        self.cov[:, :] = cov                                      # :794, in place
+        self.U[0], self.S[0] = self.engine.get("Ut")[0].T.copy(), self.engine.get("S")[0].copy()
+        self.M2, self.mu = self.engine.get("M2")[0], self.engine.get("mu")[0]
+
+    def _counters(self):
+        eng = self.engine
+        self.naccepted = int(eng.get("nacc")[0, 0])
+        self.nswap_accepted = int(eng.get("nswap")[0, 0])
+        self.swapProposed = eng.swap_proposed
+        js = eng.get("jstat")[0, 0]
+        for k, f in enumerate((self.covarianceJumpProposalSCAM, self.covarianceJumpProposalAM, self.DEJump)):
+            if f.__name__ in self.jumpDict:
+                self.jumpDict[f.__name__] = [int(js[k, 0]), int(js[k, 1])]
+
+    def _harvest(self, iters):
+        """updateChains (:331-335) for the kept walkers, read back from the AM ring."""
+        if not iters:
+            return
+        eng, kw = self.engine, self.keep_walkers
+        rows = [i % eng.cov_update for i in iters]
+        X = eng.t["AM"][:kw][:, rows].cpu().numpy()
+        aux = eng.t["AMaux"][:kw][:, rows].cpu().numpy()
+        beta0 = 1.0 / eng.temps_mh[0]
+        for n, i in enumerate(iters):
+            ind = int(i / self.thin)
+            if ind >= self._chains.shape[1]:
+                continue
+            self._chains[:, ind] = X[:, n]
+            self._lnlikes[:, ind] = aux[:, n, 0]
+            self._lnprobs[:, ind] = beta0 * aux[:, n, 0] + aux[:, n, 1]
+
+    # ------------------------------------------------------------------ host-callback path
+    def _eval_host(self, Q):
+        """logp then logl of every proposal, with the reference's short-circuit (:605-611)."""
+        lp = np.empty(Q.shape[:2])
+        ll = np.zeros(Q.shape[:2])
+        for w in range(Q.shape[0]):
+            for s in range(Q.shape[1]):
+                v = self.logp(Q[w, s])
+                lp[w, s] = v
+                if v != float(-np.inf):
+                    ll[w, s] = self.logl(Q[w, s])
+        return ll, lp
+
+    def _init_split(self, p0):
+        import torch
+        eng = self.engine
+        full = p0 if p0.ndim == 3 else np.broadcast_to(p0, (eng.W, eng.nt, eng.d)).copy()
+        eng.t["X"].copy_(torch.from_numpy(np.ascontiguousarray(full)))
+        ll, lp = self._eval_host(full)
+        ll[lp == -np.inf] = -np.inf                               # :481-483
+        eng.put("lnL", ll)
+        eng.put("lp", lp)
+        eng._store_initial()
+
+    def _split_step(self, it):
+        import torch
+        eng = self.engine
+        _lib.check(eng.lib.ptmi_propose(eng.h, it))
+        Q, qa = eng.t["Q"].cpu().numpy(), eng.t["qaux"].cpu().numpy()
+        temp_of = eng.get("temp_of")
+        dirty = False
+        if self.host_jumps or self.aux:
+            X = eng.get("X")
+            for w in range(eng.W):
+                for s in range(eng.nt):
+                    beta = 1.0 / eng.temps_mh[temp_of[w, s]]
+                    jt = int(qa[w, s, 1])
+                    if jt >= _lib.J_NTYPES:                        # a cycle entry served on the host (:1059)
+                        q, qxy = self.host_jumps[jt - _lib.J_NTYPES](X[w, s], it, beta)
+                        Q[w, s], qa[w, s, 0] = q, qxy
+                        dirty = True
+                    for aux in self.aux:                           # :1062-1065
+                        q, qxy_aux = aux(X[w, s], Q[w, s], it, beta)
+                        Q[w, s] = q
+                        qa[w, s, 0] += qxy_aux
+                        dirty = True
+        if dirty:
+            eng.t["Q"].copy_(torch.from_numpy(Q))
+            eng.t["qaux"].copy_(torch.from_numpy(qa))
+        ll, lp = self._eval_host(Q)
+        nl = torch.from_numpy(ll).to(eng.device)
+        npr = torch.from_numpy(lp).to(eng.device)
+        _lib.check(eng.lib.ptmi_accept(eng.h, it, nl.data_ptr(), npr.data_ptr()))
+        if self.host_jumps:
+            dec = eng.t["qaux"][0].cpu().numpy()
+            s0 = int(eng.get("slot_of")[0, 0])
+            jt = int(qa[0, s0, 1])
+            if jt >= _lib.J_NTYPES:
+                name = self.host_jumps[jt - _lib.J_NTYPES].__name__
+                self.jumpDict[name][0] += 1
+                self.jumpDict[name][1] += int(dec[s0, 2] > 0.5)
+
+    # ------------------------------------------------------------------ output files (:341-372, :722-766)
+    def writeOutput(self, iter):
+        if iter // self.thin >= self.ind_next_write:
+            self._counters()
+            self._writeToFile(iter)
+            if iter > 0:
+                np.save(self.outDir + "/cov.npy", self.cov)
+            if self.verbose:
+                if iter > 0:
+                    sys.stdout.write("\r")
+                percent = iter / self.Niter * 100
+                acceptance = self.naccepted / iter if iter > 0 else 0
+                elapsed = time.time() - self.tstart
+                sys.stdout.write("Finished %2.2f percent in %f s Acceptance rate = %g" % (percent, elapsed, acceptance))
+                sys.stdout.flush()
+
+    def _writeToFile(self, iter):
+        write_end = iter // self.thin + 1
+        for k in range(self.keep_walkers):
+            fname = self.fname if k == 0 else self.fname[:-4] + "_w%d.txt" % k
+            with open(fname, "a+") as fh:
+                for ind in range(self.ind_next_write, write_end):
+                    pt_acc = 1
+                    if self.nchain > 1 and self.swapProposed != 0:
+                        pt_acc = self.nswap_accepted / self.swapProposed
+                    fh.write("\t".join(["%22.22f" % (self._chains[k, ind, kk]) for kk in range(self.ndim)]))
+                    fh.write("\t%f\t%f\t%f\t%f\n" % (self._lnprobs[k, ind], self._lnlikes[k, ind],
+                                                     self.naccepted / iter if iter > 0 else 0, pt_acc))
+        self.ind_next_write = write_end
+        with open(self.outDir + "/jumps.txt", "w") as fout:
+            njumps = len(self.propCycle)
+            seen = []
+            for jump in self.propCycle:
+                if jump not in seen:
+                    seen.append(jump)
+            for jump in seen:
+                fout.write("%s %4.2g\n" % (jump.__name__, sum(1 for f in self.propCycle if f == jump) / njumps))
+        for jump in self.jumpDict:
+            with open(self.outDir + "/" + jump + "_jump.txt", "a+") as fout:
+                fout.write("%g\n" % (self.jumpDict[jump][1] / max(1, self.jumpDict[jump][0])))

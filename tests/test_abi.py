@@ -32,9 +32,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_layouts_match_the_header(lib):
     import ctypes as C
-    # 16 int32 + u64 + ptr + 2 ptr + (ptr, i64) x 2
-    assert C.sizeof(lib.Config) == 16 * 4 + 8 + 8 + 2 * 8 + 4 * 8
-    assert C.sizeof(lib.Buffers) == 17 * 8
+    assert C.sizeof(lib.Config) == 17 * 4 + 4 + 8 + 8 + 2 * 8 + 4 * 8      # 17 int32 + pad
+    assert C.sizeof(lib.Buffers) == 18 * 8
     assert [lib.lanes_for(d) for d in (2, 32, 33, 100, 256, 257, 2048)] == [lib.load().ptmi_lanes_for(d) for d in (2, 32, 33, 100, 256, 257, 2048)]
 
 

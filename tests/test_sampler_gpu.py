@@ -1,0 +1,127 @@
+"""PTSampler facade on the GPU: the reference's script surface (tests/test_simple.py of the reference is
+the workload model), output files and statistics.  Trajectories are not comparable with the reference
+here (different RNG); the oracle tests pin those."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class GaussianLikelihood(object):
+    """The workload of the reference's tests/test_simple.py:14-41 (seeded here)."""
+
+    def __init__(self, ndim=2, pmin=-10, pmax=10, seed=0):
+        rs = np.random.RandomState(seed)
+        self.a = np.ones(ndim) * pmin
+        self.b = np.ones(ndim) * pmax
+        self.mu = rs.uniform(pmin, pmax, ndim)
+        cov = 0.5 - rs.rand(ndim ** 2).reshape((ndim, ndim))
+        cov = np.triu(cov)
+        cov += cov.T - np.diag(cov.diagonal())
+        self.cov = np.dot(cov, cov)
+        self.icov = np.linalg.inv(self.cov)
+
+    def lnlikefn(self, x):
+        diff = x - self.mu
+        return -np.dot(diff, np.dot(self.icov, diff)) / 2.0
+
+    def lnpriorfn(self, x):
+        if np.all(self.a <= x) and np.all(self.b >= x):
+            return 0.0
+        return -np.inf
+
+
+class UniformJump(object):
+    def __init__(self, pmin, pmax, seed=1):
+        self.pmin, self.pmax, self.rs = pmin, pmax, np.random.RandomState(seed)
+
+    def jump(self, x, it, beta):
+        return self.rs.uniform(self.pmin, self.pmax, len(x)), 0
+
+
+def test_reference_script_surface_with_python_callbacks(tmp_path):
+    """tests/test_simple.py of the reference, through the facade: Python logl/logp + a custom jump."""
+    from ptmcmcsampler_amd import PTSampler
+    ndim, pmin, pmax = 4, 0.0, 10.0
+    glo = GaussianLikelihood(ndim, pmin, pmax, seed=3)
+    p0 = np.random.RandomState(4).uniform(pmin, pmax, ndim)
+    cov = np.eye(ndim) * 0.1 ** 2
+    s = PTSampler(ndim, glo.lnlikefn, glo.lnpriorfn, np.copy(cov), outDir=str(tmp_path), verbose=False, seed=5)
+    s.addProposalToCycle(UniformJump(pmin, pmax).jump, 5)
+    s.sample(p0, 6000, burn=500, thin=1, covUpdate=500, SCAMweight=20, AMweight=20, DEweight=20)
+    assert s._chain.shape == (6001, ndim)
+    assert np.array_equal(s._chain[0], p0) and np.isclose(s._lnlike[0], glo.lnlikefn(p0))
+    assert set(s.jumpDict) == {"jump", "covarianceJumpProposalSCAM", "covarianceJumpProposalAM", "DEJump"}
+    assert sum(v[0] for v in s.jumpDict.values()) == 6000 and s.jumpDict["jump"][0] > 300
+    assert 0.05 < s.naccepted / 6000 < 0.9
+    # lnlike column is the callback's value of the stored sample
+    for i in (1, 777, 6000):
+        assert np.isclose(s._lnlike[i], glo.lnlikefn(s._chain[i]), rtol=1e-12)
+    # posterior of the T=1 chain ~ N(mu, cov) (the box is wide): loose statistical check after burn-in
+    x = s._chain[1500:]
+    sd = np.sqrt(np.diag(glo.cov))
+    assert np.all(np.abs(x.mean(0) - glo.mu) < 0.5 * sd + 0.05)
+    # files: chain_1.txt (single chain: integer ladder), cov.npy, jumps.txt, <name>_jump.txt
+    names = set(os.listdir(tmp_path))
+    assert {"chain_1.txt", "cov.npy", "jumps.txt", "jump_jump.txt", "DEJump_jump.txt"} <= names
+    rows = open(tmp_path / "chain_1.txt").read().splitlines()
+    assert len(rows) == 6001
+    cols = rows[0].split("\t")
+    assert len(cols) == ndim + 4 and all(re.fullmatch(r"-?\d+\.\d{22}", c) for c in cols[:ndim])
+    assert np.allclose([float(c) for c in cols[:ndim]], p0)
+    fr = dict(l.split() for l in open(tmp_path / "jumps.txt").read().splitlines())
+    assert abs(float(fr["jump"]) - 5 / 65) < 0.01 and abs(float(fr["DEJump"]) - 20 / 65) < 0.01
+    assert np.load(tmp_path / "cov.npy").shape == (ndim, ndim)
+    assert s.cov is not cov and not np.array_equal(s.cov, cov)        # adapted in place
+
+
+def test_first_chain_row_matches_reference_file_format(tmp_path, golden):
+    """Row 0 of chain_<T>.txt is p0, lnprob, lnlike, 0, 1 in the reference's formats (:741-745)."""
+    from ptmcmcsampler_amd import PTSampler
+    g = golden("traj_pt4_d6")
+    d = int(g["ndim"])
+    s = PTSampler(d, ("iso",), ("flat",), np.copy(g["cov0"]), outDir=str(tmp_path), verbose=False, seed=1, ntemps=4)
+    s.sample(g["p0"], 100, covUpdate=50, burn=100, thin=1, isave=50, Tskip=10)
+    assert str(g["chainfile_name"]) == "chain_1.0.txt" and os.path.exists(tmp_path / "chain_1.0.txt")
+    mine = open(tmp_path / "chain_1.0.txt").read().splitlines()
+    ref0 = str(g["chainfile_head"][0]).split("\t")
+    got0 = mine[0].split("\t")
+    assert got0[:d] == ref0[:d]                       # "%22.22f" of p0, character for character
+    assert got0[d:d + 2] == ref0[d:d + 2]             # lnprob, lnlike of p0 ("%f")
+    assert got0[d + 2:] == ref0[d + 2:] == ["0.000000", "1.000000"]
+    assert len(mine) == 101
+
+
+def test_fused_path_statistics_dense_gaussian(tmp_path):
+    """Device likelihood + fused kernel: 16 walkers x 4 temperatures on a 10-d dense Gaussian."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 10
+    rs = np.random.RandomState(2)
+    A = rs.randn(d, d)
+    C = A @ A.T / d + 0.3 * np.eye(d)
+    mu = rs.randn(d)
+    s = PTSampler(d, ("dense", mu, np.linalg.inv(C)), ("flat",), np.eye(d) * 0.01, outDir=str(tmp_path), verbose=False,
+                  seed=11, ntemps=4, nwalkers=16, keep_walkers=16)
+    s.sample(mu + 0.1, 20000, burn=2000, thin=10, covUpdate=1000, isave=1000, Tskip=100)
+    x = s._chains[:, 300:, :].reshape(-1, d)
+    assert x.shape[0] == 16 * 1701
+    se = np.sqrt(np.diag(C) / (x.shape[0] / 40.0))
+    assert np.all(np.abs(x.mean(0) - mu) < 5 * se)
+    emp = np.cov(x.T)
+    assert np.max(np.abs(emp - C)) / np.max(np.abs(C)) < 0.15
+    assert s.swapProposed == 200 and s.nswap_accepted > 0
+    assert os.path.exists(tmp_path / "chain_1.0.txt") and os.path.exists(tmp_path / "chain_1.0_w15.txt")
+    assert len(open(tmp_path / "chain_1.0.txt").read().splitlines()) == 2001
+
+
+def test_argument_errors(tmp_path):
+    from ptmcmcsampler_amd import PTSampler
+    s = PTSampler(3, ("iso",), ("flat",), np.eye(3), outDir=str(tmp_path), verbose=False)
+    with pytest.raises(ValueError, match="isave = 1000 is not a multiple of thin =  7"):
+        s.sample(np.zeros(3), 100, thin=7)
+    s2 = PTSampler(3, ("iso",), ("flat",), np.eye(3), outDir=str(tmp_path), verbose=False)
+    with pytest.raises(ValueError, match="No jump proposals specified!"):
+        s2.sample(np.zeros(3), 100, SCAMweight=0, AMweight=0, DEweight=0)
