@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--logl", default="iso", choices=["iso", "dense"])
     ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations per host core of the CPU baseline (about 6 s)")
+    ap.add_argument("--cpu-iters", type=int, default=10000, help="iterations per host core of the CPU baseline (10-30 s of CPU work)")
     ap.add_argument("--ess-walkers", type=int, default=32)
     return ap.parse_args()
 

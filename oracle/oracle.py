@@ -90,7 +90,7 @@ def _p(a, t=_dp):
 
 def lanes_for(ndim):
     """Lanes that share one chain in the HIP kernels (fixes the summation order)."""
-    return 4 if ndim <= 32 else (16 if ndim <= 256 else 64)
+    return 4 if ndim <= 104 else (16 if ndim <= 416 else 64)
 
 
 def philox(ctr, key):
@@ -216,7 +216,16 @@ class OracleEngine(object):
                      _p(self.jstat, _up))
 
     def _svd(self, w):
-        U, S, _ = np.linalg.svd(self.cov[w])               # PTMCMCSampler.py:145,803 (host LAPACK)
+        # LAPACK results depend on the BLAS thread count in the last bits; the product pins one thread
+        # for these small factorizations (engine._blas_single_thread) and the checker must do the same
+        try:
+            from threadpoolctl import threadpool_limits
+            ctx = threadpool_limits(limits=1)
+        except ImportError:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            U, S, _ = np.linalg.svd(self.cov[w])           # PTMCMCSampler.py:145,803 (host LAPACK)
         self.Ut[w] = np.ascontiguousarray(U.T)
         self.S[w] = S
 

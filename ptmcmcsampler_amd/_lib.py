@@ -106,4 +106,4 @@ def device_count():
 
 
 def lanes_for(ndim):
-    return 4 if ndim <= 32 else (16 if ndim <= 256 else 64)
+    return 4 if ndim <= 104 else (16 if ndim <= 416 else 64)

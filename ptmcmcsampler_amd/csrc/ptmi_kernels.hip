@@ -53,6 +53,7 @@ struct KArgs {
     int d, nt, W, ntg, temp0, walker0;
     int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
     int cov_update, tskip, per_walker, logp_kind;
+    int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
 };
 
 template <int G>
@@ -139,13 +140,53 @@ __device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EP
 }
 
 // ---------------------------------------------------------------- proposals
-// One proposal for the caller's chain (PT:1048-1067, 820-985).  Returns the jump type.
-// `lg` receives log(accept uniform) (computed in the same instruction stream as the
-// Box-Muller log, on a different lane of each quad).
+// Per-chain constants of the jump scales, hoisted out of the step loop.  Same operation
+// order as the reference: scale in {10, 0.2, 1.0}; scale *= sqrt(temp) if temp <= 100
+// (PT:846-862); cd = 2.4 / sqrt(2 neff) * scale (PT:870, 928).
+struct ChainConst {
+    double cd_scam[3], cd_am[3];   // by scale branch: prob > 0.97, prob > 0.9, else
+    double de_div, de_mul;         // DE: rr * 2.4 / de_div * de_mul  (PT:976)
+};
+__device__ __forceinline__ ChainConst chain_const(double temp, double beta, int d)
+{
+    ChainConst c;
+    const double sT = temp <= 100.0 ? det_sqrt(temp) : 1.0;
+    const double base[3] = {10.0, 0.2, 1.0};
+    const double c1 = 2.4 / det_sqrt(2.0 * 1.0), cn = 2.4 / det_sqrt(2.0 * (double)d);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double sc = temp <= 100.0 ? base[j] * sT : base[j];
+        c.cd_scam[j] = c1 * sc;
+        c.cd_am[j] = cn * sc;
+    }
+    c.de_div = det_sqrt(2.0 * (double)d);
+    c.de_mul = det_sqrt(1.0 / beta);
+    return c;
+}
+
+// Kernel shapes: (lanes per chain G, register slots per lane EPL); a shape serves
+// G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
+// lane for every ndim the shape serves and need no bounds check.
+constexpr int safe_slots(int G, int EPL)
+{
+    return G == 4 ? (EPL == 26 ? 20 : EPL == 20 ? 13 : EPL == 13 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
+         : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
+         : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
+}
+// element i = gl + G*e of a table row
+#define PTMI_ROW_LOAD(dst, row, e)                                         \
+    do {                                                                   \
+        if ((e) < safe_slots(G, EPL)) dst = (row)[gl + G * (e)];           \
+        else dst = (gl + G * (e)) < d ? (row)[gl + G * (e)] : 0.0;         \
+    } while (0)
+
+// One proposal for the caller's chain (PT:1048-1067, 820-985): writes the increment dq
+// (q = x + dq) and returns the jump type.  log_u = log(accept uniform), evaluated in the
+// same instruction stream as the Box-Muller log, on another lane of each quad.
 template <int G, int EPL, bool FULL>
-__device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, double temp, double beta,
+__device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc,
                                        const double *Ut, const double *S, const double *DE,
-                                       const double (&x)[EPL], double (&q)[EPL], double &log_u, double &u_acc)
+                                       double (&dq)[EPL], double &log_u, double &u_acc)
 {
     const int d = a.d;
     // the four lanes of a quad evaluate slots A..D of this chain in one pass
@@ -159,68 +200,63 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
     log_u = quad_bcastf<1>(lg);
     u_acc = w2uniform(B0);
 
-    const int L = a.w_host + a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
-    const int pick = (int)w2index(A0, (u64)L);
-    const int ind = pick - a.w_host;
-    int jt = ind < a.w_scam ? PTMI_J_SCAM : (ind < a.w_scam + a.w_am ? PTMI_J_AM : PTMI_J_DE);
-    if (!FULL) jt = PTMI_J_SCAM;
-    if (FULL && ind < 0) {                      // a host-served cycle entry: hand the state back unchanged
+    int jt = PTMI_J_SCAM;
+    if (FULL) {
+        const int L = a.w_host + a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
+        const int pick = (int)w2index(A0, (u64)L);
+        const int ind = pick - a.w_host;
+        jt = ind < a.w_scam ? PTMI_J_SCAM : (ind < a.w_scam + a.w_am ? PTMI_J_AM : PTMI_J_DE);
+        if (ind < 0) {                          // a host-served cycle entry: hand the state back unchanged
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) q[e] = x[e];
-        return PTMI_J_NTYPES + pick;
+            for (int e = 0; e < EPL; ++e) dq[e] = 0.0;
+            return PTMI_J_NTYPES + pick;
+        }
     }
     const double prob = w2uniform(A1);
+    const int br = prob > 0.97 ? 0 : (prob > 0.9 ? 1 : 2);
 
-    if (jt == PTMI_J_SCAM || jt == PTMI_J_AM) {
-        double scale = prob > 0.97 ? 10.0 : (prob > 0.9 ? 0.2 : 1.0);
-        if (temp <= 100.0) scale *= det_sqrt(temp);  // PT:861-862
-        if (jt == PTMI_J_SCAM) {
-            const int k = (int)w2index(B1, (u64)d);
-            const double *col = Ut + (size_t)k * d;
-            double uk[EPL];
+    if (jt == PTMI_J_SCAM) {
+        const int k = (int)w2index(B1, (u64)d);
+        const double *col = Ut + (size_t)k * d;
+        double uk[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int i = gl + G * e;
-                uk[e] = i < d ? col[i] : 0.0;
+        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(uk[e], col, e);
+        const double sk = S[k];
+        const u64 D1 = quad_bcast<3>(w1);
+        const double ln1 = quad_bcastf<3>(lg);
+        const double z = det_sqrt(-2.0 * ln1) * det_cos2pi(w2uniform(D1));
+        const double cd = br == 0 ? cc.cd_scam[0] : (br == 1 ? cc.cd_scam[1] : cc.cd_scam[2]);
+        const double amp = z * cd * det_sqrt(sk);             // PT:873
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) dq[e] = amp * uk[e];
+    } else if (FULL && jt == PTMI_J_AM) {
+        const double cd = br == 0 ? cc.cd_am[0] : (br == 1 ? cc.cd_am[1] : cc.cd_am[2]);
+        double wk[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int k = gl + G * e;
+            dq[e] = 0.0;
+            wk[e] = 0.0;
+            if (k < d) {
+                u64 e0, e1;
+                philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
+                wk[e] = det_normal(e0, e1) * cd * det_sqrt(S[k]);  // PT:930
             }
-            const double sk = S[k];
-            const u64 D1 = quad_bcast<3>(w1);
-            const double ln1 = quad_bcastf<3>(lg);
-            const double z = det_sqrt(-2.0 * ln1) * det_cos2pi(w2uniform(D1));
-            const double cd = 2.4 / det_sqrt(2.0 * 1.0) * scale;  // PT:870
-            const double amp = z * cd * det_sqrt(sk);             // PT:873
+        }
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) q[e] = x[e] + amp * uk[e];
-        } else if (FULL) {
-            const double cd = 2.4 / det_sqrt(2.0 * (double)d) * scale;  // PT:928
-            double wk[EPL], acc[EPL];
+        for (int e2 = 0; e2 < EPL; ++e2) {
+            for (int src = 0; src < G; ++src) {
+                const int k = src + G * e2;
+                if (k >= d) break;
+                const double wv = group_bcast_lane<G>(wk[e2], src);
+                const double *row = Ut + (size_t)k * d;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int k = gl + G * e;
-                acc[e] = 0.0;
-                wk[e] = 0.0;
-                if (k < d) {
-                    u64 e0, e1;
-                    philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
-                    wk[e] = det_normal(e0, e1) * cd * det_sqrt(S[k]);  // PT:930
+                for (int e = 0; e < EPL; ++e) {
+                    double r;
+                    PTMI_ROW_LOAD(r, row, e);
+                    dq[e] = __builtin_fma(r, wv, dq[e]);
                 }
             }
-#pragma unroll
-            for (int e2 = 0; e2 < EPL; ++e2) {
-                for (int src = 0; src < G; ++src) {
-                    const int k = src + G * e2;
-                    if (k >= d) break;
-                    const double wv = group_bcast_lane<G>(wk[e2], src);
-                    const double *row = Ut + (size_t)k * d;
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) {
-                        const int i = gl + G * e;
-                        if (i < d) acc[e] = __builtin_fma(row[i], wv, acc[e]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) q[e] = x[e] + acc[e];
         }
     } else if (FULL) {
         const int Bn = a.de_size;
@@ -229,13 +265,15 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         const int nn = (int)(((u64)mm + 1ull + w2index(C0, (u64)(Bn - 1))) % (u64)Bn);
         double scale;
         if (prob > 0.5) scale = 1.0;
-        else scale = w2uniform(C1) * 2.4 / det_sqrt(2.0 * (double)d) * det_sqrt(1.0 / beta);  // PT:976
+        else scale = w2uniform(C1) * 2.4 / cc.de_div * cc.de_mul;  // PT:976
         const double *rm = DE + (size_t)((mm + a.de_head) % Bn) * d;
         const double *rn = DE + (size_t)((nn + a.de_head) % Bn) * d;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const int i = gl + G * e;
-            q[e] = i < d ? x[e] + scale * (rm[i] - rn[i]) : 0.0;
+            double vm, vn;
+            PTMI_ROW_LOAD(vm, rm, e);
+            PTMI_ROW_LOAD(vn, rn, e);
+            dq[e] = scale * (vm - vn);
         }
     }
     return jt;
@@ -263,79 +301,90 @@ __global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
     const int w = (int)(ch / nt);
     const int t = a.temp_of[ch];
     const int tg = a.temp0 + t;
-    const double temp = a.temps_mh[t], beta = a.beta[t];
+    const double beta = a.beta[t];
+    const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
     const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)tg);
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
     const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * d : nullptr;
     double *xrow = a.X + (size_t)ch * d;
 
-    double x[EPL], q[EPL];
+    double x[EPL], dq[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = gl + G * e;
-        x[e] = i < d ? xrow[i] : 0.0;
-    }
+    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double lnL = a.lnL[ch], lp = a.lp[ch];
     u32 nacc = 0, jp[PTMI_J_NTYPES] = {0, 0, 0}, ja[PTMI_J_NTYPES] = {0, 0, 0};
-    const bool cold = tg == 0 && a.AM != nullptr;
+    const bool cold = live && tg == 0 && a.AM != nullptr;
+    int am_row = a.am_row0;
 
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
         double log_u, u_acc;
-        const int jt = propose<G, EPL, FULL>(a, it, sid, gl, temp, beta, Ut, S, DE, x, q, log_u, u_acc);
+        const int jt = propose<G, EPL, FULL>(a, it, sid, gl, cc, Ut, S, DE, dq, log_u, u_acc);
+        if (FULL) {
 #pragma unroll
-        for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
-
+            for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
+        }
         // PT:605-612
-        const double nlp = eval_logp<G, EPL>(a, q, gl);
-        double nlnL = 0.0, nlnprob;
-        if (nlp == -__builtin_inf()) nlnprob = -__builtin_inf();
-        else {
-            nlnL = eval_logl<G, EPL, LOGL>(a, q, gl);
-            nlnprob = beta * nlnL + nlp;
+        double nlp, nlnL = 0.0, nlnprob;
+        {
+            double q[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
+            nlp = eval_logp<G, EPL>(a, q, gl);
+            if (nlp == -__builtin_inf()) nlnprob = -__builtin_inf();
+            else {
+                nlnL = eval_logl<G, EPL, LOGL>(a, q, gl);
+                nlnprob = beta * nlnL + nlp;
+            }
         }
         // PT:615-622
         const double lnprob0 = beta * lnL + lp;
         const double diff = nlnprob - lnprob0 + 0.0;
         if (diff > log_u) {
+            // x + dq again (bit-identical to q); keeping q alive instead would cost EPL more registers
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) x[e] = q[e];
+            for (int e = 0; e < EPL; ++e) {
+                double inc = dq[e];
+                asm volatile("" : "+v"(inc));
+                x[e] = x[e] + inc;
+            }
             lnL = nlnL;
             lp = nlp;
             nacc += 1;
+            if (FULL) {
 #pragma unroll
-            for (int j = 0; j < PTMI_J_NTYPES; ++j) ja[j] += (jt == j);
-        }
-        // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
-        if (cold && live) {
-            const bool swap_follows = a.tskip > 0 && a.ntg > 1 && it % a.tskip == 0;
-            if (!swap_follows) {
-                double *am = a.AM + ((size_t)w * a.cov_update + (size_t)(it % a.cov_update)) * d;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int i = gl + G * e;
-                    if (i < d) am[i] = x[e];
-                }
-                if (a.AMaux && gl == 0) {
-                    double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)(it % a.cov_update)) * 2;
-                    ax[0] = lnL;
-                    ax[1] = lp;
-                }
+                for (int j = 0; j < PTMI_J_NTYPES; ++j) ja[j] += (jt == j);
             }
         }
+        // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
+        if (cold && !(a.swap_last && k == a.nsteps - 1)) {
+            double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e;
+                if (e < safe_slots(G, EPL) || i < d) am[i] = x[e];
+            }
+            if (a.AMaux && gl == 0) {
+                double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
+                ax[0] = lnL;
+                ax[1] = lp;
+            }
+        }
+        am_row = am_row + 1 == a.cov_update ? 0 : am_row + 1;
     }
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = gl + G * e;
-            if (i < d) xrow[i] = x[e];
+            if (e < safe_slots(G, EPL) || i < d) xrow[i] = x[e];
         }
         if (gl == 0) {
             a.lnL[ch] = lnL;
             a.lp[ch] = lp;
             const size_t r = (size_t)w * nt + t;
             a.nacc[r] += nacc;
+            if (!FULL) { jp[PTMI_J_SCAM] = (u32)a.nsteps; ja[PTMI_J_SCAM] = nacc; }
 #pragma unroll
             for (int j = 0; j < PTMI_J_NTYPES; ++j) {
                 a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 0] += jp[j];
@@ -358,24 +407,23 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     const int gl = (int)(threadIdx.x % G);
     const int w = (int)(ch / nt);
     const int t = a.temp_of[ch];
-    const double temp = a.temps_mh[t], beta = a.beta[t];
+    const double beta = a.beta[t];
+    const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
     const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)(a.temp0 + t));
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
     const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
-    double x[EPL], q[EPL];
+    const double *xrow = a.X + (size_t)ch * d;
+    double x[EPL], dq[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = gl + G * e;
-        x[e] = i < d ? a.X[(size_t)ch * d + i] : 0.0;
-    }
+    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double log_u, u_acc;
-    const int jt = propose<G, EPL, true>(a, a.iter0, sid, gl, temp, beta, Ut, S, DE, x, q, log_u, u_acc);
+    const int jt = propose<G, EPL, true>(a, a.iter0, sid, gl, cc, Ut, S, DE, dq, log_u, u_acc);
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = gl + G * e;
-            if (i < d) a.Q[(size_t)ch * d + i] = q[e];
+            if (i < d) a.Q[(size_t)ch * d + i] = x[e] + dq[e];
         }
         if (gl == 0) {
             a.qaux[ch * 4 + 0] = 0.0;  // qxy of the built-in jumps (PT:836,894,952)
@@ -406,8 +454,7 @@ __global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
     const int jt = (int)a.qaux[ch * 4 + 1];
     const bool acc = diff > a.qaux[ch * 4 + 3];
     const bool cold = a.temp0 + t == 0 && a.AM != nullptr;
-    const bool swap_follows = a.tskip > 0 && a.ntg > 1 && a.iter0 % a.tskip == 0;
-    double *am = cold && !swap_follows ? a.AM + ((size_t)w * a.cov_update + (size_t)(a.iter0 % a.cov_update)) * d : nullptr;
+    double *am = cold && !a.swap_last ? a.AM + ((size_t)w * a.cov_update + (size_t)a.am_row0) * d : nullptr;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int i = gl + G * e;
@@ -420,6 +467,11 @@ __global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
     if (gl == 0) {
         const size_t r = (size_t)w * nt + t;
         if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 0] += 1;
+        if (am && a.AMaux) {
+            double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)a.am_row0) * 2;
+            ax[0] = acc ? nlnL : a.lnL[ch];
+            ax[1] = acc ? nlp : a.lp[ch];
+        }
         if (acc) {
             a.lnL[ch] = nlnL;
             a.lp[ch] = nlp;
@@ -427,11 +479,6 @@ __global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
             if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 1] += 1;
         }
         a.qaux[ch * 4 + 2] = acc ? 1.0 : 0.0;   // decision, for the host's per-name jump statistics
-        if (am && a.AMaux) {
-            double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)(a.iter0 % a.cov_update)) * 2;
-            ax[0] = acc ? nlnL : a.lnL[ch];
-            ax[1] = acc ? nlp : a.lp[ch];
-        }
     }
 }
 
@@ -571,30 +618,39 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
             const int i = ti0 + ty + 16 * p, j = tj0 + tx + 16 * r;
             acc[p][r] = (!reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
         }
-    for (int ii = 0; ii < mem; ++ii) {
-        it += 1;
-        const int bsel = ii & 1;
-        if (role < 2) {
-            double df = 0.0, ev = 0.0;
-            if (carrier) {
-                const double v = am[(size_t)ii * d + rel];
-                df = v - m;
-                m += df / (double)it;
-                ev = v - m;
+    constexpr int PF = 8;   // rows fetched ahead by the carrier threads (one HBM latency per PF rows)
+    for (int ii0 = 0; ii0 < mem; ii0 += PF) {
+        double vpre[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) vpre[u] = (carrier && ii0 + u < mem) ? am[(size_t)(ii0 + u) * d + rel] : 0.0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int ii = ii0 + u;
+            if (ii >= mem) break;
+            it += 1;
+            const int bsel = ii & 1;
+            if (role < 2) {
+                double df = 0.0, ev = 0.0;
+                if (carrier) {
+                    const double v = vpre[u];
+                    df = v - m;
+                    m += df / (double)it;
+                    ev = v - m;
+                }
+                if (role == 0) sh[bsel][0][ridx] = df;
+                else sh[bsel][1][ridx] = ev;
             }
-            if (role == 0) sh[bsel][0][ridx] = df;
-            else sh[bsel][1][ridx] = ev;
+            __syncthreads();
+            double dv[WT], evv[WT];
+#pragma unroll
+            for (int p = 0; p < WT; ++p) dv[p] = sh[bsel][0][ty + 16 * p];
+#pragma unroll
+            for (int r = 0; r < WT; ++r) evv[r] = sh[bsel][1][tx + 16 * r];
+#pragma unroll
+            for (int p = 0; p < WT; ++p)
+#pragma unroll
+                for (int r = 0; r < WT; ++r) acc[p][r] += dv[p] * evv[r];
         }
-        __syncthreads();
-        double dv[WT], evv[WT];
-#pragma unroll
-        for (int p = 0; p < WT; ++p) dv[p] = sh[bsel][0][ty + 16 * p];
-#pragma unroll
-        for (int r = 0; r < WT; ++r) evv[r] = sh[bsel][1][tx + 16 * r];
-#pragma unroll
-        for (int p = 0; p < WT; ++p)
-#pragma unroll
-            for (int r = 0; r < WT; ++r) acc[p][r] += dv[p] * evv[r];
     }
     const double den = (double)(it - 1);
     double *covw = cov ? cov + (size_t)w * cov_stride_per_walker : nullptr;
@@ -634,6 +690,7 @@ __global__ void pool_cov_kernel(const double *mu, const double *M2, double *cov_
     if (idx >= (long long)d * d) return;
     const int i = (int)(idx / d), j = (int)(idx % d);
     double mi = 0.0, mj = 0.0, M = 0.0;
+#pragma unroll 8
     for (int w = 0; w < W; ++w) {
         const double na = (double)w * (double)n_per, nb = (double)n_per, nn = na + nb;
         const double f = na * nb / nn, g = nb / nn;
@@ -704,7 +761,7 @@ struct ptmi_engine {
 struct Shape { int G, EPL; };
 static bool pick_shape(int d, Shape *s)
 {
-    static const Shape table[] = {{4, 2}, {4, 5}, {4, 8}, {16, 4}, {16, 7}, {16, 16}, {64, 8}, {64, 16}, {64, 32}};
+    static const Shape table[] = {{4, 2}, {4, 5}, {4, 8}, {4, 13}, {4, 20}, {4, 26}, {16, 7}, {16, 13}, {16, 26}, {64, 8}, {64, 16}, {64, 32}};
     const int G = ptmi_lanes_for(d);
     for (const Shape &c : table)
         if (c.G == G && c.G * c.EPL >= d) { *s = c; return true; }
@@ -757,10 +814,35 @@ static void launch_eval(ptmi_engine *h, const KArgs &a, int grid)
 #define FOR_SHAPE(G_, E_, CALL)                       \
     if (h->G == G_ && h->EPL == E_) { CALL(G_, E_); } else
 
+#ifdef PTMI_ONLY_BENCH_SHAPE   /* developer switch: compile the d=100 shape only (fast asm inspection builds) */
+#ifndef PTMI_DEV_G
+#define PTMI_DEV_G 4
+#define PTMI_DEV_E 26
+#endif
+#define DISPATCH_SHAPE(CALL) FOR_SHAPE(PTMI_DEV_G, PTMI_DEV_E, CALL) { return fail(PTMI_EUNSUPPORTED, "shape not compiled in"); }
+#else
 #define DISPATCH_SHAPE(CALL)                                                                        \
-    FOR_SHAPE(4, 2, CALL) FOR_SHAPE(4, 5, CALL) FOR_SHAPE(4, 8, CALL) FOR_SHAPE(16, 4, CALL)        \
-    FOR_SHAPE(16, 7, CALL) FOR_SHAPE(16, 16, CALL) FOR_SHAPE(64, 8, CALL) FOR_SHAPE(64, 16, CALL)   \
-    FOR_SHAPE(64, 32, CALL) { return fail(PTMI_EUNSUPPORTED, "no kernel shape for ndim=%d", h->cfg.ndim); }
+    FOR_SHAPE(4, 2, CALL) FOR_SHAPE(4, 5, CALL) FOR_SHAPE(4, 8, CALL) FOR_SHAPE(4, 13, CALL)        \
+    FOR_SHAPE(4, 20, CALL) FOR_SHAPE(4, 26, CALL) FOR_SHAPE(16, 7, CALL) FOR_SHAPE(16, 13, CALL)    \
+    FOR_SHAPE(16, 26, CALL) FOR_SHAPE(64, 8, CALL) FOR_SHAPE(64, 16, CALL) FOR_SHAPE(64, 32, CALL) { return fail(PTMI_EUNSUPPORTED, "no kernel shape for ndim=%d", h->cfg.ndim); }
+#endif
+
+// am_row0 / swap_last of a launch; a swap iteration may only be the last one of the range
+static int set_step_args(const ptmi_engine *h, KArgs *a)
+{
+    const ptmi_config &c = h->cfg;
+    a->am_row0 = (int)(a->iter0 % c.cov_update);
+    a->swap_last = 0;
+    if (c.tskip > 0 && c.ntemps_global > 1) {
+        const long long last = a->iter0 + a->nsteps - 1;
+        if (last / c.tskip != (a->iter0 - 1) / c.tskip && last % c.tskip != 0)
+            return fail(PTMI_EINVAL, "iterations %lld..%lld contain a swap iteration (Tskip=%d) before their end", a->iter0, last, c.tskip);
+        if ((last / c.tskip) - ((a->iter0 - 1) / c.tskip) > 1)
+            return fail(PTMI_EINVAL, "iterations %lld..%lld span more than one swap epoch", a->iter0, last);
+        a->swap_last = last % c.tskip == 0;
+    }
+    return PTMI_OK;
+}
 
 static int chains_grid(const ptmi_engine *h)
 {
@@ -773,7 +855,7 @@ extern "C" {
 
 const char *ptmi_last_error(void) { return g_err; }
 int ptmi_version(void) { return PTMI_VERSION; }
-int ptmi_lanes_for(int ndim) { return ndim <= 32 ? 4 : (ndim <= 256 ? 16 : 64); }
+int ptmi_lanes_for(int ndim) { return ndim <= 104 ? 4 : (ndim <= 416 ? 16 : 64); }
 
 int ptmi_device_count(int *count)
 {
@@ -888,6 +970,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     if (nsteps == 0) return PTMI_OK;
     KArgs a = make_args(h);
     a.iter0 = iter0; a.nsteps = nsteps;
+    if (int rc = set_step_args(h, &a)) return rc;
     if (h->cfg.w_host > 0) return fail(PTMI_EINVAL, "host-served jumps need the split path (ptmi_propose / ptmi_accept)");
     const bool full = h->cfg.w_am > 0 || (h->de_on && h->cfg.w_de > 0);
     if (!full && h->cfg.w_scam <= 0) return fail(PTMI_EINVAL, "empty proposal cycle");
@@ -904,6 +987,7 @@ int ptmi_propose(ptmi_handle h, int64_t iter)
     if (!h->buf.Q || !h->buf.qaux) return fail(PTMI_EINVAL, "split path needs the Q and qaux buffers");
     KArgs a = make_args(h);
     a.iter0 = iter; a.nsteps = 1;
+    if (int rc = set_step_args(h, &a)) return rc;
     const int grid = chains_grid(h);
 #define CALL_PROP(G_, E_) hipLaunchKernelGGL((propose_kernel<G_, E_>), dim3(grid), dim3(256), 0, h->stream, a)
     DISPATCH_SHAPE(CALL_PROP)
@@ -917,6 +1001,7 @@ int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL, const double 
     if (!h->buf.Q || !h->buf.qaux || !newlnL || !newlp) return fail(PTMI_EINVAL, "split path buffers missing");
     KArgs a = make_args(h);
     a.iter0 = iter; a.nsteps = 1; a.newlnL = newlnL; a.newlp = newlp;
+    if (int rc = set_step_args(h, &a)) return rc;
     const int grid = chains_grid(h);
 #define CALL_ACC(G_, E_) hipLaunchKernelGGL((accept_kernel<G_, E_>), dim3(grid), dim3(256), 0, h->stream, a)
     DISPATCH_SHAPE(CALL_ACC)

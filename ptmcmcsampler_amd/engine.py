@@ -21,6 +21,15 @@ def _torch():
     return torch
 
 
+def _blas_single_thread():
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=1)
+    except ImportError:
+        import contextlib
+        return contextlib.nullcontext()
+
+
 class PTEngine(object):
     """Chains of ``nwalkers`` x ``ntemps`` on one GPU.
 
@@ -138,7 +147,8 @@ class PTEngine(object):
     # ------------------------------------------------------------------ set-up
     def _eig_host(self, w, cov):
         """U, S of the jump covariance by LAPACK, as the reference (:145, :803)."""
-        U, S, _ = np.linalg.svd(cov)
+        with _blas_single_thread():                                   # a d x d SVD gains nothing from a 256-thread pool
+            U, S, _ = np.linalg.svd(cov)
         self.put_eig(U, S, w)
 
     def put_eig(self, U, S, w=0):
