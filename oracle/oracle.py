@@ -73,6 +73,7 @@ def lib():
                                      C.POINTER(Replay)]
         L.orc_swap_apply.argtypes = [C.POINTER(Cfg), C.POINTER(State), _ip, C.c_int64]
         L.orc_welford.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]
+        L.orc_welford2.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_int]
         L.orc_pool_cov.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]
         L.orc_de_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.orc_de_update_pooled.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]
@@ -113,12 +114,12 @@ def temperature_ladder(nchain, ndim, Tmin=1, Tmax=None):
     return np.array([1])
 
 
-def welford(AM, mu, M2, it):
-    """In-place PTMCMCSampler.py:769-794; returns cov."""
+def welford(AM, mu, M2, it, fused=False):
+    """In-place PTMCMCSampler.py:769-794; returns cov.  ``fused``: one fma per element (pooled mode)."""
     mem, d = AM.shape
     cov = np.empty((d, d))
     AMc = np.ascontiguousarray(AM)
-    lib().orc_welford(d, mem, it, _p(AMc), _p(mu), _p(M2), _p(cov))
+    lib().orc_welford2(d, mem, it, _p(AMc), _p(mu), _p(M2), _p(cov), int(fused))
     return cov
 
 
@@ -253,7 +254,7 @@ class OracleEngine(object):
         if self.temp0 == 0:
             if (it - 1) % cu == 0 and it - 1 != 0:
                 for w in range(self.W):
-                    c = welford(self.AM[w], self.mu[w], self.M2[w], it - 1)
+                    c = welford(self.AM[w], self.mu[w], self.M2[w], it - 1, fused=not self.per_walker)
                     if self.per_walker:
                         self.cov[w] = c
                 if not self.per_walker:

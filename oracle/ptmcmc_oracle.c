@@ -434,8 +434,10 @@ ORC_API void orc_swap_apply(const orc_cfg *c, orc_state *st, const int32_t *map,
 }
 
 /* ------------------------------------------------------------- Welford */
-/* PT:769-794 for one walker: mem buffered rows in buffer order. */
-ORC_API void orc_welford(int d, int mem, int64_t iter, const double *AM, double *mu, double *M2, double *cov)
+/* PT:769-794 for one walker: mem buffered rows in buffer order.  fused = 0 is the
+ * reference's arithmetic (one product, one sum); fused = 1 accumulates with one fma per
+ * element (the pooled mode of the engine, which is not a replica of a reference run). */
+ORC_API void orc_welford2(int d, int mem, int64_t iter, const double *AM, double *mu, double *M2, double *cov, int fused)
 {
     int64_t it = iter - mem;
     if (it == 0) { memset(M2, 0, sizeof(double) * d * d); memset(mu, 0, sizeof(double) * d); }
@@ -446,33 +448,61 @@ ORC_API void orc_welford(int d, int mem, int64_t iter, const double *AM, double 
         for (int j = 0; j < d; ++j) { diff[j] = row[j] - mu[j]; mu[j] += diff[j] / (double)it; }
         for (int j = 0; j < d; ++j) e[j] = row[j] - mu[j];
         for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) M2[(size_t)i * d + j] += diff[i] * e[j];
+            for (int j = 0; j < d; ++j) {
+                if (fused) M2[(size_t)i * d + j] = fma(diff[i], e[j], M2[(size_t)i * d + j]);
+                else M2[(size_t)i * d + j] += diff[i] * e[j];
+            }
     }
-    for (int i = 0; i < d * d; ++i) cov[i] = M2[i] / (double)(it - 1);
+    if (cov) for (int i = 0; i < d * d; ++i) cov[i] = M2[i] / (double)(it - 1);
     free(diff);
 }
+ORC_API void orc_welford(int d, int mem, int64_t iter, const double *AM, double *mu, double *M2, double *cov)
+{
+    orc_welford2(d, mem, iter, AM, mu, M2, cov, 0);
+}
 
-/* pooled statistics over walkers (sequential Chan et al. combination, w ascending) */
-ORC_API void orc_pool_cov(int d, int nwalkers, int64_t n_per, const double *mu, const double *M2,
-                          double *mu_out, double *cov_out)
+/* Chan et al. combination of `nin` partial statistics, inputs ascending; input k holds nb
+ * samples (the last one nb_last). */
+static void chan_combine(int d, int nin, double nb, double nb_last, const double *mu, const double *M2,
+                         double *mu_out, double *M2_out)
 {
     double *m = (double *)calloc((size_t)d, sizeof(double));
     double *M = (double *)calloc((size_t)d * d, sizeof(double));
-    for (int w = 0; w < nwalkers; ++w) {
-        const double *mw = mu + (size_t)w * d, *Mw = M2 + (size_t)w * d * d;
-        const double na = (double)w * (double)n_per, nb = (double)n_per, nn = na + nb;
-        const double f = na * nb / nn, g = nb / nn;
+    double na = 0.0;
+    for (int k = 0; k < nin; ++k) {
+        const double *mw = mu + (size_t)k * d, *Mw = M2 + (size_t)k * d * d;
+        const double nk = k == nin - 1 ? nb_last : nb, nn = na + nk;
+        const double f = na * nk / nn, g = nk / nn;
         for (int i = 0; i < d; ++i)
             for (int j = 0; j < d; ++j) {
                 const double di = mw[i] - m[i], dj = mw[j] - m[j];
                 M[(size_t)i * d + j] = (M[(size_t)i * d + j] + Mw[(size_t)i * d + j]) + (di * dj) * f;
             }
         for (int i = 0; i < d; ++i) m[i] = m[i] + (mw[i] - m[i]) * g;
+        na = nn;
     }
+    memcpy(mu_out, m, sizeof(double) * d);
+    memcpy(M2_out, M, sizeof(double) * d * d);
+    free(m); free(M);
+}
+
+/* pooled covariance over walkers: groups of 64 walkers combined in walker order, then the
+ * groups combined in order (the two-level order of the engine's pool kernels) */
+ORC_API void orc_pool_cov(int d, int nwalkers, int64_t n_per, const double *mu, const double *M2,
+                          double *mu_out, double *cov_out)
+{
+    const int GS = 64, ng = (nwalkers + GS - 1) / GS;
+    double *gm = (double *)malloc(sizeof(double) * (size_t)ng * d), *gM = (double *)malloc(sizeof(double) * (size_t)ng * d * d);
+    for (int g = 0; g < ng; ++g) {
+        const int w0 = g * GS, cnt = (w0 + GS <= nwalkers) ? GS : nwalkers - w0;
+        chan_combine(d, cnt, (double)n_per, (double)n_per, mu + (size_t)w0 * d, M2 + (size_t)w0 * d * d, gm + (size_t)g * d, gM + (size_t)g * d * d);
+    }
+    const int last = nwalkers - (ng - 1) * GS;
+    double *M = (double *)malloc(sizeof(double) * (size_t)d * d);
+    chan_combine(d, ng, (double)GS * (double)n_per, (double)last * (double)n_per, gm, gM, mu_out, M);
     const double den = (double)nwalkers * (double)n_per - 1.0;
     for (int i = 0; i < d * d; ++i) cov_out[i] = M[i] / den;
-    memcpy(mu_out, m, sizeof(double) * d);
-    free(m); free(M);
+    free(gm); free(gM); free(M);
 }
 
 /* ----------------------------------------------------------- DE buffer */

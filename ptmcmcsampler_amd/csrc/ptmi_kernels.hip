@@ -218,9 +218,10 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
     if (jt == PTMI_J_SCAM) {
         const int k = (int)w2index(B1, (u64)d);
         const double *col = Ut + (size_t)k * d;
-        double uk[EPL];
+        // the direction lands in dq (issued before the normal is computed, so its latency is covered) and
+        // is scaled in place
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(uk[e], col, e);
+        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], col, e);
         const double sk = S[k];
         const u64 D1 = quad_bcast<3>(w1);
         const double ln1 = quad_bcastf<3>(lg);
@@ -228,7 +229,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         const double cd = br == 0 ? cc.cd_scam[0] : (br == 1 ? cc.cd_scam[1] : cc.cd_scam[2]);
         const double amp = z * cd * det_sqrt(sk);             // PT:873
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) dq[e] = amp * uk[e];
+        for (int e = 0; e < EPL; ++e) dq[e] = amp * dq[e];
     } else if (FULL && jt == PTMI_J_AM) {
         const double cd = br == 0 ? cc.cd_am[0] : (br == 1 ? cc.cd_am[1] : cc.cd_am[2]);
         double wk[EPL];
@@ -592,6 +593,7 @@ __global__ void am_write_kernel(const double *X, const double *lnL, const double
 // the tile through LDS.  Every element sees exactly the reference's operation order:
 // M2[i][j] += diff[i] * (row[j] - mu_new[j]), one product and one sum, rows ascending.
 constexpr int WT = 7, WTILE = 16 * WT;
+template <bool FUSED>
 __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *mu, double *M2, double *cov, int d, int mem,
                                                      long long iter, int cov_stride_per_walker)
 {
@@ -649,7 +651,10 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
 #pragma unroll
             for (int p = 0; p < WT; ++p)
 #pragma unroll
-                for (int r = 0; r < WT; ++r) acc[p][r] += dv[p] * evv[r];
+                for (int r = 0; r < WT; ++r) {
+                    if (FUSED) acc[p][r] = __builtin_fma(dv[p], evv[r], acc[p][r]);   // pooled mode: not a reference replica
+                    else acc[p][r] += dv[p] * evv[r];                                 // PT:792, one product and one sum
+                }
         }
     }
     const double den = (double)(it - 1);
@@ -664,7 +669,9 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
                 if (covw) covw[(size_t)i * d + j] = acc[p][r] / den;
             }
         }
-    // mu is advanced by welford_mean_kernel, launched after this one (every tile needs the old mean)
+    // Several tiles per walker: mu is advanced by welford_mean_kernel, launched after this one (every tile needs
+    // the old mean).  One tile: this block's carriers hold the new mean already.
+    if (gridDim.x == 1 && role == 0 && carrier) muw[rel] = m;
 }
 
 __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem, long long iter)
@@ -683,24 +690,32 @@ __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem
     mu[(size_t)w * d + j] = m;
 }
 
-// pooled covariance: sequential Chan combination over walkers, one thread per (i,j)
-__global__ void pool_cov_kernel(const double *mu, const double *M2, double *cov_out, int d, int W, long long n_per)
+// Pooled covariance: Chan et al. combination of partial statistics (n_k, mu_k, M2_k), inputs ascending, one thread
+// per (i,j).  Level 1 (blockIdx.y = group of 64 walkers) writes group partials, level 2 combines the groups; the
+// final pass divides by N-1.
+constexpr int POOL_GS = 64;
+__global__ void pool_combine_kernel(const double *mu, const double *M2, double *mu_out, double *M2_out, int d, int nin_total,
+                                    int gs, double nb, double nb_last_input, double den)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)d * d) return;
+    const int g = (int)blockIdx.y;
+    const int k0 = g * gs, cnt = k0 + gs <= nin_total ? gs : nin_total - k0;
     const int i = (int)(idx / d), j = (int)(idx % d);
-    double mi = 0.0, mj = 0.0, M = 0.0;
-#pragma unroll 8
-    for (int w = 0; w < W; ++w) {
-        const double na = (double)w * (double)n_per, nb = (double)n_per, nn = na + nb;
-        const double f = na * nb / nn, g = nb / nn;
-        const double wi = mu[(size_t)w * d + i], wj = mu[(size_t)w * d + j];
+    const double *mw = mu + (size_t)k0 * d, *Mw = M2 + (size_t)k0 * d * d;
+    double mi = 0.0, mj = 0.0, M = 0.0, na = 0.0;
+    for (int k = 0; k < cnt; ++k) {
+        const double nk = (k0 + k == nin_total - 1) ? nb_last_input : nb, nn = na + nk;
+        const double f = na * nk / nn, gg = nk / nn;
+        const double wi = mw[(size_t)k * d + i], wj = mw[(size_t)k * d + j];
         const double di = wi - mi, dj = wj - mj;
-        M = (M + M2[(size_t)w * d * d + idx]) + (di * dj) * f;
-        mi = mi + di * g;
-        mj = mj + dj * g;
+        M = (M + Mw[(size_t)k * d * d + idx]) + (di * dj) * f;
+        mi = mi + di * gg;
+        mj = mj + dj * gg;
+        na = nn;
     }
-    cov_out[idx] = M / ((double)W * (double)n_per - 1.0);
+    M2_out[(size_t)g * d * d + idx] = den > 0.0 ? M / den : M;
+    if (mu_out && j == 0) mu_out[(size_t)g * d + i] = mi;
 }
 
 // DE history ring: rows [head, head+mem) are the oldest; overwrite them with the AM buffer
@@ -753,6 +768,7 @@ struct ptmi_engine {
     hipStream_t stream;
     double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar;
     double *d_lnlpos;   // [W][ntg] scratch for the fused swap
+    double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
     int G, EPL;
     int de_on, de_head;
     hipEvent_t ev0, ev1;
@@ -919,6 +935,11 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     }
     h->cfg.ladder = h->cfg.temps_mh = h->cfg.logl_par = h->cfg.logp_par = nullptr;  // host copies are not kept
     hipError_t e = hipMalloc((void **)&h->d_lnlpos, sizeof(double) * (size_t)c.nwalkers * c.ntemps_global);
+    if (e == hipSuccess && !c.cov_per_walker && c.temp0 == 0) {
+        const size_t ng = (size_t)(c.nwalkers + POOL_GS - 1) / POOL_GS;
+        e = hipMalloc((void **)&h->d_pool_mu, sizeof(double) * ng * c.ndim);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_pool_M2, sizeof(double) * ng * c.ndim * c.ndim);
+    }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) { ptmi_destroy(h); return fail(PTMI_EHIP, "create: %s", hipGetErrorString(e)); }
@@ -930,7 +951,7 @@ int ptmi_destroy(ptmi_handle h)
 {
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
-    (void)hipFree(h->d_lnlpos);
+    (void)hipFree(h->d_lnlpos); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -1067,13 +1088,25 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
     if (iter < c.cov_update || iter % c.cov_update) return fail(PTMI_EINVAL, "iter must be a positive multiple of cov_update");
     const int d = c.ndim, nt = (d + WTILE - 1) / WTILE;
     const int per = c.cov_per_walker;
-    hipLaunchKernelGGL(welford_kernel, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM, h->buf.mu,
-                       h->buf.M2, per ? h->buf.cov : (double *)nullptr, d, c.cov_update, (long long)iter, per ? d * d : 0);
-    hipLaunchKernelGGL(welford_mean_kernel, dim3((d + 63) / 64, c.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.AM,
-                       h->buf.mu, d, c.cov_update, (long long)iter);
-    if (!per)
-        hipLaunchKernelGGL(pool_cov_kernel, dim3((unsigned)(((long long)d * d + 255) / 256)), dim3(256), 0, h->stream,
-                           (const double *)h->buf.mu, (const double *)h->buf.M2, h->buf.cov, d, c.nwalkers, (long long)iter);
+    if (per)
+        hipLaunchKernelGGL(welford_kernel<false>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
+                           h->buf.mu, h->buf.M2, h->buf.cov, d, c.cov_update, (long long)iter, d * d);
+    else
+        hipLaunchKernelGGL(welford_kernel<true>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
+                           h->buf.mu, h->buf.M2, (double *)nullptr, d, c.cov_update, (long long)iter, 0);
+    if (nt > 1)
+        hipLaunchKernelGGL(welford_mean_kernel, dim3((d + 63) / 64, c.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.AM,
+                           h->buf.mu, d, c.cov_update, (long long)iter);
+    if (!per) {
+        const int W = c.nwalkers, ng = (W + POOL_GS - 1) / POOL_GS;
+        const unsigned gx = (unsigned)(((long long)d * d + 255) / 256);
+        const double n_per = (double)iter;
+        hipLaunchKernelGGL(pool_combine_kernel, dim3(gx, ng), dim3(256), 0, h->stream, (const double *)h->buf.mu,
+                           (const double *)h->buf.M2, h->d_pool_mu, h->d_pool_M2, d, W, POOL_GS, n_per, n_per, 0.0);
+        hipLaunchKernelGGL(pool_combine_kernel, dim3(gx, 1), dim3(256), 0, h->stream, (const double *)h->d_pool_mu,
+                           (const double *)h->d_pool_M2, (double *)nullptr, h->buf.cov, d, ng, ng, (double)POOL_GS * n_per,
+                           (double)(W - (ng - 1) * POOL_GS) * n_per, (double)W * n_per - 1.0);
+    }
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -67,7 +67,7 @@ class OracleLocal(object):
     def update_cov(self, it_done):
         o = self.o
         for w in range(o.W):
-            c = orc.welford(o.AM[w], o.mu[w], o.M2[w], it_done)
+            c = orc.welford(o.AM[w], o.mu[w], o.M2[w], it_done, fused=not o.per_walker)
             if o.per_walker:
                 o.cov[w] = c
         if not o.per_walker:
