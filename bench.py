@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--mix", default="scam", choices=["scam", "default"], help="scam: SCAM-only; default: SCAM/AM/DE 20/20/20")
     ap.add_argument("--logl", default="iso", choices=["iso", "dense"])
     ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
+    ap.add_argument("--sharded", action="store_true", help="use the sharded engine even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10000, help="iterations per host core of the CPU baseline (10-30 s of CPU work)")
     ap.add_argument("--ess-walkers", type=int, default=32)
@@ -65,6 +66,11 @@ def cpu_baseline(a, weights):
 
 def main():
     a = parse()
+    # stdout must carry exactly one JSON line: park everything else the process (and RCCL's C-level banner)
+    # prints on stderr, and keep the real stdout for the result
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     weights = (20, 0, 0) if a.mix == "scam" else (20, 20, 20)
     cpu = None
@@ -80,8 +86,10 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or a.sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     d, nt, W = a.ndim, a.ntemps, a.nwalkers
@@ -91,7 +99,7 @@ def main():
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=100, seed=1234, cov_mode=a.cov_mode, logl=logl,
               device=local)
-    if world == 1:
+    if world == 1 and not a.sharded:
         from ptmcmcsampler_amd.engine import PTEngine
         eng = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
     else:
@@ -190,7 +198,7 @@ def main():
             o.run(1000)
             out["cpu_c_oracle"] = {"value": 64 * 1000 / (time.perf_counter() - t1), "unit": "updates/s", "cores": 1,
                                    "sample": "oracle/ptmcmc_oracle.c, 8 temps x 8 walkers x 1000 iterations"}
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

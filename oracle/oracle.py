@@ -62,8 +62,9 @@ def lib():
         L = C.CDLL(_SO)
         L.orc_log.restype = L.orc_exp.restype = L.orc_cos2pi.restype = C.c_double
         L.orc_log.argtypes = L.orc_exp.argtypes = L.orc_cos2pi.argtypes = [C.c_double]
-        L.orc_normal.restype = C.c_double
-        L.orc_normal.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_normal.restype = L.orc_normal_sin.restype = L.orc_sin2pi.restype = C.c_double
+        L.orc_normal.argtypes = L.orc_normal_sin.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_sin2pi.argtypes = [C.c_double]
         L.orc_uniform.restype = C.c_double
         L.orc_uniform.argtypes = [C.c_uint64]
         L.orc_index.restype = C.c_uint64

@@ -64,7 +64,8 @@ static void philox_words(uint64_t seed, uint64_t iter, uint32_t stream, uint32_t
 /* slot numbers of the counter-based schedule (DESIGN.md "RNG schedule"):
  *   A: w0 cycle pick, w1 scale-branch uniform     B: w0 accept uniform, w1 SCAM direction / DE row mm
  *   C: w0 DE row nn offset, w1 DE scale uniform    D: (w0,w1) SCAM normal
- *   SWAP+k: w0 uniform of pair (k,k+1), stream of rank 0   AM+k: (w0,w1) normal of eigen-direction k */
+ *   SWAP+k: w0 uniform of pair (k,k+1), stream of rank 0
+ *   AM+k: (w0,w1) Box-Muller pair: cos branch -> eigen-direction k, sin branch -> direction k+lanes, (k/lanes) even */
 enum { SLOT_A = 0, SLOT_B = 1, SLOT_C = 2, SLOT_D = 3, SLOT_SWAP = 0x10000, SLOT_AM = 0x1000000 };
 
 static inline double w2uniform(uint64_t w) { return (double)(w >> 11) * 0x1.0p-53; }        /* [0,1) */
@@ -153,11 +154,54 @@ ORC_API double orc_cos2pi(double u)
     }
 }
 
+/* sin(2*pi*u), same reduction and polynomials */
+ORC_API double orc_sin2pi(double u)
+{
+    double a = 4.0 * u;
+    double q = floor(a + 0.5);
+    double r = a - q;
+    double z = r * r;
+    int qi = (int)q & 3;
+    if (qi & 1) {                   /* +-cos(pi r/2) */
+        double p = 0x1.ef6e308d6d1c4p-49;
+        p = fma(p, z, -0x1.2a0c591af8314p-41);
+        p = fma(p, z, 0x1.20c62c2f2d7f5p-34);
+        p = fma(p, z, -0x1.b6e24f44b128fp-28);
+        p = fma(p, z, 0x1.f9d38a3763cc3p-22);
+        p = fma(p, z, -0x1.a6d1f2a204a8cp-16);
+        p = fma(p, z, 0x1.e1f506891babbp-11);
+        p = fma(p, z, -0x1.55d3c7e3cbffap-6);
+        p = fma(p, z, 0x1.03c1f081b5ac4p-2);
+        p = fma(p, z, -0x1.3bd3cc9be45dep+0);
+        p = fma(p, z, 1.0);
+        return qi == 1 ? p : -p;
+    } else {                        /* +-sin(pi r/2) */
+        double p = -0x1.8a404211f9547p-45;
+        p = fma(p, z, 0x1.aaec32af93359p-38);
+        p = fma(p, z, -0x1.6fadb9f155744p-31);
+        p = fma(p, z, 0x1.e8f434d018d63p-25);
+        p = fma(p, z, -0x1.e3074fde8871fp-19);
+        p = fma(p, z, 0x1.50783487ee782p-13);
+        p = fma(p, z, -0x1.32d2cce62bd86p-8);
+        p = fma(p, z, 0x1.466bc6775aae2p-4);
+        p = fma(p, z, -0x1.4abbce625be53p-1);
+        p = fma(p, z, 0x1.921fb54442d18p+0);
+        double s = p * r;
+        return qi == 0 ? s : -s;
+    }
+}
+
 /* Box-Muller (cos branch): one normal from two words */
 ORC_API double orc_normal(uint64_t w0, uint64_t w1)
 {
     double r = sqrt(-2.0 * orc_log(w2uniform_open(w0)));
     return r * orc_cos2pi(w2uniform(w1));
+}
+/* Box-Muller, sin branch: the second normal of the same two words */
+ORC_API double orc_normal_sin(uint64_t w0, uint64_t w1)
+{
+    double r = sqrt(-2.0 * orc_log(w2uniform_open(w0)));
+    return r * orc_sin2pi(w2uniform(w1));
 }
 ORC_API double orc_uniform(uint64_t w) { return w2uniform(w); }
 ORC_API uint64_t orc_index(uint64_t w, uint64_t n) { return w2index(w, n); }
@@ -315,7 +359,13 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             for (int k = 0; k < d; ++k) {
                 double z;
                 if (r) z = rp_next(r, K_NRM, 0);
-                else { uint64_t E[2]; philox_words(c->seed, (uint64_t)it, sid, SLOT_AM + (uint32_t)k, E); z = orc_normal(E[0], E[1]); }
+                else {
+                    /* directions k and k + lanes share one Philox call (cos and sin branches of one Box-Muller) */
+                    const int which = (k / c->lanes) & 1, base = which ? k - c->lanes : k;
+                    uint64_t E[2];
+                    philox_words(c->seed, (uint64_t)it, sid, SLOT_AM + (uint32_t)base, E);
+                    z = which ? orc_normal_sin(E[0], E[1]) : orc_normal(E[0], E[1]);
+                }
                 wk[k] = z * cd * sqrt(S[k]);                            /* PT:930 */
             }
             /* q = x + U (cd sqrt(S) z): PT:923-931 up to rounding (U orthogonal) */

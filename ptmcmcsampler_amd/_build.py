@@ -1,17 +1,30 @@
-"""Builds libptmi.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libptmi.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The per-chain kernel templates are compiled once per shape (ptmi_shape.hip with -DPTMI_G/-DPTMI_E/-DPTMI_L), all
+translation units in parallel, then linked into one shared library."""
+import concurrent.futures
 import os
+import re
 import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "ptmi_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "ptmi_device.h"), os.path.join(os.path.dirname(HERE), "include", "ptmi.h")]
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 OUT = os.path.join(HERE, "libptmi.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+DEPS = [os.path.join(CSRC, f) for f in ("ptmi_abi.hip", "ptmi_shape.hip", "ptmi_mh.inc.h", "ptmi_common.h", "ptmi_device.h")] + [
+    os.path.join(os.path.dirname(HERE), "include", "ptmi.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
 def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def shapes():
+    txt = open(os.path.join(CSRC, "ptmi_common.h")).read()
+    line = re.search(r"#define PTMI_SHAPE_LIST\(X\)(.*)", txt).group(1)
+    return [(int(g), int(e)) for g, e in re.findall(r"X\((\d+),\s*(\d+)\)", line)]
 
 
 def stale():
@@ -21,13 +34,27 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in DEPS)
 
 
-def build(force=False, verbose=False):
+def _compile(job):
+    src, obj, defs = job
+    subprocess.check_call([hipcc()] + FLAGS + defs + ["-c", src, "-o", obj])
+    return obj
+
+
+def build(force=False, verbose=False, jobs=None):
     if not force and not stale():
         return OUT
-    cmd = [hipcc()] + FLAGS + ["-o", OUT + ".tmp", SRC]
+    os.makedirs(OBJ, exist_ok=True)
+    work = [(os.path.join(CSRC, "ptmi_abi.hip"), os.path.join(OBJ, "abi.o"), [])]
+    for g, e in sorted(shapes(), key=lambda s: -s[0] * s[1]):       # biggest units first
+        for fam in (1, 0, 2):
+            work.append((os.path.join(CSRC, "ptmi_shape.hip"), os.path.join(OBJ, "shape_%d_%d_%d.o" % (g, e, fam)),
+                         ["-DPTMI_G=%d" % g, "-DPTMI_E=%d" % e, "-DPTMI_L=%d" % fam]))
+    jobs = jobs or min(len(work), os.cpu_count() or 1)
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print("compiling %d translation units with %d workers" % (len(work), jobs))
+    with concurrent.futures.ThreadPoolExecutor(jobs) as pool:
+        objs = list(pool.map(_compile, work))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT + ".tmp"] + objs)
     os.replace(OUT + ".tmp", OUT)
     return OUT
 

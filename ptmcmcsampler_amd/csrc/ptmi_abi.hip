@@ -1,512 +1,19 @@
-// ptmi_kernels.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of libptmi.so.
-//
-// Hot path of a PTSampler-compatible parallel-tempering sampler, batched over
-// (walkers x temperatures) chains per GPU.  Reference behaviour cited as PT:<lines>
-// = PTMCMCSampler/PTMCMCSampler.py of nanograv/PTMCMCSampler.  See include/ptmi.h
-// for the boundary and DESIGN.md for layouts and the RNG schedule.
-#include <hip/hip_runtime.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-
+// ptmi_abi.hip -- the C ABI of libptmi.so, the engine object and the kernels that are not per-chain templates
+// (swap sweep, Welford / pooling, DE ring, self-tests).  See include/ptmi.h for the boundary and DESIGN.md.
 #include <new>
 #include <vector>
 
-#include "../../include/ptmi.h"
-#include "ptmi_device.h"
-
-using namespace ptmi;
+#include "ptmi_common.h"
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
-static int fail(int code, const char *fmt, ...)
+int ptmi_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
-}
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail(PTMI_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-// ------------------------------------------------------------- kernel args
-struct KArgs {
-    // state
-    double *X, *lnL, *lp;
-    int32_t *temp_of, *slot_of;
-    const double *Ut, *S, *DE;
-    double *AM, *AMaux;
-    u64 *nacc, *jstat;
-    // small device tables owned by the engine
-    const double *temps_mh, *beta, *logl_par, *logp_par;
-    // split path
-    double *Q, *qaux;
-    const double *newlnL, *newlp;
-    // scalars
-    u64 seed;
-    long long iter0;
-    int nsteps;
-    int d, nt, W, ntg, temp0, walker0;
-    int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
-    int cov_update, tskip, per_walker, logp_kind;
-    int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
-};
-
-template <int G>
-__device__ __forceinline__ double group_bcast_lane(double v, int src)
-{
-    // lane `src` (0..G-1) of the caller's group
-    const int lane = (int)(threadIdx.x & 63);
-    return __shfl(v, (lane & ~(G - 1)) + src, 64);
-}
-
-// ----------------------------------------------------------- log-likelihoods
-// All G lanes of a group hold q[e] = element (gl + G*e); pad elements are 0.
-template <int G, int EPL, int LOGL>
-__device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EPL], int gl)
-{
-    const int d = a.d;
-    if (LOGL == PTMI_LOGL_ISO) {
-        double p = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) p = __builtin_fma(q[e], q[e], p);
-        return -0.5 * group_sum<G>(p);
-    } else if (LOGL == PTMI_LOGL_DENSE) {
-        const double *mu = a.logl_par, *Pt = a.logl_par + d;
-        double r[EPL], v[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int i = gl + G * e;
-            r[e] = i < d ? q[e] - mu[i] : 0.0;
-            v[e] = 0.0;
-        }
-#pragma unroll
-        for (int e2 = 0; e2 < EPL; ++e2) {
-            for (int src = 0; src < G; ++src) {
-                const int j = src + G * e2;
-                if (j >= d) break;
-                const double rj = group_bcast_lane<G>(r[e2], src);
-                const double *row = Pt + (size_t)j * d;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int i = gl + G * e;
-                    if (i < d) v[e] = __builtin_fma(row[i], rj, v[e]);
-                }
-            }
-        }
-        double p = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) p = __builtin_fma(r[e], v[e], p);
-        return -0.5 * group_sum<G>(p);
-    } else {  // PTMI_LOGL_CURVED: pairs (2m, 2m+1); G is even so a pair lives in lanes (gl, gl+1) of one slot
-        double p = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int i = gl + G * e;
-            const double y = dppf64<0xB1>(q[e]);  // partner lane (xor 1)
-            double t = 0.0;
-            if (!(gl & 1) && i + 1 < d) {
-                const double x = q[e], x2 = x * x;
-                const double g = 9.0 + 4.0 * x2 + 9.0 * y;
-                const double l0 = -x2 - g * g;
-                const double ym = y - 2.0;
-                const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
-                t = det_log(det_exp(l0) + 0.5 * det_exp(l1));
-            }
-            p = __builtin_fma(t, 1.0, p);
-        }
-        return group_sum<G>(p);
-    }
-}
-
-template <int G, int EPL>
-__device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EPL], int gl)
-{
-    if (a.logp_kind == PTMI_LOGP_BOX) {
-        const double *lo = a.logp_par, *hi = a.logp_par + a.d;
-        bool ok = true;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int i = gl + G * e;
-            if (i < a.d) ok = ok && (lo[i] <= q[e]) && (hi[i] >= q[e]);
-        }
-        return group_all<G>(ok) ? 0.0 : -__builtin_inf();
-    }
-    return 0.0;
-}
-
-// ---------------------------------------------------------------- proposals
-// Per-chain constants of the jump scales, hoisted out of the step loop.  Same operation
-// order as the reference: scale in {10, 0.2, 1.0}; scale *= sqrt(temp) if temp <= 100
-// (PT:846-862); cd = 2.4 / sqrt(2 neff) * scale (PT:870, 928).
-struct ChainConst {
-    double cd_scam[3], cd_am[3];   // by scale branch: prob > 0.97, prob > 0.9, else
-    double de_div, de_mul;         // DE: rr * 2.4 / de_div * de_mul  (PT:976)
-};
-__device__ __forceinline__ ChainConst chain_const(double temp, double beta, int d)
-{
-    ChainConst c;
-    const double sT = temp <= 100.0 ? det_sqrt(temp) : 1.0;
-    const double base[3] = {10.0, 0.2, 1.0};
-    const double c1 = 2.4 / det_sqrt(2.0 * 1.0), cn = 2.4 / det_sqrt(2.0 * (double)d);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double sc = temp <= 100.0 ? base[j] * sT : base[j];
-        c.cd_scam[j] = c1 * sc;
-        c.cd_am[j] = cn * sc;
-    }
-    c.de_div = det_sqrt(2.0 * (double)d);
-    c.de_mul = det_sqrt(1.0 / beta);
-    return c;
-}
-
-// Kernel shapes: (lanes per chain G, register slots per lane EPL); a shape serves
-// G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
-// lane for every ndim the shape serves and need no bounds check.
-constexpr int safe_slots(int G, int EPL)
-{
-    return G == 4 ? (EPL == 26 ? 20 : EPL == 20 ? 13 : EPL == 13 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
-         : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
-         : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
-}
-// element i = gl + G*e of a table row
-#define PTMI_ROW_LOAD(dst, row, e)                                         \
-    do {                                                                   \
-        if ((e) < safe_slots(G, EPL)) dst = (row)[gl + G * (e)];           \
-        else dst = (gl + G * (e)) < d ? (row)[gl + G * (e)] : 0.0;         \
-    } while (0)
-
-// One proposal for the caller's chain (PT:1048-1067, 820-985): writes the increment dq
-// (q = x + dq) and returns the jump type.  log_u = log(accept uniform), evaluated in the
-// same instruction stream as the Box-Muller log, on another lane of each quad.
-template <int G, int EPL, bool FULL>
-__device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc,
-                                       const double *Ut, const double *S, const double *DE,
-                                       double (&dq)[EPL], double &log_u, double &u_acc)
-{
-    const int d = a.d;
-    // the four lanes of a quad evaluate slots A..D of this chain in one pass
-    u64 w0, w1;
-    philox_words(a.seed, (u64)it, sid, (u32)(gl & 3), w0, w1);
-    const u64 A0 = quad_bcast<0>(w0), A1 = quad_bcast<0>(w1);
-    const u64 B0 = quad_bcast<1>(w0), B1 = quad_bcast<1>(w1);
-    // one log stream: lane B -> log(accept uniform), lane D -> log(u1) of the SCAM normal
-    const double larg = (gl & 3) == 1 ? w2uniform(w0) : w2uniform_open(w0);
-    const double lg = det_log(larg);
-    log_u = quad_bcastf<1>(lg);
-    u_acc = w2uniform(B0);
-
-    int jt = PTMI_J_SCAM;
-    if (FULL) {
-        const int L = a.w_host + a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
-        const int pick = (int)w2index(A0, (u64)L);
-        const int ind = pick - a.w_host;
-        jt = ind < a.w_scam ? PTMI_J_SCAM : (ind < a.w_scam + a.w_am ? PTMI_J_AM : PTMI_J_DE);
-        if (ind < 0) {                          // a host-served cycle entry: hand the state back unchanged
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) dq[e] = 0.0;
-            return PTMI_J_NTYPES + pick;
-        }
-    }
-    const double prob = w2uniform(A1);
-    const int br = prob > 0.97 ? 0 : (prob > 0.9 ? 1 : 2);
-
-    if (jt == PTMI_J_SCAM) {
-        const int k = (int)w2index(B1, (u64)d);
-        const double *col = Ut + (size_t)k * d;
-        // the direction lands in dq (issued before the normal is computed, so its latency is covered) and
-        // is scaled in place
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], col, e);
-        const double sk = S[k];
-        const u64 D1 = quad_bcast<3>(w1);
-        const double ln1 = quad_bcastf<3>(lg);
-        const double z = det_sqrt(-2.0 * ln1) * det_cos2pi(w2uniform(D1));
-        const double cd = br == 0 ? cc.cd_scam[0] : (br == 1 ? cc.cd_scam[1] : cc.cd_scam[2]);
-        const double amp = z * cd * det_sqrt(sk);             // PT:873
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) dq[e] = amp * dq[e];
-    } else if (FULL && jt == PTMI_J_AM) {
-        const double cd = br == 0 ? cc.cd_am[0] : (br == 1 ? cc.cd_am[1] : cc.cd_am[2]);
-        double wk[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int k = gl + G * e;
-            dq[e] = 0.0;
-            wk[e] = 0.0;
-            if (k < d) {
-                u64 e0, e1;
-                philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
-                wk[e] = det_normal(e0, e1) * cd * det_sqrt(S[k]);  // PT:930
-            }
-        }
-#pragma unroll
-        for (int e2 = 0; e2 < EPL; ++e2) {
-            for (int src = 0; src < G; ++src) {
-                const int k = src + G * e2;
-                if (k >= d) break;
-                const double wv = group_bcast_lane<G>(wk[e2], src);
-                const double *row = Ut + (size_t)k * d;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    double r;
-                    PTMI_ROW_LOAD(r, row, e);
-                    dq[e] = __builtin_fma(r, wv, dq[e]);
-                }
-            }
-        }
-    } else if (FULL) {
-        const int Bn = a.de_size;
-        const u64 C0 = quad_bcast<2>(w0), C1 = quad_bcast<2>(w1);
-        const int mm = (int)w2index(B1, (u64)Bn);
-        const int nn = (int)(((u64)mm + 1ull + w2index(C0, (u64)(Bn - 1))) % (u64)Bn);
-        double scale;
-        if (prob > 0.5) scale = 1.0;
-        else scale = w2uniform(C1) * 2.4 / cc.de_div * cc.de_mul;  // PT:976
-        const double *rm = DE + (size_t)((mm + a.de_head) % Bn) * d;
-        const double *rn = DE + (size_t)((nn + a.de_head) % Bn) * d;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            double vm, vn;
-            PTMI_ROW_LOAD(vm, rm, e);
-            PTMI_ROW_LOAD(vn, rn, e);
-            dq[e] = scale * (vm - vn);
-        }
-    }
-    return jt;
-}
-
-// XCD-aware block remap: the dispatcher places block b on XCD b % 8; make consecutive
-// logical blocks (chains of one walker, sharing its Ut) land on one XCD's L2.
-__device__ __forceinline__ int logical_block()
-{
-    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
-    return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-}
-
-// ------------------------------------------------------------ fused MH steps
-template <int G, int EPL, int LOGL, bool FULL>
-__global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
-{
-    constexpr int CPB = 256 / G;
-    const int d = a.d, nt = a.nt;
-    const long long nch = (long long)a.W * nt;
-    long long ch = (long long)logical_block() * CPB + (int)(threadIdx.x / G);
-    const bool live = ch < nch;
-    if (!live) ch = nch - 1;
-    const int gl = (int)(threadIdx.x % G);
-    const int w = (int)(ch / nt);
-    const int t = a.temp_of[ch];
-    const int tg = a.temp0 + t;
-    const double beta = a.beta[t];
-    const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
-    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)tg);
-    const size_t wc = a.per_walker ? (size_t)w : 0;
-    const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
-    const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * d : nullptr;
-    double *xrow = a.X + (size_t)ch * d;
-
-    double x[EPL], dq[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
-    double lnL = a.lnL[ch], lp = a.lp[ch];
-    u32 nacc = 0, jp[PTMI_J_NTYPES] = {0, 0, 0}, ja[PTMI_J_NTYPES] = {0, 0, 0};
-    const bool cold = live && tg == 0 && a.AM != nullptr;
-    int am_row = a.am_row0;
-
-    for (int k = 0; k < a.nsteps; ++k) {
-        const long long it = a.iter0 + k;
-        double log_u, u_acc;
-        const int jt = propose<G, EPL, FULL>(a, it, sid, gl, cc, Ut, S, DE, dq, log_u, u_acc);
-        if (FULL) {
-#pragma unroll
-            for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
-        }
-        // PT:605-612
-        double nlp, nlnL = 0.0, nlnprob;
-        {
-            double q[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
-            nlp = eval_logp<G, EPL>(a, q, gl);
-            if (nlp == -__builtin_inf()) nlnprob = -__builtin_inf();
-            else {
-                nlnL = eval_logl<G, EPL, LOGL>(a, q, gl);
-                nlnprob = beta * nlnL + nlp;
-            }
-        }
-        // PT:615-622
-        const double lnprob0 = beta * lnL + lp;
-        const double diff = nlnprob - lnprob0 + 0.0;
-        if (diff > log_u) {
-            // x + dq again (bit-identical to q); keeping q alive instead would cost EPL more registers
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                double inc = dq[e];
-                asm volatile("" : "+v"(inc));
-                x[e] = x[e] + inc;
-            }
-            lnL = nlnL;
-            lp = nlp;
-            nacc += 1;
-            if (FULL) {
-#pragma unroll
-                for (int j = 0; j < PTMI_J_NTYPES; ++j) ja[j] += (jt == j);
-            }
-        }
-        // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
-        if (cold && !(a.swap_last && k == a.nsteps - 1)) {
-            double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int i = gl + G * e;
-                if (e < safe_slots(G, EPL) || i < d) am[i] = x[e];
-            }
-            if (a.AMaux && gl == 0) {
-                double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
-                ax[0] = lnL;
-                ax[1] = lp;
-            }
-        }
-        am_row = am_row + 1 == a.cov_update ? 0 : am_row + 1;
-    }
-    if (live) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int i = gl + G * e;
-            if (e < safe_slots(G, EPL) || i < d) xrow[i] = x[e];
-        }
-        if (gl == 0) {
-            a.lnL[ch] = lnL;
-            a.lp[ch] = lp;
-            const size_t r = (size_t)w * nt + t;
-            a.nacc[r] += nacc;
-            if (!FULL) { jp[PTMI_J_SCAM] = (u32)a.nsteps; ja[PTMI_J_SCAM] = nacc; }
-#pragma unroll
-            for (int j = 0; j < PTMI_J_NTYPES; ++j) {
-                a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 0] += jp[j];
-                a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 1] += ja[j];
-            }
-        }
-    }
-}
-
-// split path: proposal only / accept only, one iteration (host likelihood callbacks)
-template <int G, int EPL>
-__global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
-{
-    constexpr int CPB = 256 / G;
-    const int d = a.d, nt = a.nt;
-    const long long nch = (long long)a.W * nt;
-    long long ch = (long long)logical_block() * CPB + (int)(threadIdx.x / G);
-    const bool live = ch < nch;
-    if (!live) ch = nch - 1;
-    const int gl = (int)(threadIdx.x % G);
-    const int w = (int)(ch / nt);
-    const int t = a.temp_of[ch];
-    const double beta = a.beta[t];
-    const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
-    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)(a.temp0 + t));
-    const size_t wc = a.per_walker ? (size_t)w : 0;
-    const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
-    const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
-    const double *xrow = a.X + (size_t)ch * d;
-    double x[EPL], dq[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
-    double log_u, u_acc;
-    const int jt = propose<G, EPL, true>(a, a.iter0, sid, gl, cc, Ut, S, DE, dq, log_u, u_acc);
-    if (live) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int i = gl + G * e;
-            if (i < d) a.Q[(size_t)ch * d + i] = x[e] + dq[e];
-        }
-        if (gl == 0) {
-            a.qaux[ch * 4 + 0] = 0.0;  // qxy of the built-in jumps (PT:836,894,952)
-            a.qaux[ch * 4 + 1] = (double)jt;
-            a.qaux[ch * 4 + 2] = u_acc;
-            a.qaux[ch * 4 + 3] = log_u;
-        }
-    }
-}
-
-template <int G, int EPL>
-__global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
-{
-    constexpr int CPB = 256 / G;
-    const int d = a.d, nt = a.nt;
-    const long long nch = (long long)a.W * nt;
-    const long long ch = (long long)logical_block() * CPB + (int)(threadIdx.x / G);
-    if (ch >= nch) return;
-    const int gl = (int)(threadIdx.x % G);
-    const int w = (int)(ch / nt);
-    const int t = a.temp_of[ch];
-    const double beta = a.beta[t];
-    const double nlp = a.newlp[ch];
-    const double nlnL = a.newlnL[ch];
-    const double nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
-    const double lnprob0 = beta * a.lnL[ch] + a.lp[ch];
-    const double diff = nlnprob - lnprob0 + a.qaux[ch * 4 + 0];
-    const int jt = (int)a.qaux[ch * 4 + 1];
-    const bool acc = diff > a.qaux[ch * 4 + 3];
-    const bool cold = a.temp0 + t == 0 && a.AM != nullptr;
-    double *am = cold && !a.swap_last ? a.AM + ((size_t)w * a.cov_update + (size_t)a.am_row0) * d : nullptr;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = gl + G * e;
-        if (i < d) {
-            const double v = acc ? a.Q[(size_t)ch * d + i] : a.X[(size_t)ch * d + i];
-            if (acc) a.X[(size_t)ch * d + i] = v;
-            if (am) am[i] = v;
-        }
-    }
-    if (gl == 0) {
-        const size_t r = (size_t)w * nt + t;
-        if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 0] += 1;
-        if (am && a.AMaux) {
-            double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)a.am_row0) * 2;
-            ax[0] = acc ? nlnL : a.lnL[ch];
-            ax[1] = acc ? nlp : a.lp[ch];
-        }
-        if (acc) {
-            a.lnL[ch] = nlnL;
-            a.lp[ch] = nlp;
-            a.nacc[r] += 1;
-            if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 1] += 1;
-        }
-        a.qaux[ch * 4 + 2] = acc ? 1.0 : 0.0;   // decision, for the host's per-name jump statistics
-    }
-}
-
-// initial lnL / lp (PT:479-487)
-template <int G, int EPL, int LOGL>
-__global__ __launch_bounds__(256) void eval_state_kernel(const KArgs a)
-{
-    constexpr int CPB = 256 / G;
-    const int d = a.d;
-    const long long nch = (long long)a.W * a.nt;
-    long long ch = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
-    const bool live = ch < nch;
-    if (!live) ch = nch - 1;
-    const int gl = (int)(threadIdx.x % G);
-    double x[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = gl + G * e;
-        x[e] = i < d ? a.X[(size_t)ch * d + i] : 0.0;
-    }
-    const double lp = eval_logp<G, EPL>(a, x, gl);
-    double lnL = -__builtin_inf();
-    if (lp != -__builtin_inf()) lnL = eval_logl<G, EPL, LOGL>(a, x, gl);
-    if (live && gl == 0) {
-        a.lp[ch] = lp;
-        a.lnL[ch] = lnL;
-    }
 }
 
 // --------------------------------------------------------------------- swap
@@ -762,22 +269,12 @@ __global__ void selftest_philox_kernel(const u32 *ck, u32 *out, long long n)
 }
 
 // ------------------------------------------------------------------- engine
-struct ptmi_engine {
-    ptmi_config cfg;
-    ptmi_buffers buf;
-    hipStream_t stream;
-    double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar;
-    double *d_lnlpos;   // [W][ntg] scratch for the fused swap
-    double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
-    int G, EPL;
-    int de_on, de_head;
-    hipEvent_t ev0, ev1;
-};
-
 struct Shape { int G, EPL; };
 static bool pick_shape(int d, Shape *s)
 {
-    static const Shape table[] = {{4, 2}, {4, 5}, {4, 8}, {4, 13}, {4, 20}, {4, 26}, {16, 7}, {16, 13}, {16, 26}, {64, 8}, {64, 16}, {64, 32}};
+    static const Shape table[] = {
+#define PTMI_TABLE_ENTRY(G_, E_) {G_, E_},
+        PTMI_SHAPE_LIST(PTMI_TABLE_ENTRY)};
     const int G = ptmi_lanes_for(d);
     for (const Shape &c : table)
         if (c.G == G && c.G * c.EPL >= d) { *s = c; return true; }
@@ -802,46 +299,20 @@ static KArgs make_args(ptmi_engine *h)
     return a;
 }
 
-template <int G, int EPL, int LOGL>
-static void launch_mh_l(ptmi_engine *h, const KArgs &a, int grid, bool full)
+static ptmi_shape_fn shape_fn(int G, int EPL, int L)
 {
-    if (full) hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, true>), dim3(grid), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, false>), dim3(grid), dim3(256), 0, h->stream, a);
+#define PTMI_PICK_SHAPE(G_, E_)                                                                        \
+    if (G == G_ && EPL == E_) return L == 0 ? ptmi_shape_##G_##_##E_##_0 : (L == 1 ? ptmi_shape_##G_##_##E_##_1 : ptmi_shape_##G_##_##E_##_2);
+    PTMI_SHAPE_LIST(PTMI_PICK_SHAPE)
+    return nullptr;
 }
-template <int G, int EPL>
-static void launch_mh(ptmi_engine *h, const KArgs &a, int grid, bool full)
+static int run_shape(ptmi_engine *h, int op, KArgs &a, int grid, bool full)
 {
-    switch (h->cfg.logl_kind) {
-    case PTMI_LOGL_ISO: launch_mh_l<G, EPL, PTMI_LOGL_ISO>(h, a, grid, full); break;
-    case PTMI_LOGL_DENSE: launch_mh_l<G, EPL, PTMI_LOGL_DENSE>(h, a, grid, full); break;
-    default: launch_mh_l<G, EPL, PTMI_LOGL_CURVED>(h, a, grid, full); break;
-    }
+    const int L = (op == PTMI_OP_PROPOSE || op == PTMI_OP_ACCEPT) ? 0 : h->cfg.logl_kind;
+    ptmi_shape_fn f = shape_fn(h->G, h->EPL, L);
+    if (!f) return fail(PTMI_EUNSUPPORTED, "no kernel shape for ndim=%d", h->cfg.ndim);
+    return f(op, h, a, grid, full);
 }
-template <int G, int EPL>
-static void launch_eval(ptmi_engine *h, const KArgs &a, int grid)
-{
-    switch (h->cfg.logl_kind) {
-    case PTMI_LOGL_ISO: hipLaunchKernelGGL((eval_state_kernel<G, EPL, PTMI_LOGL_ISO>), dim3(grid), dim3(256), 0, h->stream, a); break;
-    case PTMI_LOGL_DENSE: hipLaunchKernelGGL((eval_state_kernel<G, EPL, PTMI_LOGL_DENSE>), dim3(grid), dim3(256), 0, h->stream, a); break;
-    default: hipLaunchKernelGGL((eval_state_kernel<G, EPL, PTMI_LOGL_CURVED>), dim3(grid), dim3(256), 0, h->stream, a); break;
-    }
-}
-
-#define FOR_SHAPE(G_, E_, CALL)                       \
-    if (h->G == G_ && h->EPL == E_) { CALL(G_, E_); } else
-
-#ifdef PTMI_ONLY_BENCH_SHAPE   /* developer switch: compile the d=100 shape only (fast asm inspection builds) */
-#ifndef PTMI_DEV_G
-#define PTMI_DEV_G 4
-#define PTMI_DEV_E 26
-#endif
-#define DISPATCH_SHAPE(CALL) FOR_SHAPE(PTMI_DEV_G, PTMI_DEV_E, CALL) { return fail(PTMI_EUNSUPPORTED, "shape not compiled in"); }
-#else
-#define DISPATCH_SHAPE(CALL)                                                                        \
-    FOR_SHAPE(4, 2, CALL) FOR_SHAPE(4, 5, CALL) FOR_SHAPE(4, 8, CALL) FOR_SHAPE(4, 13, CALL)        \
-    FOR_SHAPE(4, 20, CALL) FOR_SHAPE(4, 26, CALL) FOR_SHAPE(16, 7, CALL) FOR_SHAPE(16, 13, CALL)    \
-    FOR_SHAPE(16, 26, CALL) FOR_SHAPE(64, 8, CALL) FOR_SHAPE(64, 16, CALL) FOR_SHAPE(64, 32, CALL) { return fail(PTMI_EUNSUPPORTED, "no kernel shape for ndim=%d", h->cfg.ndim); }
-#endif
 
 // am_row0 / swap_last of a launch; a swap iteration may only be the last one of the range
 static int set_step_args(const ptmi_engine *h, KArgs *a)
@@ -978,8 +449,8 @@ int ptmi_eval_state(ptmi_handle h)
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
     const KArgs a = make_args(h);
     const int grid = chains_grid(h);
-#define CALL_EVAL(G_, E_) launch_eval<G_, E_>(h, a, grid)
-    DISPATCH_SHAPE(CALL_EVAL)
+    KArgs aa = a;
+    if (int rc = run_shape(h, PTMI_OP_EVAL, aa, grid, false)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -996,8 +467,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     const bool full = h->cfg.w_am > 0 || (h->de_on && h->cfg.w_de > 0);
     if (!full && h->cfg.w_scam <= 0) return fail(PTMI_EINVAL, "empty proposal cycle");
     const int grid = chains_grid(h);
-#define CALL_MH(G_, E_) launch_mh<G_, E_>(h, a, grid, full)
-    DISPATCH_SHAPE(CALL_MH)
+    if (int rc = run_shape(h, PTMI_OP_MH, a, grid, full)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -1010,8 +480,7 @@ int ptmi_propose(ptmi_handle h, int64_t iter)
     a.iter0 = iter; a.nsteps = 1;
     if (int rc = set_step_args(h, &a)) return rc;
     const int grid = chains_grid(h);
-#define CALL_PROP(G_, E_) hipLaunchKernelGGL((propose_kernel<G_, E_>), dim3(grid), dim3(256), 0, h->stream, a)
-    DISPATCH_SHAPE(CALL_PROP)
+    if (int rc = run_shape(h, PTMI_OP_PROPOSE, a, grid, true)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -1024,8 +493,7 @@ int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL, const double 
     a.iter0 = iter; a.nsteps = 1; a.newlnL = newlnL; a.newlp = newlp;
     if (int rc = set_step_args(h, &a)) return rc;
     const int grid = chains_grid(h);
-#define CALL_ACC(G_, E_) hipLaunchKernelGGL((accept_kernel<G_, E_>), dim3(grid), dim3(256), 0, h->stream, a)
-    DISPATCH_SHAPE(CALL_ACC)
+    if (int rc = run_shape(h, PTMI_OP_ACCEPT, a, grid, true)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -1,0 +1,79 @@
+// ptmi_common.h -- declarations shared by the translation units of libptmi.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ptmi.h"
+#include "ptmi_device.h"
+
+using namespace ptmi;
+
+// thread-local error message of the C ABI (defined in ptmi_abi.hip)
+int ptmi_fail(int code, const char *fmt, ...);
+#define fail ptmi_fail
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(PTMI_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------- kernel args
+struct KArgs {
+    // state
+    double *X, *lnL, *lp;
+    int32_t *temp_of, *slot_of;
+    const double *Ut, *S, *DE;
+    double *AM, *AMaux;
+    u64 *nacc, *jstat;
+    // small device tables owned by the engine
+    const double *temps_mh, *beta, *logl_par, *logp_par;
+    // split path
+    double *Q, *qaux;
+    const double *newlnL, *newlp;
+    // scalars
+    u64 seed;
+    long long iter0;
+    int nsteps;
+    int d, nt, W, ntg, temp0, walker0;
+    int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
+    int cov_update, tskip, per_walker, logp_kind;
+    int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
+};
+
+template <int G>
+__device__ __forceinline__ double group_bcast_lane(double v, int src)
+{
+    // lane `src` (0..G-1) of the caller's group
+    const int lane = (int)(threadIdx.x & 63);
+    return __shfl(v, (lane & ~(G - 1)) + src, 64);
+}
+
+// ------------------------------------------------------------------- engine
+struct ptmi_engine {
+    ptmi_config cfg;
+    ptmi_buffers buf;
+    hipStream_t stream;
+    double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar;
+    double *d_lnlpos;   // [W][ntg] scratch for the fused swap
+    double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
+    int G, EPL;
+    int de_on, de_head;
+    hipEvent_t ev0, ev1;
+};
+
+
+// The per-chain kernels are templates over the shape (lanes per chain G, register slots per lane EPL).  Each shape
+// and likelihood family is compiled in its own translation unit (ptmi_shape.hip with -DPTMI_G -DPTMI_E -DPTMI_L) so
+// the build runs in parallel;
+// this is the entry point a shape unit exports.
+enum { PTMI_OP_MH = 0, PTMI_OP_EVAL = 1, PTMI_OP_PROPOSE = 2, PTMI_OP_ACCEPT = 3 };
+typedef int (*ptmi_shape_fn)(int op, ptmi_engine *h, KArgs &a, int grid, bool full);
+#define PTMI_SHAPE_LIST(X) X(4, 2) X(4, 5) X(4, 8) X(4, 14) X(4, 20) X(4, 26) X(16, 7) X(16, 13) X(16, 26) X(64, 8) X(64, 16) X(64, 32)
+// one unit per (shape, likelihood family); the split-path kernels live in the family-0 unit
+#define PTMI_DECLARE_SHAPE(G_, E_)                                                        \
+    int ptmi_shape_##G_##_##E_##_0(int op, ptmi_engine *h, KArgs &a, int grid, bool full); \
+    int ptmi_shape_##G_##_##E_##_1(int op, ptmi_engine *h, KArgs &a, int grid, bool full); \
+    int ptmi_shape_##G_##_##E_##_2(int op, ptmi_engine *h, KArgs &a, int grid, bool full);
+PTMI_SHAPE_LIST(PTMI_DECLARE_SHAPE)

@@ -128,7 +128,8 @@ __device__ __forceinline__ double det_exp(double x)
     return __longlong_as_double((long long)(yb + ((u64)(long long)(k + 1000) << 52))) * 0x1.0p-1000;
 }
 
-__device__ __forceinline__ double det_cos2pi(double u)
+// cos(2 pi u) and sin(2 pi u), u in [0,1): exact quarter-turn reduction, Taylor in r
+__device__ __forceinline__ void det_sincos2pi(double u, double &sn_out, double &cs_out)
 {
     const double a = 4.0 * u;
     const double q = __builtin_floor(a + 0.5);
@@ -145,7 +146,7 @@ __device__ __forceinline__ double det_cos2pi(double u)
     ps = __builtin_fma(ps, z, 0x1.466bc6775aae2p-4);
     ps = __builtin_fma(ps, z, -0x1.4abbce625be53p-1);
     ps = __builtin_fma(ps, z, 0x1.921fb54442d18p+0);
-    const double sn = ps * r;
+    const double sn = ps * r;       // sin(pi r / 2)
     double pc = 0x1.ef6e308d6d1c4p-49;
     pc = __builtin_fma(pc, z, -0x1.2a0c591af8314p-41);
     pc = __builtin_fma(pc, z, 0x1.20c62c2f2d7f5p-34);
@@ -156,9 +157,23 @@ __device__ __forceinline__ double det_cos2pi(double u)
     pc = __builtin_fma(pc, z, -0x1.55d3c7e3cbffap-6);
     pc = __builtin_fma(pc, z, 0x1.03c1f081b5ac4p-2);
     pc = __builtin_fma(pc, z, -0x1.3bd3cc9be45dep+0);
-    pc = __builtin_fma(pc, z, 1.0);
-    const double v = (qi & 1) ? sn : pc;
-    return (qi == 1 || qi == 2) ? -v : v;
+    pc = __builtin_fma(pc, z, 1.0);  // cos(pi r / 2)
+    const double cv = (qi & 1) ? sn : pc;
+    cs_out = (qi == 1 || qi == 2) ? -cv : cv;
+    const double sv = (qi & 1) ? pc : sn;
+    sn_out = (qi >= 2) ? -sv : sv;
+}
+__device__ __forceinline__ double det_cos2pi(double u)
+{
+    double s, c;
+    det_sincos2pi(u, s, c);
+    return c;
+}
+__device__ __forceinline__ double det_sin2pi(double u)
+{
+    double s, c;
+    det_sincos2pi(u, s, c);
+    return s;
 }
 
 __device__ __forceinline__ double det_sqrt(double x) { return __dsqrt_rn(x); }

@@ -1,0 +1,22 @@
+// ptmi_shape.hip -- one kernel shape per translation unit: compile with -DPTMI_G=<lanes> -DPTMI_E=<slots>.
+#include "ptmi_mh.inc.h"
+
+#if !defined(PTMI_G) || !defined(PTMI_E) || !defined(PTMI_L)
+#error "compile with -DPTMI_G=<lanes per chain> -DPTMI_E=<register slots per lane> -DPTMI_L=<likelihood family>"
+#endif
+#define PTMI_CAT_(a, b, c) ptmi_shape_##a##_##b##_##c
+#define PTMI_CAT(a, b, c) PTMI_CAT_(a, b, c)
+
+int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid, bool full)
+{
+    constexpr int G = PTMI_G, E = PTMI_E, L = PTMI_L;
+    switch (op) {
+    case PTMI_OP_MH: return launch_mh_l<G, E, L>(h, a, grid, full);
+    case PTMI_OP_EVAL: hipLaunchKernelGGL((eval_state_kernel<G, E, L>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
+#if PTMI_L == 0
+    case PTMI_OP_PROPOSE: hipLaunchKernelGGL((propose_kernel<G, E>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
+    case PTMI_OP_ACCEPT: hipLaunchKernelGGL((accept_kernel<G, E>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
+#endif
+    }
+    return fail(PTMI_EINVAL, "unknown shape op %d", op);
+}

@@ -46,6 +46,9 @@ def test_math_close_to_libm():
     err = max(abs(L.orc_cos2pi(float(u)) - float(mpmath.cos(2 * mpmath.pi * mpmath.mpf(float(u))))) for u in us)
     assert err < 2.3e-16                                  # about one ulp at |cos| ~ 1
     assert L.orc_cos2pi(0.25) == 0.0 and L.orc_cos2pi(0.5) == -1.0 and L.orc_cos2pi(0.0) == 1.0
+    err = max(abs(L.orc_sin2pi(float(u)) - float(mpmath.sin(2 * mpmath.pi * mpmath.mpf(float(u))))) for u in us)
+    assert err < 2.3e-16
+    assert L.orc_sin2pi(0.25) == 1.0 and L.orc_sin2pi(0.5) == 0.0 and L.orc_sin2pi(0.75) == -1.0
 
 
 def test_normal_and_uniform_moments():
@@ -53,6 +56,8 @@ def test_normal_and_uniform_moments():
     rs = np.random.RandomState(1)
     w = rs.randint(0, 2 ** 63, size=(200000, 2)).astype(np.uint64) * np.uint64(2) + rs.randint(0, 2, (200000, 2)).astype(np.uint64)
     z = np.array([L.orc_normal(int(a), int(b)) for a, b in w[:50000]])
+    zs = np.array([L.orc_normal_sin(int(a), int(b)) for a, b in w[:50000]])
+    assert abs(zs.mean()) < 0.02 and abs(zs.std() - 1) < 0.02 and abs(np.corrcoef(z, zs)[0, 1]) < 0.02
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 4).mean() - 3) < 0.15
     assert L.orc_uniform(2 ** 64 - 1) < 1.0 and L.orc_uniform(0) == 0.0
     assert L.orc_index(2 ** 64 - 1, 10) == 9 and L.orc_index(0, 10) == 0
