@@ -40,6 +40,7 @@ struct KArgs {
     int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
     int cov_update, tskip, per_walker, logp_kind;
     int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
+    int lds_u;                   // staged kernels: the block's Ut is copied to LDS (else read from global)
 };
 
 template <int G>

@@ -4,9 +4,100 @@
 #pragma once
 #include "ptmi_common.h"
 
+// ------------------------------------------------------------- lane groups
+// Contiguous layout (STR = false): the G lanes of a chain are adjacent (a quad for G = 4).
+// Strided layout (STR = true, G = 4 only): chain c of a wave owns lanes {c, c+16, c+32, c+48}, gl = lane >> 4.
+// That is the C/D layout of v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 reg), so a
+// table-times-vector product computed on the matrix cores lands directly in the chain's registers (below).
+// Pairing orders of the reductions are the same in both layouts, so results are bit-identical.
+template <bool STR, int J>
+__device__ __forceinline__ u64 grp_bcast(u64 v)
+{
+    if (STR) return (u64)__shfl((long long)v, (int)(threadIdx.x & 15) + 16 * J, 64);
+    return quad_bcast<J>(v);
+}
+template <bool STR, int J>
+__device__ __forceinline__ double grp_bcastf(double v)
+{
+    if (STR) return __shfl(v, (int)(threadIdx.x & 15) + 16 * J, 64);
+    return quad_bcastf<J>(v);
+}
+template <int G, bool STR>
+__device__ __forceinline__ double grp_sum(double p)
+{
+    if (STR) {
+        p = p + __shfl_xor(p, 32, 64);   // gl ^ 2
+        p = p + __shfl_xor(p, 16, 64);   // gl ^ 1
+        return p;
+    }
+    return group_sum<G>(p);
+}
+template <int G, bool STR>
+__device__ __forceinline__ bool grp_all(bool ok)
+{
+    if (STR) {
+        const u64 m = __ballot(ok) >> (threadIdx.x & 15);
+        return (m & 0x0001000100010001ull) == 0x0001000100010001ull;
+    }
+    return group_all<G>(ok);
+}
+template <bool STR>
+__device__ __forceinline__ double grp_xor1(double v)
+{
+    if (STR) return __shfl_xor(v, 16, 64);
+    return dppf64<0xB1>(v);
+}
+
+// out[e] = sum_k T[k][i] * vec_k  for the caller's elements i = gl + 4 e, all 16 chains of the wave at once, on
+// v_mfma_f64_16x16x4_f64 (strided layout).  The instruction is a k-ascending fma chain (tools/mfma_probe.hip),
+// i.e. exactly the order of the scalar definition.  T is row-major with leading dimension ld.  PADDED: T has
+// 4*ceil(d/4) rows and 16*NT columns, zero filled (the LDS copy); otherwise bounds are checked per lane.
+// Must be called by ALL lanes of the wave (the A operand of a matrix instruction comes from every lane).
+typedef double ptmi_d4 __attribute__((ext_vector_type(4)));
+template <int EPL>
+struct MfmaAcc {
+    static constexpr int NT = (4 * EPL + 15) / 16;
+    ptmi_d4 t[NT];
+    __device__ __forceinline__ double at(int e) const { return t[e >> 2][e & 3]; }   // element gl + 4e (compile-time e)
+};
+template <int EPL, bool PADDED>
+__device__ __forceinline__ void mfma_tab_vec(const double *T, int ld, int d, const double (&vec)[EPL], MfmaAcc<EPL> &acc)
+{
+    constexpr int NT = MfmaAcc<EPL>::NT;
+    const int c = (int)(threadIdx.x & 15), g = (int)((threadIdx.x & 63) >> 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc.t[t] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
+    // software pipeline of depth one: the table row block of step e+1 is in flight while step e multiplies; the
+    // scheduling barrier keeps the compiler from hoisting all 4*EPL*NT/4 loads to the top (register blow-up)
+    double cur[NT], nxt[NT];
+    auto fetch = [&](int e, double (&dst)[NT]) {
+        const int k = 4 * e + g;
+        const double *row = T + (size_t)k * ld + c;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (PADDED) dst[t] = row[16 * t];
+            else dst[t] = (k < d && 16 * t + c < d) ? row[16 * t] : 0.0;
+        }
+    };
+    fetch(0, cur);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        if (4 * e < d) {                                   // wave-uniform
+            if (e + 1 < EPL && 4 * (e + 1) < d) fetch(e + 1, nxt);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t], vec[e], acc.t[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+constexpr int mfma_ld(int EPL) { return 16 * ((4 * EPL + 15) / 16); }
+
 // ----------------------------------------------------------- log-likelihoods
 // All G lanes of a group hold q[e] = element (gl + G*e); pad elements are 0.
-template <int G, int EPL, int LOGL>
+// STR: strided lane layout; with it the dense product runs on the matrix cores from the LDS copy of Pt.
+template <int G, int EPL, int LOGL, bool STR>
 __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EPL], int gl, const double *Pt)
 {
     const int d = a.d;
@@ -14,7 +105,7 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
         double p = 0.0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) p = __builtin_fma(q[e], q[e], p);
-        return -0.5 * group_sum<G>(p);
+        return -0.5 * grp_sum<G, STR>(p);
     } else if (LOGL == PTMI_LOGL_DENSE) {
         const double *mu = a.logl_par;
         double r[EPL], v[EPL];
@@ -23,6 +114,14 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
             const int i = gl + G * e;
             r[e] = i < d ? q[e] - mu[i] : 0.0;
             v[e] = 0.0;
+        }
+        if (STR) {
+            MfmaAcc<EPL> acc;
+            mfma_tab_vec<EPL, true>(Pt, mfma_ld(EPL), d, r, acc);
+            double p = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) p = __builtin_fma(r[e], acc.at(e), p);
+            return -0.5 * grp_sum<G, STR>(p);
         }
 #pragma unroll
         for (int e2 = 0; e2 < EPL; ++e2) {
@@ -42,13 +141,13 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
         double p = 0.0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) p = __builtin_fma(r[e], v[e], p);
-        return -0.5 * group_sum<G>(p);
+        return -0.5 * grp_sum<G, STR>(p);
     } else {  // PTMI_LOGL_CURVED: pairs (2m, 2m+1); G is even so a pair lives in lanes (gl, gl+1) of one slot
         double p = 0.0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = gl + G * e;
-            const double y = dppf64<0xB1>(q[e]);  // partner lane (xor 1)
+            const double y = grp_xor1<STR>(q[e]);  // partner lane (gl ^ 1)
             double t = 0.0;
             if (!(gl & 1) && i + 1 < d) {
                 const double x = q[e], x2 = x * x;
@@ -60,11 +159,11 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
             }
             p = __builtin_fma(t, 1.0, p);
         }
-        return group_sum<G>(p);
+        return grp_sum<G, STR>(p);
     }
 }
 
-template <int G, int EPL>
+template <int G, int EPL, bool STR>
 __device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EPL], int gl)
 {
     if (a.logp_kind == PTMI_LOGP_BOX) {
@@ -75,7 +174,7 @@ __device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EP
             const int i = gl + G * e;
             if (i < a.d) ok = ok && (lo[i] <= q[e]) && (hi[i] >= q[e]);
         }
-        return group_all<G>(ok) ? 0.0 : -__builtin_inf();
+        return grp_all<G, STR>(ok) ? 0.0 : -__builtin_inf();
     }
     return 0.0;
 }
@@ -124,21 +223,24 @@ constexpr int safe_slots(int G, int EPL)
 // One proposal for the caller's chain (PT:1048-1067, 820-985): writes the increment dq
 // (q = x + dq) and returns the jump type.  log_u = log(accept uniform), evaluated in the
 // same instruction stream as the Box-Muller log, on another lane of each quad.
-template <int G, int EPL, bool FULL>
+// STR: strided lane layout (see "lane groups"); then Ut is the zero-padded LDS copy when ut_padded, and the AM
+// product runs on the matrix cores for all 16 chains of the wave at once.
+template <int G, int EPL, bool FULL, bool STR>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc,
-                                       const double *Ut, const double *S, const double *DE,
+                                       const double *Ut, bool ut_padded, const double *S, const double *DE,
                                        double (&dq)[EPL], double &log_u, double &u_acc)
 {
     const int d = a.d;
+    const int uld = (STR && ut_padded) ? mfma_ld(EPL) : d;   // leading dimension of the Ut table
     // the four lanes of a quad evaluate slots A..D of this chain in one pass
     u64 w0, w1;
     philox_words(a.seed, (u64)it, sid, (u32)(gl & 3), w0, w1);
-    const u64 A0 = quad_bcast<0>(w0), A1 = quad_bcast<0>(w1);
-    const u64 B0 = quad_bcast<1>(w0), B1 = quad_bcast<1>(w1);
+    const u64 A0 = grp_bcast<STR, 0>(w0), A1 = grp_bcast<STR, 0>(w1);
+    const u64 B0 = grp_bcast<STR, 1>(w0), B1 = grp_bcast<STR, 1>(w1);
     // one log stream: lane B -> log(accept uniform), lane D -> log(u1) of the SCAM normal
     const double larg = (gl & 3) == 1 ? w2uniform(w0) : w2uniform_open(w0);
     const double lg = det_log(larg);
-    log_u = quad_bcastf<1>(lg);
+    log_u = grp_bcastf<STR, 1>(lg);
     u_acc = w2uniform(B0);
 
     int jt = PTMI_J_SCAM;
@@ -150,66 +252,31 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         if (ind < 0) {                          // a host-served cycle entry: hand the state back unchanged
 #pragma unroll
             for (int e = 0; e < EPL; ++e) dq[e] = 0.0;
-            return PTMI_J_NTYPES + pick;
+            jt = PTMI_J_NTYPES + pick;
         }
     }
     const double prob = w2uniform(A1);
     const int br = prob > 0.97 ? 0 : (prob > 0.9 ? 1 : 2);
+    // the words of slots C and D are fetched outside the divergent branches (cross-lane reads need their source active)
+    const u64 C0 = FULL ? grp_bcast<STR, 2>(w0) : 0, C1 = FULL ? grp_bcast<STR, 2>(w1) : 0;
+    const u64 D1 = grp_bcast<STR, 3>(w1);
+    const double ln1 = grp_bcastf<STR, 3>(lg);
 
     if (jt == PTMI_J_SCAM) {
         const int k = (int)w2index(B1, (u64)d);
-        const double *col = Ut + (size_t)k * d;
+        const double *col = Ut + (size_t)k * uld;
         // the direction lands in dq (issued before the normal is computed, so its latency is covered) and
         // is scaled in place
 #pragma unroll
         for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], col, e);
         const double sk = S[k];
-        const u64 D1 = quad_bcast<3>(w1);
-        const double ln1 = quad_bcastf<3>(lg);
         const double z = det_sqrt(-2.0 * ln1) * det_cos2pi(w2uniform(D1));
         const double cd = br == 0 ? cc.cd_scam[0] : (br == 1 ? cc.cd_scam[1] : cc.cd_scam[2]);
         const double amp = z * cd * det_sqrt(sk);             // PT:873
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dq[e] = amp * dq[e];
-    } else if (FULL && jt == PTMI_J_AM) {
-        const double cd = br == 0 ? cc.cd_am[0] : (br == 1 ? cc.cd_am[1] : cc.cd_am[2]);
-        double wk[EPL];
-        // directions k = gl + G*e and k + G (slots e even / odd) are the cos and sin branches of ONE Box-Muller
-#pragma unroll
-        for (int e = 0; e < EPL; e += 2) {
-            const int k = gl + G * e;
-            dq[e] = 0.0;
-            wk[e] = 0.0;
-            if (e + 1 < EPL) { dq[e + 1] = 0.0; wk[e + 1] = 0.0; }
-            if (k < d) {
-                u64 e0, e1;
-                philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
-                const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
-                double sn, cs;
-                det_sincos2pi(w2uniform(e1), sn, cs);
-                wk[e] = (r * cs) * cd * det_sqrt(S[k]);                        // PT:930
-                if (e + 1 < EPL && k + G < d) wk[e + 1] = (r * sn) * cd * det_sqrt(S[k + G]);
-            }
-        }
-#pragma unroll
-        for (int e2 = 0; e2 < EPL; ++e2) {
-#pragma unroll 1
-            for (int src = 0; src < G; ++src) {
-                const int k = src + G * e2;
-                if (k >= d) break;
-                const double wv = group_bcast_lane<G>(wk[e2], src);
-                const double *row = Ut + (size_t)k * d;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    double r;
-                    PTMI_ROW_LOAD(r, row, e);
-                    dq[e] = __builtin_fma(r, wv, dq[e]);
-                }
-            }
-        }
-    } else if (FULL) {
+    } else if (FULL && jt == PTMI_J_DE) {
         const int Bn = a.de_size;
-        const u64 C0 = quad_bcast<2>(w0), C1 = quad_bcast<2>(w1);
         const int mm = (int)w2index(B1, (u64)Bn);
         const int nn = (int)(((u64)mm + 1ull + w2index(C0, (u64)(Bn - 1))) % (u64)Bn);
         double scale;
@@ -225,6 +292,61 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
             dq[e] = scale * (vm - vn);
         }
     }
+    if (FULL) {
+        // AM (PT:879-933): q = x + U (cd sqrt(S) z).  Weights per chain (divergent), product per wave.
+        const bool is_am = jt == PTMI_J_AM;
+        if (!STR ? is_am : __any(is_am)) {
+            const double cd = br == 0 ? cc.cd_am[0] : (br == 1 ? cc.cd_am[1] : cc.cd_am[2]);
+            double wk[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) wk[e] = 0.0;
+            if (is_am) {
+                // directions k = gl + G*e and k + G (slots e even / odd) are the cos and sin branches of ONE Box-Muller
+#pragma unroll
+                for (int e = 0; e < EPL; e += 2) {
+                    const int k = gl + G * e;
+                    if (k < d) {
+                        u64 e0, e1;
+                        philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
+                        const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
+                        double sn, cs;
+                        det_sincos2pi(w2uniform(e1), sn, cs);
+                        wk[e] = (r * cs) * cd * det_sqrt(S[k]);                        // PT:930
+                        if (e + 1 < EPL && k + G < d) wk[e + 1] = (r * sn) * cd * det_sqrt(S[k + G]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // one Box-Muller at a time: interleaving them only costs registers
+                }
+            }
+            if (STR) {
+                MfmaAcc<EPL> acc;
+                if (ut_padded) mfma_tab_vec<EPL, true>(Ut, uld, d, wk, acc);
+                else mfma_tab_vec<EPL, false>(Ut, uld, d, wk, acc);
+                if (is_am) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) dq[e] = acc.at(e);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dq[e] = 0.0;
+#pragma unroll
+                for (int e2 = 0; e2 < EPL; ++e2) {
+#pragma unroll 1
+                    for (int src = 0; src < G; ++src) {
+                        const int k = src + G * e2;
+                        if (k >= d) break;
+                        const double wv = group_bcast_lane<G>(wk[e2], src);
+                        const double *row = Ut + (size_t)k * d;
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            double r;
+                            PTMI_ROW_LOAD(r, row, e);
+                            dq[e] = __builtin_fma(r, wv, dq[e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
     return jt;
 }
 
@@ -237,16 +359,22 @@ __device__ __forceinline__ int logical_block()
 }
 
 // ------------------------------------------------------------ fused MH steps
+// STAGE (G = 4 shapes, chosen by the host when all chains of a block share their tables): strided lane layout,
+// the dense precision matrix and -- if it still fits -- the block's Ut are copied to LDS zero-padded, and the
+// table-times-vector products of the AM proposal and of the dense likelihood run on the matrix cores.
 template <int G, int EPL, int LOGL, bool FULL, bool STAGE>
 __global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
 {
     constexpr int CPB = 256 / G;
+    constexpr bool STR = STAGE;
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
-    long long ch = (long long)logical_block() * CPB + (int)(threadIdx.x / G);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int cib = STR ? wave * 16 + (lane & 15) : (int)(threadIdx.x / G);       // chain in block
+    const int gl = STR ? lane >> 4 : (int)(threadIdx.x % G);
+    long long ch = (long long)logical_block() * CPB + cib;
     const bool live = ch < nch;
     if (!live) ch = nch - 1;
-    const int gl = (int)(threadIdx.x % G);
     const int w = (int)(ch / nt);
     const int t = a.temp_of[ch];
     const int tg = a.temp0 + t;
@@ -258,26 +386,32 @@ __global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
     const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * d : nullptr;
     double *xrow = a.X + (size_t)ch * d;
 
-    // STAGE: the tables every chain of the block walks row by row (the block's Ut for AM / SCAM, the precision
-    // matrix of the dense likelihood) are copied to LDS once per launch.  The host picks STAGE when they fit in
-    // 160 KiB and all chains of a block share them.
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int LD = mfma_ld(EPL);
+    const int tab_n = 4 * ((d + 3) / 4) * LD;                      // doubles of one zero-padded LDS table
     const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr;
-    const double *Pt = PtG, *Utab = Ut;
+    // LDS pointers are derived from smem at their use so that they stay LDS (ds_read) accesses
+#define PTMI_PL (smem)
+#define PTMI_UL (smem + (LOGL == PTMI_LOGL_DENSE ? (size_t)tab_n : 0))
+    // with the dense likelihood both tables may not fit: then Ut stays in global memory (host decides, a.lds_u)
+    constexpr bool UT_ALWAYS_LDS = LOGL != PTMI_LOGL_DENSE;
+    const double *UtBlock = Ut;
     if (STAGE) {
-        const int n = d * d;
-        double *Pl = smem, *Ul = smem + (LOGL == PTMI_LOGL_DENSE ? (size_t)n : 0);
         if (LOGL == PTMI_LOGL_DENSE) {
-            for (int i = (int)threadIdx.x; i < n; i += 256) Pl[i] = PtG[i];
-            Pt = Pl;
+            for (int i = (int)threadIdx.x; i < tab_n; i += 256) {
+                const int r = i / LD, c = i % LD;
+                PTMI_PL[i] = (r < d && c < d) ? PtG[(size_t)r * d + c] : 0.0;
+            }
         }
-        if (FULL) {
-            // all chains of the block belong to one walker (or the table is pooled): take the first chain's
-            const long long ch0 = (long long)logical_block() * CPB;
-            const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
-            const double *src = a.Ut + w0 * d * d;
-            for (int i = (int)threadIdx.x; i < n; i += 256) Ul[i] = src[i];
-            Utab = Ul;
+        // all chains of the block belong to one walker (or the table is pooled): the first chain's table
+        const long long ch0 = (long long)logical_block() * CPB;
+        const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
+        UtBlock = a.Ut + w0 * d * d;
+        if (FULL && (UT_ALWAYS_LDS || a.lds_u)) {
+            for (int i = (int)threadIdx.x; i < tab_n; i += 256) {
+                const int r = i / LD, c = i % LD;
+                PTMI_UL[i] = (r < d && c < d) ? UtBlock[(size_t)r * d + c] : 0.0;
+            }
         }
         __syncthreads();
     }
@@ -293,7 +427,9 @@ __global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
         double log_u, u_acc;
-        const int jt = propose<G, EPL, FULL>(a, it, sid, gl, cc, Utab, S, DE, dq, log_u, u_acc);
+        int jt;
+        if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR>(a, it, sid, gl, cc, PTMI_UL, true, S, DE, dq, log_u, u_acc);
+        else jt = propose<G, EPL, FULL, STR>(a, it, sid, gl, cc, UtBlock, false, S, DE, dq, log_u, u_acc);
         if (FULL) {
 #pragma unroll
             for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
@@ -304,12 +440,12 @@ __global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
             double q[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
-            nlp = eval_logp<G, EPL>(a, q, gl);
-            if (nlp == -__builtin_inf()) nlnprob = -__builtin_inf();
-            else {
-                nlnL = eval_logl<G, EPL, LOGL>(a, q, gl, Pt);
-                nlnprob = beta * nlnL + nlp;
-            }
+            nlp = eval_logp<G, EPL, STR>(a, q, gl);
+            // the reference skips logl when the prior is -inf (PT:607-608); the value is unused then, and the
+            // matrix-core path needs every lane, so it is evaluated unconditionally
+            if (STAGE) nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, PTMI_PL);
+            else nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, PtG);
+            nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
         }
         // PT:615-622
         const double lnprob0 = beta * lnL + lp;
@@ -391,7 +527,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double log_u, u_acc;
-    const int jt = propose<G, EPL, true>(a, a.iter0, sid, gl, cc, Ut, S, DE, dq, log_u, u_acc);
+    const int jt = propose<G, EPL, true, false>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -472,9 +608,9 @@ __global__ __launch_bounds__(256) void eval_state_kernel(const KArgs a)
         const int i = gl + G * e;
         x[e] = i < d ? a.X[(size_t)ch * d + i] : 0.0;
     }
-    const double lp = eval_logp<G, EPL>(a, x, gl);
+    const double lp = eval_logp<G, EPL, false>(a, x, gl);
     double lnL = -__builtin_inf();
-    if (lp != -__builtin_inf()) lnL = eval_logl<G, EPL, LOGL>(a, x, gl, LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr);
+    if (lp != -__builtin_inf()) lnL = eval_logl<G, EPL, LOGL, false>(a, x, gl, LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr);
     if (live && gl == 0) {
         a.lp[ch] = lp;
         a.lnL[ch] = lnL;
@@ -486,10 +622,12 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
 {
     const ptmi_config &c = h->cfg;
     constexpr bool WANTS = G == 4 && (FULL || LOGL == PTMI_LOGL_DENSE);   // the tables fit only for the small-ndim shapes
+    a.lds_u = 0;
     if (WANTS) {
-        const size_t tab = sizeof(double) * (size_t)c.ndim * c.ndim;
-        const size_t lds = tab * ((FULL ? 1 : 0) + (LOGL == PTMI_LOGL_DENSE ? 1 : 0));
+        const size_t tab = sizeof(double) * (size_t)(4 * ((c.ndim + 3) / 4)) * mfma_ld(EPL);   // zero-padded copy
         const bool one_table_per_block = !FULL || !c.cov_per_walker || c.ntemps % (256 / G) == 0;
+        size_t lds = LOGL == PTMI_LOGL_DENSE ? tab : 0;
+        if (FULL && lds + tab <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
         if (lds <= 160 * 1024 && one_table_per_block) {
             auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, WANTS>;
             if (lds > 64 * 1024) {
