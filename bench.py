@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix = FP64 vector
 
 
 def parse():
@@ -172,6 +173,13 @@ def main():
                      "kernel": "mh_steps_kernel", "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,
                      "algorithmic_bytes_per_update": bytes_per_update, "kernel_time_share_of_wall": kern_ms * 1e-3 / wall},
     }
+    if a.logl == "dense":
+        # config 3: the dense contraction bounds the kernel: 2d^2+3d flop per likelihood, +2d^2 per AM proposal
+        flops = 2 * d * d + 3 * d + (2 * d * d * weights[1] / float(sum(weights)) if weights[1] else 0.0)
+        tf = flops * nt * W * avg_steps / (avg_launch_ms * 1e-3) / 1e12
+        out["roofline"].update({"bound": "mfma", "achieved": tf, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf / F64_MATRIX_PEAK_TFLOPS, "algorithmic_flops_per_update": flops})
+        out["config"]["workload"] = out["config"]["workload"].replace("BASELINE configs[1]", "BASELINE configs[2]")
     if rank == 0:
         acc = eng.get("nacc").astype(np.float64)
         out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / (a.steps + a.warmup))

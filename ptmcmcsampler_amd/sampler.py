@@ -65,6 +65,35 @@ class _function_wrapper(object):
         return self.f(x, *self.args, **self.kwargs)
 
 
+class _PerRankJump(object):
+    """A stateful gradient jump, one instance per (walker, temperature rank): in the reference every MPI rank
+    builds its own HMC / NUTS object (PTMCMCSampler.py:226-258), with its own step size and adaptation state."""
+
+    def __init__(self, sampler, factory):
+        import contextlib
+        import io
+        self.sampler, self.factory, self.inst = sampler, factory, {}
+        self.proto = factory()                               # prints the reference's construction warning once
+        self.name = self.proto.__name__
+        self._quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+
+    @property
+    def __name__(self):
+        return self.name
+
+    def __call__(self, x, iter, beta):
+        key = self.sampler._ctx
+        j = self.inst.get(key)
+        if j is None:
+            if not self.inst:
+                j = self.proto
+            else:
+                with self._quiet():
+                    j = self.factory()
+            self.inst[key] = j
+        return j(x, iter, beta)
+
+
 class PTSampler(object):
     def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
                  logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
@@ -107,6 +136,7 @@ class PTSampler(object):
         self.mu = np.zeros(ndim)
         self.propCycle, self.jumpDict, self.aux = [], {}, []
         self.engine = None
+        self._ctx = (0, 0)
 
     # ------------------------------------------------------------------ proposal cycle API
     def addProposalToCycle(self, func, weight):
@@ -165,8 +195,19 @@ class PTSampler(object):
         self._chain, self._lnlike, self._lnprob = self._chains[0], self._lnlikes[0], self._lnprobs[0]
         self.ind_next_write = 0
         self.naccepted = self.swapProposed = self.nswap_accepted = 0
-        if self.logl_grad is not None and self.logp_grad is not None and (NUTSweight or HMCweight or MALAweight):
-            raise NotImplementedError("gradient jumps (nutsjump.py) are not built yet; pass NUTSweight=HMCweight=MALAweight=0")
+        if self.logl_grad is not None and self.logp_grad is not None:                  # :226-258, same order
+            from .gradjump import HMCJump, MALAJump, NUTSJump
+            lg, pg, cov, nb = self.logl_grad, self.logp_grad, self.cov, self.burn
+            if MALAweight > 0:
+                self.addProposalToCycle(_PerRankJump(self, lambda: MALAJump(lg, pg, cov, nb)), MALAweight)
+                print("WARNING: MALA jumps are not working properly yet")
+            if HMCweight > 0:
+                self.addProposalToCycle(_PerRankJump(self, lambda: HMCJump(lg, pg, cov, nb, stepsize=HMCstepsize, nminsteps=2,
+                                                                          nmaxsteps=HMCsteps)), HMCweight)
+            if NUTSweight > 0:
+                self.addProposalToCycle(_PerRankJump(self, lambda: NUTSJump(lg, pg, cov, nb, trajectoryDir=None,
+                                                                           write_burnin=False, force_trajlen=None,
+                                                                           force_epsilon=None, delta=0.6)), NUTSweight)
         self.addProposalToCycle(self.covarianceJumpProposalSCAM, self.SCAMweight)     # :261
         self.addProposalToCycle(self.covarianceJumpProposalAM, self.AMweight)         # :264
         if len(self.propCycle) == 0:
@@ -330,6 +371,7 @@ class PTSampler(object):
                     beta = 1.0 / eng.temps_mh[temp_of[w, s]]
                     jt = int(qa[w, s, 1])
                     if jt >= _lib.J_NTYPES:                        # a cycle entry served on the host (:1059)
+                        self._ctx = (w, int(temp_of[w, s]))
                         q, qxy = self.host_jumps[jt - _lib.J_NTYPES](X[w, s], it, beta)
                         Q[w, s], qa[w, s, 0] = q, qxy
                         dirty = True

@@ -449,6 +449,48 @@ def gen_trajectories(PT, out):
                   SCAMweight=20, AMweight=0, DEweight=0), seed=1234)
 
 
+def gen_gradjump(out):
+    """HMC and NUTS jumps of the reference (nutsjump.py) on a dense Gaussian, global np.random seeded."""
+    import contextlib
+    import io
+    from PTMCMCSampler.nutsjump import HMCJump, MALAJump, NUTSJump
+    rs = np.random.RandomState(12)
+    d = 5
+    A = rs.randn(d, d)
+    P = np.linalg.inv(A @ A.T / d + 0.3 * np.eye(d))
+    cov = np.linalg.inv(P) * 0.8
+
+    def ll_grad(x):
+        return -0.5 * np.dot(x, np.dot(P, x)), -np.dot(P, x)
+
+    def lp_grad(x):
+        return 0.0, np.zeros_like(x)
+
+    res = dict(P=P, cov=cov)
+    for tag, make, ncall in (("nuts", lambda: NUTSJump(ll_grad, lp_grad, cov, nburn=25, delta=0.6), 45),
+                             ("nuts_forced", lambda: NUTSJump(ll_grad, lp_grad, cov, nburn=10, force_trajlen=5, force_epsilon=0.3), 12),
+                             ("mala", lambda: MALAJump(ll_grad, lp_grad, cov, nburn=25), 20),
+                             ("hmc", lambda: HMCJump(ll_grad, lp_grad, cov, nburn=25, stepsize=0.15, nminsteps=2, nmaxsteps=20), 30)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            j = make()
+        np.random.seed(2024)
+        x = rs.randn(d)
+        xs, qs, qxys, eps = [x.copy()], [], [], []
+        for it in range(1, ncall + 1):
+            beta = 1.0 if it % 7 else 0.4
+            q, qxy = j(x, it, beta)
+            qs.append(np.array(q))
+            qxys.append(float(qxy))
+            eps.append(float(j.epsilon) if j.epsilon is not None else -1.0)
+            if it % 3:                      # the sampler would accept or not; feed some proposals back
+                x = np.array(q)
+            xs.append(x.copy())
+        res[tag + "_x"], res[tag + "_q"] = np.asarray(xs), np.asarray(qs)
+        res[tag + "_qxy"], res[tag + "_eps"] = np.asarray(qxys), np.asarray(eps)
+        res[tag + "_name"] = j.__name__
+    np.savez_compressed(os.path.join(out, "gradjump.npz"), **res)
+
+
 def main():
     PT = import_reference()
     tmp = tempfile.mkdtemp()
@@ -458,6 +500,7 @@ def main():
     gen_debuffer(PT, HERE, tmp)
     gen_ptswap(PT, HERE, tmp)
     gen_trajectories(PT, HERE)
+    gen_gradjump(HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d B" % (f, os.path.getsize(os.path.join(HERE, f))))

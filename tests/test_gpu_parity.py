@@ -279,3 +279,29 @@ def test_full_size_properties_and_subset_parity(mods):
         assert_same(X[w0], o.X[0], "walker %d X" % w0)
         assert_same(so[w0], o.slot_of[0], "walker %d slot_of" % w0)
         assert_same(g.get("nswap")[w0], o.nswap[0], "walker %d nswap" % w0)
+
+
+@pytest.mark.parametrize("d,nt,W", [(1, 1, 1), (2, 1, 3), (3, 2, 1), (7, 5, 13), (33, 3, 11), (104, 2, 9), (105, 2, 5), (417, 2, 2)])
+def test_ragged_and_boundary_sizes(mods, d, nt, W):
+    """Sizes that do not fill a block or a shape: one dimension, one temperature (no swaps), chain counts that
+    are not multiples of the block, the last ndim of the 4-lane shapes (104) and the first of the next ones."""
+    kw = dict(weights=(20, 20, 20), cov_update=30, burn=60, tskip=7 if nt > 1 else 0, seed=d * 100 + nt, rs=d + 1)
+    g, o = _pair(mods, d, nt, W, **kw)
+    n = 150 if d < 200 else 70
+    g.run(n)
+    o.run(n)
+    _compare(g, o, "ragged d=%d nt=%d W=%d " % (d, nt, W))
+    assert_same(g.get("cov"), o.cov, "cov")
+
+
+def test_minus_inf_start_and_nan_safety(mods):
+    """A start outside the prior (lnL = lp = -inf, PTMCMCSampler.py:481-483) can only leave through a finite proposal."""
+    d = 4
+    p0 = np.zeros((3, 2, d))
+    p0[0] = 5.0                       # walker 0 starts outside the box
+    g, o = _pair(mods, d, 2, 3, logp=("box", -np.ones(d), np.ones(d)), p0=p0, cov0=np.eye(d) * 4.0,
+                 weights=(20, 20, 0), cov_update=50, burn=100, tskip=5, seed=4)
+    assert np.isneginf(o.lnL[0]).all() and np.isneginf(g.get("lnL")[0]).all()
+    g.run(120)
+    o.run(120)
+    _compare(g, o, "inf-start ")

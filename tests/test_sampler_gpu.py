@@ -125,3 +125,27 @@ def test_argument_errors(tmp_path):
     s2 = PTSampler(3, ("iso",), ("flat",), np.eye(3), outDir=str(tmp_path), verbose=False)
     with pytest.raises(ValueError, match="No jump proposals specified!"):
         s2.sample(np.zeros(3), 100, SCAMweight=0, AMweight=0, DEweight=0)
+
+
+def test_gradient_jumps_through_the_facade(tmp_path, capsys):
+    """logl_grad / logp_grad given: HMC and NUTS join the cycle as in the reference (PTMCMCSampler.py:226-258)."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 4
+    rs = np.random.RandomState(8)
+    A = rs.randn(d, d)
+    C = A @ A.T / d + 0.4 * np.eye(d)
+    P = np.linalg.inv(C)
+    ll = lambda x: -0.5 * x @ P @ x                       # noqa: E731
+    lp = lambda x: 0.0                                    # noqa: E731
+    s = PTSampler(d, ll, lp, np.copy(C) * 0.5, logl_grad=lambda x: (ll(x), -P @ x), logp_grad=lambda x: (0.0, np.zeros(d)),
+                  outDir=str(tmp_path), verbose=False, seed=3, ntemps=2)
+    np.random.seed(10)
+    s.sample(np.zeros(d), 1500, burn=300, thin=1, covUpdate=300, SCAMweight=10, AMweight=10, DEweight=10, NUTSweight=10,
+             HMCweight=10, MALAweight=0, HMCstepsize=0.3, HMCsteps=20, Tskip=50)
+    out = capsys.readouterr().out
+    assert out.count("WARNING: GradientJumps not yet adaptive") == 2        # once per jump type
+    assert {"HMCJump", "NUTSJUMP", "covarianceJumpProposalSCAM", "DEJump"} <= set(s.jumpDict)
+    prop, acc = s.jumpDict["NUTSJUMP"]
+    assert prop > 150 and acc / prop > 0.97               # NUTS proposals are constructed to be accepted
+    x = s._chain[400:]
+    assert np.max(np.abs(np.cov(x.T) - C)) / np.max(C) < 0.35
