@@ -112,6 +112,7 @@ class PTEngine(object):
         self.h = C.c_void_p()
         _lib.check(self.lib.ptmi_create(C.byref(cfg), C.byref(buf), C.byref(self.h)))
         self.de_on = False
+        self.de_head = 0
         self.iter = 0
         self.swap_proposed = 0
         self.eig_epochs = 0
@@ -190,6 +191,7 @@ class PTEngine(object):
     def update_de(self):
         if self.owns_cold and self.t["DE"] is not None:
             _lib.check(self.lib.ptmi_update_de(self.h))
+            self.de_head = (self.de_head + min(self.cov_update, self.burn)) % self.burn
 
     def set_de_active(self, on=True):
         _lib.check(self.lib.ptmi_set_de_active(self.h, int(on)))
@@ -197,6 +199,29 @@ class PTEngine(object):
 
     def set_de_head(self, head):
         _lib.check(self.lib.ptmi_set_de_head(self.h, int(head)))
+        self.de_head = int(head)
+
+    # ------------------------------------------------------------------ checkpoint
+    def checkpoint(self):
+        """Everything needed to continue bit-identically: device arrays, ring head, DE flag, iteration.
+        (The RNG is counter based: its whole state is the iteration number.)"""
+        self.sync()
+        st = {"t_" + k: v.cpu().numpy() for k, v in self.t.items() if v is not None and k not in ("Q", "qaux")}
+        st.update(iter=self.iter, de_on=int(self.de_on), de_head=self.de_head, swap_proposed=self.swap_proposed,
+                  eig_epochs=self.eig_epochs)
+        return st
+
+    def restore(self, st):
+        torch = _torch()
+        for k, v in self.t.items():
+            if v is not None and "t_" + k in st:
+                v.copy_(torch.from_numpy(np.ascontiguousarray(st["t_" + k])).to(v.dtype))
+        self.iter, self.swap_proposed = int(st["iter"]), int(st["swap_proposed"])
+        self.eig_epochs = int(st["eig_epochs"])
+        if self.t["DE"] is not None:
+            self.set_de_head(int(st["de_head"]))
+            if int(st["de_on"]):
+                self.set_de_active(True)
 
     # pieces of the swap for a ladder sharded over GPUs (see sharded.py)
     def gather_lnl(self, out):

@@ -219,9 +219,13 @@ class PTSampler(object):
         self.fname = self.outDir + "/chain_{0}.txt".format(self.temp)                # :285
         self.writeHotChains, self.hotChain = writeHotChains, hotChain
         self.resumeLength = 0
-        if self.resume:
-            raise NotImplementedError("resume (PTMCMCSampler.py:290-319) is not built yet")
-        open(self.fname, "w").close()
+        self._ckpt = os.path.join(self.outDir, "ptmi_checkpoint.npz")
+        self._resuming = bool(self.resume) and os.path.isfile(self._ckpt) and os.path.isfile(self.fname)
+        if self._resuming:
+            if self.verbose:
+                print("Resuming run from chain file {0}".format(self.fname))
+        else:
+            open(self.fname, "w").close()
         # ---- engine
         self.host_jumps = [f for f in self.propCycle if self._builtin(f) < 0]
         self.split = self.logl is not None or bool(self.host_jumps) or bool(self.aux)
@@ -254,14 +258,17 @@ class PTSampler(object):
                             writeHotChains=writeHotChains, hotChain=hotChain)
         eng = self.engine
         p0 = np.asarray(p0, dtype=np.float64)
-        if self.split:
-            self._init_split(p0)
-        else:
-            eng.init_state(p0)
         self.tstart = time.time()
-        self._harvest([i0])
-        if i0 % self.isave == 0:
-            self.writeOutput(i0)
+        if i0 == 0 and self._resuming:
+            i0 = self._load_checkpoint()                       # continue where the last complete save stopped
+        else:
+            if self.split:
+                self._init_split(p0)
+            else:
+                eng.init_state(p0)
+            self._harvest([i0])
+            if i0 % self.isave == 0:
+                self.writeOutput(i0)
         it = i0 + 1
         message = "\nRun Complete"
         while it <= self.Niter:
@@ -298,6 +305,39 @@ class PTSampler(object):
         self.writeOutput(self.Niter)
         if self.verbose:
             print(message)
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    # The reference resumes by replaying its text chain file (PTMCMCSampler.py:290-319, 591-599): the adaptive
+    # state and the RNG are not restored there.  Here every save also writes the device state; with the
+    # counter-based RNG a resumed run continues bit-identically to an uninterrupted one (host-side jump objects --
+    # custom, HMC, NUTS -- keep their own state and are not part of the checkpoint).
+    def _save_checkpoint(self, iter):
+        st = self.engine.checkpoint()
+        st["iter"] = iter
+        st.update(f_chains=self._chains, f_lnlikes=self._lnlikes, f_lnprobs=self._lnprobs,
+                  f_ind_next_write=self.ind_next_write,
+                  f_jump_names=np.asarray(list(self.jumpDict), dtype=str),
+                  f_jump_counts=np.asarray([self.jumpDict[k] for k in self.jumpDict], dtype=np.int64).reshape(-1, 2),
+                  f_de_in_cycle=int(self.DEJump in self.propCycle))
+        tmp = self._ckpt + ".tmp.npz"
+        np.savez(tmp, **st)
+        os.replace(tmp, self._ckpt)
+
+    def _load_checkpoint(self):
+        st = np.load(self._ckpt, allow_pickle=False)
+        self.engine.restore(st)
+        n = min(self._chains.shape[1], st["f_chains"].shape[1])
+        self._chains[:, :n], self._lnlikes[:, :n], self._lnprobs[:, :n] = st["f_chains"][:, :n], st["f_lnlikes"][:, :n], st["f_lnprobs"][:, :n]
+        self.ind_next_write = int(st["f_ind_next_write"])
+        if int(st["f_de_in_cycle"]) and self.DEJump not in self.propCycle:
+            self.addProposalToCycle(self.DEJump, self.DEweight)
+        for name, cnt in zip(st["f_jump_names"], st["f_jump_counts"]):
+            self.jumpDict[str(name)] = [int(cnt[0]), int(cnt[1])]
+        self._mirror_cov()
+        self.resumeLength = self.ind_next_write
+        i0 = int(st["iter"])
+        print("Resuming with", self.resumeLength, "samples from file representing", i0 + 1, "original samples")
+        return i0
 
     # ------------------------------------------------------------------ bookkeeping
     def _mirror_cov(self):
@@ -403,6 +443,8 @@ class PTSampler(object):
             self._writeToFile(iter)
             if iter > 0:
                 np.save(self.outDir + "/cov.npy", self.cov)
+                self.engine.iter = iter
+                self._save_checkpoint(iter)
             if self.verbose:
                 if iter > 0:
                     sys.stdout.write("\r")
