@@ -95,17 +95,6 @@ def main():
 
     d, nt, W = a.ndim, a.ntemps, a.nwalkers
     logl = ("iso",)
-    # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
-    # summary applies only to the exact workload it was measured on
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        key = "ndim=%d ntemps=%d nwalkers=%d mix=%s logl=%s steps_per_launch=%d" % (d, nt, W, a.mix, a.logl, int(round(avg_steps)))
-        if tr.get("workload") == key:
-            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, " + ", ".join(tr["source"])
-            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_update * nt * W * avg_steps
-    except (OSError, ValueError):
-        pass
     if a.logl == "dense":
         A = np.random.default_rng(0).standard_normal((d, d))
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))

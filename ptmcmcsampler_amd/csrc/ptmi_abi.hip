@@ -25,34 +25,59 @@ __global__ void gather_lnl_kernel(const double *lnL, const int32_t *slot_of, dou
     out[i] = lnL[w * nt + slot_of[i]];
 }
 
-// PT:666-686, one lane per walker, hot -> cold with the carried map.  When the whole
-// ladder is local (slot_of != nullptr) the slot tables are rewritten in place: position
-// k+1 becomes final at step k and positions <= k are still untouched.
-__global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *lnL_pos, const double *lnL_rows,
-                                  int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
-                                  long long iter, u64 seed, int walker0)
+// PT:666-686 in two kernels.  swap_prepare_kernel (one thread per position and walker) does everything that does
+// not depend on the carried state: the pair's uniform, and the two terms of the acceptance sum that involve only
+// position k's own likelihood.  swap_sweep_kernel (one lane per walker) then runs the hot -> cold recurrence with
+// the carried map: per pair two divisions, an exp and a compare.  Scratch is position-major [n][W] so the sweep's
+// reads are coalesced.  When the whole ladder is local (slot_of != nullptr) the slot tables are rewritten in place:
+// position k+1 becomes final at step k and positions <= k are still untouched.
+__global__ void swap_prepare_kernel(int W, int n, const double *ladder, const double *lnL_pos, const double *lnL_rows,
+                                    const int32_t *slot_of, double *pre, int32_t *prow, long long iter, u64 seed, int walker0)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * W) return;
+    const int k = (int)(idx / W), w = (int)(idx % W);
+    const size_t nW = (size_t)n * W;
+    const bool fused = slot_of != nullptr;
+    const int row = fused ? slot_of[(size_t)w * n + k] : 0;
+    const double L = fused ? lnL_rows[(size_t)w * n + row] : lnL_pos[(size_t)w * n + k];
+    double u = 0.0, a = 0.0, b = 0.0;
+    if (k < n - 1) {
+        const u32 sid = (u32)((u64)(walker0 + w) * (u32)n + 0u);      // rank 0's stream (PT:679)
+        u64 w0, w1;
+        philox_words(seed, (u64)iter, sid, SLOT_SWAP + (u32)k, w0, w1);
+        u = w2uniform(w0);
+        a = -L / ladder[k];
+        b = L / ladder[k + 1];
+    }
+    pre[idx] = u;
+    pre[nW + idx] = L;
+    pre[2 * nW + idx] = a;
+    pre[3 * nW + idx] = b;
+    if (fused) prow[idx] = row;
+}
+
+__global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *pre, const int32_t *prow,
+                                  int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal)
 {
     const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (w >= W) return;
-    const u32 sid = (u32)((u64)(walker0 + w) * (u32)n + 0u);
+    const size_t nW = (size_t)n * W;
     const bool fused = slot_of != nullptr;
     int32_t *so = fused ? slot_of + (size_t)w * n : nullptr;
     int32_t *to = fused ? temp_of + (size_t)w * n : nullptr;
-    const double *Lp = fused ? lnL_rows + (size_t)w * n : lnL_pos + (size_t)w * n;
     int c = n - 1;                         // position whose state is carried at k+1
-    int crow = fused ? so[n - 1] : 0;
-    double Lc = fused ? Lp[crow] : Lp[n - 1];
+    int crow = fused ? prow[(size_t)(n - 1) * W + w] : 0;
+    double Lc = pre[nW + (size_t)(n - 1) * W + w];
     for (int k = n - 2; k >= 0; --k) {
-        u64 w0, w1;
-        philox_words(seed, (u64)iter, sid, SLOT_SWAP + (u32)k, w0, w1);
-        const double u = w2uniform(w0);
-        const int krow = fused ? so[k] : 0;
-        const double La = fused ? Lp[krow] : Lp[k];
+        const size_t o = (size_t)k * W + w;
+        const double u = pre[o], La = pre[nW + o];
+        const int krow = fused ? prow[o] : 0;
         const double Tk = ladder[k], Tk1 = ladder[k + 1];
-        double la = -La / Tk;
+        double la = pre[2 * nW + o];       // -L[k] / T[k]
         la += -Lc / Tk1;
         la += Lc / Tk;
-        la += La / Tk1;
+        la += pre[3 * nW + o];             //  L[k] / T[k+1]
         const bool acc = u <= det_exp(la);
         // position k+1 is final: it keeps the carried state, or takes position k's
         const int fin = acc ? k : c;
@@ -405,7 +430,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         return rc;
     }
     h->cfg.ladder = h->cfg.temps_mh = h->cfg.logl_par = h->cfg.logp_par = nullptr;  // host copies are not kept
-    hipError_t e = hipMalloc((void **)&h->d_lnlpos, sizeof(double) * (size_t)c.nwalkers * c.ntemps_global);
+    hipError_t e = hipMalloc((void **)&h->d_pre, sizeof(double) * 4 * (size_t)c.nwalkers * c.ntemps_global);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_prow, sizeof(int32_t) * (size_t)c.nwalkers * c.ntemps_global);
     if (e == hipSuccess && !c.cov_per_walker && c.temp0 == 0) {
         const size_t ng = (size_t)(c.nwalkers + POOL_GS - 1) / POOL_GS;
         e = hipMalloc((void **)&h->d_pool_mu, sizeof(double) * ng * c.ndim);
@@ -422,7 +448,7 @@ int ptmi_destroy(ptmi_handle h)
 {
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
-    (void)hipFree(h->d_lnlpos); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
+    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -517,9 +543,13 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
     if (!h->buf.nswap) return fail(PTMI_EINVAL, "nswap buffer missing");
     if (c.ntemps < 2) return PTMI_OK;
     const int W = c.nwalkers;
+    const long long tot = (long long)W * c.ntemps;
+    hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps, h->d_ladder,
+                       (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, h->d_pre, h->d_prow,
+                       (long long)iter, c.seed, c.walker0);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps, h->d_ladder,
-                       (const double *)nullptr, (const double *)h->buf.lnL, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr,
-                       (u64 *)h->buf.nswap, 0, c.ntemps, (long long)iter, c.seed, c.walker0);
+                       (const double *)h->d_pre, (const int32_t *)h->d_prow, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr,
+                       (u64 *)h->buf.nswap, 0, c.ntemps);
     HIPCHK(hipGetLastError());
     return ptmi_swap_write_am(h, iter);
 }
@@ -540,9 +570,13 @@ int ptmi_swap_sweep(ptmi_handle h, int64_t iter, const double *lnL_pos_global, i
     if (!h->buf.nswap) return fail(PTMI_EINVAL, "nswap buffer missing");
     const ptmi_config &c = h->cfg;
     const int W = c.nwalkers;
+    const long long tot = (long long)W * c.ntemps_global;
+    hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global,
+                       h->d_ladder, lnL_pos_global, (const double *)nullptr, (const int32_t *)nullptr, h->d_pre, h->d_prow,
+                       (long long)iter, c.seed, c.walker0);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps_global, h->d_ladder,
-                       lnL_pos_global, (const double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, map, (u64 *)h->buf.nswap,
-                       c.temp0, c.ntemps, (long long)iter, c.seed, c.walker0);
+                       (const double *)h->d_pre, (const int32_t *)h->d_prow, (int32_t *)nullptr, (int32_t *)nullptr, map,
+                       (u64 *)h->buf.nswap, c.temp0, c.ntemps);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -57,7 +57,8 @@ struct ptmi_engine {
     ptmi_buffers buf;
     hipStream_t stream;
     double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar;
-    double *d_lnlpos;   // [W][ntg] scratch for the fused swap
+    double *d_pre;      // [4][ntg][W] scratch of the swap (uniforms, likelihoods, own-likelihood terms)
+    int32_t *d_prow;    // [ntg][W] rows by position (fused swap)
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
     int G, EPL;
     int de_on, de_head;

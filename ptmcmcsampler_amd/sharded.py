@@ -46,7 +46,8 @@ def plan_exchange(map_glob, slot_of, temp0, nt, rank, world):
     new_slot = torch.zeros_like(so)
     loc_src = (src_pos - temp0).clamp(0, nt - 1)
     new_slot[local_dst] = torch.gather(so, 1, loc_src)[local_dst]
-    # rows that leave: ordered by (destination rank, walker, destination position)
+    # rows that leave / arrive.  Three host synchronisations in all (two nonzero, one count read-back); the index
+    # lists only hold the rows that cross a block edge.
     leaving = dst_rank != rank
     lw, lp_ = torch.nonzero(leaving, as_tuple=True)                          # row-major (w, local source position)
     free_slots = so[lw, lp_]                                                 # k-th leaving row of a walker frees the k-th slot
@@ -54,24 +55,17 @@ def plan_exchange(map_glob, slot_of, temp0, nt, rank, world):
     aw, aj = torch.nonzero(arriving, as_tuple=True)                          # row-major (w, local destination)
     assert free_slots.numel() == aw.numel()
     new_slot[aw, aj] = free_slots                                            # per walker the counts match, so the lists align
-    send_idx, send_counts, recv_w, recv_j, recv_counts = [], [], [], [], []
-    for q in range(world):
-        if q == rank:
-            send_counts.append(0)
-            recv_counts.append(0)
-            continue
-        sel = dst_rank[lw, lp_] == q
-        sw, sp, sd = lw[sel], lp_[sel], dst_pos[lw, lp_][sel]
-        order = torch.argsort(sw * ntg + sd)                                 # receiver's order: (walker, destination position)
-        send_idx.append(torch.stack([sw[order], so[sw, sp][order]], 1))
-        send_counts.append(int(sel.sum()))
-        rsel = src_rank[aw, aj] == q
-        recv_w.append(aw[rsel])
-        recv_j.append(aj[rsel])
-        recv_counts.append(int(rsel.sum()))
-    cat = lambda xs, width=None: (torch.cat(xs) if xs else torch.zeros((0,) if width is None else (0, width), dtype=torch.long, device=dev))  # noqa: E731
-    return dict(new_slot=new_slot, send_idx=cat(send_idx, 2), send_counts=send_counts,
-                recv_w=cat(recv_w), recv_j=cat(recv_j), recv_counts=recv_counts)
+    lq, ld = dst_rank[lw, lp_], dst_pos[lw, lp_]
+    order = torch.argsort(lq * (W * ntg) + lw * ntg + ld)                    # by destination rank, then the receiver's (walker, position)
+    send_idx = torch.stack([lw[order], free_slots[order]], 1)
+    aq = src_rank[aw, aj]
+    rorder = torch.argsort(aq * (W * nt) + aw * nt + aj)                     # by source rank, then (walker, position)
+    counts = torch.zeros((2, world), dtype=torch.long, device=dev)
+    counts[0].scatter_add_(0, lq, torch.ones_like(lq))
+    counts[1].scatter_add_(0, aq, torch.ones_like(aq))
+    counts = counts.cpu().tolist()
+    return dict(new_slot=new_slot, send_idx=send_idx, send_counts=counts[0],
+                recv_w=aw[rorder], recv_j=aj[rorder], recv_counts=counts[1])
 
 
 class ShardedPTEngine(object):
