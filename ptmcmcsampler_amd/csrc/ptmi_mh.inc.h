@@ -363,7 +363,7 @@ __device__ __forceinline__ int logical_block()
 // the dense precision matrix and -- if it still fits -- the block's Ut are copied to LDS zero-padded, and the
 // table-times-vector products of the AM proposal and of the dense likelihood run on the matrix cores.
 template <int G, int EPL, int LOGL, bool FULL, bool STAGE>
-__global__ __launch_bounds__(256) void mh_steps_kernel(const KArgs a)
+__global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
 {
     constexpr int CPB = 256 / G;
     constexpr bool STR = STAGE;
