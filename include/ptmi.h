@@ -69,6 +69,7 @@ typedef struct ptmi_config {
     int32_t tskip;           /* swap period (:624); 0 = never */
     int32_t cov_per_walker;  /* 1: Ut/S/DE/cov per walker (faithful replicas); 0: one pooled set */
     int32_t device;          /* HIP device ordinal */
+    int32_t ngroups;         /* parameter groups (PTMCMCSampler.py:129-145); 0 or 1 = one group of all parameters */
     uint64_t seed;
     void *stream;            /* hipStream_t to launch on; NULL = the null stream */
     const double *ladder;    /* host [ntemps_global]  temperatures used by the swap (:658) */
@@ -77,6 +78,8 @@ typedef struct ptmi_config {
     int64_t logl_par_len;
     const double *logp_par;  /* host, per logp_kind */
     int64_t logp_par_len;
+    const int32_t *group_size;  /* host [ngroups] parameters per group (ngroups > 1 only) */
+    const double *group_mask;   /* host [ngroups][ndim] 1.0 where a parameter belongs to the group (ngroups > 1 only) */
 } ptmi_config;
 
 /* Device buffers, caller-owned.  W = nwalkers, T = ntemps, d = ndim,
@@ -87,8 +90,10 @@ typedef struct ptmi_buffers {
     double *lp;         /* [W][T]      log-prior of the row in a slot */
     int32_t *temp_of;   /* [W][T]      local rank held by a slot */
     int32_t *slot_of;   /* [W][T]      slot holding a local rank */
-    double *Ut;         /* [Wc][d][d]  eigenvectors, one per ROW (Ut[k][i] = U[i][k] of :145,803) */
-    double *S;          /* [Wc][d]     eigenvalues */
+    double *Ut;         /* [Wc][Ng][d][d]  eigenvectors, one per ROW (Ut[k][i] = U[i][k] of :145,803); Ng = max(ngroups,1);
+                         *              a group's vectors are embedded in the full space (zero outside the group, zero rows
+                         *              beyond its size) */
+    double *S;          /* [Wc][Ng][d]  eigenvalues (zero beyond the group's size) */
     double *DE;         /* [Wc][de_size][d]  DE history ring (optional) */
     double *AM;         /* [W][cov_update][d] samples of the rank-0 chain (:327-328); only where temp0 == 0 */
     uint64_t *nacc;     /* [W][T]      accepted MH updates per rank (:621) */

@@ -31,8 +31,9 @@ _up = C.POINTER(C.c_uint64)
 class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "ndim", "ntemps", "nwalkers", "lanes", "logl_kind", "logp_kind", "w_scam", "w_am", "w_de",
-        "de_on", "de_size", "cov_update", "tskip", "cov_per_walker", "ntemps_global", "temp0", "walker0", "pad_")] + [
-        ("seed", C.c_uint64), ("logl_par", _dp), ("logp_par", _dp), ("temps_mh", _dp), ("beta", _dp)]
+        "de_on", "de_size", "cov_update", "tskip", "cov_per_walker", "ntemps_global", "temp0", "walker0", "ngroups")] + [
+        ("seed", C.c_uint64), ("logl_par", _dp), ("logp_par", _dp), ("temps_mh", _dp), ("beta", _dp),
+        ("gsize", _ip), ("gmask", _dp)]
 
 
 class State(C.Structure):
@@ -163,7 +164,7 @@ class OracleEngine(object):
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
-                 ntemps_global=None, temp0=0, walker0=0):
+                 ntemps_global=None, temp0=0, walker0=0, groups=None):
         self.d, self.nt, self.W = ndim, ntemps, nwalkers
         self.ntg = ntemps if ntemps_global is None else ntemps_global
         self.temp0, self.walker0 = temp0, walker0
@@ -183,9 +184,15 @@ class OracleEngine(object):
         self.lp = np.zeros((W, nt))
         self.temp_of = np.tile(np.arange(nt, dtype=np.int32), (W, 1))
         self.slot_of = self.temp_of.copy()
+        self.groups = [np.arange(d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
+        self.ngr = len(self.groups)
+        self.gsize = np.asarray([len(g) for g in self.groups], dtype=np.int32)
+        self.gmask = np.zeros((self.ngr, d))
+        for gi, g in enumerate(self.groups):
+            self.gmask[gi, g] = 1.0
         self.cov = np.tile(np.asarray(cov0, dtype=np.float64), (self.Wc, 1, 1))
-        self.Ut = np.zeros((self.Wc, d, d))
-        self.S = np.zeros((self.Wc, d))
+        self.Ut = np.zeros((self.Wc, self.ngr, d, d))
+        self.S = np.zeros((self.Wc, self.ngr, d))
         for w in range(self.Wc):
             self._svd(w)
         self.mu = np.zeros((W, d))
@@ -206,9 +213,9 @@ class OracleEngine(object):
         self.cfg = Cfg(ndim=d, ntemps=nt, nwalkers=W, lanes=self.lanes, logl_kind=LOGL[logl[0]],
                        logp_kind=LOGP[logp[0]], w_scam=weights[0], w_am=weights[1], w_de=weights[2], de_on=0,
                        de_size=burn, cov_update=cov_update, tskip=tskip, cov_per_walker=int(self.per_walker),
-                       ntemps_global=self.ntg, temp0=temp0, walker0=walker0, seed=seed,
+                       ntemps_global=self.ntg, temp0=temp0, walker0=walker0, ngroups=self.ngr, seed=seed,
                        logl_par=_p(self._par_l), logp_par=_p(self._par_p), temps_mh=_p(self.temps_mh),
-                       beta=_p(self.beta))
+                       beta=_p(self.beta), gsize=_p(self.gsize, _ip), gmask=_p(self.gmask))
         self.iter = 0
 
     # -- helpers
@@ -226,14 +233,18 @@ class OracleEngine(object):
         except ImportError:
             import contextlib
             ctx = contextlib.nullcontext()
-        with ctx:
-            U, S, _ = np.linalg.svd(self.cov[w])           # PTMCMCSampler.py:145,803 (host LAPACK)
-        self.Ut[w] = np.ascontiguousarray(U.T)
-        self.S[w] = S
+        for gi, g in enumerate(self.groups):               # per-group SVD, PTMCMCSampler.py:139-145, 797-803
+            with ctx:
+                U, S, _ = np.linalg.svd(self.cov[w][np.ix_(g, g)])
+            self.set_eig(U, S, w, gi)
 
-    def set_eig(self, U, S, w=0):
-        self.Ut[w] = np.ascontiguousarray(np.asarray(U).T)
-        self.S[w] = S
+    def set_eig(self, U, S, w=0, gi=0):
+        """Embed a group's eigenvectors (columns of U) in the full space, one per row."""
+        g = self.groups[gi]
+        self.Ut[w, gi] = 0.0
+        self.S[w, gi] = 0.0
+        self.Ut[w, gi][np.ix_(np.arange(len(g)), g)] = np.asarray(U).T
+        self.S[w, gi, :len(g)] = S
 
     def init_state(self, p0):
         p0 = np.asarray(p0, dtype=np.float64)

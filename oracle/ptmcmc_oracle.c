@@ -219,12 +219,14 @@ typedef struct {
     int32_t de_on, de_size;           /* DE in the cycle; rows in a DE buffer (= burn, PT:221) */
     int32_t cov_update, tskip;        /* AM-buffer length (PT:220); swap period (PT:624), 0 = never */
     int32_t cov_per_walker;           /* 1: Ut/S/DE per walker, 0: one shared set */
-    int32_t ntemps_global, temp0, walker0, pad_;
+    int32_t ntemps_global, temp0, walker0, ngroups;   /* ngroups: parameter groups (PT:129-145); 0 or 1 = one full group */
     uint64_t seed;
     const double *logl_par;           /* DENSE: mu[d], Pt[d*d] (Pt[j*d+i] = P[i][j]) */
     const double *logp_par;           /* BOX: lo[d], hi[d] */
     const double *temps_mh;           /* [ntemps] temperature of each local rank as the MH step sees it (PT:278-282) */
     const double *beta;               /* [ntemps] 1/temps_mh */
+    const int32_t *gsize;             /* [ngroups] parameters per group (NULL with one full group) */
+    const double *gmask;              /* [ngroups][d] 1 where the parameter belongs to the group */
 } orc_cfg;
 
 typedef struct {
@@ -232,7 +234,8 @@ typedef struct {
     double *lnL, *lp;   /* [W][ntemps]      by SLOT */
     int32_t *temp_of;   /* [W][ntemps]      local rank held by the row in a slot */
     int32_t *slot_of;   /* [W][ntemps]      inverse */
-    double *Ut, *S;     /* [Wc][d][d] eigvec-major (Ut[k][i] = U[i][k]); [Wc][d] */
+    double *Ut, *S;     /* [Wc][ngroups][d][d] eigvec-major, embedded in the full space (Ut[k][i] = U[i][k], zero
+                         * outside the group and for k >= group size); [Wc][ngroups][d] */
     double *DE;         /* [Wc][de_size][d] */
     double *AM;         /* [W][cov_update][d] */
     uint64_t *nacc;     /* [W][ntemps]      by RANK */
@@ -325,7 +328,7 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
     double *wk = buf + 3 * d;
     const double temp = c->temps_mh[t], beta = c->beta[t];
     const size_t wc = c->cov_per_walker ? (size_t)w : 0;
-    const double *Ut = st->Ut + wc * d * d, *S = st->S + wc * d;
+    const int ngr = c->ngroups > 1 ? c->ngroups : 1;
     const uint32_t sid = (uint32_t)((uint64_t)(c->walker0 + w) * (uint32_t)c->ntemps_global + (uint32_t)(c->temp0 + t));
     orc_replay *r = rp ? rp + t : NULL;
     uint64_t A[2], B[2], C[2], D[2];
@@ -336,7 +339,16 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
     const int ind = r ? (int)rp_next(r, K_INT, L) : (int)w2index(A[0], (uint64_t)L);
     const int jt = ind < c->w_scam ? J_SCAM : (ind < c->w_scam + c->w_am ? J_AM : J_DE);
 
-    if (r) (void)rp_next(r, K_INT, 1);          /* group pick, one group (PT:839,897,955) */
+    /* group pick (PT:839,897,955); counter mode: word C0 for SCAM / AM, D0 for DE (the words those jumps leave unused) */
+    int g = 0;
+    if (r) g = (int)rp_next(r, K_INT, ngr);
+    else if (ngr > 1) {
+        if (jt == J_DE) { philox_words(c->seed, (uint64_t)it, sid, SLOT_D, D); g = (int)w2index(D[0], (uint64_t)ngr); }
+        else { philox_words(c->seed, (uint64_t)it, sid, SLOT_C, C); g = (int)w2index(C[0], (uint64_t)ngr); }
+    }
+    const int ng = (c->ngroups > 1) ? c->gsize[g] : d;
+    const double *Ut = st->Ut + (wc * ngr + g) * (size_t)d * d, *S = st->S + (wc * ngr + g) * (size_t)d;
+    const double *gm = (c->ngroups > 1) ? c->gmask + (size_t)g * d : NULL;
 
     if (jt == J_SCAM || jt == J_AM) {
         const double prob = r ? rp_next(r, K_UNI, 0) : w2uniform(A[1]);
@@ -345,18 +357,18 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
         if (jt == J_SCAM) {
             int k;
             double z;
-            if (r) { k = (int)rp_next(r, K_INT, d); z = rp_next(r, K_NRM, 0); }
+            if (r) { k = (int)rp_next(r, K_INT, ng); z = rp_next(r, K_NRM, 0); }
             else {
                 philox_words(c->seed, (uint64_t)it, sid, SLOT_D, D);
-                k = (int)w2index(B[1], (uint64_t)d);
+                k = (int)w2index(B[1], (uint64_t)ng);
                 z = orc_normal(D[0], D[1]);
             }
             const double cd = 2.4 / sqrt(2.0 * 1.0) * scale;            /* PT:870, neff = 1 */
             const double a = z * cd * sqrt(S[k]);                       /* PT:873 */
             for (int i = 0; i < d; ++i) q[i] = x[i] + a * Ut[(size_t)k * d + i];
         } else {
-            const double cd = 2.4 / sqrt(2.0 * (double)d) * scale;      /* PT:928 */
-            for (int k = 0; k < d; ++k) {
+            const double cd = 2.4 / sqrt(2.0 * (double)ng) * scale;     /* PT:928 */
+            for (int k = 0; k < ng; ++k) {
                 double z;
                 if (r) z = rp_next(r, K_NRM, 0);
                 else {
@@ -370,7 +382,7 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             }
             /* q = x + U (cd sqrt(S) z): PT:923-931 up to rounding (U orthogonal) */
             for (int i = 0; i < d; ++i) tmp[i] = 0.0;
-            for (int k = 0; k < d; ++k)
+            for (int k = 0; k < ng; ++k)
                 for (int i = 0; i < d; ++i) tmp[i] = fma(Ut[(size_t)k * d + i], wk[k], tmp[i]);
             for (int i = 0; i < d; ++i) q[i] = x[i] + tmp[i];
         }
@@ -393,10 +405,11 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             double rr;
             if (r) rr = rp_next(r, K_UNI, 0);
             else rr = w2uniform(C[1]);
-            scale = rr * 2.4 / sqrt(2.0 * (double)d) * sqrt(1.0 / beta); /* PT:976 */
+            scale = rr * 2.4 / sqrt(2.0 * (double)ng) * sqrt(1.0 / beta); /* PT:976 */
         }
         const double *DE = st->DE + wc * (size_t)Bn * d;
-        for (int i = 0; i < d; ++i) q[i] = x[i] + scale * (DE[(size_t)mm * d + i] - DE[(size_t)nn * d + i]);
+        for (int i = 0; i < d; ++i)
+            q[i] = (!gm || gm[i] != 0.0) ? x[i] + scale * (DE[(size_t)mm * d + i] - DE[(size_t)nn * d + i]) : x[i] + 0.0;
     }
     st->jstat[(((size_t)w * nt + t) * J_NTYPES + jt) * 2 + 0] += 1;
 

@@ -1,5 +1,7 @@
 // ptmi_abi.hip -- the C ABI of libptmi.so, the engine object and the kernels that are not per-chain templates
 // (swap sweep, Welford / pooling, DE ring, self-tests).  See include/ptmi.h for the boundary and DESIGN.md.
+#include <math.h>
+
 #include <new>
 #include <vector>
 
@@ -316,6 +318,7 @@ static KArgs make_args(ptmi_engine *h)
     a.Ut = b.Ut; a.S = b.S; a.DE = b.DE; a.AM = c.temp0 == 0 ? b.AM : nullptr; a.AMaux = c.temp0 == 0 ? b.AMaux : nullptr;
     a.nacc = (u64 *)b.nacc; a.jstat = (u64 *)b.jstat;
     a.temps_mh = h->d_temps; a.beta = h->d_beta; a.logl_par = h->d_loglpar; a.logp_par = h->d_logppar;
+    a.gsize = h->d_gsize; a.gmask = h->d_gmask; a.gcn = h->d_gcn; a.gdiv = h->d_gdiv; a.ngroups = c.ngroups > 1 ? c.ngroups : 1;
     a.Q = b.Q; a.qaux = b.qaux;
     a.seed = c.seed;
     a.d = c.ndim; a.nt = c.ntemps; a.W = c.nwalkers; a.ntg = c.ntemps_global; a.temp0 = c.temp0; a.walker0 = c.walker0;
@@ -405,6 +408,12 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (c.logl_kind == PTMI_LOGL_CURVED && (c.ndim & 1)) return fail(PTMI_EINVAL, "curved logl needs an even ndim");
     if (c.logp_kind == PTMI_LOGP_BOX && c.logp_par_len != 2LL * c.ndim) return fail(PTMI_EINVAL, "box prior needs lo[d] + hi[d]");
     if (!c.ladder || !c.temps_mh) return fail(PTMI_EINVAL, "ladder / temps_mh missing");
+    if (c.ngroups < 0 || c.ngroups > 1024) return fail(PTMI_EINVAL, "ngroups out of range");
+    if (c.ngroups > 1) {
+        if (!c.group_size || !c.group_mask) return fail(PTMI_EINVAL, "group_size / group_mask missing");
+        for (int g = 0; g < c.ngroups; ++g)
+            if (c.group_size[g] < 1 || c.group_size[g] > c.ndim) return fail(PTMI_EINVAL, "group %d has %d parameters", g, c.group_size[g]);
+    }
     if (!buf->X || !buf->lnL || !buf->lp || !buf->temp_of || !buf->slot_of || !buf->Ut || !buf->S || !buf->nacc || !buf->jstat)
         return fail(PTMI_EINVAL, "a required device buffer is NULL");
     if (c.w_de > 0 && !buf->DE) return fail(PTMI_EINVAL, "DE weight > 0 but no DE buffer");
@@ -429,7 +438,26 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         ptmi_destroy(h);
         return rc;
     }
-    h->cfg.ladder = h->cfg.temps_mh = h->cfg.logl_par = h->cfg.logp_par = nullptr;  // host copies are not kept
+    {   // per-group constants of the AM / DE scales: 2.4/sqrt(2 n_g) (PT:928) and sqrt(2 n_g) (PT:976)
+        const int Ng = c.ngroups > 1 ? c.ngroups : 1;
+        std::vector<double> gcn((size_t)Ng), gdiv((size_t)Ng), gmask((size_t)Ng * c.ndim, 1.0);
+        std::vector<int32_t> gsize((size_t)Ng, c.ndim);
+        for (int g = 0; g < Ng; ++g) {
+            if (c.ngroups > 1) gsize[(size_t)g] = c.group_size[g];
+            gcn[(size_t)g] = 2.4 / sqrt(2.0 * (double)gsize[(size_t)g]);
+            gdiv[(size_t)g] = sqrt(2.0 * (double)gsize[(size_t)g]);
+        }
+        if (c.ngroups > 1) memcpy(gmask.data(), c.group_mask, sizeof(double) * gmask.size());
+        hipError_t e2 = hipMalloc((void **)&h->d_gsize, sizeof(int32_t) * Ng);
+        if (e2 == hipSuccess) e2 = hipMemcpy(h->d_gsize, gsize.data(), sizeof(int32_t) * Ng, hipMemcpyHostToDevice);
+        if (e2 != hipSuccess || (rc = upload(&h->d_gcn, gcn.data(), Ng)) || (rc = upload(&h->d_gdiv, gdiv.data(), Ng)) ||
+            (rc = upload(&h->d_gmask, gmask.data(), (long long)gmask.size()))) {
+            ptmi_destroy(h);
+            return e2 != hipSuccess ? fail(PTMI_EHIP, "group tables: %s", hipGetErrorString(e2)) : rc;
+        }
+    }
+    h->cfg.ladder = h->cfg.temps_mh = h->cfg.logl_par = h->cfg.logp_par = h->cfg.group_mask = nullptr;  // host copies are not kept
+    h->cfg.group_size = nullptr;
     hipError_t e = hipMalloc((void **)&h->d_pre, sizeof(double) * 4 * (size_t)c.nwalkers * c.ntemps_global);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_prow, sizeof(int32_t) * (size_t)c.nwalkers * c.ntemps_global);
     if (e == hipSuccess && !c.cov_per_walker && c.temp0 == 0) {
@@ -448,7 +476,8 @@ int ptmi_destroy(ptmi_handle h)
 {
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
-    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
+    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow);
+    (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;

@@ -29,6 +29,8 @@ struct KArgs {
     u64 *nacc, *jstat;
     // small device tables owned by the engine
     const double *temps_mh, *beta, *logl_par, *logp_par;
+    const int32_t *gsize;                 // [Ng] parameters per group
+    const double *gmask, *gcn, *gdiv;     // [Ng][d] membership; [Ng] 2.4/sqrt(2 n_g); [Ng] sqrt(2 n_g)
     // split path
     double *Q, *qaux;
     const double *newlnL, *newlp;
@@ -38,7 +40,7 @@ struct KArgs {
     int nsteps;
     int d, nt, W, ntg, temp0, walker0;
     int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
-    int cov_update, tskip, per_walker, logp_kind;
+    int cov_update, tskip, per_walker, logp_kind, ngroups;
     int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
     int lds_u;                   // staged kernels: the block's Ut is copied to LDS (else read from global)
 };
@@ -56,7 +58,8 @@ struct ptmi_engine {
     ptmi_config cfg;
     ptmi_buffers buf;
     hipStream_t stream;
-    double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar;
+    double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar, *d_gmask, *d_gcn, *d_gdiv;
+    int32_t *d_gsize;
     double *d_pre;      // [4][ntg][W] scratch of the swap (uniforms, likelihoods, own-likelihood terms)
     int32_t *d_prow;    // [ntg][W] rows by position (fused swap)
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance

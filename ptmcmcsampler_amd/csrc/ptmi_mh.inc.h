@@ -184,22 +184,21 @@ __device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EP
 // order as the reference: scale in {10, 0.2, 1.0}; scale *= sqrt(temp) if temp <= 100
 // (PT:846-862); cd = 2.4 / sqrt(2 neff) * scale (PT:870, 928).
 struct ChainConst {
-    double cd_scam[3], cd_am[3];   // by scale branch: prob > 0.97, prob > 0.9, else
-    double de_div, de_mul;         // DE: rr * 2.4 / de_div * de_mul  (PT:976)
+    double cd_scam[3], sc[3];      // by scale branch: prob > 0.97, prob > 0.9, else; sc = scale (AM: cd = 2.4/sqrt(2 n_g) * sc)
+    double de_mul;                 // DE: rr * 2.4 / sqrt(2 n_g) * de_mul  (PT:976)
 };
 __device__ __forceinline__ ChainConst chain_const(double temp, double beta, int d)
 {
     ChainConst c;
     const double sT = temp <= 100.0 ? det_sqrt(temp) : 1.0;
     const double base[3] = {10.0, 0.2, 1.0};
-    const double c1 = 2.4 / det_sqrt(2.0 * 1.0), cn = 2.4 / det_sqrt(2.0 * (double)d);
+    const double c1 = 2.4 / det_sqrt(2.0 * 1.0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double sc = temp <= 100.0 ? base[j] * sT : base[j];
         c.cd_scam[j] = c1 * sc;
-        c.cd_am[j] = cn * sc;
+        c.sc[j] = sc;
     }
-    c.de_div = det_sqrt(2.0 * (double)d);
     c.de_mul = det_sqrt(1.0 / beta);
     return c;
 }
@@ -258,12 +257,22 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
     const double prob = w2uniform(A1);
     const int br = prob > 0.97 ? 0 : (prob > 0.9 ? 1 : 2);
     // the words of slots C and D are fetched outside the divergent branches (cross-lane reads need their source active)
-    const u64 C0 = FULL ? grp_bcast<STR, 2>(w0) : 0, C1 = FULL ? grp_bcast<STR, 2>(w1) : 0;
+    const u64 C0 = grp_bcast<STR, 2>(w0), C1 = FULL ? grp_bcast<STR, 2>(w1) : 0;
     const u64 D1 = grp_bcast<STR, 3>(w1);
     const double ln1 = grp_bcastf<STR, 3>(lg);
+    // parameter group (PT:839,897,955): word C0 for SCAM / AM, D0 for DE -- the words those jumps leave unused.
+    // A group's eigenvectors are embedded in the full space, so the jumps below only change the table they read.
+    int g = 0, ng = d;
+    if (a.ngroups > 1) {
+        const u64 D0 = grp_bcast<STR, 3>(w0);
+        g = (int)w2index(jt == PTMI_J_DE ? D0 : C0, (u64)a.ngroups);
+        ng = a.gsize[g];
+        Ut += (size_t)g * d * d;
+        S += (size_t)g * d;
+    }
 
     if (jt == PTMI_J_SCAM) {
-        const int k = (int)w2index(B1, (u64)d);
+        const int k = (int)w2index(B1, (u64)ng);
         const double *col = Ut + (size_t)k * uld;
         // the direction lands in dq (issued before the normal is computed, so its latency is covered) and
         // is scaled in place
@@ -281,7 +290,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         const int nn = (int)(((u64)mm + 1ull + w2index(C0, (u64)(Bn - 1))) % (u64)Bn);
         double scale;
         if (prob > 0.5) scale = 1.0;
-        else scale = w2uniform(C1) * 2.4 / cc.de_div * cc.de_mul;  // PT:976
+        else scale = w2uniform(C1) * 2.4 / a.gdiv[g] * cc.de_mul;  // PT:976
         const double *rm = DE + (size_t)((mm + a.de_head) % Bn) * d;
         const double *rn = DE + (size_t)((nn + a.de_head) % Bn) * d;
 #pragma unroll
@@ -290,13 +299,17 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
             PTMI_ROW_LOAD(vm, rm, e);
             PTMI_ROW_LOAD(vn, rn, e);
             dq[e] = scale * (vm - vn);
+            if (a.ngroups > 1) {                       // only the group's parameters move (PT:978-983)
+                const int i = gl + G * e;
+                if (i < d && a.gmask[(size_t)g * d + i] == 0.0) dq[e] = 0.0;
+            }
         }
     }
     if (FULL) {
         // AM (PT:879-933): q = x + U (cd sqrt(S) z).  Weights per chain (divergent), product per wave.
         const bool is_am = jt == PTMI_J_AM;
         if (!STR ? is_am : __any(is_am)) {
-            const double cd = br == 0 ? cc.cd_am[0] : (br == 1 ? cc.cd_am[1] : cc.cd_am[2]);
+            const double cd = a.gcn[g] * (br == 0 ? cc.sc[0] : (br == 1 ? cc.sc[1] : cc.sc[2]));   // PT:928
             double wk[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) wk[e] = 0.0;
@@ -305,14 +318,14 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
 #pragma unroll
                 for (int e = 0; e < EPL; e += 2) {
                     const int k = gl + G * e;
-                    if (k < d) {
+                    if (k < ng) {
                         u64 e0, e1;
                         philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
                         const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
                         double sn, cs;
                         det_sincos2pi(w2uniform(e1), sn, cs);
                         wk[e] = (r * cs) * cd * det_sqrt(S[k]);                        // PT:930
-                        if (e + 1 < EPL && k + G < d) wk[e + 1] = (r * sn) * cd * det_sqrt(S[k + G]);
+                        if (e + 1 < EPL && k + G < ng) wk[e + 1] = (r * sn) * cd * det_sqrt(S[k + G]);
                     }
                     __builtin_amdgcn_sched_barrier(0);     // one Box-Muller at a time: interleaving them only costs registers
                 }
@@ -333,7 +346,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
 #pragma unroll 1
                     for (int src = 0; src < G; ++src) {
                         const int k = src + G * e2;
-                        if (k >= d) break;
+                        if (k >= ng) break;
                         const double wv = group_bcast_lane<G>(wk[e2], src);
                         const double *row = Ut + (size_t)k * d;
 #pragma unroll
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
     const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)tg);
     const size_t wc = a.per_walker ? (size_t)w : 0;
-    const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
+    const double *Ut = a.Ut + wc * a.ngroups * d * d, *S = a.S + wc * a.ngroups * d;
     const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * d : nullptr;
     double *xrow = a.X + (size_t)ch * d;
 
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
     const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)(a.temp0 + t));
     const size_t wc = a.per_walker ? (size_t)w : 0;
-    const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
+    const double *Ut = a.Ut + wc * a.ngroups * d * d, *S = a.S + wc * a.ngroups * d;
     const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
     const double *xrow = a.X + (size_t)ch * d;
     double x[EPL], dq[EPL];
@@ -625,7 +638,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     a.lds_u = 0;
     if (WANTS) {
         const size_t tab = sizeof(double) * (size_t)(4 * ((c.ndim + 3) / 4)) * mfma_ld(EPL);   // zero-padded copy
-        const bool one_table_per_block = !FULL || !c.cov_per_walker || c.ntemps % (256 / G) == 0;
+        const bool one_table_per_block = c.ngroups <= 1 && (!FULL || !c.cov_per_walker || c.ntemps % (256 / G) == 0);
         size_t lds = LOGL == PTMI_LOGL_DENSE ? tab : 0;
         if (FULL && lds + tab <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
         if (lds <= 160 * 1024 && one_table_per_block) {

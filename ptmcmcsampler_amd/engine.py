@@ -47,7 +47,7 @@ class PTEngine(object):
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
-                 w_host=0, keep_lnl=False):
+                 w_host=0, keep_lnl=False, groups=None):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -68,6 +68,15 @@ class PTEngine(object):
         if cov_mode not in ("per_walker", "pooled"):
             raise ValueError("cov_mode must be 'per_walker' or 'pooled'")
         self.Wc = self.W if self.per_walker else 1
+        # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
+        self.groups = [np.arange(self.d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
+        self.ngr = len(self.groups)
+        self.gsize = np.ascontiguousarray([len(g) for g in self.groups], dtype=np.int32)
+        self.gmask = np.zeros((self.ngr, self.d))
+        for gi, g in enumerate(self.groups):
+            if len(g) < 1 or g.min() < 0 or g.max() >= self.d:
+                raise ValueError("group %d has indices outside [0, %d)" % (gi, self.d))
+            self.gmask[gi, g] = 1.0
         self.device = torch.device("cuda", device)
         self.dev_index = device
         d, nt, W, Wc = self.d, self.nt, self.W, self.Wc
@@ -79,7 +88,7 @@ class PTEngine(object):
             X=z((W, nt, d)), lnL=z((W, nt)), lp=z((W, nt)),
             temp_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
             slot_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
-            Ut=z((Wc, d, d)), S=z((Wc, d)),
+            Ut=z((Wc, self.ngr, d, d)), S=z((Wc, self.ngr, d)),
             DE=z((Wc, self.burn, d)) if has_de else None,
             AM=z((W, self.cov_update, d)) if self.owns_cold else None,
             nacc=z((W, nt), i64), jstat=z((W, nt, _lib.J_NTYPES, 2), i64), nswap=z((W, self.ntg), i64),
@@ -103,7 +112,8 @@ class PTEngine(object):
             ndim=d, ntemps=nt, nwalkers=W, ntemps_global=self.ntg, temp0=self.temp0, walker0=self.walker0,
             logl_kind=_lib.LOGL[logl[0]], logp_kind=_lib.LOGP[logp[0]], w_host=int(w_host), w_scam=self.weights[0], w_am=self.weights[1],
             w_de=self.weights[2] if has_de else 0, de_size=self.burn, cov_update=self.cov_update, tskip=self.tskip,
-            cov_per_walker=int(self.per_walker), device=device, seed=self.seed,
+            cov_per_walker=int(self.per_walker), device=device, ngroups=self.ngr if self.ngr > 1 else 0, seed=self.seed,
+            group_size=self.gsize.ctypes.data_as(C.POINTER(C.c_int32)), group_mask=self.gmask.ctypes.data_as(_lib._dp),
             stream=C.c_void_p(self.stream.cuda_stream),
             ladder=self.ladder.ctypes.data_as(_lib._dp), temps_mh=self.temps_mh.ctypes.data_as(_lib._dp),
             logl_par=self._par_l.ctypes.data_as(_lib._dp) if len(self._par_l) else None, logl_par_len=len(self._par_l),
@@ -148,14 +158,21 @@ class PTEngine(object):
     # ------------------------------------------------------------------ set-up
     def _eig_host(self, w, cov):
         """U, S of the jump covariance by LAPACK, as the reference (:145, :803)."""
-        with _blas_single_thread():                                   # a d x d SVD gains nothing from a 256-thread pool
-            U, S, _ = np.linalg.svd(cov)
-        self.put_eig(U, S, w)
+        for gi, g in enumerate(self.groups):                          # per group, :139-145 and :797-803
+            with _blas_single_thread():                               # a small SVD gains nothing from a 256-thread pool
+                U, S, _ = np.linalg.svd(cov[np.ix_(g, g)] if self.ngr > 1 or len(g) != self.d else cov)
+            self.put_eig(U, S, w, gi)
 
-    def put_eig(self, U, S, w=0):
+    def put_eig(self, U, S, w=0, gi=0):
+        """Upload a group's eigenvectors (columns of U) embedded in the full space, one per row."""
         torch = _torch()
-        self.t["Ut"][w].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(U).T)))
-        self.t["S"][w].copy_(torch.from_numpy(np.ascontiguousarray(S)))
+        g = self.groups[gi]
+        Ut = np.zeros((self.d, self.d))
+        Sv = np.zeros(self.d)
+        Ut[np.ix_(np.arange(len(g)), g)] = np.asarray(U).T
+        Sv[:len(g)] = S
+        self.t["Ut"][w, gi].copy_(torch.from_numpy(Ut))
+        self.t["S"][w, gi].copy_(torch.from_numpy(Sv))
 
     def init_state(self, p0):
         """Initial point(s): ``p0`` of shape [d] (broadcast) or [W][nt][d] (by slot)."""

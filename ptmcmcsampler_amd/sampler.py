@@ -127,11 +127,11 @@ class PTSampler(object):
         self.groups = groups
         if groups is None:
             self.groups = [np.arange(0, self.ndim)]
-        elif len(groups) != 1 or len(groups[0]) != ndim or not np.array_equal(np.sort(groups[0]), np.arange(ndim)):
-            raise NotImplementedError("parameter groups (PTMCMCSampler.py:139-145) are not supported yet")
         self.cov = cov                                       # kept by reference and updated in place (:134, :794)
-        self.U, self.S = [[]], [[]]
-        self.U[0], self.S[0], _ = np.linalg.svd(np.asarray(self.cov, dtype=np.float64))   # :145
+        self.U, self.S = [[]] * len(self.groups), [[]] * len(self.groups)
+        for ct, group in enumerate(self.groups):             # :139-145
+            cg = np.asarray(self.cov, dtype=np.float64)[np.ix_(np.asarray(group), np.asarray(group))]
+            self.U[ct], self.S[ct], _ = np.linalg.svd(cg)
         self.M2 = np.zeros((ndim, ndim))
         self.mu = np.zeros(ndim)
         self.propCycle, self.jumpDict, self.aux = [], {}, []
@@ -236,7 +236,7 @@ class PTSampler(object):
             logl=self.logl_spec or ("iso",), logp=self.logp_spec or ("flat",),
             weights=(self.SCAMweight, self.AMweight, self.DEweight), cov_update=covUpdate, burn=burn, tskip=Tskip,
             seed=self.seed, cov_mode=self.cov_mode, hot_chain=hotChain, device=self.device_index, split=self.split,
-            w_host=len(self.host_jumps), keep_lnl=True)
+            w_host=len(self.host_jumps), keep_lnl=True, groups=None if len(self.groups) == 1 and len(self.groups[0]) == self.ndim and np.array_equal(np.asarray(self.groups[0]), np.arange(self.ndim)) else self.groups)
 
     # ------------------------------------------------------------------ sample (:374-528)
     def sample(self, p0, Niter, ladder=None, Tmin=1, Tmax=None, Tskip=100, isave=1000, covUpdate=1000, SCAMweight=20,
@@ -343,7 +343,11 @@ class PTSampler(object):
     def _mirror_cov(self):
         cov = self.engine.get("cov")[0]
         self.cov[:, :] = cov                                      # :794, in place
-        self.U[0], self.S[0] = self.engine.get("Ut")[0].T.copy(), self.engine.get("S")[0].copy()
+        Ut, Sv = self.engine.get("Ut")[0], self.engine.get("S")[0]
+        for ct, group in enumerate(self.groups):
+            g = np.asarray(group)
+            self.U[ct] = Ut[ct][np.ix_(np.arange(len(g)), g)].T.copy()
+            self.S[ct] = Sv[ct][:len(g)].copy()
         self.M2, self.mu = self.engine.get("M2")[0], self.engine.get("mu")[0]
 
     def _counters(self):

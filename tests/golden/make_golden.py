@@ -343,7 +343,7 @@ def gen_ptswap(PT, out, tmp):
     np.savez_compressed(os.path.join(out, "ptswap.npz"), **res)
 
 
-def run_traj(PT, name, out, ndim, nranks, logl, logp, p0, cov0, sample_kw, seed, extra=None, hot=False):
+def run_traj(PT, name, out, ndim, nranks, logl, logp, p0, cov0, sample_kw, seed, extra=None, hot=False, groups=None):
     """Full sample() run with per-rank recorded draws and per-epoch cov snapshots."""
     tmp = tempfile.mkdtemp()
     world = World(nranks)
@@ -355,6 +355,8 @@ def run_traj(PT, name, out, ndim, nranks, logl, logp, p0, cov0, sample_kw, seed,
         try:
             comm = ThreadComm(world, r) if nranks > 1 else None
             kw = dict(outDir=tmp, verbose=False, seed=seed)
+            if groups is not None:
+                kw["groups"] = [np.asarray(g) for g in groups]
             if comm is not None:
                 kw["comm"] = comm
             s = PT.PTSampler(ndim, logl, logp, np.copy(cov0), **kw)
@@ -384,6 +386,9 @@ def run_traj(PT, name, out, ndim, nranks, logl, logp, p0, cov0, sample_kw, seed,
         raise errs[0]
 
     res = dict(extra or {})
+    if groups is not None:
+        res["groups_flat"] = np.concatenate([np.asarray(g) for g in groups])
+        res["groups_size"] = np.asarray([len(g) for g in groups])
     res["ndim"], res["nranks"], res["seed"] = ndim, nranks, seed
     res["p0"], res["cov0"] = p0, cov0
     for k, v in sample_kw.items():
@@ -442,6 +447,15 @@ def gen_trajectories(PT, out):
              dict(Niter=240, covUpdate=40, burn=80, thin=2, isave=40, Tskip=8,
                   SCAMweight=20, AMweight=20, DEweight=20), seed=31337, hot=True,
              extra=dict(box_lo=lo, box_hi=hi, dense_mu=mu, dense_icov=icov))
+    # T6/T7: parameter groups (per-group SVD and group-restricted jumps, PTMCMCSampler.py:129-145, 839, 897, 955)
+    d = 6
+    run_traj(PT, "traj_groups_d6", out, d, 1, iso_logl, flat_logp, rs.randn(d) * 0.3, np.eye(d) * 0.02,
+             dict(Niter=500, covUpdate=100, burn=200, thin=1, isave=100, Tskip=100,
+                  SCAMweight=20, AMweight=20, DEweight=20), seed=606, groups=[[0, 1, 2], [3, 4, 5]])
+    d = 5
+    run_traj(PT, "traj_groups_pt2_d5", out, d, 2, iso_logl, flat_logp, rs.randn(d) * 0.3, np.eye(d) * 0.02,
+             dict(Niter=300, covUpdate=50, burn=100, thin=1, isave=50, Tskip=10,
+                  SCAMweight=20, AMweight=20, DEweight=20), seed=707, groups=[[0, 1, 2, 3, 4], [3, 1], [2]])
     # T5: the SCAM-only slice at the bench dimension (d=100), 2 temperatures, adaptation off
     d = 100
     run_traj(PT, "traj_pt2_scam_d100", out, d, 2, iso_logl, flat_logp, np.zeros(d), np.eye(d) * 0.01,

@@ -305,3 +305,15 @@ def test_minus_inf_start_and_nan_safety(mods):
     g.run(120)
     o.run(120)
     _compare(g, o, "inf-start ")
+
+
+@pytest.mark.parametrize("d,groups", [(6, [[0, 1, 2], [3, 4, 5]]), (5, [[0, 1, 2, 3, 4], [3, 1], [2]]), (40, [list(range(0, 40, 2)), list(range(1, 40, 2)), [7]])])
+def test_parameter_groups(mods, d, groups):
+    """Per-group SVD and group-restricted SCAM / AM / DE (PTMCMCSampler.py:129-145, 839, 897, 955)."""
+    g, o = _pair(mods, d, 3, 5, groups=groups, weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=13, rs=d)
+    g.run(250)
+    o.run(250)
+    _compare(g, o, "groups d=%d " % d)
+    assert_same(g.get("Ut"), o.Ut, "Ut")
+    assert_same(g.get("S"), o.S, "S")
+    assert o.jstat[..., 0].sum(axis=(0, 1)).min() > 0

@@ -137,7 +137,10 @@ def _engine_from_traj(g):
     d, n = int(g["ndim"]), int(g["nranks"])
     logl = ("dense", g["dense_mu"], g["dense_icov"]) if "dense_mu" in g else ("iso",)
     logp = ("box", g["box_lo"], g["box_hi"]) if "box_lo" in g else ("flat",)
-    e = orc.OracleEngine(d, n, 1, g["cov0"], ladder=g["ladder"], logl=logl, logp=logp,
+    groups = None
+    if "groups_flat" in g:
+        groups = np.split(g["groups_flat"], np.cumsum(g["groups_size"])[:-1])
+    e = orc.OracleEngine(d, n, 1, g["cov0"], ladder=g["ladder"], logl=logl, logp=logp, groups=groups,
                          weights=(int(g["kw_SCAMweight"]), int(g["kw_AMweight"]), int(g["kw_DEweight"])),
                          cov_update=int(g["kw_covUpdate"]), burn=int(g["kw_burn"]), tskip=int(g["kw_Tskip"]),
                          hot_chain=bool(g["hot"]))
@@ -146,7 +149,7 @@ def _engine_from_traj(g):
 
 
 @pytest.mark.parametrize("name", ["traj_single_d5", "traj_single_box_d4", "traj_pt4_d6", "traj_pt3_dense_d8",
-                                  "traj_pt2_scam_d100"])
+                                  "traj_pt2_scam_d100", "traj_groups_d6", "traj_groups_pt2_d5"])
 def test_full_trajectory_matches_reference(golden, name):
     """sample() end to end (PTMCMCSampler.py:495-629) replayed from each rank's recorded draws."""
     g = golden(name)
@@ -159,7 +162,7 @@ def test_full_trajectory_matches_reference(golden, name):
 
     def spy(w):
         orig(w)
-        epochs.append((e.mu[0].copy(), e.M2[0].copy(), e.cov[0].copy(), e.Ut[0].T.copy(), e.S[0].copy()))
+        epochs.append((e.mu[0].copy(), e.M2[0].copy(), e.cov[0].copy(), None, e.S[0, 0, :e.gsize[0]].copy()))
 
     e._svd = spy
     rec = e.run(niter, replay=replay, record=True)
