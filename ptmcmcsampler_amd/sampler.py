@@ -218,6 +218,14 @@ class PTSampler(object):
         self.temp = self.ladder[0]
         self.fname = self.outDir + "/chain_{0}.txt".format(self.temp)                # :285
         self.writeHotChains, self.hotChain = writeHotChains, hotChain
+        # the hotter ranks of walker 0 (the other MPI ranks' own chain files in the reference, :285-288, :346)
+        self._hot_names = []
+        if writeHotChains and self.nchain > 1:
+            self._hot = np.zeros((self.nchain - 1, N, self.ndim))
+            self._hot_lnl, self._hot_lnp = np.zeros((self.nchain - 1, N)), np.zeros((self.nchain - 1, N))
+            for r in range(1, self.nchain):
+                last_hot = hotChain and r == self.nchain - 1
+                self._hot_names.append(self.outDir + ("/chain_hot.txt" if last_hot else "/chain_{0}.txt".format(self.ladder[r])))
         self.resumeLength = 0
         self._ckpt = os.path.join(self.outDir, "ptmi_checkpoint.npz")
         self._resuming = bool(self.resume) and os.path.isfile(self._ckpt) and os.path.isfile(self.fname)
@@ -226,6 +234,8 @@ class PTSampler(object):
                 print("Resuming run from chain file {0}".format(self.fname))
         else:
             open(self.fname, "w").close()
+            for f in self._hot_names:
+                open(f, "w").close()
         # ---- engine
         self.host_jumps = [f for f in self.propCycle if self._builtin(f) < 0]
         self.split = self.logl is not None or bool(self.host_jumps) or bool(self.aux)
@@ -267,6 +277,8 @@ class PTSampler(object):
             else:
                 eng.init_state(p0)
             self._harvest([i0])
+            if self._hot_names:
+                self._harvest_hot(i0)
             if i0 % self.isave == 0:
                 self.writeOutput(i0)
         it = i0 + 1
@@ -286,10 +298,14 @@ class PTSampler(object):
                 self._split_step(it)
             else:
                 end = min(eng._segment_end(it, self.Niter), ((it - 1) // self.isave + 1) * self.isave)
+                if self._hot_names:                                  # hot ranks are sampled from the state, at thin multiples
+                    end = min(end, ((it - 1) // self.thin + 1) * self.thin)
                 eng.mh_steps(it, end - it + 1)
             if self.Tskip > 0 and self.nchain > 1 and end % self.Tskip == 0:
                 eng.swap(end)
             self._harvest([i for i in range(it, end + 1) if i % self.thin == 0])
+            if self._hot_names and end % self.thin == 0:
+                self._harvest_hot(end)
             if end % self.isave == 0:
                 self.writeOutput(end)
             if self.neff and end % 1000 == 0 and end > 2 * self.burn:                               # :510-521
@@ -376,6 +392,18 @@ class PTSampler(object):
             self._chains[:, ind] = X[:, n]
             self._lnlikes[:, ind] = aux[:, n, 0]
             self._lnprobs[:, ind] = beta0 * aux[:, n, 0] + aux[:, n, 1]
+
+    def _harvest_hot(self, i):
+        """Current state of walker 0's ranks 1.. (post-swap, like updateChains at :627)."""
+        eng = self.engine
+        ind = int(i / self.thin)
+        if ind >= self._hot.shape[1]:
+            return
+        rows = eng.t["slot_of"][0, 1:].long()
+        self._hot[:, ind] = eng.t["X"][0, rows].cpu().numpy()
+        lnl, lp = eng.t["lnL"][0, rows].cpu().numpy(), eng.t["lp"][0, rows].cpu().numpy()
+        self._hot_lnl[:, ind] = lnl
+        self._hot_lnp[:, ind] = (1.0 / eng.temps_mh[1:]) * lnl + lp
 
     # ------------------------------------------------------------------ host-callback path
     def _eval_host(self, Q):
@@ -470,6 +498,17 @@ class PTSampler(object):
                     fh.write("\t".join(["%22.22f" % (self._chains[k, ind, kk]) for kk in range(self.ndim)]))
                     fh.write("\t%f\t%f\t%f\t%f\n" % (self._lnprobs[k, ind], self._lnlikes[k, ind],
                                                      self.naccepted / iter if iter > 0 else 0, pt_acc))
+        if self._hot_names:
+            nacc, nsw = self.engine.get("nacc")[0], self.engine.get("nswap")[0]
+            for r, fname in enumerate(self._hot_names, start=1):
+                with open(fname, "a+") as fh:
+                    for ind in range(self.ind_next_write, write_end):
+                        pt_acc = 1
+                        if r < self.nchain - 1 and self.swapProposed != 0:
+                            pt_acc = int(nsw[r]) / self.swapProposed
+                        fh.write("\t".join(["%22.22f" % (self._hot[r - 1, ind, kk]) for kk in range(self.ndim)]))
+                        fh.write("\t%f\t%f\t%f\t%f\n" % (self._hot_lnp[r - 1, ind], self._hot_lnl[r - 1, ind],
+                                                         int(nacc[r]) / iter if iter > 0 else 0, pt_acc))
         self.ind_next_write = write_end
         with open(self.outDir + "/jumps.txt", "w") as fout:
             njumps = len(self.propCycle)

@@ -178,3 +178,23 @@ def test_resume_continues_bit_identically(tmp_path):
     # the rate columns are "as of the time of writing" (PTMCMCSampler.py:741-745): identical in both runs
     assert fa == fb
     assert a.jumpDict == b2.jumpDict and a.naccepted == b2.naccepted
+
+
+def test_write_hot_chains_and_groups(tmp_path):
+    """writeHotChains / hotChain file naming (PTMCMCSampler.py:281-288) and parameter groups through the facade."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 6
+    groups = [np.array([0, 1, 2]), np.array([3, 4, 5])]
+    s = PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, groups=groups, outDir=str(tmp_path), verbose=False, seed=9, ntemps=3)
+    s.sample(np.zeros(d), 400, burn=100, thin=5, covUpdate=100, isave=100, Tskip=10, writeHotChains=True, hotChain=True)
+    names = sorted(os.listdir(tmp_path))
+    t1 = float(s.ladder[1])
+    assert "chain_1.0.txt" in names and "chain_hot.txt" in names and "chain_{0}.txt".format(t1) in names
+    for f in ("chain_1.0.txt", "chain_hot.txt", "chain_{0}.txt".format(t1)):
+        rows = np.loadtxt(tmp_path / f)
+        assert rows.shape == (81, d + 4)
+        assert np.allclose(rows[:, d + 1], -0.5 * (rows[:, :d] ** 2).sum(1), atol=2e-6)       # lnlike column, "%f"
+    hot = np.loadtxt(tmp_path / "chain_hot.txt")
+    assert np.all(hot[:, d] == 0.0) or np.allclose(hot[1:, d], hot[1:, d + 1] / 1e80, atol=1e-6)   # lnprob = lnlike / 1e80
+    assert len(s.U) == 2 and s.U[0].shape == (3, 3) and s.S[1].shape == (3,)
+    assert np.abs(s.cov[0, 3]) < np.abs(s.cov[0, 0])          # adapted, and the facade mirrors the device covariance
