@@ -131,7 +131,9 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *mu, double *M2, double *cov, int d, int mem,
                                                      long long iter, int cov_stride_per_walker)
 {
-    __shared__ double sh[2][2][WTILE];  // [buf][diff|e][WTILE]
+    constexpr int PF = 8;       // rows fetched ahead by the carrier threads (one HBM latency per PF rows)
+    constexpr int RB = 4;       // rows handed to the tile per barrier
+    __shared__ double sh[2][RB][2][WTILE];  // [buf][row][diff|e][WTILE]
     const int w = (int)blockIdx.z;
     const int ti0 = (int)blockIdx.y * WTILE, tj0 = (int)blockIdx.x * WTILE;
     const int tx = (int)(threadIdx.x & 15), ty = (int)(threadIdx.x >> 4);
@@ -154,41 +156,51 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
             const int i = ti0 + ty + 16 * p, j = tj0 + tx + 16 * r;
             acc[p][r] = (!reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
         }
-    constexpr int PF = 8;   // rows fetched ahead by the carrier threads (one HBM latency per PF rows)
+    int bsel = 0;
     for (int ii0 = 0; ii0 < mem; ii0 += PF) {
         double vpre[PF];
 #pragma unroll
         for (int u = 0; u < PF; ++u) vpre[u] = (carrier && ii0 + u < mem) ? am[(size_t)(ii0 + u) * d + rel] : 0.0;
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int ii = ii0 + u;
-            if (ii >= mem) break;
-            it += 1;
-            const int bsel = ii & 1;
+        for (int u0 = 0; u0 < PF; u0 += RB) {
+            if (ii0 + u0 >= mem) break;
+            // the carriers advance the running mean through RB rows (the recurrence is theirs alone) ...
             if (role < 2) {
-                double df = 0.0, ev = 0.0;
-                if (carrier) {
-                    const double v = vpre[u];
-                    df = v - m;
-                    m += df / (double)it;
-                    ev = v - m;
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    double df = 0.0, ev = 0.0;
+                    if (carrier && ii0 + u0 + u < mem) {
+                        const double v = vpre[u0 + u];
+                        df = v - m;
+                        m += df / (double)(it + 1 + u);
+                        ev = v - m;
+                    }
+                    if (role == 0) sh[bsel][u][0][ridx] = df;
+                    else sh[bsel][u][1][ridx] = ev;
                 }
-                if (role == 0) sh[bsel][0][ridx] = df;
-                else sh[bsel][1][ridx] = ev;
             }
             __syncthreads();
-            double dv[WT], evv[WT];
+            // ... and the whole tile applies the RB rank-1 updates, rows ascending (rows past the end carry zeros)
 #pragma unroll
-            for (int p = 0; p < WT; ++p) dv[p] = sh[bsel][0][ty + 16 * p];
+            for (int u = 0; u < RB; ++u) {
+                double dv[WT], evv[WT];
 #pragma unroll
-            for (int r = 0; r < WT; ++r) evv[r] = sh[bsel][1][tx + 16 * r];
+                for (int p = 0; p < WT; ++p) dv[p] = sh[bsel][u][0][ty + 16 * p];
 #pragma unroll
-            for (int p = 0; p < WT; ++p)
+                for (int r = 0; r < WT; ++r) evv[r] = sh[bsel][u][1][tx + 16 * r];
+                if (ii0 + u0 + u < mem) {
 #pragma unroll
-                for (int r = 0; r < WT; ++r) {
-                    if (FUSED) acc[p][r] = __builtin_fma(dv[p], evv[r], acc[p][r]);   // pooled mode: not a reference replica
-                    else acc[p][r] += dv[p] * evv[r];                                 // PT:792, one product and one sum
+                    for (int p = 0; p < WT; ++p)
+#pragma unroll
+                        for (int r = 0; r < WT; ++r) {
+                            if (FUSED) acc[p][r] = __builtin_fma(dv[p], evv[r], acc[p][r]);   // pooled mode: not a reference replica
+                            else acc[p][r] += dv[p] * evv[r];                                 // PT:792, one product and one sum
+                        }
                 }
+            }
+            const int done = mem - (ii0 + u0) < RB ? mem - (ii0 + u0) : RB;
+            it += done;
+            bsel ^= 1;
         }
     }
     const double den = (double)(it - 1);
