@@ -128,6 +128,15 @@ __device__ __forceinline__ double det_exp(double x)
     return __longlong_as_double((long long)(yb + ((u64)(long long)(k + 1000) << 52))) * 0x1.0p-1000;
 }
 
+// p*z + c with the constant c held in a scalar register pair: keeps the 21 Taylor coefficients out of the vector
+// register file (hipcc otherwise parks each in a VGPR pair and copies it before every v_fmac)
+__device__ __forceinline__ double fma_sconst(double p, double z, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+    return r;
+}
+
 // cos(2 pi u) and sin(2 pi u), u in [0,1): exact quarter-turn reduction, Taylor in r
 __device__ __forceinline__ void det_sincos2pi(double u, double &sn_out, double &cs_out)
 {
@@ -137,27 +146,27 @@ __device__ __forceinline__ void det_sincos2pi(double u, double &sn_out, double &
     const double z = r * r;
     const int qi = (int)q & 3;
     double ps = -0x1.8a404211f9547p-45;
-    ps = __builtin_fma(ps, z, 0x1.aaec32af93359p-38);
-    ps = __builtin_fma(ps, z, -0x1.6fadb9f155744p-31);
-    ps = __builtin_fma(ps, z, 0x1.e8f434d018d63p-25);
-    ps = __builtin_fma(ps, z, -0x1.e3074fde8871fp-19);
-    ps = __builtin_fma(ps, z, 0x1.50783487ee782p-13);
-    ps = __builtin_fma(ps, z, -0x1.32d2cce62bd86p-8);
-    ps = __builtin_fma(ps, z, 0x1.466bc6775aae2p-4);
-    ps = __builtin_fma(ps, z, -0x1.4abbce625be53p-1);
-    ps = __builtin_fma(ps, z, 0x1.921fb54442d18p+0);
+    ps = fma_sconst(ps, z, 0x1.aaec32af93359p-38);
+    ps = fma_sconst(ps, z, -0x1.6fadb9f155744p-31);
+    ps = fma_sconst(ps, z, 0x1.e8f434d018d63p-25);
+    ps = fma_sconst(ps, z, -0x1.e3074fde8871fp-19);
+    ps = fma_sconst(ps, z, 0x1.50783487ee782p-13);
+    ps = fma_sconst(ps, z, -0x1.32d2cce62bd86p-8);
+    ps = fma_sconst(ps, z, 0x1.466bc6775aae2p-4);
+    ps = fma_sconst(ps, z, -0x1.4abbce625be53p-1);
+    ps = fma_sconst(ps, z, 0x1.921fb54442d18p+0);
     const double sn = ps * r;       // sin(pi r / 2)
     double pc = 0x1.ef6e308d6d1c4p-49;
-    pc = __builtin_fma(pc, z, -0x1.2a0c591af8314p-41);
-    pc = __builtin_fma(pc, z, 0x1.20c62c2f2d7f5p-34);
-    pc = __builtin_fma(pc, z, -0x1.b6e24f44b128fp-28);
-    pc = __builtin_fma(pc, z, 0x1.f9d38a3763cc3p-22);
-    pc = __builtin_fma(pc, z, -0x1.a6d1f2a204a8cp-16);
-    pc = __builtin_fma(pc, z, 0x1.e1f506891babbp-11);
-    pc = __builtin_fma(pc, z, -0x1.55d3c7e3cbffap-6);
-    pc = __builtin_fma(pc, z, 0x1.03c1f081b5ac4p-2);
-    pc = __builtin_fma(pc, z, -0x1.3bd3cc9be45dep+0);
-    pc = __builtin_fma(pc, z, 1.0);  // cos(pi r / 2)
+    pc = fma_sconst(pc, z, -0x1.2a0c591af8314p-41);
+    pc = fma_sconst(pc, z, 0x1.20c62c2f2d7f5p-34);
+    pc = fma_sconst(pc, z, -0x1.b6e24f44b128fp-28);
+    pc = fma_sconst(pc, z, 0x1.f9d38a3763cc3p-22);
+    pc = fma_sconst(pc, z, -0x1.a6d1f2a204a8cp-16);
+    pc = fma_sconst(pc, z, 0x1.e1f506891babbp-11);
+    pc = fma_sconst(pc, z, -0x1.55d3c7e3cbffap-6);
+    pc = fma_sconst(pc, z, 0x1.03c1f081b5ac4p-2);
+    pc = fma_sconst(pc, z, -0x1.3bd3cc9be45dep+0);
+    pc = fma_sconst(pc, z, 1.0);  // cos(pi r / 2)
     const double cv = (qi & 1) ? sn : pc;
     cs_out = (qi == 1 || qi == 2) ? -cv : cv;
     const double sv = (qi & 1) ? pc : sn;
