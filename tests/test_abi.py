@@ -34,7 +34,7 @@ def test_struct_layouts_match_the_header(lib):
     import ctypes as C
     assert C.sizeof(lib.Config) == 18 * 4 + 8 + 8 + 2 * 8 + 4 * 8 + 2 * 8   # 18 int32, seed, stream, 2+4+2 pointers/lengths
     assert C.sizeof(lib.Buffers) == 18 * 8
-    assert [lib.lanes_for(d) for d in (2, 32, 33, 100, 104, 105, 256, 416, 417, 2048)] == [lib.load().ptmi_lanes_for(d) for d in (2, 32, 33, 100, 104, 105, 256, 416, 417, 2048)]
+    assert [lib.lanes_for(d) for d in (2, 32, 33, 100, 104, 105, 256, 416, 417, 640, 641, 1024, 1025, 2048)] == [lib.load().ptmi_lanes_for(d) for d in (2, 32, 33, 100, 104, 105, 256, 416, 417, 640, 641, 1024, 1025, 2048)]
 
 
 def test_no_cpu_fallback(lib):
