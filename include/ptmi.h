@@ -150,6 +150,20 @@ int ptmi_swap_sweep(ptmi_handle h, int64_t iter, const double *lnL_pos_global /*
                     int32_t *map /* dev [W][ntemps_global] */);
 int ptmi_swap_write_am(ptmi_handle h, int64_t iter);
 
+/* Device-side form of pieces 2 and 3, with no host synchronisation (what ShardedPTEngine uses on GPUs):
+ *  - ptmi_swap_sweep_blocks: the sweep reading lnL exactly as an all-gather delivers it, [nranks][W][T];
+ *  - ptmi_exchange_pack: rewrites slot_of / temp_of for this block from the map and copies the rows that leave
+ *    into send[q][w][0..d+1] (state, lnL, lp), q = destination GPU.  One sweep moves at most one row of a walker
+ *    to a colder block and at most one to the next hotter block, so [nranks][W] slots are always enough;
+ *  - (caller) all-to-all with equal splits: send[q] goes to GPU q, recv[q] comes from GPU q;
+ *  - ptmi_exchange_apply: stores the rows that arrived (the pack step recorded where each one goes).
+ * ptmi_exchange_status reports (after a sync) whether a plan ever exceeded those bounds (must stay 0). */
+int ptmi_swap_sweep_blocks(ptmi_handle h, int64_t iter, const double *lnL_blocks /* dev [nranks][W][T] */,
+                           int32_t *map /* dev [W][ntemps_global] */);
+int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send /* dev [nranks][W][d+2] */);
+int ptmi_exchange_apply(ptmi_handle h, const double *recv /* dev [nranks][W][d+2] */);
+int ptmi_exchange_status(ptmi_handle h, int32_t *violations);
+
 /* _updateRecursive (:769-794) for every walker at iteration `iter` (= the multiple of
  * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 the
  * walkers' statistics are pooled into cov[0].  The eigendecomposition (:797-803) is a

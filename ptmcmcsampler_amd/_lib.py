@@ -37,7 +37,8 @@ class Buffers(C.Structure):
 SYMBOLS = (
     "ptmi_last_error", "ptmi_version", "ptmi_device_count", "ptmi_lanes_for", "ptmi_create", "ptmi_destroy",
     "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_swap", "ptmi_swap_gather_lnl",
-    "ptmi_swap_sweep", "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept",
+    "ptmi_swap_sweep", "ptmi_swap_sweep_blocks", "ptmi_exchange_pack", "ptmi_exchange_apply", "ptmi_exchange_status",
+    "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept",
     "ptmi_selftest_math", "ptmi_selftest_philox", "ptmi_malloc", "ptmi_free", "ptmi_memcpy_h2d", "ptmi_memcpy_d2h",
     "ptmi_memset", "ptmi_timer_start", "ptmi_timer_stop_ms",
 )
@@ -80,6 +81,10 @@ def load():
     L.ptmi_swap_gather_lnl.argtypes = [H, C.c_void_p]
     L.ptmi_swap_sweep.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]
     L.ptmi_swap_write_am.argtypes = [H, C.c_int64]
+    L.ptmi_swap_sweep_blocks.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]
+    L.ptmi_exchange_pack.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.ptmi_exchange_apply.argtypes = [H, C.c_void_p]
+    L.ptmi_exchange_status.argtypes = [H, C.POINTER(C.c_int32)]
     L.ptmi_update_cov.argtypes = [H, C.c_int64]
     L.ptmi_propose.argtypes = [H, C.c_int64]
     L.ptmi_accept.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]

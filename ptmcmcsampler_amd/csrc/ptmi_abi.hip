@@ -34,7 +34,8 @@ __global__ void gather_lnl_kernel(const double *lnL, const int32_t *slot_of, dou
 // reads are coalesced.  When the whole ladder is local (slot_of != nullptr) the slot tables are rewritten in place:
 // position k+1 becomes final at step k and positions <= k are still untouched.
 __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const double *lnL_pos, const double *lnL_rows,
-                                    const int32_t *slot_of, double *pre, int32_t *prow, long long iter, u64 seed, int walker0)
+                                    const int32_t *slot_of, double *pre, int32_t *prow, long long iter, u64 seed, int walker0,
+                                    int block_nt /* > 0: lnL_pos is [n / block_nt][W][block_nt], as all-gathered */)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * W) return;
@@ -42,7 +43,8 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
     const size_t nW = (size_t)n * W;
     const bool fused = slot_of != nullptr;
     const int row = fused ? slot_of[(size_t)w * n + k] : 0;
-    const double L = fused ? lnL_rows[(size_t)w * n + row] : lnL_pos[(size_t)w * n + k];
+    const double L = fused ? lnL_rows[(size_t)w * n + row]
+                   : (block_nt > 0 ? lnL_pos[((size_t)(k / block_nt) * W + w) * block_nt + k % block_nt] : lnL_pos[(size_t)w * n + k]);
     double u = 0.0, a = 0.0, b = 0.0;
     if (k < n - 1) {
         const u32 sid = (u32)((u64)(walker0 + w) * (u32)n + 0u);      // rank 0's stream (PT:679)
@@ -488,7 +490,7 @@ int ptmi_destroy(ptmi_handle h)
 {
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
-    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow);
+    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_xint);
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -587,7 +589,7 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
     const long long tot = (long long)W * c.ntemps;
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps, h->d_ladder,
                        (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, h->d_pre, h->d_prow,
-                       (long long)iter, c.seed, c.walker0);
+                       (long long)iter, c.seed, c.walker0, 0);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps, h->d_ladder,
                        (const double *)h->d_pre, (const int32_t *)h->d_prow, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr,
                        (u64 *)h->buf.nswap, 0, c.ntemps);
@@ -605,20 +607,143 @@ int ptmi_swap_gather_lnl(ptmi_handle h, double *out)
     return PTMI_OK;
 }
 
-int ptmi_swap_sweep(ptmi_handle h, int64_t iter, const double *lnL_pos_global, int32_t *map)
+static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t *map, int block_nt)
 {
-    if (!h || !lnL_pos_global || !map) return fail(PTMI_EINVAL, "NULL argument");
+    if (!h || !lnL || !map) return fail(PTMI_EINVAL, "NULL argument");
     if (!h->buf.nswap) return fail(PTMI_EINVAL, "nswap buffer missing");
     const ptmi_config &c = h->cfg;
     const int W = c.nwalkers;
     const long long tot = (long long)W * c.ntemps_global;
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global,
-                       h->d_ladder, lnL_pos_global, (const double *)nullptr, (const int32_t *)nullptr, h->d_pre, h->d_prow,
-                       (long long)iter, c.seed, c.walker0);
+                       h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, h->d_pre, h->d_prow,
+                       (long long)iter, c.seed, c.walker0, block_nt);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps_global, h->d_ladder,
                        (const double *)h->d_pre, (const int32_t *)h->d_prow, (int32_t *)nullptr, (int32_t *)nullptr, map,
                        (u64 *)h->buf.nswap, c.temp0, c.ntemps);
     HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+int ptmi_swap_sweep(ptmi_handle h, int64_t iter, const double *lnL_pos_global, int32_t *map)
+{
+    return sweep_global(h, iter, lnL_pos_global, map, 0);
+}
+int ptmi_swap_sweep_blocks(ptmi_handle h, int64_t iter, const double *lnL_blocks, int32_t *map)
+{
+    if (h && h->cfg.ntemps_global % h->cfg.ntemps) return fail(PTMI_EINVAL, "the ladder is not a whole number of blocks");
+    return sweep_global(h, iter, lnL_blocks, map, h ? h->cfg.ntemps : 0);
+}
+
+// ---- device-side exchange of the rows that cross a block edge --------------------------------------------------
+// One thread per walker.  From the global map it (1) inverts it, (2) lists this block's leaving rows (local
+// source, remote destination) and arriving rows (local destination, remote source), both in ascending local
+// position -- the k-th arrival takes the slot the k-th departure frees, the rule of sharded.py's plan_exchange --
+// and (3) rewrites slot_of / temp_of.  A hot -> cold sweep moves at most one row of a walker down out of a block
+// (the carried state) and at most one up (displaced by one level), hence the fixed [2][W] / [nranks][W] tables.
+__global__ void exchange_plan_kernel(int W, int nt, int ntg, int temp0, int nranks, const int32_t *map, int32_t *slot_of,
+                                     int32_t *temp_of, int32_t *inv, int32_t *newslot, int32_t *arr_slot, int32_t *lv_slot,
+                                     int32_t *lv_rank, int32_t *err)
+{
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= W) return;
+    const int me = temp0 / nt;
+    const int32_t *m = map + (size_t)w * ntg;
+    int32_t *iv = inv + (size_t)w * ntg, *so = slot_of + (size_t)w * nt, *to = temp_of + (size_t)w * nt, *ns = newslot + (size_t)w * nt;
+    for (int j = 0; j < ntg; ++j) iv[m[j]] = j;
+    for (int q = 0; q < nranks; ++q) arr_slot[(size_t)q * W + w] = -1;
+    int nlv = 0, freed[2] = {-1, -1};
+    lv_slot[w] = lv_slot[W + w] = -1;
+    lv_rank[w] = lv_rank[W + w] = -1;
+    for (int p = 0; p < nt; ++p) {
+        const int q = iv[temp0 + p] / nt;
+        if (q != me) {
+            if (nlv < 2) { freed[nlv] = so[p]; lv_slot[(size_t)nlv * W + w] = so[p]; lv_rank[(size_t)nlv * W + w] = q; }
+            else atomicAdd(err, 1);
+            ++nlv;
+        }
+    }
+    int narr = 0;
+    for (int j = 0; j < nt; ++j) {
+        const int src = m[temp0 + j], q = src / nt;
+        if (q == me) ns[j] = so[src - temp0];
+        else {
+            const int slot = narr < 2 ? freed[narr] : -1;
+            if (slot < 0 || arr_slot[(size_t)q * W + w] >= 0) atomicAdd(err, 1);
+            else arr_slot[(size_t)q * W + w] = slot;
+            ns[j] = slot < 0 ? 0 : slot;
+            ++narr;
+        }
+    }
+    if (narr != nlv) atomicAdd(err, 1);
+    // two destinations on one GPU would collide in send[q][w]
+    if (nlv == 2 && lv_rank[w] == lv_rank[W + w]) atomicAdd(err, 1);
+    for (int j = 0; j < nt; ++j) { so[j] = ns[j]; to[ns[j]] = j; }
+}
+__global__ void exchange_pack_kernel(int W, int nt, int d, const double *X, const double *lnL, const double *lp,
+                                     const int32_t *lv_slot, const int32_t *lv_rank, double *send)
+{
+    const int w = (int)blockIdx.x, k = (int)blockIdx.y;
+    const int slot = lv_slot[(size_t)k * W + w];
+    if (slot < 0) return;
+    const size_t r = (size_t)w * nt + slot;
+    double *dst = send + ((size_t)lv_rank[(size_t)k * W + w] * W + w) * (d + 2);
+    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) dst[i] = X[r * d + i];
+    if (threadIdx.x == 0) { dst[d] = lnL[r]; dst[d + 1] = lp[r]; }
+}
+__global__ void exchange_apply_kernel(int W, int nt, int d, double *X, double *lnL, double *lp, const int32_t *arr_slot,
+                                      const double *recv)
+{
+    const int w = (int)blockIdx.x, q = (int)blockIdx.y;
+    const int slot = arr_slot[(size_t)q * W + w];
+    if (slot < 0) return;
+    const size_t r = (size_t)w * nt + slot;
+    const double *src = recv + ((size_t)q * W + w) * (d + 2);
+    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) X[r * d + i] = src[i];
+    if (threadIdx.x == 0) { lnL[r] = src[d]; lp[r] = src[d + 1]; }
+}
+
+static size_t xint_count(const ptmi_config &c)
+{
+    const size_t W = (size_t)c.nwalkers, nr = (size_t)(c.ntemps_global / c.ntemps);
+    return W * c.ntemps_global + W * c.ntemps + nr * W + 4 * W + 1;
+}
+int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send)
+{
+    if (!h || !map || !send) return fail(PTMI_EINVAL, "NULL argument");
+    const ptmi_config &c = h->cfg;
+    if (c.ntemps_global % c.ntemps) return fail(PTMI_EINVAL, "the ladder is not a whole number of blocks");
+    const int W = c.nwalkers, nr = c.ntemps_global / c.ntemps;
+    if (!h->d_xint) {
+        HIPCHK(hipMalloc((void **)&h->d_xint, sizeof(int32_t) * xint_count(c)));
+        HIPCHK(hipMemsetAsync(h->d_xint, 0, sizeof(int32_t) * xint_count(c), h->stream));
+    }
+    int32_t *inv = h->d_xint, *newslot = inv + (size_t)W * c.ntemps_global, *arr = newslot + (size_t)W * c.ntemps;
+    int32_t *lvs = arr + (size_t)nr * W, *lvr = lvs + 2 * (size_t)W, *err = lvr + 2 * (size_t)W;
+    hipLaunchKernelGGL(exchange_plan_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps, c.ntemps_global, c.temp0, nr,
+                       map, h->buf.slot_of, h->buf.temp_of, inv, newslot, arr, lvs, lvr, err);
+    hipLaunchKernelGGL(exchange_pack_kernel, dim3(W, 2), dim3(64), 0, h->stream, W, c.ntemps, c.ndim, (const double *)h->buf.X,
+                       (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)lvs, (const int32_t *)lvr, send);
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+int ptmi_exchange_apply(ptmi_handle h, const double *recv)
+{
+    if (!h || !recv) return fail(PTMI_EINVAL, "NULL argument");
+    if (!h->d_xint) return fail(PTMI_EINVAL, "ptmi_exchange_apply without a preceding ptmi_exchange_pack");
+    const ptmi_config &c = h->cfg;
+    const int W = c.nwalkers, nr = c.ntemps_global / c.ntemps;
+    const int32_t *arr = h->d_xint + (size_t)W * c.ntemps_global + (size_t)W * c.ntemps;
+    hipLaunchKernelGGL(exchange_apply_kernel, dim3(W, nr), dim3(64), 0, h->stream, W, c.ntemps, c.ndim, h->buf.X, h->buf.lnL,
+                       h->buf.lp, arr, recv);
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+int ptmi_exchange_status(ptmi_handle h, int32_t *violations)
+{
+    if (!h || !violations) return fail(PTMI_EINVAL, "NULL argument");
+    *violations = 0;
+    if (!h->d_xint) return PTMI_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(violations, h->d_xint + xint_count(h->cfg) - 1, sizeof(int32_t), hipMemcpyDeviceToHost));
     return PTMI_OK;
 }
 

@@ -62,6 +62,7 @@ struct ptmi_engine {
     int32_t *d_gsize;
     double *d_pre;      // [4][ntg][W] scratch of the swap (uniforms, likelihoods, own-likelihood terms)
     int32_t *d_prow;    // [ntg][W] rows by position (fused swap)
+    int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
     int G, EPL;
     int de_on, de_head;

@@ -250,6 +250,21 @@ class PTEngine(object):
     def write_am(self, it):
         _lib.check(self.lib.ptmi_swap_write_am(self.h, it))
 
+    # device-side exchange (no host synchronisation), see include/ptmi.h
+    def sweep_blocks(self, it, lnl_blocks, map_out):
+        _lib.check(self.lib.ptmi_swap_sweep_blocks(self.h, it, lnl_blocks.data_ptr(), map_out.data_ptr()))
+
+    def exchange_pack(self, map_dev, send):
+        _lib.check(self.lib.ptmi_exchange_pack(self.h, map_dev.data_ptr(), send.data_ptr()))
+
+    def exchange_apply(self, recv):
+        _lib.check(self.lib.ptmi_exchange_apply(self.h, recv.data_ptr()))
+
+    def exchange_violations(self):
+        v = C.c_int32(0)
+        _lib.check(self.lib.ptmi_exchange_status(self.h, C.byref(v)))
+        return v.value
+
     def _epochs(self, it):
         cu, burn = self.cov_update, self.burn
         if (it - 1) % cu == 0 and it - 1 != 0:

@@ -68,14 +68,32 @@ def plan_exchange(map_glob, slot_of, temp0, nt, rank, world):
                 recv_w=aw[rorder], recv_j=aj[rorder], recv_counts=counts[1])
 
 
-class ShardedPTEngine(object):
-    """One ladder of ``ntemps_global`` ranks sharded over ``group``; same interface as PTEngine."""
+class DistComm(object):
+    """The three collectives the sharded engine needs, over torch.distributed ("nccl" = RCCL, or gloo)."""
 
-    def __init__(self, ndim, ntemps_global, nwalkers, cov0, group=None, local_factory=None, **kw):
-        torch = _torch()
+    def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.root = dist.get_global_rank(group, 0) if group is not None else 0
+
+    def all_gather(self, out, inp):
+        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        self.dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+
+    def broadcast(self, t):
+        self.dist.broadcast(t, src=self.root, group=self.group)
+
+
+class ShardedPTEngine(object):
+    """One ladder of ``ntemps_global`` ranks sharded over ``group``; same interface as PTEngine."""
+
+    def __init__(self, ndim, ntemps_global, nwalkers, cov0, group=None, local_factory=None, comm=None, **kw):
+        torch = _torch()
+        self.comm = comm if comm is not None else DistComm(group)
+        self.rank, self.world = self.comm.rank, self.comm.world
         if ntemps_global % self.world:
             raise ValueError("ntemps_global=%d is not a multiple of the %d ranks" % (ntemps_global, self.world))
         self.ntg, self.nt = ntemps_global, ntemps_global // self.world
@@ -93,7 +111,13 @@ class ShardedPTEngine(object):
         self.de_head = 0
         self._lnl_loc = torch.zeros((self.W, self.nt), dtype=torch.float64, device=self.device)
         self._map = torch.zeros((self.W, self.ntg), dtype=torch.int32, device=self.device)
+        self._parts = torch.empty((self.world * self.W, self.nt), dtype=torch.float64, device=self.device)
         self.rows_moved = 0
+        # device-side exchange (HIP engines): fixed [world][W][d+2] buffers, no host synchronisation per swap
+        self.device_exchange = hasattr(L, "exchange_pack")
+        if self.device_exchange:
+            self._send = torch.zeros((self.world, self.W, self.d + 2), dtype=torch.float64, device=self.device)
+            self._recv = torch.zeros_like(self._send)
 
     # delegation
     def get(self, name):
@@ -113,12 +137,19 @@ class ShardedPTEngine(object):
 
     # ---- swap epoch ----------------------------------------------------------------------
     def swap(self, it):
-        torch, dist, L = _torch(), self.dist, self.local
+        torch, L = _torch(), self.local
         W, nt, ntg, d = self.W, self.nt, self.ntg, self.d
         L.gather_lnl(self._lnl_loc)
-        parts = torch.empty((self.world * W, nt), dtype=torch.float64, device=self.device)
-        dist.all_gather_into_tensor(parts, self._lnl_loc, group=self.group)
-        lnl_glob = parts.view(self.world, W, nt).permute(1, 0, 2).reshape(W, ntg).contiguous()
+        self.comm.all_gather(self._parts, self._lnl_loc)                      # [world][W][nt]
+        if self.device_exchange:
+            L.sweep_blocks(it, self._parts, self._map)                        # identical on every rank
+            L.exchange_pack(self._map, self._send)                            # tables rewritten, leaving rows packed
+            self.comm.all_to_all(self._recv, self._send)                      # equal splits: send[q] -> rank q
+            L.exchange_apply(self._recv)
+            L.write_am(it)
+            self.swap_proposed += 1
+            return
+        lnl_glob = self._parts.view(self.world, W, nt).permute(1, 0, 2).reshape(W, ntg).contiguous()
         L.sweep(it, lnl_glob, self._map)                                      # identical on every rank
         plan = plan_exchange(self._map, L.t["slot_of"], self.temp0, nt, self.rank, self.world)
         X, lnL, lp = L.t["X"], L.t["lnL"], L.t["lp"]
@@ -127,8 +158,7 @@ class ShardedPTEngine(object):
             if si.numel() else torch.zeros((0, d + 2), dtype=torch.float64, device=self.device)
         nrecv = int(sum(plan["recv_counts"]))
         recv = torch.empty((nrecv, d + 2), dtype=torch.float64, device=self.device)
-        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=plan["recv_counts"],
-                               input_split_sizes=plan["send_counts"], group=self.group)
+        self.comm.all_to_all(recv, send.contiguous(), plan["recv_counts"], plan["send_counts"])
         new_slot = plan["new_slot"]
         if nrecv:
             rw, rj = plan["recv_w"], plan["recv_j"]
@@ -149,8 +179,7 @@ class ShardedPTEngine(object):
         if self.owns_cold:
             L.update_cov(it_done)
         for name in ("cov", "Ut", "S"):
-            self.dist.broadcast(L.t[name], src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                                group=self.group)
+            self.comm.broadcast(L.t[name])
 
     def update_de(self):
         torch, L = _torch(), self.local
@@ -163,7 +192,7 @@ class ShardedPTEngine(object):
             rows = L.t["DE"][:, idx].contiguous()
         else:
             rows = torch.empty((L.t["DE"].shape[0], mem, self.d), dtype=torch.float64, device=self.device)
-        self.dist.broadcast(rows, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        self.comm.broadcast(rows)
         if not self.owns_cold:
             L.t["DE"][:, idx] = rows
             L.set_de_head((self.de_head + mem) % size)

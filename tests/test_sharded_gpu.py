@@ -52,3 +52,60 @@ def test_sharded_world1_equals_single_engine_and_oracle(world1, cov_mode):
         assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), name
         assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(c).view(np.uint8)), name
     assert s.swap_proposed == g.swap_proposed == n // 10
+
+
+@pytest.mark.parametrize("nranks,cov_mode", [(2, "per_walker"), (4, "pooled"), (8, "per_walker")])
+def test_device_exchange_with_emulated_ranks(nranks, cov_mode):
+    """Several temperature blocks on ONE GPU (one thread per rank, in-process communicator): the device-side
+    exchange (ptmi_swap_sweep_blocks / ptmi_exchange_pack / ptmi_exchange_apply) must reproduce the single-engine
+    run and the oracle bit for bit, with rows really crossing block edges."""
+    import sys
+    import threading
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from thread_comm import ThreadComm, ThreadWorld
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd.engine import PTEngine
+    from ptmcmcsampler_amd.sharded import ShardedPTEngine
+    d, ntb, W, n = 10, 3, 33, 330
+    ntg = ntb * nranks
+    kw = dict(weights=(20, 20, 20), cov_update=50, burn=100, tskip=10, seed=5, cov_mode=cov_mode)
+    cov0 = np.eye(d) * 0.05
+    p0 = np.random.RandomState(3).randn(W, ntg, d) * 0.4
+    ref = orc.OracleEngine(d, ntg, W, cov0, **kw)
+    ref.init_state(p0)
+    ref.run(n)
+    world = ThreadWorld(nranks)
+    engines, errs = [None] * nranks, []
+
+    def rank_main(r):
+        try:
+            e = ShardedPTEngine(d, ntg, W, cov0, comm=ThreadComm(world, r), **kw)
+            assert e.device_exchange
+            engines[r] = e
+            e.init_state(p0)
+            e.run(n)
+            e.sync()
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            world.bar.abort()
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    moved = 0
+    for r, e in enumerate(engines):
+        L, sl = e.local, slice(r * ntb, (r + 1) * ntb)
+        assert L.exchange_violations() == 0
+        for name in ("X", "lnL", "lp"):
+            assert np.array_equal(L.by_temp(name), ref.by_temp(getattr(ref, name))[:, sl]), (r, name)
+        assert np.array_equal(L.get("nacc"), ref.nacc[:, sl]) and np.array_equal(L.get("jstat"), ref.jstat[:, sl])
+        assert np.array_equal(L.get("nswap")[:, sl], ref.nswap[:, sl])
+        assert np.array_equal(L.get("Ut"), ref.Ut) and np.array_equal(L.get("S"), ref.S)
+        if r == 0:
+            assert np.array_equal(L.get("AM"), ref.AM) and np.array_equal(L.get("M2"), ref.M2)
+        assert e.swap_proposed == n // 10
+        # rows that are not where they started prove that states crossed block edges
+        moved += int((np.abs(L.by_temp("X") - p0[:, sl]).sum(-1) > 0).sum())
+    assert ref.nswap[:, ntb - 1].sum() > 0, "no swap was ever accepted across the first block edge"
