@@ -499,7 +499,8 @@ ORC_API void orc_swap_apply(const orc_cfg *c, orc_state *st, const int32_t *map,
 /* ------------------------------------------------------------- Welford */
 /* PT:769-794 for one walker: mem buffered rows in buffer order.  fused = 0 is the
  * reference's arithmetic (one product, one sum); fused = 1 accumulates with one fma per
- * element (the pooled mode of the engine, which is not a replica of a reference run). */
+ * element and advances the mean by diff * (1/it) (the pooled mode of the engine, which is not a
+ * replica of a reference run). */
 ORC_API void orc_welford2(int d, int mem, int64_t iter, const double *AM, double *mu, double *M2, double *cov, int fused)
 {
     int64_t it = iter - mem;
@@ -508,7 +509,12 @@ ORC_API void orc_welford2(int d, int mem, int64_t iter, const double *AM, double
     for (int ii = 0; ii < mem; ++ii) {
         it += 1;
         const double *row = AM + (size_t)ii * d;
-        for (int j = 0; j < d; ++j) { diff[j] = row[j] - mu[j]; mu[j] += diff[j] / (double)it; }
+        const double rinv = 1.0 / (double)it;              /* fused variant: one reciprocal per row, then a product */
+        for (int j = 0; j < d; ++j) {
+            diff[j] = row[j] - mu[j];
+            if (fused) mu[j] = mu[j] + diff[j] * rinv;
+            else mu[j] += diff[j] / (double)it;
+        }
         for (int j = 0; j < d; ++j) e[j] = row[j] - mu[j];
         for (int i = 0; i < d; ++i)
             for (int j = 0; j < d; ++j) {

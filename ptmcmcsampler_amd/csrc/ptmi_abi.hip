@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
                     if (carrier && ii0 + u0 + u < mem) {
                         const double v = vpre[u0 + u];
                         df = v - m;
-                        m += df / (double)(it + 1 + u);
+                        if (FUSED) m = m + df * (1.0 / (double)(it + 1 + u));
+                        else m += df / (double)(it + 1 + u);
                         ev = v - m;
                     }
                     if (role == 0) sh[bsel][u][0][ridx] = df;
@@ -222,7 +223,106 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
     if (gridDim.x == 1 && role == 0 && carrier) muw[rel] = m;
 }
 
-__global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem, long long iter)
+// Pooled-mode Welford on the matrix cores (d <= 112: one block per walker).  The rank-1 updates of RC buffered rows
+// are one [d x RC] . [RC x d] product: v_mfma_f64_16x16x4_f64 accumulates it as a row-ascending fma chain, which is
+// exactly the fused scalar definition (orc_welford2 with fused = 1), so the result is bit-identical.
+// The 49 tiles of 16x16 are dealt round-robin over the four waves (12/12/12/13: the f64 matrix pipe retires one
+// instruction per 64 cycles per SIMD, so the balance across SIMDs is what matters; the waves that also carry the
+// mean recurrence get the lighter share).  The first 112 threads are the carriers: they run the mean recurrence of
+// their column one chunk ahead and hand the diff / e rows over through a double-buffered LDS chunk.  The
+// reciprocals 1/(it+1+r) are the same for every column and walker: computed once per block into LDS.
+typedef double wf_d4 __attribute__((ext_vector_type(4)));
+constexpr int WRC = 16;                                     // rows per chunk (4 matrix instructions deep)
+constexpr int WF_NT = (WT * WT + 3) / 4;                    // tiles per wave (13)
+constexpr int WF_THREADS = 256;
+constexpr int WF_MAXMEM = 2048;                             // reciprocal table (cov_update rows)
+__global__ __launch_bounds__(WF_THREADS, 2) void welford_mfma_kernel(const double *AM, double *mu, double *M2, int d, int mem, long long iter)
+{
+    __shared__ double Dl[2][WRC][WTILE], El[2][WRC][WTILE];
+    __shared__ double rcp[WF_MAXMEM];
+    const int w = (int)blockIdx.x;
+    const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane & 15, g = lane >> 4;
+    const double *am = AM + (size_t)w * mem * d;
+    double *muw = mu + (size_t)w * d, *M2w = M2 + (size_t)w * d * d;
+    const long long it0 = iter - mem;
+    const bool reset = it0 == 0;
+    const int col = (int)threadIdx.x;                       // carrier threads own one column each
+    const bool carrier = col < WTILE;
+    const bool incol = col < d;
+    double m = incol && !reset ? muw[col] : 0.0;
+    for (int r = (int)threadIdx.x; r < mem; r += WF_THREADS) rcp[r] = 1.0 / (double)(it0 + 1 + r);
+
+    const int res = (wave + 1) & 3;                         // wave 3 takes the 13-tile share
+    wf_d4 acc[WF_NT];
+    int offa[WF_NT], offb[WF_NT];                           // column offsets of the tile's D and E fragments
+#pragma unroll
+    for (int n = 0; n < WF_NT; ++n) {
+        const int t = res + 4 * n;
+        const bool live = t < WT * WT;
+        const int ti = live ? t / WT : 0, tj = live ? t % WT : 0;
+        offa[n] = __builtin_amdgcn_readfirstlane(ti * 16);   // wave-uniform: scalar registers
+        offb[n] = __builtin_amdgcn_readfirstlane(tj * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
+            acc[n][r] = (live && !reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
+        }
+    }
+    // The AM rows of the following chunk are requested as soon as the current ones are consumed, so the HBM latency
+    // of the row reads overlaps the matrix work on the chunk in between.
+    double v[WRC];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < WRC; ++u) v[u] = (incol && r0 + u < mem) ? am[(size_t)(r0 + u) * d + col] : 0.0;
+    };
+    auto produce = [&](int r0, int buf) {
+#pragma unroll
+        for (int u = 0; u < WRC; ++u) {
+            double df = 0.0, ev = 0.0;
+            if (incol && r0 + u < mem) {
+                df = v[u] - m;
+                m = m + df * rcp[r0 + u];
+                ev = v[u] - m;
+            }
+            Dl[buf][u][col] = df;                           // rows past the end and padded columns carry zeros
+            El[buf][u][col] = ev;
+        }
+        fetch(r0 + WRC);
+    };
+    if (carrier) fetch(0);
+    __syncthreads();                                        // reciprocal table
+    if (carrier) produce(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = 0; r0 < mem; r0 += WRC) {
+        if (carrier && r0 + WRC < mem) produce(r0 + WRC, buf ^ 1);
+        const double *Db = &Dl[buf][0][0] + g * WTILE + c, *Eb = &El[buf][0][0] + g * WTILE + c;
+#pragma unroll
+        for (int k0 = 0; k0 < WRC; k0 += 4)
+#pragma unroll
+            for (int n = 0; n < WF_NT; ++n)
+                if (n < WF_NT - 1 || res == 0)
+                    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Db[k0 * WTILE + offa[n]], Eb[k0 * WTILE + offb[n]], acc[n], 0, 0, 0);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int n = 0; n < WF_NT; ++n) {
+        const int t = res + 4 * n;
+        if (t < WT * WT) {
+            const int ti = t / WT, tj = t % WT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
+                if (i < d && j < d) M2w[(size_t)i * d + j] = acc[n][r];
+            }
+        }
+    }
+    if (incol) muw[col] = m;
+}
+
+__global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem, long long iter, int fused)
 {
     const int w = (int)blockIdx.y;
     const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -233,7 +333,8 @@ __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem
     for (int ii = 0; ii < mem; ++ii) {
         it += 1;
         const double df = am[(size_t)ii * d + j] - m;
-        m += df / (double)it;
+        if (fused) m = m + df * (1.0 / (double)it);
+        else m += df / (double)it;
     }
     mu[(size_t)w * d + j] = m;
 }
@@ -759,12 +860,15 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
     if (per)
         hipLaunchKernelGGL(welford_kernel<false>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
                            h->buf.mu, h->buf.M2, h->buf.cov, d, c.cov_update, (long long)iter, d * d);
+    else if (d <= WTILE && c.cov_update <= WF_MAXMEM)
+        hipLaunchKernelGGL(welford_mfma_kernel, dim3(c.nwalkers), dim3(WF_THREADS), 0, h->stream, (const double *)h->buf.AM, h->buf.mu,
+                           h->buf.M2, d, c.cov_update, (long long)iter);
     else
         hipLaunchKernelGGL(welford_kernel<true>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
                            h->buf.mu, h->buf.M2, (double *)nullptr, d, c.cov_update, (long long)iter, 0);
     if (nt > 1)
         hipLaunchKernelGGL(welford_mean_kernel, dim3((d + 63) / 64, c.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.AM,
-                           h->buf.mu, d, c.cov_update, (long long)iter);
+                           h->buf.mu, d, c.cov_update, (long long)iter, per ? 0 : 1);
     if (!per) {
         const int W = c.nwalkers, ng = (W + POOL_GS - 1) / POOL_GS;
         const unsigned gx = (unsigned)(((long long)d * d + 255) / 256);
