@@ -224,7 +224,8 @@ constexpr int safe_slots(int G, int EPL)
 // same instruction stream as the Box-Muller log, on another lane of each quad.
 // STR: strided lane layout (see "lane groups"); then Ut is the zero-padded LDS copy when ut_padded, and the AM
 // product runs on the matrix cores for all 16 chains of the wave at once.
-template <int G, int EPL, bool FULL, bool STR>
+// GRP: parameter groups (compile-time: with one group every bound below is the wave-uniform d).
+template <int G, int EPL, bool FULL, bool STR, bool GRP>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
                                        double (&dq)[EPL], double &log_u, double &u_acc)
@@ -263,7 +264,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
     // parameter group (PT:839,897,955): word C0 for SCAM / AM, D0 for DE -- the words those jumps leave unused.
     // A group's eigenvectors are embedded in the full space, so the jumps below only change the table they read.
     int g = 0, ng = d;
-    if (a.ngroups > 1) {
+    if (GRP) {
         const u64 D0 = grp_bcast<STR, 3>(w0);
         g = (int)w2index(jt == PTMI_J_DE ? D0 : C0, (u64)a.ngroups);
         ng = a.gsize[g];
@@ -299,7 +300,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
             PTMI_ROW_LOAD(vm, rm, e);
             PTMI_ROW_LOAD(vn, rn, e);
             dq[e] = scale * (vm - vn);
-            if (a.ngroups > 1) {                       // only the group's parameters move (PT:978-983)
+            if (GRP) {                                 // only the group's parameters move (PT:978-983)
                 const int i = gl + G * e;
                 if (i < d && a.gmask[(size_t)g * d + i] == 0.0) dq[e] = 0.0;
             }
@@ -375,7 +376,7 @@ __device__ __forceinline__ int logical_block()
 // STAGE (G = 4 shapes, chosen by the host when all chains of a block share their tables): strided lane layout,
 // the dense precision matrix and -- if it still fits -- the block's Ut are copied to LDS zero-padded, and the
 // table-times-vector products of the AM proposal and of the dense likelihood run on the matrix cores.
-template <int G, int EPL, int LOGL, bool FULL, bool STAGE>
+template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP>
 __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
 {
     constexpr int CPB = 256 / G;
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         const long long it = a.iter0 + k;
         double log_u, u_acc;
         int jt;
-        if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR>(a, it, sid, gl, cc, PTMI_UL, true, S, DE, dq, log_u, u_acc);
-        else jt = propose<G, EPL, FULL, STR>(a, it, sid, gl, cc, UtBlock, false, S, DE, dq, log_u, u_acc);
+        if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, PTMI_UL, true, S, DE, dq, log_u, u_acc);
+        else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, UtBlock, false, S, DE, dq, log_u, u_acc);
         if (FULL) {
 #pragma unroll
             for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 }
 
 // split path: proposal only / accept only, one iteration (host likelihood callbacks)
-template <int G, int EPL>
+template <int G, int EPL, bool GRP>
 __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
 {
     constexpr int CPB = 256 / G;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double log_u, u_acc;
-    const int jt = propose<G, EPL, true, false>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
+    const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -642,7 +643,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
         size_t lds = LOGL == PTMI_LOGL_DENSE ? tab : 0;
         if (FULL && lds + tab <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
         if (lds <= 160 * 1024 && one_table_per_block) {
-            auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, WANTS>;
+            auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, WANTS, false>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
@@ -651,7 +652,8 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             return PTMI_OK;
         }
     }
-    hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false>), dim3(grid), dim3(256), 0, h->stream, a);
+    if (c.ngroups > 1) hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, true>), dim3(grid), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
     return PTMI_OK;
 }
 template <int G, int EPL, int LOGL>

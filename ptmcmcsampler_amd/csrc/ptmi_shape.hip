@@ -14,7 +14,10 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
     case PTMI_OP_MH: return launch_mh_l<G, E, L>(h, a, grid, full);
     case PTMI_OP_EVAL: hipLaunchKernelGGL((eval_state_kernel<G, E, L>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
 #if PTMI_L == 0
-    case PTMI_OP_PROPOSE: hipLaunchKernelGGL((propose_kernel<G, E>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
+    case PTMI_OP_PROPOSE:
+        if (h->cfg.ngroups > 1) hipLaunchKernelGGL((propose_kernel<G, E, true>), dim3(grid), dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL((propose_kernel<G, E, false>), dim3(grid), dim3(256), 0, h->stream, a);
+        return PTMI_OK;
     case PTMI_OP_ACCEPT: hipLaunchKernelGGL((accept_kernel<G, E>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
 #endif
     }
