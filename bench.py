@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--mix", default="scam", choices=["scam", "default"], help="scam: SCAM-only; default: SCAM/AM/DE 20/20/20")
     ap.add_argument("--logl", default="iso", choices=["iso", "dense"])
     ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
+    ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--sharded", action="store_true", help="use the sharded engine even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10000, help="iterations per host core of the CPU baseline (10-30 s of CPU work)")
@@ -99,7 +100,7 @@ def main():
         A = np.random.default_rng(0).standard_normal((d, d))
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=100, seed=1234, cov_mode=a.cov_mode, logl=logl,
-              device=local)
+              device=local, swap_mode=a.swap_mode)
     if world == 1 and not a.sharded:
         from ptmcmcsampler_amd.engine import PTEngine
         eng = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
@@ -166,7 +167,7 @@ def main():
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %d-d %s Gaussian logl, %d temps x %d walkers per GPU, %s cycle, "
-                               "Tskip=100, covUpdate=1000, cov_mode=%s" % (d, a.logl, nt, W, a.mix, a.cov_mode),
+                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s" % (d, a.logl, nt, W, a.mix, a.swap_mode, a.cov_mode),
                    "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "parallelism": "temperature blocks x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -53,6 +53,14 @@ enum { PTMI_LOGP_FLAT = 0,     /* 0 everywhere */
 /* proposal types; also the index into jstat */
 enum { PTMI_J_SCAM = 0, PTMI_J_AM = 1, PTMI_J_DE = 2, PTMI_J_NTYPES = 3 };
 
+/* ptmi_config.swap_mode.  SWEEP is PTswap as the reference runs it: every adjacent pair is tried, hottest first, and
+ * a state can travel several ranks in one call.  ODDEVEN tries, at swap epoch e = iter / tskip, only the pairs
+ * (k, k+1) with k = e (mod 2): the pairs are disjoint, so all of them are decided at once on the device and a
+ * sharded ladder moves at most one row per walker across each block edge.  Same pair test, same uniform (the one the
+ * sweep would have used for pair k); it is a different, equally valid, Markov kernel -- not a replica of a
+ * reference run. */
+enum { PTMI_SWAP_SWEEP = 0, PTMI_SWAP_ODDEVEN = 1 };
+
 typedef struct ptmi_config {
     int32_t ndim;            /* parameters per chain */
     int32_t ntemps;          /* temperature ranks held by THIS handle (a contiguous block) */
@@ -70,6 +78,7 @@ typedef struct ptmi_config {
     int32_t cov_per_walker;  /* 1: Ut/S/DE/cov per walker (faithful replicas); 0: one pooled set */
     int32_t device;          /* HIP device ordinal */
     int32_t ngroups;         /* parameter groups (PTMCMCSampler.py:129-145); 0 or 1 = one group of all parameters */
+    int32_t swap_mode;       /* PTMI_SWAP_SWEEP (the reference's hot -> cold sweep, :666-686) or PTMI_SWAP_ODDEVEN */
     uint64_t seed;
     void *stream;            /* hipStream_t to launch on; NULL = the null stream */
     const double *ladder;    /* host [ntemps_global]  temperatures used by the swap (:658) */

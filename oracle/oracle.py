@@ -73,6 +73,8 @@ def lib():
         L.orc_mh_steps.argtypes = [C.POINTER(Cfg), C.POINTER(State), C.c_int64, C.c_int, C.POINTER(Replay)]
         L.orc_swap_sweep.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int64, C.c_uint64, C.c_int, _ip, _up,
                                      C.POINTER(Replay)]
+        L.orc_swap_oddeven.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int64, C.c_uint64, C.c_int, C.c_int, _ip, _up]
+        L.orc_swap_oddeven.restype = None
         L.orc_swap_apply.argtypes = [C.POINTER(Cfg), C.POINTER(State), _ip, C.c_int64]
         L.orc_welford.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]
         L.orc_welford2.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_int]
@@ -146,6 +148,22 @@ def swap_sweep(ladder, lnL_pos, it=0, seed=0, walker0=0, uniforms=None):
     return m, acc
 
 
+def swap_parity(it, tskip):
+    """Odd/even mode: swap epoch e = it / tskip tries the pairs (k, k+1) with k = e (mod 2)."""
+    return int((it // tskip if tskip > 0 else it) & 1)
+
+
+def swap_oddeven(ladder, lnL_pos, parity, it=0, seed=0, walker0=0):
+    """Odd/even counterpart of swap_sweep (engine mode, not in the reference)."""
+    lnL_pos = np.ascontiguousarray(np.atleast_2d(lnL_pos), dtype=np.float64)
+    W, n = lnL_pos.shape
+    ladder = np.ascontiguousarray(ladder, dtype=np.float64)
+    m = np.zeros((W, n), dtype=np.int32)
+    acc = np.zeros((W, n), dtype=np.uint64)
+    lib().orc_swap_oddeven(W, n, _p(ladder), _p(lnL_pos), it, seed, walker0, parity, _p(m, _ip), _p(acc, _up))
+    return m, acc
+
+
 def make_replay(kinds, vals, bounds):
     kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
     vals = np.ascontiguousarray(vals, dtype=np.float64)
@@ -164,7 +182,9 @@ class OracleEngine(object):
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
-                 ntemps_global=None, temp0=0, walker0=0, groups=None):
+                 ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep"):
+        assert swap_mode in ("sweep", "oddeven")
+        self.swap_mode = swap_mode
         self.d, self.nt, self.W = ndim, ntemps, nwalkers
         self.ntg = ntemps if ntemps_global is None else ntemps_global
         self.temp0, self.walker0 = temp0, walker0
@@ -296,9 +316,14 @@ class OracleEngine(object):
         assert self.nt == self.ntg
         lnL_pos = np.ascontiguousarray(self.by_temp(self.lnL))
         m = np.zeros((self.W, self.nt), dtype=np.int32)
-        err = lib().orc_swap_sweep(self.W, self.nt, _p(self.ladder), _p(lnL_pos), it, self.seed, self.walker0,
-                                   _p(m, _ip), _p(self.nswap, _up), replay0)
-        assert err == 0, "replay error %d" % err
+        if self.swap_mode == "oddeven":
+            assert replay0 is None
+            lib().orc_swap_oddeven(self.W, self.nt, _p(self.ladder), _p(lnL_pos), it, self.seed, self.walker0,
+                                   swap_parity(it, self.tskip), _p(m, _ip), _p(self.nswap, _up))
+        else:
+            err = lib().orc_swap_sweep(self.W, self.nt, _p(self.ladder), _p(lnL_pos), it, self.seed, self.walker0,
+                                       _p(m, _ip), _p(self.nswap, _up), replay0)
+            assert err == 0, "replay error %d" % err
         lib().orc_swap_apply(C.byref(self.cfg), C.byref(self._state()), _p(m, _ip), it)
         self.swap_proposed += 1
         return m

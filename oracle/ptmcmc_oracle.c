@@ -480,6 +480,33 @@ ORC_API int orc_swap_sweep(int nwalkers, int n, const double *ladder, const doub
     return rp0 ? (int)rp0->err : 0;
 }
 
+/* Odd/even swap mode of the engine (include/ptmi.h, PTMI_SWAP_ODDEVEN; not in the reference): only the disjoint
+ * pairs (k, k+1), k = parity (mod 2), are tried, each with the pair test of PT:672-679 and the uniform the sweep
+ * would have used for pair k.  Same outputs as orc_swap_sweep. */
+ORC_API void orc_swap_oddeven(int nwalkers, int n, const double *ladder, const double *lnL_pos, int64_t iter,
+                              uint64_t seed, int walker0, int parity, int32_t *map, uint64_t *acc)
+{
+    for (int w = 0; w < nwalkers; ++w) {
+        const double *L = lnL_pos + (size_t)w * n;
+        int32_t *m = map + (size_t)w * n;
+        for (int j = 0; j < n; ++j) m[j] = j;
+        const uint32_t sid = (uint32_t)((uint64_t)(walker0 + w) * (uint32_t)n + 0u);
+        for (int k = parity; k + 1 < n; k += 2) {
+            uint64_t W[2];
+            philox_words(seed, (uint64_t)iter, sid, SLOT_SWAP + (uint32_t)k, W);
+            double la = -L[k] / ladder[k];
+            la += -L[k + 1] / ladder[k + 1];
+            la += L[k + 1] / ladder[k];
+            la += L[k] / ladder[k + 1];
+            if (w2uniform(W[0]) <= orc_exp(la)) {
+                m[k] = k + 1;
+                m[k + 1] = k;
+                acc[(size_t)w * n + k] += 1;
+            }
+        }
+    }
+}
+
 /* single-process application of a sweep to the slot tables (all ranks local) */
 ORC_API void orc_swap_apply(const orc_cfg *c, orc_state *st, const int32_t *map, int64_t iter)
 {

@@ -19,11 +19,13 @@ _dp = C.POINTER(C.c_double)
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "ndim", "ntemps", "nwalkers", "ntemps_global", "temp0", "walker0", "logl_kind", "logp_kind",
-        "w_host", "w_scam", "w_am", "w_de", "de_size", "cov_update", "tskip", "cov_per_walker", "device", "ngroups")] + [
+        "w_host", "w_scam", "w_am", "w_de", "de_size", "cov_update", "tskip", "cov_per_walker", "device", "ngroups", "swap_mode")] + [
         ("seed", C.c_uint64), ("stream", C.c_void_p), ("ladder", _dp), ("temps_mh", _dp),
         ("logl_par", _dp), ("logl_par_len", C.c_int64), ("logp_par", _dp), ("logp_par_len", C.c_int64),
         ("group_size", C.POINTER(C.c_int32)), ("group_mask", _dp)]
 
+
+SWAP_MODES = {"sweep": 0, "oddeven": 1}      # PTMI_SWAP_SWEEP, PTMI_SWAP_ODDEVEN
 
 BUFFER_FIELDS = ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "DE", "AM", "nacc", "jstat", "nswap",
                  "mu", "M2", "cov", "Q", "qaux", "AMaux")

@@ -61,8 +61,11 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
     if (fused) prow[idx] = row;
 }
 
+// parity >= 0 (odd/even mode): only the pairs with k = parity (mod 2) are tried; an untried pair never accepts, so
+// the carried state is always position k+1's own and the recurrence degenerates into independent pair tests.
 __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *pre, const int32_t *prow,
-                                  int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal)
+                                  int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
+                                  int parity)
 {
     const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (w >= W) return;
@@ -82,7 +85,7 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
         la += -Lc / Tk1;
         la += Lc / Tk;
         la += pre[3 * nW + o];             //  L[k] / T[k+1]
-        const bool acc = u <= det_exp(la);
+        const bool acc = (parity < 0 || (k & 1) == parity) && u <= det_exp(la);
         // position k+1 is final: it keeps the carried state, or takes position k's
         const int fin = acc ? k : c;
         if (map) map[(size_t)w * n + k + 1] = fin;
@@ -103,6 +106,35 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
     if (fused) {
         so[0] = crow;
         to[crow] = 0;
+    }
+}
+
+// Odd/even mode with the whole ladder local: one thread per (walker, tried pair), the slot tables rewritten in place
+// (the pairs are disjoint).  The pair test is the sweep's, term by term.
+__global__ void swap_oddeven_kernel(int W, int n, const double *ladder, const double *lnL_rows, int32_t *slot_of,
+                                    int32_t *temp_of, u64 *nswap, long long iter, u64 seed, int walker0, int parity)
+{
+    const int npairs = (n - parity) / 2;                    // k = parity, parity + 2, ... <= n - 2
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)npairs * W) return;
+    const int w = (int)(idx / npairs), k = parity + 2 * (int)(idx % npairs);
+    int32_t *so = slot_of + (size_t)w * n, *to = temp_of + (size_t)w * n;
+    const int rk = so[k], rk1 = so[k + 1];
+    const double Lk = lnL_rows[(size_t)w * n + rk], Lk1 = lnL_rows[(size_t)w * n + rk1];
+    const u32 sid = (u32)((u64)(walker0 + w) * (u32)n + 0u);
+    u64 w0, w1;
+    philox_words(seed, (u64)iter, sid, SLOT_SWAP + (u32)k, w0, w1);
+    const double Tk = ladder[k], Tk1 = ladder[k + 1];
+    double la = -Lk / Tk;
+    la += -Lk1 / Tk1;
+    la += Lk1 / Tk;
+    la += Lk / Tk1;
+    if (w2uniform(w0) <= det_exp(la)) {
+        so[k] = rk1;
+        so[k + 1] = rk;
+        to[rk1] = k;
+        to[rk] = k + 1;
+        nswap[(size_t)w * n + k] += 1;
     }
 }
 
@@ -524,6 +556,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (c.logp_kind == PTMI_LOGP_BOX && c.logp_par_len != 2LL * c.ndim) return fail(PTMI_EINVAL, "box prior needs lo[d] + hi[d]");
     if (!c.ladder || !c.temps_mh) return fail(PTMI_EINVAL, "ladder / temps_mh missing");
     if (c.ngroups < 0 || c.ngroups > 1024) return fail(PTMI_EINVAL, "ngroups out of range");
+    if (c.swap_mode != PTMI_SWAP_SWEEP && c.swap_mode != PTMI_SWAP_ODDEVEN) return fail(PTMI_EINVAL, "unknown swap_mode %d", c.swap_mode);
     if (c.ngroups > 1) {
         if (!c.group_size || !c.group_mask) return fail(PTMI_EINVAL, "group_size / group_mask missing");
         for (int g = 0; g < c.ngroups; ++g)
@@ -679,6 +712,12 @@ int ptmi_swap_write_am(ptmi_handle h, int64_t iter)
     return PTMI_OK;
 }
 
+// odd/even mode: swap epoch e = iter / tskip tries the pairs (k, k+1) with k = e (mod 2)
+static int swap_parity(const ptmi_config &c, int64_t iter)
+{
+    return (int)((c.tskip > 0 ? iter / c.tskip : iter) & 1);
+}
+
 int ptmi_swap(ptmi_handle h, int64_t iter)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
@@ -688,12 +727,22 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
     if (c.ntemps < 2) return PTMI_OK;
     const int W = c.nwalkers;
     const long long tot = (long long)W * c.ntemps;
+    if (c.swap_mode == PTMI_SWAP_ODDEVEN) {
+        const int parity = swap_parity(c, iter);
+        const long long np = (long long)W * ((c.ntemps - parity) / 2);
+        if (np > 0)
+            hipLaunchKernelGGL(swap_oddeven_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps,
+                               h->d_ladder, (const double *)h->buf.lnL, h->buf.slot_of, h->buf.temp_of, (u64 *)h->buf.nswap,
+                               (long long)iter, c.seed, c.walker0, parity);
+        HIPCHK(hipGetLastError());
+        return ptmi_swap_write_am(h, iter);
+    }
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps, h->d_ladder,
                        (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, h->d_pre, h->d_prow,
                        (long long)iter, c.seed, c.walker0, 0);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps, h->d_ladder,
                        (const double *)h->d_pre, (const int32_t *)h->d_prow, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr,
-                       (u64 *)h->buf.nswap, 0, c.ntemps);
+                       (u64 *)h->buf.nswap, 0, c.ntemps, -1);
     HIPCHK(hipGetLastError());
     return ptmi_swap_write_am(h, iter);
 }
@@ -720,7 +769,7 @@ static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t 
                        (long long)iter, c.seed, c.walker0, block_nt);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps_global, h->d_ladder,
                        (const double *)h->d_pre, (const int32_t *)h->d_prow, (int32_t *)nullptr, (int32_t *)nullptr, map,
-                       (u64 *)h->buf.nswap, c.temp0, c.ntemps);
+                       (u64 *)h->buf.nswap, c.temp0, c.ntemps, c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -40,14 +40,15 @@ class PTEngine(object):
     reference run (own covariance, eigenvectors and DE history); ``"pooled"`` adapts one
     covariance from all walkers' rank-0 samples.  ``logl`` / ``logp`` select the built-in
     device likelihood / prior: ("iso",), ("dense", mu, P), ("curved",); ("flat",),
-    ("box", lo, hi).
+    ("box", lo, hi).  ``swap_mode``: ``"sweep"`` is the reference's hot -> cold PTswap; ``"oddeven"`` tries
+    the disjoint pairs (k, k+1), k = swap epoch (mod 2), all at once (see include/ptmi.h).
     """
 
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
-                 w_host=0, keep_lnl=False, groups=None):
+                 w_host=0, keep_lnl=False, groups=None, swap_mode="sweep"):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -112,7 +113,8 @@ class PTEngine(object):
             ndim=d, ntemps=nt, nwalkers=W, ntemps_global=self.ntg, temp0=self.temp0, walker0=self.walker0,
             logl_kind=_lib.LOGL[logl[0]], logp_kind=_lib.LOGP[logp[0]], w_host=int(w_host), w_scam=self.weights[0], w_am=self.weights[1],
             w_de=self.weights[2] if has_de else 0, de_size=self.burn, cov_update=self.cov_update, tskip=self.tskip,
-            cov_per_walker=int(self.per_walker), device=device, ngroups=self.ngr if self.ngr > 1 else 0, seed=self.seed,
+            cov_per_walker=int(self.per_walker), device=device, ngroups=self.ngr if self.ngr > 1 else 0,
+            swap_mode=_lib.SWAP_MODES[swap_mode], seed=self.seed,
             group_size=self.gsize.ctypes.data_as(C.POINTER(C.c_int32)), group_mask=self.gmask.ctypes.data_as(_lib._dp),
             stream=C.c_void_p(self.stream.cuda_stream),
             ladder=self.ladder.ctypes.data_as(_lib._dp), temps_mh=self.temps_mh.ctypes.data_as(_lib._dp),

@@ -97,13 +97,14 @@ class _PerRankJump(object):
 class PTSampler(object):
     def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
                  logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
-                 nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1):
+                 nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1, swap_mode="sweep"):
         self.comm = comm if comm is not None else _DummyComm()
         if self.comm.Get_size() != 1:
             raise NotImplementedError(
                 "one process drives all temperatures here: run without mpirun and pass ntemps=%d" % self.comm.Get_size())
         self.MPIrank, self.nchain = 0, int(ntemps) if ntemps else 1
         self.nwalkers, self.device_index, self.cov_mode = int(nwalkers), device, cov_mode
+        self.swap_mode = swap_mode                          # "sweep" = PTswap as the reference; "oddeven" see PTEngine
         self.keep_walkers = max(1, min(int(keep_walkers), self.nwalkers))
         self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
         self.stream = np.random.default_rng(self.seed)      # for host-side custom jumps that want a generator
@@ -246,6 +247,7 @@ class PTSampler(object):
             logl=self.logl_spec or ("iso",), logp=self.logp_spec or ("flat",),
             weights=(self.SCAMweight, self.AMweight, self.DEweight), cov_update=covUpdate, burn=burn, tskip=Tskip,
             seed=self.seed, cov_mode=self.cov_mode, hot_chain=hotChain, device=self.device_index, split=self.split,
+            swap_mode=self.swap_mode,
             w_host=len(self.host_jumps), keep_lnl=True, groups=None if len(self.groups) == 1 and len(self.groups[0]) == self.ndim and np.array_equal(np.asarray(self.groups[0]), np.arange(self.ndim)) else self.groups)
 
     # ------------------------------------------------------------------ sample (:374-528)

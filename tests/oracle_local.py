@@ -53,9 +53,13 @@ class OracleLocal(object):
         lg = np.ascontiguousarray(lnl_glob.numpy())
         m = np.zeros((o.W, o.ntg), dtype=np.int32)
         acc = np.zeros((o.W, o.ntg), dtype=np.uint64)
-        err = orc.lib().orc_swap_sweep(o.W, o.ntg, orc._p(o.ladder), orc._p(lg), it, o.seed, o.walker0,
-                                       orc._p(m, orc._ip), orc._p(acc, orc._up), None)
-        assert err == 0
+        if o.swap_mode == "oddeven":
+            orc.lib().orc_swap_oddeven(o.W, o.ntg, orc._p(o.ladder), orc._p(lg), it, o.seed, o.walker0,
+                                       orc.swap_parity(it, o.tskip), orc._p(m, orc._ip), orc._p(acc, orc._up))
+        else:
+            err = orc.lib().orc_swap_sweep(o.W, o.ntg, orc._p(o.ladder), orc._p(lg), it, o.seed, o.walker0,
+                                           orc._p(m, orc._ip), orc._p(acc, orc._up), None)
+            assert err == 0
         o.nswap[:, o.temp0:o.temp0 + o.nt] += acc[:, o.temp0:o.temp0 + o.nt]
         map_out.copy_(torch.from_numpy(m))
 

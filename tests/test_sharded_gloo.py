@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cov_mode, out_dir):
+def _worker(rank, world, port, cov_mode, swap_mode, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -31,7 +31,7 @@ def _worker(rank, world, port, cov_mode, out_dir):
         from oracle_local import OracleLocal
         from ptmcmcsampler_amd.sharded import ShardedPTEngine
         d, ntg, W, n = 6, 8, 5, 330
-        kw = dict(weights=(20, 20, 20), cov_update=50, burn=100, tskip=10, seed=99, cov_mode=cov_mode)
+        kw = dict(weights=(20, 20, 20), cov_update=50, burn=100, tskip=10, seed=99, cov_mode=cov_mode, swap_mode=swap_mode)
         rs = np.random.RandomState(1)
         cov0 = np.eye(d) * 0.05
         p0 = rs.randn(W, ntg, d) * 0.5
@@ -62,9 +62,10 @@ def _worker(rank, world, port, cov_mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cov_mode", [(2, "per_walker"), (2, "pooled"), (4, "per_walker")])
-def test_sharded_equals_single_process(tmp_path, world, cov_mode):
-    mp.spawn(_worker, args=(world, _free_port(), cov_mode, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,cov_mode,swap_mode", [(2, "per_walker", "sweep"), (2, "pooled", "sweep"), (4, "per_walker", "sweep"),
+                                                      (2, "per_walker", "oddeven")])
+def test_sharded_equals_single_process(tmp_path, world, cov_mode, swap_mode):
+    mp.spawn(_worker, args=(world, _free_port(), cov_mode, swap_mode, str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok_%d" % r for r in range(world)]
 
 
