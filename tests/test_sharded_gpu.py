@@ -109,3 +109,15 @@ def test_device_exchange_with_emulated_ranks(nranks, cov_mode):
         # rows that are not where they started prove that states crossed block edges
         moved += int((np.abs(L.by_temp("X") - p0[:, sl]).sum(-1) > 0).sum())
     assert ref.nswap[:, ntb - 1].sum() > 0, "no swap was ever accepted across the first block edge"
+
+
+def test_two_real_processes_share_the_gpu_over_gloo():
+    """True multi-process run of ShardedPTEngine + DistComm (two ranks on cuda:0, gloo moving device tensors),
+    both swap modes, against the oracle: tools/two_proc_one_gpu.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "two_proc_one_gpu.py"), "2"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "all ranks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
