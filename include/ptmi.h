@@ -51,7 +51,7 @@ enum { PTMI_LOGP_FLAT = 0,     /* 0 everywhere */
        PTMI_LOGP_BOX = 1 };    /* 0 inside [lo,hi], -inf outside ; par = lo[d], hi[d] */
 
 /* proposal types; also the index into jstat */
-enum { PTMI_J_SCAM = 0, PTMI_J_AM = 1, PTMI_J_DE = 2, PTMI_J_NTYPES = 3 };
+enum { PTMI_J_SCAM = 0, PTMI_J_AM = 1, PTMI_J_DE = 2, PTMI_J_NUTS = 3, PTMI_J_HMC = 4, PTMI_J_NTYPES = 5 };
 
 /* ptmi_config.swap_mode.  SWEEP is PTswap as the reference runs it: every adjacent pair is tried, hottest first, and
  * a state can travel several ranks in one call.  ODDEVEN tries, at swap epoch e = iter / tskip, only the pairs
@@ -79,6 +79,15 @@ typedef struct ptmi_config {
     int32_t device;          /* HIP device ordinal */
     int32_t ngroups;         /* parameter groups (PTMCMCSampler.py:129-145); 0 or 1 = one group of all parameters */
     int32_t swap_mode;       /* PTMI_SWAP_SWEEP (the reference's hot -> cold sweep, :666-686) or PTMI_SWAP_ODDEVEN */
+    /* Gradient jumps on the built-in likelihoods (the reference adds them when logl_grad / logp_grad are given,
+     * :225-258; nutsjump.py): cycle += [NUTS]*w_nuts + [HMC]*w_hmc.  ndim <= 32 in this version. */
+    int32_t w_nuts, w_hmc;
+    int32_t gj_nburn;        /* nburn of the jump objects (= burn, :227,238,251) */
+    int32_t hmc_min, hmc_max;/* HMC takes randint(hmc_min, hmc_max) leapfrogs (:240-241: 2, HMCsteps) */
+    int32_t nuts_maxdepth;   /* tree heights 0..nuts_maxdepth per call (the reference has no cap); <= 24 */
+    int32_t pad0_;
+    double hmc_eps;          /* HMCstepsize (:239) */
+    double nuts_delta;       /* target acceptance of NUTS' dual averaging (0.6, :256) */
     uint64_t seed;
     void *stream;            /* hipStream_t to launch on; NULL = the null stream */
     const double *ladder;    /* host [ntemps_global]  temperatures used by the swap (:658) */
@@ -89,6 +98,9 @@ typedef struct ptmi_config {
     int64_t logp_par_len;
     const int32_t *group_size;  /* host [ngroups] parameters per group (ngroups > 1 only) */
     const double *group_mask;   /* host [ngroups][ndim] 1.0 where a parameter belongs to the group (ngroups > 1 only) */
+    const double *gj_tab;       /* host [3][ndim][ndim] whitening tables of the gradient jumps from L = cholesky(cov)
+                                 * (nutsjump.py:53-54), each used as out[i] = sum_k T[k][i] v[k]: backward T = L
+                                 * (x = L^T q), forward T = L^-1 (q = L^-T x), gradient T = L^T.  NULL without them */
 } ptmi_config;
 
 /* Device buffers, caller-owned.  W = nwalkers, T = ntemps, d = ndim,
@@ -116,6 +128,9 @@ typedef struct ptmi_buffers {
                          *              accept uniform, log(accept uniform) (optional) */
     double *AMaux;      /* [W][cov_update][2]  lnL and lp of the rank-0 chain beside each AM row: the
                          *              _lnlike/_lnprob columns of updateChains (:331-335) (optional) */
+    double *gj;         /* [W][T][8]   by RANK: the attributes of a rank's NUTSJump / HMCJump object (nutsjump.py:379-433):
+                         *              epsilon, mu, Hbar, epsilonbar (starts at 1), NUTS calls, HMC calls, have-epsilon flag, -
+                         *              (needed with w_nuts + w_hmc > 0, together with Q and qaux) */
 } ptmi_buffers;
 
 typedef struct ptmi_engine *ptmi_handle;

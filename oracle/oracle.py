@@ -21,7 +21,10 @@ _SO = os.path.join(_HERE, "libptmcmc_oracle.so")
 
 LOGL = {"iso": 0, "dense": 1, "curved": 2}
 LOGP = {"flat": 0, "box": 1}
-J_SCAM, J_AM, J_DE, J_NTYPES = 0, 1, 2, 3
+J_SCAM, J_AM, J_DE, J_NUTS, J_HMC, J_NTYPES = 0, 1, 2, 3, 4, 5
+J = {"scam": 0, "am": 1, "de": 2, "nuts": 3, "hmc": 4}
+K_INT, K_UNI, K_NRM, K_SHUF, K_EXP = 0, 1, 2, 3, 4
+GJ_EPS, GJ_MU, GJ_HBAR, GJ_EPSBAR, GJ_NITER, GJ_HITER, GJ_HAVE_EPS, GJ_NSTATE = 0, 1, 2, 3, 4, 5, 6, 8
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -33,12 +36,14 @@ class Cfg(C.Structure):
         "ndim", "ntemps", "nwalkers", "lanes", "logl_kind", "logp_kind", "w_scam", "w_am", "w_de",
         "de_on", "de_size", "cov_update", "tskip", "cov_per_walker", "ntemps_global", "temp0", "walker0", "ngroups")] + [
         ("seed", C.c_uint64), ("logl_par", _dp), ("logp_par", _dp), ("temps_mh", _dp), ("beta", _dp),
-        ("gsize", _ip), ("gmask", _dp)]
+        ("gsize", _ip), ("gmask", _dp)] + [(n, C.c_int32) for n in (
+        "w_nuts", "w_hmc", "gj_nburn", "hmc_min", "hmc_max", "nuts_maxdepth")] + [
+        ("hmc_eps", C.c_double), ("nuts_delta", C.c_double), ("gj_tab", _dp)]
 
 
 class State(C.Structure):
     _fields_ = [("X", _dp), ("lnL", _dp), ("lp", _dp), ("temp_of", _ip), ("slot_of", _ip), ("Ut", _dp), ("S", _dp),
-                ("DE", _dp), ("AM", _dp), ("nacc", _up), ("jstat", _up)]
+                ("DE", _dp), ("AM", _dp), ("nacc", _up), ("jstat", _up), ("gj", _dp)]
 
 
 class Replay(C.Structure):
@@ -82,6 +87,8 @@ def lib():
         L.orc_de_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.orc_de_update_pooled.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.orc_eval_state.argtypes = [C.POINTER(Cfg), C.POINTER(State)]
+        L.orc_gradjump.argtypes = [C.POINTER(Cfg), C.c_int, _dp, C.c_int64, C.c_double, _dp, C.c_uint64,
+                                   C.POINTER(Replay), _dp, _dp, C.POINTER(C.c_int64)]
         L.orc_logl.restype = C.c_double
         L.orc_logl.argtypes = [C.POINTER(Cfg), _dp]
         assert L.orc_sizeof_cfg() == C.sizeof(Cfg)
@@ -164,6 +171,49 @@ def swap_oddeven(ladder, lnL_pos, parity, it=0, seed=0, walker0=0):
     return m, acc
 
 
+def gj_tables(cov):
+    """Whitening tables of the gradient jumps from L = cholesky(cov) (nutsjump.py:53-54), in the layout the kernels
+    and the oracle read: [backward L, forward L^-1, gradient L^T], each used as out[i] = sum_k T[k][i] v[k]."""
+    import scipy.linalg as sl
+    cov = np.asarray(cov, dtype=np.float64)
+    L = sl.cholesky(cov, lower=True)
+    Li = sl.solve_triangular(L, np.eye(len(cov)), trans=0, lower=True)
+    return np.ascontiguousarray(np.stack([L, Li, L.T]))
+
+
+def gj_state():
+    st = np.zeros(GJ_NSTATE)
+    st[GJ_EPSBAR] = 1.0
+    return st
+
+
+def gradjump(kind, x, it, beta, state, cov, logl=("iso",), logp=("flat",), nburn=100, delta=0.6, hmc=(0.1, 2, 300),
+             maxdepth=12, lanes=None, seed=0, sid=0, replay=None):
+    """One NUTS / HMC jump call on the point x through the oracle (state: gj_state(), updated in place).
+    replay = (kinds, vals, bounds) of the reference's global np.random draws."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    d = len(x)
+    par_l, par_p = np.zeros(1), np.zeros(1)
+    if logl[0] == "dense":
+        par_l = np.concatenate([np.asarray(logl[1], float), np.ascontiguousarray(np.asarray(logl[2], float).T).ravel()])
+    if logp[0] == "box":
+        par_p = np.concatenate([np.asarray(logp[1], float), np.asarray(logp[2], float)])
+    tab = gj_tables(cov)
+    cfg = Cfg(ndim=d, ntemps=1, nwalkers=1, lanes=lanes_for(d) if lanes is None else lanes, logl_kind=LOGL[logl[0]],
+              logp_kind=LOGP[logp[0]], seed=seed, logl_par=_p(par_l), logp_par=_p(par_p), gj_nburn=nburn,
+              hmc_eps=hmc[0], hmc_min=hmc[1], hmc_max=hmc[2], nuts_maxdepth=maxdepth, nuts_delta=delta, gj_tab=_p(tab))
+    q, qxy, nleap = np.zeros(d), np.zeros(1), C.c_int64(0)
+    rp = keep = None
+    if replay is not None:
+        rp, keep = make_replay(*replay)
+    err = lib().orc_gradjump(C.byref(cfg), J[kind], _p(x), it, beta, _p(state), sid, C.byref(rp) if rp is not None else None,
+                             _p(q), _p(qxy), C.byref(nleap))
+    assert err == 0, "replay error %d" % err
+    if rp is not None:
+        assert rp.pos == rp.n, "unused draws: %d of %d" % (rp.pos, rp.n)
+    return q, float(qxy[0]), int(nleap.value)
+
+
 def make_replay(kinds, vals, bounds):
     kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
     vals = np.ascontiguousarray(vals, dtype=np.float64)
@@ -182,7 +232,8 @@ class OracleEngine(object):
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
-                 ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep"):
+                 ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep",
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10):
         assert swap_mode in ("sweep", "oddeven")
         self.swap_mode = swap_mode
         self.d, self.nt, self.W = ndim, ntemps, nwalkers
@@ -221,6 +272,11 @@ class OracleEngine(object):
         self.AM = np.zeros((W, cov_update, d))
         self.nacc = np.zeros((W, nt), dtype=np.uint64)
         self.jstat = np.zeros((W, nt, J_NTYPES, 2), dtype=np.uint64)
+        # gradient jumps (PTMCMCSampler.py:225-258): whitening from the INITIAL covariance, never adapted (nutsjump.py:45)
+        self.grad_weights = tuple(int(v) for v in grad_weights)
+        self.gj_tab = gj_tables(cov0) if sum(self.grad_weights) else np.zeros(1)
+        self.gj = np.zeros((W, nt, GJ_NSTATE))
+        self.gj[..., GJ_EPSBAR] = 1.0
         self.nswap = np.zeros((W, self.ntg), dtype=np.uint64)
         self.swap_proposed = 0
         self._par_l = np.zeros(1)
@@ -235,14 +291,17 @@ class OracleEngine(object):
                        de_size=burn, cov_update=cov_update, tskip=tskip, cov_per_walker=int(self.per_walker),
                        ntemps_global=self.ntg, temp0=temp0, walker0=walker0, ngroups=self.ngr, seed=seed,
                        logl_par=_p(self._par_l), logp_par=_p(self._par_p), temps_mh=_p(self.temps_mh),
-                       beta=_p(self.beta), gsize=_p(self.gsize, _ip), gmask=_p(self.gmask))
+                       beta=_p(self.beta), gsize=_p(self.gsize, _ip), gmask=_p(self.gmask),
+                       w_nuts=self.grad_weights[0], w_hmc=self.grad_weights[1], gj_nburn=burn, hmc_eps=hmc[0],
+                       hmc_min=hmc[1], hmc_max=hmc[2], nuts_maxdepth=nuts_maxdepth, nuts_delta=nuts_delta,
+                       gj_tab=_p(self.gj_tab))
         self.iter = 0
 
     # -- helpers
     def _state(self):
         return State(_p(self.X), _p(self.lnL), _p(self.lp), _p(self.temp_of, _ip), _p(self.slot_of, _ip), _p(self.Ut),
                      _p(self.S), _p(self.DE), _p(self.AM) if self.temp0 == 0 else None, _p(self.nacc, _up),
-                     _p(self.jstat, _up))
+                     _p(self.jstat, _up), _p(self.gj))
 
     def _svd(self, w):
         # LAPACK results depend on the BLAS thread count in the last bits; the product pins one thread

@@ -66,7 +66,8 @@ static void philox_words(uint64_t seed, uint64_t iter, uint32_t stream, uint32_t
  *   C: w0 DE row nn offset, w1 DE scale uniform    D: (w0,w1) SCAM normal
  *   SWAP+k: w0 uniform of pair (k,k+1), stream of rank 0
  *   AM+k: (w0,w1) Box-Muller pair: cos branch -> eigen-direction k, sin branch -> direction k+lanes, (k/lanes) even */
-enum { SLOT_A = 0, SLOT_B = 1, SLOT_C = 2, SLOT_D = 3, SLOT_SWAP = 0x10000, SLOT_AM = 0x1000000 };
+enum { SLOT_A = 0, SLOT_B = 1, SLOT_C = 2, SLOT_D = 3, SLOT_SWAP = 0x10000, SLOT_AM = 0x1000000,
+       SLOT_GJ = 0x2000000 /* + 4096 * (momenta draw of the call) + direction */, SLOT_GJS = 0x3000000 /* + scalar draw of the call */ };
 
 static inline double w2uniform(uint64_t w) { return (double)(w >> 11) * 0x1.0p-53; }        /* [0,1) */
 static inline double w2uniform_open(uint64_t w) { return (double)((w >> 11) + 1) * 0x1.0p-53; } /* (0,1] */
@@ -209,8 +210,10 @@ ORC_API uint64_t orc_index(uint64_t w, uint64_t n) { return w2index(w, n); }
 /* ------------------------------------------------------------- config */
 enum { LOGL_ISO = 0, LOGL_DENSE = 1, LOGL_CURVED = 2 };
 enum { LOGP_FLAT = 0, LOGP_BOX = 1 };
-enum { J_SCAM = 0, J_AM = 1, J_DE = 2, J_NTYPES = 3 };
-enum { K_INT = 0, K_UNI = 1, K_NRM = 2, K_SHUF = 3 };
+enum { J_SCAM = 0, J_AM = 1, J_DE = 2, J_NUTS = 3, J_HMC = 4, J_NTYPES = 5 };
+enum { K_INT = 0, K_UNI = 1, K_NRM = 2, K_SHUF = 3, K_EXP = 4 };
+/* per-rank state of the gradient jumps (the attributes of a rank's NUTSJump / HMCJump object, NJ:379-433) */
+enum { GJ_EPS = 0, GJ_MU = 1, GJ_HBAR = 2, GJ_EPSBAR = 3, GJ_NITER = 4, GJ_HITER = 5, GJ_HAVE_EPS = 6, GJ_NSTATE = 8 };
 
 typedef struct {
     int32_t ndim, ntemps, nwalkers, lanes;
@@ -227,6 +230,16 @@ typedef struct {
     const double *beta;               /* [ntemps] 1/temps_mh */
     const int32_t *gsize;             /* [ngroups] parameters per group (NULL with one full group) */
     const double *gmask;              /* [ngroups][d] 1 where the parameter belongs to the group */
+    /* gradient jumps on the built-in likelihoods (PT:225-258): cycle += [NUTS]*w_nuts + [HMC]*w_hmc */
+    int32_t w_nuts, w_hmc;
+    int32_t gj_nburn;                 /* nburn of the jump objects (= burn, PT:227,238,251) */
+    int32_t hmc_min, hmc_max;         /* HMC: randint(hmc_min, hmc_max) leapfrogs (PT:240-241: 2, HMCsteps) */
+    int32_t nuts_maxdepth;            /* tree heights built per call are 0..nuts_maxdepth (the reference has no cap) */
+    double hmc_eps;                   /* HMCstepsize */
+    double nuts_delta;                /* target acceptance of the dual averaging (0.6, PT:256) */
+    const double *gj_tab;             /* [3][d][d] whitening tables from L = cholesky(cov0) (NJ:53-54), each used as
+                                       * out[i] = sum_k T[k][i] v[k]:  backward T[k][i] = L[k][i] (x = L^T q),
+                                       * forward T[k][i] = Linv[k][i] (q = Linv^T x), gradient T[k][i] = L[i][k] */
 } orc_cfg;
 
 typedef struct {
@@ -240,6 +253,7 @@ typedef struct {
     double *AM;         /* [W][cov_update][d] */
     uint64_t *nacc;     /* [W][ntemps]      by RANK */
     uint64_t *jstat;    /* [W][ntemps][J_NTYPES][2]  (proposed, accepted) by RANK */
+    double *gj;         /* [W][ntemps][GJ_NSTATE]    gradient-jump state by RANK (NULL without gradient jumps) */
 } orc_state;
 
 typedef struct {
@@ -315,6 +329,336 @@ static double eval_logl(const orc_cfg *c, const double *q, double *tmp /* 2d */)
     return NAN;
 }
 
+
+/* ------------------------------------------------------- gradient jumps */
+/* nutsjump.py of the reference on the built-in likelihoods (their gradients are analytic here; the reference takes
+ * them from the user's logl_grad / logp_grad callbacks).  NJ:<lines> = PTMCMCSampler/nutsjump.py. */
+typedef struct {
+    orc_replay *r;          /* replay of the reference's global np.random draws, or NULL: counter mode */
+    uint64_t seed, it;
+    uint32_t sid, nm, ns;   /* stream; momenta draws and scalar draws used so far in this call */
+    int lanes;
+} gj_rng;
+
+static void gj_momenta(gj_rng *g, int d, double *r)             /* NJ:92-94  np.random.randn(ndim) */
+{
+    if (g->r) { for (int i = 0; i < d; ++i) r[i] = rp_next(g->r, K_NRM, 0); return; }
+    const uint32_t block = g->nm++;
+    for (int k = 0; k < d; ++k) {                               /* paired like the AM normals */
+        const int which = (k / g->lanes) & 1, base = which ? k - g->lanes : k;
+        uint64_t E[2];
+        philox_words(g->seed, g->it, g->sid, SLOT_GJ + 4096u * block + (uint32_t)base, E);
+        r[k] = which ? orc_normal_sin(E[0], E[1]) : orc_normal(E[0], E[1]);
+    }
+}
+static double gj_uniform(gj_rng *g)
+{
+    if (g->r) return rp_next(g->r, K_UNI, 0);
+    uint64_t W[2];
+    philox_words(g->seed, g->it, g->sid, SLOT_GJS + g->ns++, W);
+    return w2uniform(W[0]);
+}
+static double gj_exponential(gj_rng *g)
+{
+    if (g->r) return rp_next(g->r, K_EXP, 0);
+    uint64_t W[2];
+    philox_words(g->seed, g->it, g->sid, SLOT_GJS + g->ns++, W);
+    return -orc_log(w2uniform_open(W[0]));
+}
+static int gj_randint(gj_rng *g, int lo, int hi)                /* np.random.randint(lo, hi) */
+{
+    if (g->r) return (int)rp_next(g->r, K_INT, hi);
+    uint64_t W[2];
+    philox_words(g->seed, g->it, g->sid, SLOT_GJS + g->ns++, W);
+    return lo + (int)w2index(W[0], (uint64_t)(hi - lo));
+}
+
+static void tab_vec(const double *T, const double *v, double *out, int d)
+{
+    for (int i = 0; i < d; ++i) out[i] = 0.0;
+    for (int k = 0; k < d; ++k)
+        for (int i = 0; i < d; ++i) out[i] = fma(T[(size_t)k * d + i], v[k], out[i]);
+}
+
+/* logl and its gradient for the built-in families (same value as eval_logl) */
+static double eval_logl_grad(const orc_cfg *c, const double *q, double *tmp /* 2d */, double *g)
+{
+    const int d = c->ndim;
+    const double ll = eval_logl(c, q, tmp);
+    if (c->logl_kind == LOGL_ISO) {
+        for (int i = 0; i < d; ++i) g[i] = -q[i];
+    } else if (c->logl_kind == LOGL_DENSE) {                   /* symmetric P: grad = -P (x - mu); tmp + d holds P r */
+        for (int i = 0; i < d; ++i) g[i] = -tmp[d + i];
+    } else {
+        for (int i = 0; i < d; ++i) g[i] = 0.0;
+        for (int i = 0; i + 1 < d; i += 2) {
+            const double x = q[i], y = q[i + 1], x2 = x * x;
+            const double gg = 9.0 + 4.0 * x2 + 9.0 * y;
+            const double l0 = -x2 - gg * gg;
+            const double ym = y - 2.0;
+            const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
+            const double e0 = orc_exp(l0), e1 = 0.5 * orc_exp(l1);
+            const double sum = e0 + e1;
+            const double d0x = -2.0 * x - 16.0 * gg * x, d0y = -18.0 * gg;
+            const double d1x = -16.0 * x, d1y = -16.0 * ym;
+            g[i] = (e0 * d0x + e1 * d1x) / sum;
+            g[i + 1] = (e0 * d0y + e1 * d1y) / sum;
+        }
+    }
+    return ll;
+}
+
+typedef struct {
+    const orc_cfg *c;
+    double beta;
+    double *w;              /* workspace: 5 d-vectors */
+    int64_t nleap;          /* leapfrogs taken (statistics) */
+} gj_ctx;
+
+/* beta*logl + logp and its gradient in the whitened coordinates (NJ:71-90) */
+static double func_grad_white(gj_ctx *G, const double *q, double *gradw)
+{
+    const orc_cfg *c = G->c;
+    const int d = c->ndim;
+    double *x = G->w, *g = G->w + d, *tmp = G->w + 2 * d;     /* tmp: 2d */
+    tab_vec(c->gj_tab, q, x, d);                                /* backward: x = L^T q */
+    const double ll = eval_logl_grad(c, x, tmp, g);
+    const double lp = eval_logp(c, x);                          /* gradient of the built-in priors is zero */
+    for (int i = 0; i < d; ++i) g[i] = G->beta * g[i] + 0.0;
+    tab_vec(c->gj_tab + 2 * (size_t)d * d, g, gradw, d);
+    return G->beta * ll + lp;
+}
+
+static double loghamiltonian(const orc_cfg *c, double logl, const double *r)     /* NJ:133-147 */
+{
+    return logl - 0.5 * lane_dot(r, r, c->ndim, c->lanes);
+}
+
+/* NJ:149-169: half kick, drift, gradient, half kick; outputs may not alias inputs */
+static double leapfrog(gj_ctx *G, const double *theta, const double *r, const double *grad, double eps,
+                       double *thetap, double *rp, double *gradp)
+{
+    const int d = G->c->ndim;
+    const double he = 0.5 * eps;
+    for (int i = 0; i < d; ++i) { rp[i] = r[i] + he * grad[i]; thetap[i] = theta[i] + eps * rp[i]; }
+    const double logpp = func_grad_white(G, thetap, gradp);
+    for (int i = 0; i < d; ++i) rp[i] = rp[i] + he * gradp[i];
+    G->nleap++;
+    return logpp;
+}
+
+static double orc_pow_neg(double x, double e) { return orc_exp(-e * orc_log(x)); }   /* x ** -e, x > 0 */
+
+/* HMCJump.__call__ (NJ:238-291) */
+static void hmc_call(gj_ctx *G, gj_rng *rng, double *st, const double *x, double *qout, double *qxy)
+{
+    const orc_cfg *c = G->c;
+    const int d = c->ndim;
+    double *v = (double *)malloc(sizeof(double) * 7 * (size_t)d);
+    double *q = v, *p = v + d, *grad = v + 2 * d, *q1 = v + 3 * d, *p1 = v + 4 * d, *g1 = v + 5 * d;
+    st[GJ_HITER] += 1.0;
+    tab_vec(c->gj_tab + (size_t)d * d, x, q, d);                 /* forward */
+    const double logp0 = func_grad_white(G, q, grad);
+    gj_momenta(rng, d, p);
+    const double joint0 = loghamiltonian(c, logp0, p);
+    const int nsteps = gj_randint(rng, c->hmc_min, c->hmc_max);
+    double joint1 = joint0;
+    for (int k = 0; k < nsteps; ++k) {
+        const double logp1 = leapfrog(G, q, p, grad, c->hmc_eps, q1, p1, g1);
+        memcpy(q, q1, sizeof(double) * d); memcpy(p, p1, sizeof(double) * d); memcpy(grad, g1, sizeof(double) * d);
+        joint1 = loghamiltonian(c, logp1, p);
+        if (joint1 - 1000.0 < joint0) break;                    /* NJ:284-286 */
+    }
+    tab_vec(c->gj_tab, q, qout, d);
+    *qxy = joint1 - joint0;
+    free(v);
+}
+
+typedef struct {
+    double *v;              /* 8 d-vectors: tm rm gm tp rp gp theta grad */
+    double logp, alpha;
+    int64_t n, nalpha, ip, im;
+    int s;
+} gj_tree;
+#define T_TM(t) ((t)->v)
+#define T_RM(t) ((t)->v + d)
+#define T_GM(t) ((t)->v + 2 * d)
+#define T_TP(t) ((t)->v + 3 * d)
+#define T_RP(t) ((t)->v + 4 * d)
+#define T_GP(t) ((t)->v + 5 * d)
+#define T_TH(t) ((t)->v + 6 * d)
+#define T_GR(t) ((t)->v + 7 * d)
+
+static int stop_criterion(const orc_cfg *c, const double *tm, const double *tp, const double *rm, const double *rp, double *tmp)
+{                                                               /* NJ:465-493 (force_trajlen is None) */
+    const int d = c->ndim;
+    for (int i = 0; i < d; ++i) tmp[i] = tp[i] - tm[i];
+    const double a = lane_dot(tmp, rm, d, c->lanes), b = lane_dot(tmp, rp, d, c->lanes);
+    return (a >= 0.0) & (b >= 0.0);
+}
+
+/* NJ:495-652 */
+static void build_tree(gj_ctx *G, gj_rng *rng, const double *theta, const double *r, const double *grad, double logu,
+                       int v, int j, double eps, double joint0, int64_t ind, gj_tree *t, double *tmp)
+{
+    const orc_cfg *c = G->c;
+    const int d = c->ndim;
+    t->v = (double *)malloc(sizeof(double) * 8 * (size_t)d);
+    if (j == 0) {
+        const double logpp = leapfrog(G, theta, r, grad, (double)v * eps, T_TH(t), T_RM(t), T_GR(t));
+        const double joint = loghamiltonian(c, logpp, T_RM(t));
+        t->n = logu < joint;
+        t->s = (logu - 1000.0) < joint;
+        memcpy(T_TM(t), T_TH(t), sizeof(double) * d); memcpy(T_TP(t), T_TH(t), sizeof(double) * d);
+        memcpy(T_RP(t), T_RM(t), sizeof(double) * d);
+        memcpy(T_GM(t), T_GR(t), sizeof(double) * d); memcpy(T_GP(t), T_GR(t), sizeof(double) * d);
+        t->logp = logpp;
+        const double e = orc_exp(joint - joint0);
+        t->alpha = e < 1.0 ? e : 1.0;                          /* Python's min(1.0, e): 1.0 when e is NaN */
+        t->nalpha = 1;
+        if (v == 1) { t->ip = ind + 1; t->im = ind; } else { t->ip = ind; t->im = ind + 1; }
+        return;
+    }
+    build_tree(G, rng, theta, r, grad, logu, v, j - 1, eps, joint0, ind, t, tmp);
+    if (t->s == 1) {
+        gj_tree u;
+        if (v == -1) {
+            build_tree(G, rng, T_TM(t), T_RM(t), T_GM(t), logu, v, j - 1, eps, joint0, t->im, &u, tmp);
+            memcpy(T_TM(t), T_TM(&u), sizeof(double) * 3 * d);  /* tm, rm, gm are adjacent */
+        } else {
+            build_tree(G, rng, T_TP(t), T_RP(t), T_GP(t), logu, v, j - 1, eps, joint0, t->ip, &u, tmp);
+            memcpy(T_TP(t), T_TP(&u), sizeof(double) * 3 * d);
+        }
+        t->ip = u.ip; t->im = u.im;
+        const double den = (double)(t->n + u.n) > 1.0 ? (double)(t->n + u.n) : 1.0;
+        if (gj_uniform(rng) < (double)u.n / den) {
+            memcpy(T_TH(t), T_TH(&u), sizeof(double) * 2 * d);  /* theta, grad */
+            t->logp = u.logp;
+        }
+        t->n += u.n;
+        t->s = t->s && u.s && stop_criterion(c, T_TM(t), T_TP(t), T_RM(t), T_RP(t), tmp);
+        t->alpha += u.alpha; t->nalpha += u.nalpha;
+        free(u.v);
+    }
+}
+
+static double accept_ratio(const orc_cfg *c, double logpp, const double *rp, double logp0, const double *r0)
+{
+    return orc_exp(loghamiltonian(c, logpp, rp) - loghamiltonian(c, logp0, r0));
+}
+
+/* NJ:435-463; the two loops are bounded at 100 turns here (the reference's are not) */
+static double find_reasonable_epsilon(gj_ctx *G, gj_rng *rng, const double *theta0, const double *grad0, double logp0, double *v /* 4d */)
+{
+    const orc_cfg *c = G->c;
+    const int d = c->ndim;
+    double *r0 = v, *tp = v + d, *rp = v + 2 * d, *gp = v + 3 * d;
+    double eps = 1.0;
+    gj_momenta(rng, d, r0);
+    double logpp = leapfrog(G, theta0, r0, grad0, eps, tp, rp, gp);
+    int ginf = 0;
+    for (int i = 0; i < d; ++i) ginf |= isinf(gp[i]) != 0;
+    double k = 1.0;
+    for (int n = 0; n < 100 && (isinf(logpp) || ginf); ++n) {  /* gradprime is not refreshed (NJ:449-452) */
+        k *= 0.5;
+        double *g2 = G->w + 4 * d;
+        logpp = leapfrog(G, theta0, r0, grad0, eps * k, tp, rp, g2);
+    }
+    eps = 0.5 * k * eps;
+    double ap = accept_ratio(c, logpp, rp, logp0, r0);
+    const double a = 2.0 * (double)(ap > 0.5) - 1.0;
+    for (int n = 0; n < 100 && ((a > 0.0 ? ap : 1.0 / ap) > (a > 0.0 ? 0.5 : 2.0)); ++n) {
+        eps = eps * (a > 0.0 ? 2.0 : 0.5);
+        logpp = leapfrog(G, theta0, r0, grad0, eps, tp, rp, gp);
+        ap = accept_ratio(c, logpp, rp, logp0, r0);
+    }
+    return eps;
+}
+
+/* NUTSJump.__call__ (NJ:654-840) with force_trajlen = force_epsilon = None */
+static void nuts_call(gj_ctx *G, gj_rng *rng, double *st, const double *x, int64_t iter, double *qout, double *qxy)
+{
+    const orc_cfg *c = G->c;
+    const int d = c->ndim;
+    double *v = (double *)malloc(sizeof(double) * 14 * (size_t)d);
+    double *q = v, *grad = v + d, *r0 = v + 2 * d, *sample = v + 3 * d, *tmp = v + 4 * d;
+    double *ends = v + 5 * d;                                   /* tm rm gm tp rp gp */
+    double *fre = v + 11 * d;                                   /* 3d for find_reasonable_epsilon (+ r0 slot) */
+    st[GJ_NITER] += 1.0;
+    tab_vec(c->gj_tab + (size_t)d * d, x, q, d);
+    const double logp = func_grad_white(G, q, grad);
+    if (st[GJ_HAVE_EPS] == 0.0) {
+        double *w4 = (double *)malloc(sizeof(double) * 4 * (size_t)d);
+        st[GJ_EPS] = find_reasonable_epsilon(G, rng, q, grad, logp, w4);
+        free(w4);
+        st[GJ_MU] = orc_log(10.0 * st[GJ_EPS]);
+        st[GJ_HAVE_EPS] = 1.0;
+    }
+    (void)fre;
+    gj_momenta(rng, d, r0);
+    const double joint = loghamiltonian(c, logp, r0);
+    const double logu = joint - gj_exponential(rng);
+    memcpy(sample, q, sizeof(double) * d);
+    double lnprob = logp;
+    double *tm = ends, *rm = ends + d, *gm = ends + 2 * d, *tp = ends + 3 * d, *rp = ends + 4 * d, *gp = ends + 5 * d;
+    memcpy(tm, q, sizeof(double) * d); memcpy(tp, q, sizeof(double) * d);
+    memcpy(rm, r0, sizeof(double) * d); memcpy(rp, r0, sizeof(double) * d);
+    memcpy(gm, grad, sizeof(double) * d); memcpy(gp, grad, sizeof(double) * d);
+    int j = 0, s = 1;
+    int64_t n = 1, ip = 0, im = 0;
+    double alpha = 0.0; int64_t nalpha = 1;
+    while (s == 1) {
+        const int dir = 2 * (gj_uniform(rng) < 0.5) - 1;
+        gj_tree t;
+        if (dir == -1) {
+            build_tree(G, rng, tm, rm, gm, logu, dir, j, st[GJ_EPS], joint, im, &t, tmp);
+            memcpy(tm, T_TM(&t), sizeof(double) * 3 * d);
+        } else {
+            build_tree(G, rng, tp, rp, gp, logu, dir, j, st[GJ_EPS], joint, ip, &t, tmp);
+            memcpy(tp, T_TP(&t), sizeof(double) * 3 * d);
+        }
+        ip = t.ip; im = t.im;
+        if (t.s == 1) {
+            const double ratio = (double)t.n / (double)n;
+            if (gj_uniform(rng) < (1.0 < ratio ? 1.0 : ratio)) { memcpy(sample, T_TH(&t), sizeof(double) * d); lnprob = t.logp; }
+        }
+        n += t.n;
+        s = t.s && stop_criterion(c, tm, tp, rm, rp, tmp);
+        alpha = t.alpha; nalpha = t.nalpha;
+        free(t.v);
+        j += 1;
+        if (j > c->nuts_maxdepth) s = 0;                       /* cap (not in the reference) */
+    }
+    /* dual averaging (NJ:805-816) */
+    const double it_call = st[GJ_NITER];
+    double eta = 1.0 / (it_call + 10.0);
+    st[GJ_HBAR] = (1.0 - eta) * st[GJ_HBAR] + eta * (c->nuts_delta - alpha / (double)nalpha);
+    if (iter <= c->gj_nburn) {
+        st[GJ_EPS] = orc_exp(st[GJ_MU] - sqrt(it_call) / 0.05 * st[GJ_HBAR]);
+        eta = orc_pow_neg(it_call, 0.75);
+        st[GJ_EPSBAR] = orc_exp((1.0 - eta) * orc_log(st[GJ_EPSBAR]) + eta * orc_log(st[GJ_EPS]));
+    } else {
+        st[GJ_EPS] = st[GJ_EPSBAR];
+    }
+    tab_vec(c->gj_tab, sample, qout, d);
+    *qxy = logp - lnprob;                                       /* undoes the outer Hastings ratio (NJ:838) */
+    free(v);
+}
+
+/* one jump call on a single point: the unit the reference fixture (tests/golden/gradjump.npz) pins.
+ * kind: J_NUTS or J_HMC; state: GJ_NSTATE doubles (EPSBAR starts at 1.0). */
+ORC_API int orc_gradjump(const orc_cfg *c, int kind, const double *x, int64_t iter, double beta, double *state,
+                         uint64_t sid, orc_replay *rp, double *q, double *qxy, int64_t *nleap)
+{
+    gj_ctx G = { c, beta, (double *)malloc(sizeof(double) * 5 * (size_t)c->ndim), 0 };
+    gj_rng rng = { rp, c->seed, (uint64_t)iter, (uint32_t)sid, 0, 0, c->lanes };
+    if (kind == J_NUTS) nuts_call(&G, &rng, state, x, iter, q, qxy);
+    else hmc_call(&G, &rng, state, x, q, qxy);
+    if (nleap) *nleap = G.nleap;
+    free(G.w);
+    return rp ? (int)rp->err : 0;
+}
+
 /* ------------------------------------------------------------ MH steps */
 /* One Metropolis-Hastings update of one chain: PT:601-622 with _jump PT:1048-1067,
  * SCAM PT:820-876, AM PT:879-933, DE PT:936-985. */
@@ -335,13 +679,17 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
     if (!r) { philox_words(c->seed, (uint64_t)it, sid, SLOT_A, A); philox_words(c->seed, (uint64_t)it, sid, SLOT_B, B); }
 
     /* pick from the weighted cycle (PT:1058) */
-    const int L = c->w_scam + c->w_am + (c->de_on ? c->w_de : 0);
+    const int w_de = c->de_on ? c->w_de : 0;
+    const int L = c->w_scam + c->w_am + w_de + c->w_nuts + c->w_hmc;
     const int ind = r ? (int)rp_next(r, K_INT, L) : (int)w2index(A[0], (uint64_t)L);
-    const int jt = ind < c->w_scam ? J_SCAM : (ind < c->w_scam + c->w_am ? J_AM : J_DE);
+    const int jt = ind < c->w_scam ? J_SCAM : (ind < c->w_scam + c->w_am ? J_AM : (ind < c->w_scam + c->w_am + w_de ? J_DE :
+                   (ind < c->w_scam + c->w_am + w_de + c->w_nuts ? J_NUTS : J_HMC)));
+    double qxy = 0.0;
 
     /* group pick (PT:839,897,955); counter mode: word C0 for SCAM / AM, D0 for DE (the words those jumps leave unused) */
     int g = 0;
-    if (r) g = (int)rp_next(r, K_INT, ngr);
+    if (jt >= J_NUTS) g = 0;                                        /* the gradient jumps move all parameters */
+    else if (r) g = (int)rp_next(r, K_INT, ngr);
     else if (ngr > 1) {
         if (jt == J_DE) { philox_words(c->seed, (uint64_t)it, sid, SLOT_D, D); g = (int)w2index(D[0], (uint64_t)ngr); }
         else { philox_words(c->seed, (uint64_t)it, sid, SLOT_C, C); g = (int)w2index(C[0], (uint64_t)ngr); }
@@ -350,7 +698,14 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
     const double *Ut = st->Ut + (wc * ngr + g) * (size_t)d * d, *S = st->S + (wc * ngr + g) * (size_t)d;
     const double *gm = (c->ngroups > 1) ? c->gmask + (size_t)g * d : NULL;
 
-    if (jt == J_SCAM || jt == J_AM) {
+    if (jt >= J_NUTS) {
+        gj_ctx G = { c, beta, (double *)malloc(sizeof(double) * 5 * (size_t)d), 0 };
+        gj_rng rng = { r, c->seed, (uint64_t)it, sid, 0, 0, c->lanes };
+        double *gst = st->gj + ((size_t)w * nt + t) * GJ_NSTATE;
+        if (jt == J_NUTS) nuts_call(&G, &rng, gst, x, it, q, &qxy);
+        else hmc_call(&G, &rng, gst, x, q, &qxy);
+        free(G.w);
+    } else if (jt == J_SCAM || jt == J_AM) {
         const double prob = r ? rp_next(r, K_UNI, 0) : w2uniform(A[1]);
         double scale = prob > 0.97 ? 10.0 : (prob > 0.9 ? 0.2 : 1.0);
         if (temp <= 100.0) scale *= sqrt(temp);                         /* PT:861-862 */
@@ -422,7 +777,7 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
     /* Hastings test (PT:615-622); lnprob0 is always 1/T*lnL + logp(x) of the held state */
     const double lnprob0 = beta * st->lnL[ch] + st->lp[ch];
     const double u = r ? rp_next(r, K_UNI, 0) : w2uniform(B[0]);
-    const double diff = newlnprob - lnprob0 + 0.0;
+    const double diff = newlnprob - lnprob0 + qxy;                  /* qxy = 0 for SCAM / AM / DE */
     if (diff > orc_log(u)) {
         memcpy(x, q, sizeof(double) * d);
         st->lnL[ch] = newlnL; st->lp[ch] = lp;

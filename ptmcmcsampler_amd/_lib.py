@@ -10,7 +10,8 @@ SO = os.path.join(HERE, "libptmi.so")
 
 LOGL = {"iso": 0, "dense": 1, "curved": 2}
 LOGP = {"flat": 0, "box": 1}
-J_SCAM, J_AM, J_DE, J_NTYPES = 0, 1, 2, 3
+J_SCAM, J_AM, J_DE, J_NUTS, J_HMC, J_NTYPES = 0, 1, 2, 3, 4, 5
+GJ_NSTATE, GJ_EPSBAR = 8, 3
 JUMP_NAMES = ("covarianceJumpProposalSCAM", "covarianceJumpProposalAM", "DEJump")
 
 _dp = C.POINTER(C.c_double)
@@ -19,16 +20,17 @@ _dp = C.POINTER(C.c_double)
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "ndim", "ntemps", "nwalkers", "ntemps_global", "temp0", "walker0", "logl_kind", "logp_kind",
-        "w_host", "w_scam", "w_am", "w_de", "de_size", "cov_update", "tskip", "cov_per_walker", "device", "ngroups", "swap_mode")] + [
-        ("seed", C.c_uint64), ("stream", C.c_void_p), ("ladder", _dp), ("temps_mh", _dp),
+        "w_host", "w_scam", "w_am", "w_de", "de_size", "cov_update", "tskip", "cov_per_walker", "device", "ngroups", "swap_mode",
+        "w_nuts", "w_hmc", "gj_nburn", "hmc_min", "hmc_max", "nuts_maxdepth", "pad0_")] + [
+        ("hmc_eps", C.c_double), ("nuts_delta", C.c_double), ("seed", C.c_uint64), ("stream", C.c_void_p), ("ladder", _dp), ("temps_mh", _dp),
         ("logl_par", _dp), ("logl_par_len", C.c_int64), ("logp_par", _dp), ("logp_par_len", C.c_int64),
-        ("group_size", C.POINTER(C.c_int32)), ("group_mask", _dp)]
+        ("group_size", C.POINTER(C.c_int32)), ("group_mask", _dp), ("gj_tab", _dp)]
 
 
 SWAP_MODES = {"sweep": 0, "oddeven": 1}      # PTMI_SWAP_SWEEP, PTMI_SWAP_ODDEVEN
 
 BUFFER_FIELDS = ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "DE", "AM", "nacc", "jstat", "nswap",
-                 "mu", "M2", "cov", "Q", "qaux", "AMaux")
+                 "mu", "M2", "cov", "Q", "qaux", "AMaux", "gj")
 
 
 class Buffers(C.Structure):

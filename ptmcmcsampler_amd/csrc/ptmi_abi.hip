@@ -471,6 +471,9 @@ static KArgs make_args(ptmi_engine *h)
     a.d = c.ndim; a.nt = c.ntemps; a.W = c.nwalkers; a.ntg = c.ntemps_global; a.temp0 = c.temp0; a.walker0 = c.walker0;
     a.w_host = c.w_host; a.w_scam = c.w_scam; a.w_am = c.w_am; a.w_de = c.w_de; a.de_on = h->de_on; a.de_size = c.de_size; a.de_head = h->de_head;
     a.cov_update = c.cov_update; a.tskip = c.tskip; a.per_walker = c.cov_per_walker; a.logp_kind = c.logp_kind;
+    a.w_nuts = c.w_nuts; a.w_hmc = c.w_hmc; a.gj_nburn = c.gj_nburn; a.hmc_min = c.hmc_min; a.hmc_max = c.hmc_max;
+    a.nuts_maxdepth = c.nuts_maxdepth; a.hmc_eps = c.hmc_eps; a.nuts_delta = c.nuts_delta;
+    a.gj_tab = h->d_gj_tab; a.gj = b.gj; a.gj_scr = h->d_gj_scr; a.gj_scal = h->d_gj_scal;
     return a;
 }
 
@@ -483,7 +486,7 @@ static ptmi_shape_fn shape_fn(int G, int EPL, int L)
 }
 static int run_shape(ptmi_engine *h, int op, KArgs &a, int grid, bool full)
 {
-    const int L = (op == PTMI_OP_PROPOSE || op == PTMI_OP_ACCEPT) ? 0 : h->cfg.logl_kind;
+    const int L = (op == PTMI_OP_PROPOSE || op == PTMI_OP_ACCEPT) ? 0 : h->cfg.logl_kind;   // the split kernels live in family 0
     ptmi_shape_fn f = shape_fn(h->G, h->EPL, L);
     if (!f) return fail(PTMI_EUNSUPPORTED, "no kernel shape for ndim=%d", h->cfg.ndim);
     return f(op, h, a, grid, full);
@@ -562,6 +565,17 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         for (int g = 0; g < c.ngroups; ++g)
             if (c.group_size[g] < 1 || c.group_size[g] > c.ndim) return fail(PTMI_EINVAL, "group %d has %d parameters", g, c.group_size[g]);
     }
+    const bool gj = c.w_nuts + c.w_hmc > 0;
+    if (c.w_nuts < 0 || c.w_hmc < 0) return fail(PTMI_EINVAL, "negative gradient-jump weight");
+    if (gj) {
+        if (!c.gj_tab) return fail(PTMI_EINVAL, "gradient jumps need the whitening tables (gj_tab)");
+        if (!buf->gj || !buf->Q || !buf->qaux) return fail(PTMI_EINVAL, "gradient jumps need the gj, Q and qaux buffers");
+        if (c.ndim > 32) return fail(PTMI_EUNSUPPORTED, "gradient jumps on the device are built for ndim <= 32 (got %d)", c.ndim);
+        if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "gradient jumps with parameter groups are not built");
+        if (c.w_host > 0) return fail(PTMI_EUNSUPPORTED, "gradient jumps on the device cannot be mixed with host-served jumps");
+        if (c.nuts_maxdepth < 0 || c.nuts_maxdepth > 24) return fail(PTMI_EINVAL, "nuts_maxdepth out of range");
+        if (c.w_hmc > 0 && (c.hmc_min < 0 || c.hmc_max <= c.hmc_min)) return fail(PTMI_EINVAL, "HMC needs 0 <= hmc_min < hmc_max");
+    }
     if (!buf->X || !buf->lnL || !buf->lp || !buf->temp_of || !buf->slot_of || !buf->Ut || !buf->S || !buf->nacc || !buf->jstat)
         return fail(PTMI_EINVAL, "a required device buffer is NULL");
     if (c.w_de > 0 && !buf->DE) return fail(PTMI_EINVAL, "DE weight > 0 but no DE buffer");
@@ -604,6 +618,19 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
             return e2 != hipSuccess ? fail(PTMI_EHIP, "group tables: %s", hipGetErrorString(e2)) : rc;
         }
     }
+    if (gj) {
+        const size_t nch = (size_t)c.nwalkers * c.ntemps, lanes = (size_t)s.G * s.EPL;
+        const size_t nvec = (size_t)GJV_TOP + (size_t)GJL_VECS * (c.nuts_maxdepth + 1);
+        hipError_t e3 = hipMalloc((void **)&h->d_gj_scr, sizeof(double) * nvec * lanes * nch);
+        if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_scal, sizeof(double) * (size_t)GJS_SCALARS * (c.nuts_maxdepth + 1) * nch);
+        if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_lnL, sizeof(double) * nch);
+        if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_lp, sizeof(double) * nch);
+        if (e3 != hipSuccess || (rc = upload(&h->d_gj_tab, c.gj_tab, 3LL * c.ndim * c.ndim))) {
+            ptmi_destroy(h);
+            return e3 != hipSuccess ? fail(PTMI_EHIP, "gradient-jump scratch: %s", hipGetErrorString(e3)) : rc;
+        }
+    }
+    h->cfg.gj_tab = nullptr;
     h->cfg.ladder = h->cfg.temps_mh = h->cfg.logl_par = h->cfg.logp_par = h->cfg.group_mask = nullptr;  // host copies are not kept
     h->cfg.group_size = nullptr;
     hipError_t e = hipMalloc((void **)&h->d_pre, sizeof(double) * 4 * (size_t)c.nwalkers * c.ntemps_global);
@@ -626,6 +653,7 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
     (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_xint);
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
+    (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_lnL); (void)hipFree(h->d_gj_lp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -667,6 +695,23 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     a.iter0 = iter0; a.nsteps = nsteps;
     if (int rc = set_step_args(h, &a)) return rc;
     if (h->cfg.w_host > 0) return fail(PTMI_EINVAL, "host-served jumps need the split path (ptmi_propose / ptmi_accept)");
+    if (h->cfg.w_nuts + h->cfg.w_hmc > 0) {
+        // with gradient jumps in the cycle every iteration is four launches: cycle pick + SCAM/AM/DE proposals, NUTS / HMC
+        // for the chains that picked them, the likelihood of the proposals, the Hastings test (no host round trip)
+        const int grid = chains_grid(h);
+        for (int k = 0; k < nsteps; ++k) {
+            KArgs s = a;
+            s.iter0 = iter0 + k; s.nsteps = 1;
+            s.newlnL = h->d_gj_lnL; s.newlp = h->d_gj_lp;
+            if (int rc = set_step_args(h, &s)) return rc;
+            int rc;
+            if ((rc = run_shape(h, PTMI_OP_PROPOSE, s, grid, true)) || (rc = run_shape(h, PTMI_OP_GRADJUMP, s, grid, true)) ||
+                (rc = run_shape(h, PTMI_OP_EVALQ, s, grid, true)) || (rc = run_shape(h, PTMI_OP_ACCEPT, s, grid, true)))
+                return rc;
+        }
+        HIPCHK(hipGetLastError());
+        return PTMI_OK;
+    }
     const bool full = h->cfg.w_am > 0 || (h->de_on && h->cfg.w_de > 0);
     if (!full && h->cfg.w_scam <= 0) return fail(PTMI_EINVAL, "empty proposal cycle");
     const int grid = chains_grid(h);

@@ -43,7 +43,22 @@ struct KArgs {
     int cov_update, tskip, per_walker, logp_kind, ngroups;
     int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
     int lds_u;                   // staged kernels: the block's Ut is copied to LDS (else read from global)
+    // gradient jumps (ptmi_gj.inc.h)
+    int w_nuts, w_hmc, gj_nburn, hmc_min, hmc_max, nuts_maxdepth;
+    double hmc_eps, nuts_delta;
+    const double *gj_tab;        // [3][d][d] backward, forward, gradient tables
+    double *gj;                  // [W][T][8] per-rank jump state
+    double *gj_scr, *gj_scal;    // scratch of the tree build: [slot][e][chain][lane], [level][scalar][chain]
 };
+
+// gradient jumps (ptmi_gj.inc.h): per-rank state, Philox slots, layout of a chain's tree scratch
+enum { GJ_EPS = 0, GJ_MU = 1, GJ_HBAR = 2, GJ_EPSBAR = 3, GJ_NITER = 4, GJ_HITER = 5, GJ_HAVE_EPS = 6, GJ_NSTATE = 8 };
+constexpr u32 SLOT_GJ = 0x2000000u;    // + 4096 * (momenta draw of the call) + direction
+constexpr u32 SLOT_GJS = 0x3000000u;   // + scalar draw of the call
+// vector slots of a chain's scratch: the two ends and the sample of the outer loop, then 4 per tree level
+enum { GJV_TM = 0, GJV_RM = 1, GJV_GM = 2, GJV_TP = 3, GJV_RP = 4, GJV_GP = 5, GJV_SAMPLE = 6, GJV_TOP = 7 };
+enum { GJL_FAR_T = 0, GJL_FAR_R = 1, GJL_CAND_T = 2, GJL_CAND_G = 3, GJL_VECS = 4 };
+enum { GJS_LOGP = 0, GJS_N = 1, GJS_ALPHA = 2, GJS_NALPHA = 3, GJS_H = 4, GJS_SCALARS = 8 };
 
 template <int G>
 __device__ __forceinline__ double group_bcast_lane(double v, int src)
@@ -63,6 +78,7 @@ struct ptmi_engine {
     double *d_pre;      // [4][ntg][W] scratch of the swap (uniforms, likelihoods, own-likelihood terms)
     int32_t *d_prow;    // [ntg][W] rows by position (fused swap)
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
+    double *d_gj_tab, *d_gj_scr, *d_gj_scal, *d_gj_lnL, *d_gj_lp;   // gradient jumps: tables, tree scratch, lnL / lp of the proposals
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
     int G, EPL;
     int de_on, de_head;
@@ -74,7 +90,9 @@ struct ptmi_engine {
 // and likelihood family is compiled in its own translation unit (ptmi_shape.hip with -DPTMI_G -DPTMI_E -DPTMI_L) so
 // the build runs in parallel;
 // this is the entry point a shape unit exports.
-enum { PTMI_OP_MH = 0, PTMI_OP_EVAL = 1, PTMI_OP_PROPOSE = 2, PTMI_OP_ACCEPT = 3 };
+enum { PTMI_OP_MH = 0, PTMI_OP_EVAL = 1, PTMI_OP_PROPOSE = 2, PTMI_OP_ACCEPT = 3, PTMI_OP_GRADJUMP = 4, PTMI_OP_EVALQ = 5 };
+// jump types the fused kernel counts (the gradient jumps run on the split path)
+enum { PTMI_J_FUSED = 3 };
 typedef int (*ptmi_shape_fn)(int op, ptmi_engine *h, KArgs &a, int grid, bool full);
 #define PTMI_SHAPE_LIST(X) X(4, 2) X(4, 5) X(4, 8) X(4, 14) X(4, 20) X(4, 26) X(16, 7) X(16, 13) X(16, 26) X(64, 8) X(64, 16) X(64, 32)
 // one unit per (shape, likelihood family); the split-path kernels live in the family-0 unit

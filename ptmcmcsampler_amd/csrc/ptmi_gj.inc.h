@@ -1,0 +1,460 @@
+// ptmi_gj.inc.h -- gradient jumps (HMC, NUTS) on the device for the built-in likelihoods.
+// Behaviour: PTMCMCSampler/nutsjump.py of the reference (NJ:<lines>): GradientJump whitening NJ:51-54,71-90,
+// leapfrog NJ:149-169, HMCJump NJ:238-291, NUTSJump NJ:379-840 (find_reasonable_epsilon NJ:435-463, stop_criterion
+// NJ:465-493, build_tree NJ:495-652, __call__ + dual averaging NJ:654-840).  The reference takes the gradients from
+// the user's Python callbacks; here they are analytic for the built-in families, and the recursion of build_tree is
+// unrolled into a loop with an explicit stack of pending left subtrees in global scratch (same merges, same order of
+// draws).  Checked bit for bit against oracle/ptmcmc_oracle.c (nuts_call / hmc_call), which replays the reference.
+#pragma once
+#include "ptmi_common.h"
+
+
+template <int G, int EPL, int LOGL>
+struct GradJump {
+    const KArgs &a;
+    const int gl, d;
+    const long long ch, nch;
+    const double beta;
+    const long long it;
+    const u32 sid;
+    u32 nm = 0, ns = 0;          // momenta / scalar draws used so far in this call
+
+    __device__ __forceinline__ GradJump(const KArgs &a_, int gl_, long long ch_, double beta_, long long it_, u32 sid_)
+        : a(a_), gl(gl_), d(a_.d), ch(ch_), nch((long long)a_.W * a_.nt), beta(beta_), it(it_), sid(sid_) {}
+
+    // ---- scratch: [slot][e][chain][lane] so that a wave's access is one contiguous run
+    __device__ __forceinline__ void vload(int slot, double (&v)[EPL]) const
+    {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = a.gj_scr[((size_t)(slot * EPL + e) * nch + ch) * G + gl];
+    }
+    __device__ __forceinline__ void vstore(int slot, const double (&v)[EPL]) const
+    {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) a.gj_scr[((size_t)(slot * EPL + e) * nch + ch) * G + gl] = v[e];
+    }
+    __device__ __forceinline__ double &scal(int level, int k) const { return a.gj_scal[((size_t)(level * GJS_SCALARS + k)) * nch + ch]; }
+
+    // ---- draws (every lane of the chain evaluates the same counters)
+    __device__ __forceinline__ void momenta(double (&r)[EPL])           // NJ:92-94
+    {
+        const u32 block = nm++;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) r[e] = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; e += 2) {                               // directions k and k + G share one Box-Muller
+            const int k = gl + G * e;
+            if (k < d) {
+                u64 e0, e1;
+                philox_words(a.seed, (u64)it, sid, SLOT_GJ + 4096u * block + (u32)k, e0, e1);
+                const double rr = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
+                double sn, cs;
+                det_sincos2pi(w2uniform(e1), sn, cs);
+                r[e] = rr * cs;
+                if (e + 1 < EPL && k + G < d) r[e + 1] = rr * sn;
+            }
+        }
+    }
+    __device__ __forceinline__ u64 scalar_word()
+    {
+        u64 w0, w1;
+        philox_words(a.seed, (u64)it, sid, SLOT_GJS + ns++, w0, w1);
+        return w0;
+    }
+    __device__ __forceinline__ double uniform() { return w2uniform(scalar_word()); }
+    __device__ __forceinline__ double exponential() { return -det_log(w2uniform_open(scalar_word())); }
+    __device__ __forceinline__ int randint(int lo, int hi) { return lo + (int)w2index(scalar_word(), (u64)(hi - lo)); }
+
+    // ---- linear algebra in the chain's lane layout (element i = gl + G e; pads are zero)
+    __device__ __forceinline__ double dot(const double (&x)[EPL], const double (&y)[EPL]) const
+    {
+        double p = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) p = __builtin_fma(x[e], y[e], p);
+        return group_sum<G>(p);
+    }
+    // out[i] = sum_k T[k][i] v[k], k ascending, one fma per term
+    __device__ __forceinline__ void tab_vec(const double *T, const double (&v)[EPL], double (&out)[EPL]) const
+    {
+        double acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.0;
+#pragma unroll
+        for (int e2 = 0; e2 < EPL; ++e2) {
+#pragma unroll 1
+            for (int src = 0; src < G; ++src) {
+                const int k = src + G * e2;
+                if (k >= d) break;
+                const double vk = group_bcast_lane<G>(v[e2], src);
+                const double *row = T + (size_t)k * d;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int i = gl + G * e;
+                    if (i < d) acc[e] = __builtin_fma(row[i], vk, acc[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) out[e] = acc[e];
+    }
+
+    // logl and its gradient (the value is eval_logl's, operation for operation)
+    __device__ __forceinline__ double logl_grad(const double (&x)[EPL], double (&g)[EPL]) const
+    {
+        if (LOGL == PTMI_LOGL_ISO) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) g[e] = -x[e];
+            return -0.5 * dot(x, x);
+        } else if (LOGL == PTMI_LOGL_DENSE) {
+            const double *mu = a.logl_par, *Pt = a.logl_par + d;
+            double r[EPL], v[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e;
+                r[e] = i < d ? x[e] - mu[i] : 0.0;
+            }
+            tab_vec(Pt, r, v);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) g[e] = -v[e];
+            return -0.5 * dot(r, v);
+        } else {
+            double p = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e;
+                const double other = dppf64<0xB1>(x[e]);                 // partner lane (gl ^ 1)
+                const bool even = !(gl & 1);
+                const bool pair = even ? i + 1 < d : i < d;              // both members of the pair exist
+                const double xx = even ? x[e] : other, y = even ? other : x[e];
+                double t = 0.0, gv = 0.0;
+                if (pair) {
+                    const double x2 = xx * xx;
+                    const double gg = 9.0 + 4.0 * x2 + 9.0 * y;
+                    const double l0 = -x2 - gg * gg;
+                    const double ym = y - 2.0;
+                    const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
+                    const double e0 = det_exp(l0), e1 = 0.5 * det_exp(l1);
+                    const double sum = e0 + e1;
+                    if (even) {
+                        t = det_log(sum);
+                        const double d0x = -2.0 * xx - 16.0 * gg * xx, d1x = -16.0 * xx;
+                        gv = (e0 * d0x + e1 * d1x) / sum;
+                    } else {
+                        const double d0y = -18.0 * gg, d1y = -16.0 * ym;
+                        gv = (e0 * d0y + e1 * d1y) / sum;
+                    }
+                }
+                g[e] = gv;
+                p = __builtin_fma(t, 1.0, p);
+            }
+            return group_sum<G>(p);
+        }
+    }
+    __device__ __forceinline__ double logp(const double (&x)[EPL]) const
+    {
+        if (a.logp_kind == PTMI_LOGP_BOX) {
+            const double *lo = a.logp_par, *hi = a.logp_par + d;
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e;
+                if (i < d) ok = ok && (lo[i] <= x[e]) && (hi[i] >= x[e]);
+            }
+            return group_all<G>(ok) ? 0.0 : -__builtin_inf();
+        }
+        return 0.0;
+    }
+    // beta*logl + logp and its gradient in the whitened coordinates (NJ:71-90)
+    __device__ __forceinline__ double func_grad_white(const double (&q)[EPL], double (&gradw)[EPL]) const
+    {
+        double x[EPL], g[EPL];
+        tab_vec(a.gj_tab, q, x);                                         // backward: x = L^T q
+        const double ll = logl_grad(x, g);
+        const double lp = logp(x);                                       // the built-in priors have zero gradient
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) g[e] = beta * g[e] + 0.0;
+        tab_vec(a.gj_tab + 2 * (size_t)d * d, g, gradw);
+        return beta * ll + lp;
+    }
+    __device__ __forceinline__ double joint_of(double logl, const double (&r)[EPL]) const { return logl - 0.5 * dot(r, r); }
+
+    // NJ:149-169; outputs may alias the inputs
+    __device__ __forceinline__ double leapfrog(const double (&theta)[EPL], const double (&r)[EPL], const double (&grad)[EPL], double eps,
+                                               double (&to)[EPL], double (&ro)[EPL], double (&go)[EPL]) const
+    {
+        const double he = 0.5 * eps;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const double rh = r[e] + he * grad[e];
+            ro[e] = rh;
+            to[e] = theta[e] + eps * rh;
+        }
+        const double lpp = func_grad_white(to, go);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ro[e] = ro[e] + he * go[e];
+        return lpp;
+    }
+    __device__ __forceinline__ bool keep_going(const double (&tm)[EPL], const double (&tp)[EPL], const double (&rm)[EPL],
+                                               const double (&rp)[EPL]) const                  // NJ:465-493
+    {
+        double dt[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) dt[e] = tp[e] - tm[e];
+        const double x = dot(dt, rm), y = dot(dt, rp);
+        return (x >= 0.0) & (y >= 0.0);
+    }
+    __device__ __forceinline__ bool any_inf(const double (&v)[EPL]) const
+    {
+        bool fin = true;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) fin = fin && !__builtin_isinf(v[e]);
+        return !group_all<G>(fin);
+    }
+
+    // ------------------------------------------------------------------ HMC (NJ:238-291)
+    __device__ __forceinline__ double hmc(double *st, const double (&x)[EPL], double (&qout)[EPL])
+    {
+        double q[EPL], p[EPL], grad[EPL];
+        st[GJ_HITER] += 1.0;
+        tab_vec(a.gj_tab + (size_t)d * d, x, q);                         // forward
+        const double logp0 = func_grad_white(q, grad);
+        momenta(p);
+        const double joint0 = joint_of(logp0, p);
+        const int nsteps = randint(a.hmc_min, a.hmc_max);
+        double joint1 = joint0;
+        for (int k = 0; k < nsteps; ++k) {
+            const double logp1 = leapfrog(q, p, grad, a.hmc_eps, q, p, grad);
+            joint1 = joint_of(logp1, p);
+            if (joint1 - 1000.0 < joint0) break;                         // NJ:284-286
+        }
+        tab_vec(a.gj_tab, q, qout);
+        return joint1 - joint0;
+    }
+
+    // ------------------------------------------------------------------ NUTS
+    // NJ:435-463; both loops bounded at 100 turns (the reference's are not)
+    __device__ __forceinline__ double find_reasonable_epsilon(const double (&theta0)[EPL], const double (&grad0)[EPL], double logp0)
+    {
+        double r0[EPL], tp[EPL], rp[EPL], gp[EPL];
+        double eps = 1.0;
+        momenta(r0);
+        double logpp = leapfrog(theta0, r0, grad0, eps, tp, rp, gp);
+        const bool ginf = any_inf(gp);                                   // not refreshed in the loop (NJ:449-452)
+        double k = 1.0;
+        for (int n = 0; n < 100 && (__builtin_isinf(logpp) || ginf); ++n) {
+            k *= 0.5;
+            logpp = leapfrog(theta0, r0, grad0, eps * k, tp, rp, gp);
+        }
+        eps = 0.5 * k * eps;
+        double ap = det_exp(joint_of(logpp, rp) - joint_of(logp0, r0));
+        const bool up = ap > 0.5;
+        for (int n = 0; n < 100 && ((up ? ap : 1.0 / ap) > (up ? 0.5 : 2.0)); ++n) {
+            eps = eps * (up ? 2.0 : 0.5);
+            logpp = leapfrog(theta0, r0, grad0, eps, tp, rp, gp);
+            ap = det_exp(joint_of(logpp, rp) - joint_of(logp0, r0));
+        }
+        return eps;
+    }
+
+    struct Tree {                // what the current (sub)tree hands upward; its growth end is the caller's (tg, rg, gg)
+        double far_t[EPL], far_r[EPL], cand_t[EPL], cand_g[EPL];
+        double logp, alpha;
+        long long n, nalpha;
+        int s;
+    };
+
+    // NJ:495-652 as a loop: leaves are generated left to right in direction v from the growth end; a finished subtree
+    // is merged with the pending left sibling of the same height on the stack, or waits there for its right sibling.
+    // A left subtree that stopped (s = 0) is handed up unchanged to the height of the next pending sibling (or the root).
+    __device__ __forceinline__ void build_tree(double (&tg)[EPL], double (&rg)[EPL], double (&gg)[EPL], double logu, int v, int j,
+                                               double eps, double joint0, Tree &cur)
+    {
+        int sp = 0;
+        for (;;) {
+            const double logpp = leapfrog(tg, rg, gg, (double)v * eps, tg, rg, gg);
+            const double joint = joint_of(logpp, rg);
+            cur.n = logu < joint;
+            cur.s = (logu - 1000.0) < joint;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { cur.far_t[e] = tg[e]; cur.far_r[e] = rg[e]; cur.cand_t[e] = tg[e]; cur.cand_g[e] = gg[e]; }
+            cur.logp = logpp;
+            const double ex = det_exp(joint - joint0);
+            cur.alpha = ex < 1.0 ? ex : 1.0;                             // Python's min(1.0, e): 1.0 when e is NaN
+            cur.nalpha = 1;
+            int h = 0;
+            for (;;) {
+                const int top_h = sp > 0 ? (int)scal(sp - 1, GJS_H) : -1;
+                if (sp > 0 && top_h == h) {                              // cur is the right sibling of the stack top
+                    --sp;
+                    const int base = GJV_TOP + sp * GJL_VECS;
+                    const long long tn = (long long)scal(sp, GJS_N);
+                    const long long tot = tn + cur.n;
+                    const double den = (double)tot > 1.0 ? (double)tot : 1.0;
+                    const bool take_u = uniform() < (double)cur.n / den;
+                    if (!take_u) {
+                        vload(base + GJL_CAND_T, cur.cand_t);
+                        vload(base + GJL_CAND_G, cur.cand_g);
+                        cur.logp = scal(sp, GJS_LOGP);
+                    }
+                    vload(base + GJL_FAR_T, cur.far_t);
+                    vload(base + GJL_FAR_R, cur.far_r);
+                    cur.n = tot;
+                    const bool go = v == 1 ? keep_going(cur.far_t, tg, cur.far_r, rg) : keep_going(tg, cur.far_t, rg, cur.far_r);
+                    cur.s = cur.s && go;                                 // the popped tree has s = 1
+                    cur.alpha = scal(sp, GJS_ALPHA) + cur.alpha;
+                    cur.nalpha = (long long)scal(sp, GJS_NALPHA) + cur.nalpha;
+                    h += 1;
+                    continue;
+                }
+                if (h == j) return;
+                if (cur.s == 0) {
+                    if (sp == 0) return;
+                    h = top_h;
+                    continue;
+                }
+                const int base = GJV_TOP + sp * GJL_VECS;                // push: wait for the right sibling
+                vstore(base + GJL_FAR_T, cur.far_t);
+                vstore(base + GJL_FAR_R, cur.far_r);
+                vstore(base + GJL_CAND_T, cur.cand_t);
+                vstore(base + GJL_CAND_G, cur.cand_g);
+                scal(sp, GJS_LOGP) = cur.logp;                           // every lane of the chain writes the same values
+                scal(sp, GJS_N) = (double)cur.n;
+                scal(sp, GJS_ALPHA) = cur.alpha;
+                scal(sp, GJS_NALPHA) = (double)cur.nalpha;
+                scal(sp, GJS_H) = (double)h;
+                __threadfence_block();
+                ++sp;
+                break;
+            }
+        }
+    }
+
+    // NUTSJump.__call__ (NJ:654-840), force_trajlen = force_epsilon = None.  Returns qxy.
+    __device__ __forceinline__ double nuts(double *st, const double (&x)[EPL], double (&qout)[EPL])
+    {
+        double q[EPL], grad[EPL], r0[EPL];
+        st[GJ_NITER] += 1.0;
+        tab_vec(a.gj_tab + (size_t)d * d, x, q);
+        const double logp0 = func_grad_white(q, grad);
+        if (st[GJ_HAVE_EPS] == 0.0) {
+            st[GJ_EPS] = find_reasonable_epsilon(q, grad, logp0);
+            st[GJ_MU] = det_log(10.0 * st[GJ_EPS]);
+            st[GJ_HAVE_EPS] = 1.0;
+        }
+        momenta(r0);
+        const double joint = joint_of(logp0, r0);
+        const double logu = joint - exponential();
+        double lnprob = logp0;
+        vstore(GJV_SAMPLE, q);
+        vstore(GJV_TM, q); vstore(GJV_RM, r0); vstore(GJV_GM, grad);
+        vstore(GJV_TP, q); vstore(GJV_RP, r0); vstore(GJV_GP, grad);
+        int j = 0, s = 1;
+        long long n = 1;
+        double alpha = 0.0;
+        long long nalpha = 1;
+        const double eps = st[GJ_EPS];
+        while (s == 1) {
+            const int dir = 2 * (int)(uniform() < 0.5) - 1;
+            double tg[EPL], rg[EPL], gg[EPL];
+            const int eb = dir == -1 ? GJV_TM : GJV_TP;
+            vload(eb, tg); vload(eb + 1, rg); vload(eb + 2, gg);
+            Tree t;
+            build_tree(tg, rg, gg, logu, dir, j, eps, joint, t);
+            vstore(eb, tg); vstore(eb + 1, rg); vstore(eb + 2, gg);
+            if (t.s == 1) {
+                const double ratio = (double)t.n / (double)n;
+                if (uniform() < (1.0 < ratio ? 1.0 : ratio)) { vstore(GJV_SAMPLE, t.cand_t); lnprob = t.logp; }
+            }
+            n += t.n;
+            double to[EPL], ro[EPL];
+            const int ob = dir == -1 ? GJV_TP : GJV_TM;                  // the other end
+            vload(ob, to); vload(ob + 1, ro);
+            const bool go = dir == -1 ? keep_going(tg, to, rg, ro) : keep_going(to, tg, ro, rg);
+            s = t.s && go;
+            alpha = t.alpha;
+            nalpha = t.nalpha;
+            j += 1;
+            if (j > a.nuts_maxdepth) s = 0;                              // cap (not in the reference)
+        }
+        // dual averaging (NJ:805-816): gamma = 0.05, t0 = 10, kappa = 0.75
+        const double it_call = st[GJ_NITER];
+        double eta = 1.0 / (it_call + 10.0);
+        st[GJ_HBAR] = (1.0 - eta) * st[GJ_HBAR] + eta * (a.nuts_delta - alpha / (double)nalpha);
+        if (it <= (long long)a.gj_nburn) {
+            st[GJ_EPS] = det_exp(st[GJ_MU] - det_sqrt(it_call) / 0.05 * st[GJ_HBAR]);
+            eta = det_exp(-0.75 * det_log(it_call));
+            st[GJ_EPSBAR] = det_exp((1.0 - eta) * det_log(st[GJ_EPSBAR]) + eta * det_log(st[GJ_EPS]));
+        } else {
+            st[GJ_EPS] = st[GJ_EPSBAR];
+        }
+        double sample[EPL];
+        vload(GJV_SAMPLE, sample);
+        tab_vec(a.gj_tab, sample, qout);
+        return logp0 - lnprob;                                           // undoes the outer Hastings ratio (NJ:838)
+    }
+};
+
+// One iteration's gradient-jump proposals: chains whose cycle pick (propose_kernel, qaux[1]) is NUTS or HMC get their
+// proposal q in Q and qxy in qaux[0]; the others are left alone.
+template <int G, int EPL, int LOGL>
+__global__ __launch_bounds__(256) void gradjump_kernel(const KArgs a)
+{
+    constexpr int CPB = 256 / G;
+    const int d = a.d, nt = a.nt;
+    const long long nch = (long long)a.W * nt;
+    const long long ch = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
+    if (ch >= nch) return;
+    const int jt = (int)a.qaux[ch * 4 + 1];
+    if (jt != PTMI_J_NUTS && jt != PTMI_J_HMC) return;
+    const int gl = (int)(threadIdx.x % G);
+    const int w = (int)(ch / nt);
+    const int t = a.temp_of[ch];
+    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)(a.temp0 + t));
+    GradJump<G, EPL, LOGL> gj(a, gl, ch, a.beta[t], a.iter0, sid);
+    double x[EPL], q[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = gl + G * e;
+        x[e] = i < d ? a.X[(size_t)ch * d + i] : 0.0;
+    }
+    double *stg = a.gj + ((size_t)w * nt + t) * GJ_NSTATE;
+    double st[GJ_NSTATE];
+#pragma unroll
+    for (int k = 0; k < GJ_NSTATE; ++k) st[k] = stg[k];
+    const double qxy = jt == PTMI_J_NUTS ? gj.nuts(st, x, q) : gj.hmc(st, x, q);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = gl + G * e;
+        if (i < d) a.Q[(size_t)ch * d + i] = q[e];
+    }
+    if (gl == 0) {
+#pragma unroll
+        for (int k = 0; k < GJ_NSTATE; ++k) stg[k] = st[k];
+        a.qaux[ch * 4 + 0] = qxy;
+    }
+}
+
+// logp / logl of the proposals Q (the device likelihood in the place of the host callbacks of the split path)
+template <int G, int EPL, int LOGL>
+__global__ __launch_bounds__(256) void eval_q_kernel(const KArgs a, double *newlnL, double *newlp)
+{
+    constexpr int CPB = 256 / G;
+    const int d = a.d;
+    const long long nch = (long long)a.W * a.nt;
+    long long ch = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
+    const bool live = ch < nch;
+    if (!live) ch = nch - 1;
+    const int gl = (int)(threadIdx.x % G);
+    double q[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = gl + G * e;
+        q[e] = i < d ? a.Q[(size_t)ch * d + i] : 0.0;
+    }
+    const double lp = eval_logp<G, EPL, false>(a, q, gl);
+    const double lnL = eval_logl<G, EPL, LOGL, false>(a, q, gl, LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr);
+    if (live && gl == 0) {
+        newlp[ch] = lp;
+        newlnL[ch] = lnL;
+    }
+}

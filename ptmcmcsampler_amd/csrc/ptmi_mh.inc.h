@@ -225,7 +225,9 @@ constexpr int safe_slots(int G, int EPL)
 // STR: strided lane layout (see "lane groups"); then Ut is the zero-padded LDS copy when ut_padded, and the AM
 // product runs on the matrix cores for all 16 chains of the wave at once.
 // GRP: parameter groups (compile-time: with one group every bound below is the wave-uniform d).
-template <int G, int EPL, bool FULL, bool STR, bool GRP>
+// GJ: the cycle also holds the gradient jumps (split path only): such a pick hands the state back unchanged and
+// gradjump_kernel fills in the proposal.
+template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
                                        double (&dq)[EPL], double &log_u, double &u_acc)
@@ -245,10 +247,16 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
 
     int jt = PTMI_J_SCAM;
     if (FULL) {
-        const int L = a.w_host + a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
+        const int w_de = a.de_on ? a.w_de : 0;
+        const int L = a.w_host + a.w_scam + a.w_am + w_de + (GJ ? a.w_nuts + a.w_hmc : 0);
         const int pick = (int)w2index(A0, (u64)L);
         const int ind = pick - a.w_host;
         jt = ind < a.w_scam ? PTMI_J_SCAM : (ind < a.w_scam + a.w_am ? PTMI_J_AM : PTMI_J_DE);
+        if (GJ && ind >= a.w_scam + a.w_am + w_de) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dq[e] = 0.0;
+            jt = ind < a.w_scam + a.w_am + w_de + a.w_nuts ? PTMI_J_NUTS : PTMI_J_HMC;
+        }
         if (ind < 0) {                          // a host-served cycle entry: hand the state back unchanged
 #pragma unroll
             for (int e = 0; e < EPL; ++e) dq[e] = 0.0;
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 #pragma unroll
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double lnL = a.lnL[ch], lp = a.lp[ch];
-    u32 nacc = 0, jp[PTMI_J_NTYPES] = {0, 0, 0}, ja[PTMI_J_NTYPES] = {0, 0, 0};
+    u32 nacc = 0, jp[PTMI_J_FUSED] = {0, 0, 0}, ja[PTMI_J_FUSED] = {0, 0, 0};
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
 
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, UtBlock, false, S, DE, dq, log_u, u_acc);
         if (FULL) {
 #pragma unroll
-            for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
+            for (int j = 0; j < PTMI_J_FUSED; ++j) jp[j] += (jt == j);
         }
         // PT:605-612
         double nlp, nlnL = 0.0, nlnprob;
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             nacc += 1;
             if (FULL) {
 #pragma unroll
-                for (int j = 0; j < PTMI_J_NTYPES; ++j) ja[j] += (jt == j);
+                for (int j = 0; j < PTMI_J_FUSED; ++j) ja[j] += (jt == j);
             }
         }
         // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             a.nacc[r] += nacc;
             if (!FULL) { jp[PTMI_J_SCAM] = (u32)a.nsteps; ja[PTMI_J_SCAM] = nacc; }
 #pragma unroll
-            for (int j = 0; j < PTMI_J_NTYPES; ++j) {
+            for (int j = 0; j < PTMI_J_FUSED; ++j) {
                 a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 0] += jp[j];
                 a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 1] += ja[j];
             }
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 }
 
 // split path: proposal only / accept only, one iteration (host likelihood callbacks)
-template <int G, int EPL, bool GRP>
+template <int G, int EPL, bool GRP, bool GJ>
 __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
 {
     constexpr int CPB = 256 / G;
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double log_u, u_acc;
-    const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
+    const int jt = propose<G, EPL, true, false, GRP, GJ>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {

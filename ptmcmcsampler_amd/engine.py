@@ -48,7 +48,8 @@ class PTEngine(object):
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
-                 w_host=0, keep_lnl=False, groups=None, swap_mode="sweep"):
+                 w_host=0, keep_lnl=False, groups=None, swap_mode="sweep",
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -78,6 +79,16 @@ class PTEngine(object):
             if len(g) < 1 or g.min() < 0 or g.max() >= self.d:
                 raise ValueError("group %d has indices outside [0, %d)" % (gi, self.d))
             self.gmask[gi, g] = 1.0
+        # gradient jumps on the built-in likelihoods (PTMCMCSampler.py:225-258): (NUTSweight, HMCweight); the whitening
+        # comes from the INITIAL covariance and is never adapted (nutsjump.py:45, 53-54)
+        self.grad_weights = tuple(int(w) for w in grad_weights)
+        has_gj = sum(self.grad_weights) > 0
+        self.gj_tab = np.zeros(0)
+        if has_gj:
+            import scipy.linalg as sl
+            L = sl.cholesky(np.asarray(cov0, dtype=np.float64), lower=True)
+            Li = sl.solve_triangular(L, np.eye(self.d), trans=0, lower=True)
+            self.gj_tab = np.ascontiguousarray(np.stack([L, Li, L.T]))
         self.device = torch.device("cuda", device)
         self.dev_index = device
         d, nt, W, Wc = self.d, self.nt, self.W, self.Wc
@@ -95,9 +106,12 @@ class PTEngine(object):
             nacc=z((W, nt), i64), jstat=z((W, nt, _lib.J_NTYPES, 2), i64), nswap=z((W, self.ntg), i64),
             mu=z((W, d)) if self.owns_cold else None, M2=z((W, d, d)) if self.owns_cold else None,
             cov=z((Wc, d, d)),
-            Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
+            Q=z((W, nt, d)) if (split or has_gj) else None, qaux=z((W, nt, 4)) if (split or has_gj) else None,
             AMaux=z((W, self.cov_update, 2)) if (keep_lnl and self.owns_cold) else None,
+            gj=z((W, nt, _lib.GJ_NSTATE)) if has_gj else None,
         )
+        if has_gj:
+            self.t["gj"][..., _lib.GJ_EPSBAR] = 1.0
         cov0 = np.asarray(cov0, dtype=np.float64)
         self.t["cov"].copy_(torch.from_numpy(np.broadcast_to(cov0, (Wc, d, d)).copy()))
         # likelihood / prior parameters
@@ -115,6 +129,9 @@ class PTEngine(object):
             w_de=self.weights[2] if has_de else 0, de_size=self.burn, cov_update=self.cov_update, tskip=self.tskip,
             cov_per_walker=int(self.per_walker), device=device, ngroups=self.ngr if self.ngr > 1 else 0,
             swap_mode=_lib.SWAP_MODES[swap_mode], seed=self.seed,
+            w_nuts=self.grad_weights[0], w_hmc=self.grad_weights[1], gj_nburn=self.burn, hmc_eps=float(hmc[0]),
+            hmc_min=int(hmc[1]), hmc_max=int(hmc[2]), nuts_maxdepth=int(nuts_maxdepth), nuts_delta=float(nuts_delta),
+            gj_tab=self.gj_tab.ctypes.data_as(_lib._dp) if has_gj else None,
             group_size=self.gsize.ctypes.data_as(C.POINTER(C.c_int32)), group_mask=self.gmask.ctypes.data_as(_lib._dp),
             stream=C.c_void_p(self.stream.cuda_stream),
             ladder=self.ladder.ctypes.data_as(_lib._dp), temps_mh=self.temps_mh.ctypes.data_as(_lib._dp),

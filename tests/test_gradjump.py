@@ -54,3 +54,83 @@ def test_nuts_targets_the_distribution():
         xs.append(x)
     xs = np.asarray(xs[300:])
     assert np.max(np.abs(np.cov(xs.T) - C)) / np.max(C) < 0.25
+
+
+class _RecordGlobalDraws(object):
+    """Records the global np.random draws of one jump call as an oracle replay (kinds, values, bounds)."""
+
+    def __init__(self, orc):
+        self.orc, self.k, self.v, self.b = orc, [], [], []
+
+    def _put(self, kind, vals, bound=0):
+        for x in np.atleast_1d(vals):
+            self.k.append(kind)
+            self.v.append(float(x))
+            self.b.append(bound)
+
+    def __enter__(self):
+        o = self.o = (np.random.randn, np.random.exponential, np.random.uniform, np.random.randint)
+        orc = self.orc
+
+        def randn(*a):
+            r = o[0](*a)
+            self._put(orc.K_NRM, r)
+            return r
+
+        def exponential(*a, **kw):
+            r = o[1](*a, **kw)
+            self._put(orc.K_EXP, r)
+            return r
+
+        def uniform(*a, **kw):
+            r = o[2](*a, **kw)
+            self._put(orc.K_UNI, r)
+            return r
+
+        def randint(lo, hi=None, *a, **kw):
+            r = o[3](lo, hi, *a, **kw)
+            self._put(orc.K_INT, r, hi if hi is not None else lo)
+            return r
+
+        np.random.randn, np.random.exponential, np.random.uniform, np.random.randint = randn, exponential, uniform, randint
+        return self
+
+    def __exit__(self, *exc):
+        np.random.randn, np.random.exponential, np.random.uniform, np.random.randint = self.o
+
+
+@pytest.mark.parametrize("tag", ["nuts", "hmc"])
+def test_oracle_gradient_jumps_replay_the_reference(golden, tag):
+    """The C oracle's NUTS / HMC (what the device kernels are checked against) fed the reference's own draws: the
+    draws are recorded from the host restatement, which the test above pins to the reference bit for bit."""
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd.gradjump import HMCJump, NUTSJump
+    g = golden("gradjump")
+    P, cov = g["P"], g["cov"]
+    d = len(P)
+
+    def ll_grad(x):
+        return -0.5 * np.dot(x, np.dot(P, x)), -np.dot(P, x)
+
+    def lp_grad(x):
+        return 0.0, np.zeros_like(x)
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        j = NUTSJump(ll_grad, lp_grad, cov, nburn=25, delta=0.6) if tag == "nuts" else \
+            HMCJump(ll_grad, lp_grad, cov, nburn=25, stepsize=0.15, nminsteps=2, nmaxsteps=20)
+    kw = dict(nburn=25) if tag == "nuts" else dict(nburn=25, hmc=(0.15, 2, 20))
+    np.random.seed(2024)
+    xs, st, leaps = g[tag + "_x"], orc.gj_state(), 0
+    for it in range(1, len(g[tag + "_q"]) + 1):
+        beta = 1.0 if it % 7 else 0.4
+        with _RecordGlobalDraws(orc) as rec:
+            q, _ = j(xs[it - 1], it, beta)
+        assert np.array_equal(q, g[tag + "_q"][it - 1])
+        qo, qxyo, nl = orc.gradjump(tag, xs[it - 1], it, beta, st, cov, logl=("dense", np.zeros(d), P),
+                                    replay=(rec.k, rec.v, rec.b), lanes=4, **kw)      # asserts every draw is consumed, in kind
+        leaps += nl
+        np.testing.assert_allclose(qo, g[tag + "_q"][it - 1], rtol=0, atol=1e-10)
+        assert abs(qxyo - g[tag + "_qxy"][it - 1]) < 1e-10
+        if tag == "nuts":
+            assert abs(st[orc.GJ_EPS] - g["nuts_eps"][it - 1]) < 1e-10 * g["nuts_eps"][it - 1]
+    assert leaps > (100 if tag == "nuts" else 20)

@@ -1,0 +1,68 @@
+"""Device-side NUTS / HMC (csrc/ptmi_gj.inc.h) against the oracle's restatement of nutsjump.py, bit for bit.
+The oracle functions are pinned to the reference in tests/test_gradjump.py (replay of the reference's draws)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(d, nt, W, cov0, **kw):
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd.engine import PTEngine
+    g, o = PTEngine(d, nt, W, cov0, **kw), orc.OracleEngine(d, nt, W, cov0, **kw)
+    return g, o
+
+
+def _same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        ok = np.array_equal(a.view(np.uint64), b.astype(np.float64).view(np.uint64))
+    else:
+        ok = np.array_equal(a.astype(np.int64), b.astype(np.int64))
+    if not ok:
+        bad = np.argwhere(~((a == b) | ((a != a) & (b != b))))
+        raise AssertionError("%s differs at %d places, first %s: %r vs %r" % (what, len(bad), bad[:1], a[tuple(bad[0])], b[tuple(bad[0])]))
+
+
+CASES = [
+    dict(d=5, nt=3, W=6, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10)),
+    dict(d=20, nt=4, W=5, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.08, 2, 50)),
+    dict(d=8, nt=2, W=4, logl=("dense",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0)),
+    dict(d=32, nt=2, W=3, logl=("iso",), logp=("box", -3.0, 3.0), grad_weights=(5, 20), weights=(10, 0, 10)),
+    dict(d=2, nt=3, W=7, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.08, 2, 50)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s" % (c["d"], c["logl"][0]))
+def test_device_gradient_jumps_bit_exact(case):
+    c = dict(case)
+    d, nt, W = c.pop("d"), c.pop("nt"), c.pop("W")
+    rs = np.random.RandomState(d)
+    if c["logl"][0] == "dense":
+        A = rs.randn(d, d)
+        c["logl"] = ("dense", rs.randn(d) * 0.1, np.linalg.inv(A @ A.T / d + 0.5 * np.eye(d)))
+    if c["logp"][0] == "box":
+        c["logp"] = ("box", np.full(d, c["logp"][1]), np.full(d, c["logp"][2]))
+    A = rs.randn(d, d)
+    cov0 = (A @ A.T / d + np.eye(d)) * (1.0 if c["logl"][0] == "curved" else 0.3)
+    kw = dict(cov_update=50, burn=100, tskip=10, seed=31, **c)
+    g, o = _pair(d, nt, W, cov0, **kw)
+    p0 = rs.randn(W, nt, d) * 0.3
+    if c["logl"][0] == "curved":
+        p0 = np.tile(np.array([-0.1, -0.5] * (d // 2)), (W, nt, 1)) + rs.randn(W, nt, d) * 0.05
+    g.init_state(p0)
+    o.init_state(p0)
+    n = 260
+    g.run(n)
+    o.run(n)
+    g.sync()
+    for name in ("X", "lnL", "lp", "temp_of", "slot_of", "nacc", "jstat", "nswap", "AM"):
+        _same(g.get(name), getattr(o, name), name)
+    _same(g.get("gj"), o.gj, "gradient-jump state")
+    js = o.jstat.sum(axis=(0, 1))
+    if c["grad_weights"][0]:
+        assert js[3, 0] > 0 and js[3, 0] == js[3, 1], "NUTS proposals are always accepted (NJ:838)"
+        assert (o.gj[..., 4] > 0).all()
+    if c["grad_weights"][1]:
+        assert js[4, 0] > 0
+    assert js[:, 0].sum() == W * nt * n
