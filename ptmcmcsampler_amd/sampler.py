@@ -116,7 +116,11 @@ class PTSampler(object):
         if (self.logl_spec is None) != (self.logp_spec is None):
             raise ValueError("logl and logp must both be callables or both be device specifications")
         self.logl_grad = self.logp_grad = None
-        if logl_grad is not None and logp_grad is not None:
+        # device likelihoods have analytic gradients built in: logl_grad=True, logp_grad=True turns the gradient jumps on
+        self.device_grads = self.logl_spec is not None and logl_grad is True and logp_grad is True
+        if self.logl_spec is not None and not self.device_grads and (logl_grad is not None or logp_grad is not None):
+            raise ValueError("with a device likelihood pass logl_grad=True, logp_grad=True to use its built-in gradients")
+        if self.logl_spec is None and logl_grad is not None and logp_grad is not None:
             self.logl_grad = _function_wrapper(logl_grad, loglargs, loglkwargs)
             self.logp_grad = _function_wrapper(logp_grad, logpargs, logpkwargs)
         self.outDir, self.verbose, self.resume = outDir, verbose, resume
@@ -209,9 +213,19 @@ class PTSampler(object):
                 self.addProposalToCycle(_PerRankJump(self, lambda: NUTSJump(lg, pg, cov, nb, trajectoryDir=None,
                                                                            write_burnin=False, force_trajlen=None,
                                                                            force_epsilon=None, delta=0.6)), NUTSweight)
+        self._grad_weights = (0, 0)
+        if self.device_grads:                                                          # :226-258 on the device (csrc/ptmi_gj.inc.h)
+            if MALAweight > 0 and self.verbose:
+                print("WARNING: MALAJump is not built for the device likelihoods (the reference flags it as not working, "
+                      "PTMCMCSampler.py:230-231): MALAweight ignored")
+            self._grad_weights = (int(NUTSweight), int(HMCweight))
+            for name, wgt in (("HMCJump", HMCweight), ("NUTSJUMP", NUTSweight)):       # the reference's jump names
+                if wgt > 0:
+                    self.jumpDict[name] = [0, 0]
+                    open(self.outDir + "/" + name + "_jump.txt", "w").close()
         self.addProposalToCycle(self.covarianceJumpProposalSCAM, self.SCAMweight)     # :261
         self.addProposalToCycle(self.covarianceJumpProposalAM, self.AMweight)         # :264
-        if len(self.propCycle) == 0:
+        if len(self.propCycle) == 0 and sum(self._grad_weights) == 0:
             raise ValueError("No jump proposals specified!")
         self.randomizeProposalCycle()
         if self.ladder is None:
@@ -247,7 +261,7 @@ class PTSampler(object):
             logl=self.logl_spec or ("iso",), logp=self.logp_spec or ("flat",),
             weights=(self.SCAMweight, self.AMweight, self.DEweight), cov_update=covUpdate, burn=burn, tskip=Tskip,
             seed=self.seed, cov_mode=self.cov_mode, hot_chain=hotChain, device=self.device_index, split=self.split,
-            swap_mode=self.swap_mode,
+            swap_mode=self.swap_mode, grad_weights=self._grad_weights, hmc=(HMCstepsize, 2, HMCsteps),
             w_host=len(self.host_jumps), keep_lnl=True, groups=None if len(self.groups) == 1 and len(self.groups[0]) == self.ndim and np.array_equal(np.asarray(self.groups[0]), np.arange(self.ndim)) else self.groups)
 
     # ------------------------------------------------------------------ sample (:374-528)
@@ -260,7 +274,7 @@ class PTSampler(object):
             raise ValueError("isave = %d is not a multiple of thin =  %d" % (isave, thin))
         if Niter % thin != 0:
             print("Niter = %d is not a multiple of thin = %d.  The last %d samples will be lost" % (Niter, thin, Niter % thin))
-        if self.logl_grad is None:
+        if self.logl_grad is None and not self.device_grads:
             NUTSweight = MALAweight = HMCweight = 0
         if i0 == 0:
             self.initialize(Niter, ladder=ladder, Tmin=Tmin, Tmax=Tmax, Tskip=Tskip, isave=isave, covUpdate=covUpdate,
@@ -377,6 +391,9 @@ class PTSampler(object):
         for k, f in enumerate((self.covarianceJumpProposalSCAM, self.covarianceJumpProposalAM, self.DEJump)):
             if f.__name__ in self.jumpDict:
                 self.jumpDict[f.__name__] = [int(js[k, 0]), int(js[k, 1])]
+        for k, name in ((_lib.J_NUTS, "NUTSJUMP"), (_lib.J_HMC, "HMCJump")):
+            if self._grad_weights[k - _lib.J_NUTS] > 0:
+                self.jumpDict[name] = [int(js[k, 0]), int(js[k, 1])]
 
     def _harvest(self, iters):
         """updateChains (:331-335) for the kept walkers, read back from the AM ring."""

@@ -66,3 +66,69 @@ def test_device_gradient_jumps_bit_exact(case):
     if c["grad_weights"][1]:
         assert js[4, 0] > 0
     assert js[:, 0].sum() == W * nt * n
+
+
+def test_sharded_ladder_with_gradient_jumps():
+    """Config-5 shape in small: curved likelihood, box prior, DE + SCAM + NUTS + HMC, ladder sharded over two
+    emulated ranks on one GPU == the oracle's single-process run."""
+    import os
+    import sys
+    import threading
+    sys.path.insert(0, os.path.dirname(__file__))
+    from thread_comm import ThreadComm, ThreadWorld
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd.sharded import ShardedPTEngine
+    d, ntb, W, n, nranks = 20, 4, 6, 230, 2
+    ntg = ntb * nranks
+    kw = dict(logl=("curved",), logp=("box", np.full(d, -10.0), np.full(d, 10.0)), weights=(10, 0, 10), grad_weights=(10, 10),
+              hmc=(0.08, 2, 50), cov_update=50, burn=100, tskip=10, seed=9, cov_mode="per_walker")
+    cov0 = np.eye(d)
+    p0 = np.tile(np.array([-0.1, -0.5] * (d // 2)), (W, ntg, 1)) + np.random.RandomState(1).randn(W, ntg, d) * 0.05
+    ref = orc.OracleEngine(d, ntg, W, cov0, **kw)
+    ref.init_state(p0)
+    ref.run(n)
+    world = ThreadWorld(nranks)
+    engines, errs = [None] * nranks, []
+
+    def rank_main(r):
+        try:
+            e = ShardedPTEngine(d, ntg, W, cov0, comm=ThreadComm(world, r), **kw)
+            engines[r] = e
+            e.init_state(p0)
+            e.run(n)
+            e.sync()
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            world.bar.abort()
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for r, e in enumerate(engines):
+        L, sl = e.local, slice(r * ntb, (r + 1) * ntb)
+        so = L.get("slot_of")
+        bt = lambda a: np.take_along_axis(a, so.reshape(so.shape + (1,) * (a.ndim - 2)), axis=1)  # noqa: E731
+        _same(bt(L.get("X")), ref.by_temp(ref.X)[:, sl], "X")
+        _same(L.get("gj"), ref.gj[:, sl], "gradient-jump state")
+        _same(L.get("jstat"), ref.jstat[:, sl], "jstat")
+    assert ref.jstat[..., 3, 0].sum() > 0 and ref.nswap.sum() > 0
+
+
+def test_facade_runs_device_gradient_jumps(tmp_path):
+    """PTSampler with a device likelihood and logl_grad=True: NUTS / HMC enter the cycle under the reference's jump
+    names, their statistics and files are written, NUTS is always accepted."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 4
+    s = PTSampler(d, ("curved",), ("box", np.full(d, -10.0), np.full(d, 10.0)), np.eye(d), outDir=str(tmp_path), ntemps=3, nwalkers=4,
+                  logl_grad=True, logp_grad=True, seed=5, verbose=False)
+    s.sample(np.array([-0.1, -0.5] * (d // 2)), 400, burn=100, covUpdate=100, thin=1, isave=100, Tskip=10, SCAMweight=10, AMweight=10,
+             DEweight=10, NUTSweight=10, HMCweight=10, MALAweight=0, HMCsteps=50, HMCstepsize=0.08)
+    assert s.jumpDict["NUTSJUMP"][0] > 0 and s.jumpDict["NUTSJUMP"][0] == s.jumpDict["NUTSJUMP"][1]
+    assert s.jumpDict["HMCJump"][0] > 0
+    assert sum(v[0] for v in s.jumpDict.values()) == 400
+    for name in ("NUTSJUMP_jump.txt", "HMCJump_jump.txt", "covarianceJumpProposalSCAM_jump.txt", "chain_1.0.txt"):
+        assert (tmp_path / name).exists(), name
+    chain = np.loadtxt(tmp_path / "chain_1.0.txt")
+    assert chain.shape[1] == d + 4 and len(chain) in (400, 401) and np.isfinite(chain).all()
