@@ -32,8 +32,9 @@ def parse():
     ap.add_argument("--ndim", type=int, default=100)
     ap.add_argument("--ntemps", type=int, default=64, help="temperature ranks per GPU")
     ap.add_argument("--nwalkers", type=int, default=4096)
-    ap.add_argument("--mix", default="scam", choices=["scam", "default"], help="scam: SCAM-only; default: SCAM/AM/DE 20/20/20")
-    ap.add_argument("--logl", default="iso", choices=["iso", "dense"])
+    ap.add_argument("--mix", default="scam", choices=["scam", "default", "nuts"],
+                    help="scam: SCAM-only; default: SCAM/AM/DE 20/20/20; nuts: SCAM/DE/NUTS 10/10/10 (BASELINE configs[4])")
+    ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
     ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--sharded", action="store_true", help="use the sharded engine even with one rank (testing)")
@@ -74,9 +75,9 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
-    weights = (20, 0, 0) if a.mix == "scam" else (20, 20, 20)
+    weights = {"scam": (20, 0, 0), "default": (20, 20, 20), "nuts": (10, 0, 10)}[a.mix]
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl != "curved":   # the NumPy port covers the Gaussian configs
         cpu = cpu_baseline(a, weights)
         log("cpu baseline %.3g updates/s on %d cores" % (cpu["value"], cpu["cores"]))
     import numpy as np
@@ -107,13 +108,19 @@ def main():
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=100, seed=1234, cov_mode=a.cov_mode, logl=logl,
               device=local, swap_mode=a.swap_mode)
+    cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
+    if a.logl == "curved":                      # examples/curved_likelihood.ipynb: box prior [-10, 10], cov = I, start near the mode
+        kw.update(logl=("curved",), logp=("box", np.full(d, -10.0), np.full(d, 10.0)))
+        cov0, p0 = np.eye(d), np.array([-0.1, -0.5] * (d // 2) + [0.0] * (d % 2))
+    if a.mix == "nuts":
+        kw.update(grad_weights=(10, 0))
     if world == 1 and not a.sharded:
         from ptmcmcsampler_amd.engine import PTEngine
-        eng = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+        eng = PTEngine(d, nt, W, cov0, **kw)
     else:
         from ptmcmcsampler_amd.sharded import ShardedPTEngine
-        eng = ShardedPTEngine(d, nt * world, W, np.eye(d) * 0.01, group=dist.group.WORLD, **kw)
-    eng.init_state(np.zeros(d))
+        eng = ShardedPTEngine(d, nt * world, W, cov0, group=dist.group.WORLD, **kw)
+    eng.init_state(p0)
     log("engine ready")
 
     def fence():

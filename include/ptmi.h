@@ -130,7 +130,7 @@ typedef struct ptmi_buffers {
                          *              _lnlike/_lnprob columns of updateChains (:331-335) (optional) */
     double *gj;         /* [W][T][8]   by RANK: the attributes of a rank's NUTSJump / HMCJump object (nutsjump.py:379-433):
                          *              epsilon, mu, Hbar, epsilonbar (starts at 1), NUTS calls, HMC calls, have-epsilon flag, -
-                         *              (needed with w_nuts + w_hmc > 0, together with Q and qaux) */
+                         *              (needed with w_nuts + w_hmc > 0) */
 } ptmi_buffers;
 
 typedef struct ptmi_engine *ptmi_handle;

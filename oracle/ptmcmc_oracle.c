@@ -408,6 +408,9 @@ static double eval_logl_grad(const orc_cfg *c, const double *q, double *tmp /* 2
     return ll;
 }
 
+static int64_t g_leapfrogs;     /* statistics only: leapfrogs taken since the library was loaded */
+ORC_API int64_t orc_leapfrog_count(void) { return g_leapfrogs; }
+
 typedef struct {
     const orc_cfg *c;
     double beta;
@@ -444,6 +447,7 @@ static double leapfrog(gj_ctx *G, const double *theta, const double *r, const do
     const double logpp = func_grad_white(G, thetap, gradp);
     for (int i = 0; i < d; ++i) rp[i] = rp[i] + he * gradp[i];
     G->nleap++;
+    g_leapfrogs++;
     return logpp;
 }
 

@@ -547,7 +547,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (c.ndim < 1 || c.ntemps < 1 || c.nwalkers < 1) return fail(PTMI_EINVAL, "ndim/ntemps/nwalkers must be >= 1");
     if (c.ntemps_global < c.ntemps || c.temp0 < 0 || c.temp0 + c.ntemps > c.ntemps_global)
         return fail(PTMI_EINVAL, "temperature block [%d,%d) outside ladder of %d", c.temp0, c.temp0 + c.ntemps, c.ntemps_global);
-    if (c.w_host < 0 || c.w_scam < 0 || c.w_am < 0 || c.w_de < 0 || c.w_host + c.w_scam + c.w_am <= 0)
+    if (c.w_host < 0 || c.w_scam < 0 || c.w_am < 0 || c.w_de < 0 || c.w_nuts < 0 || c.w_hmc < 0 ||
+        c.w_host + c.w_scam + c.w_am + c.w_nuts + c.w_hmc <= 0)
         return fail(PTMI_EINVAL, "No jump proposals specified! (PTMCMCSampler.py:267)");
     if (c.cov_update < 1) return fail(PTMI_EINVAL, "cov_update must be >= 1");
     if (c.w_de > 0 && c.de_size < 2) return fail(PTMI_EINVAL, "de_size must be >= 2 when DE is used");
@@ -569,7 +570,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (c.w_nuts < 0 || c.w_hmc < 0) return fail(PTMI_EINVAL, "negative gradient-jump weight");
     if (gj) {
         if (!c.gj_tab) return fail(PTMI_EINVAL, "gradient jumps need the whitening tables (gj_tab)");
-        if (!buf->gj || !buf->Q || !buf->qaux) return fail(PTMI_EINVAL, "gradient jumps need the gj, Q and qaux buffers");
+        if (!buf->gj) return fail(PTMI_EINVAL, "gradient jumps need the gj buffer");
         if (c.ndim > 32) return fail(PTMI_EUNSUPPORTED, "gradient jumps on the device are built for ndim <= 32 (got %d)", c.ndim);
         if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "gradient jumps with parameter groups are not built");
         if (c.w_host > 0) return fail(PTMI_EUNSUPPORTED, "gradient jumps on the device cannot be mixed with host-served jumps");
@@ -623,8 +624,6 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         const size_t nvec = (size_t)GJV_TOP + (size_t)GJL_VECS * (c.nuts_maxdepth + 1);
         hipError_t e3 = hipMalloc((void **)&h->d_gj_scr, sizeof(double) * nvec * lanes * nch);
         if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_scal, sizeof(double) * (size_t)GJS_SCALARS * (c.nuts_maxdepth + 1) * nch);
-        if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_lnL, sizeof(double) * nch);
-        if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_lp, sizeof(double) * nch);
         if (e3 != hipSuccess || (rc = upload(&h->d_gj_tab, c.gj_tab, 3LL * c.ndim * c.ndim))) {
             ptmi_destroy(h);
             return e3 != hipSuccess ? fail(PTMI_EHIP, "gradient-jump scratch: %s", hipGetErrorString(e3)) : rc;
@@ -653,7 +652,7 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
     (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_xint);
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
-    (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_lnL); (void)hipFree(h->d_gj_lp);
+    (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -695,20 +694,8 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     a.iter0 = iter0; a.nsteps = nsteps;
     if (int rc = set_step_args(h, &a)) return rc;
     if (h->cfg.w_host > 0) return fail(PTMI_EINVAL, "host-served jumps need the split path (ptmi_propose / ptmi_accept)");
-    if (h->cfg.w_nuts + h->cfg.w_hmc > 0) {
-        // with gradient jumps in the cycle every iteration is four launches: cycle pick + SCAM/AM/DE proposals, NUTS / HMC
-        // for the chains that picked them, the likelihood of the proposals, the Hastings test (no host round trip)
-        const int grid = chains_grid(h);
-        for (int k = 0; k < nsteps; ++k) {
-            KArgs s = a;
-            s.iter0 = iter0 + k; s.nsteps = 1;
-            s.newlnL = h->d_gj_lnL; s.newlp = h->d_gj_lp;
-            if (int rc = set_step_args(h, &s)) return rc;
-            int rc;
-            if ((rc = run_shape(h, PTMI_OP_PROPOSE, s, grid, true)) || (rc = run_shape(h, PTMI_OP_GRADJUMP, s, grid, true)) ||
-                (rc = run_shape(h, PTMI_OP_EVALQ, s, grid, true)) || (rc = run_shape(h, PTMI_OP_ACCEPT, s, grid, true)))
-                return rc;
-        }
+    if (h->cfg.w_nuts + h->cfg.w_hmc > 0) {      // the fused kernel with the NUTS / HMC branch (csrc/ptmi_gj.inc.h)
+        if (int rc = run_shape(h, PTMI_OP_MH_GJ, a, chains_grid(h), true)) return rc;
         HIPCHK(hipGetLastError());
         return PTMI_OK;
     }

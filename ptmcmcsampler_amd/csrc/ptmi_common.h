@@ -78,7 +78,7 @@ struct ptmi_engine {
     double *d_pre;      // [4][ntg][W] scratch of the swap (uniforms, likelihoods, own-likelihood terms)
     int32_t *d_prow;    // [ntg][W] rows by position (fused swap)
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
-    double *d_gj_tab, *d_gj_scr, *d_gj_scal, *d_gj_lnL, *d_gj_lp;   // gradient jumps: tables, tree scratch, lnL / lp of the proposals
+    double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
     int G, EPL;
     int de_on, de_head;
@@ -90,8 +90,8 @@ struct ptmi_engine {
 // and likelihood family is compiled in its own translation unit (ptmi_shape.hip with -DPTMI_G -DPTMI_E -DPTMI_L) so
 // the build runs in parallel;
 // this is the entry point a shape unit exports.
-enum { PTMI_OP_MH = 0, PTMI_OP_EVAL = 1, PTMI_OP_PROPOSE = 2, PTMI_OP_ACCEPT = 3, PTMI_OP_GRADJUMP = 4, PTMI_OP_EVALQ = 5 };
-// jump types the fused kernel counts (the gradient jumps run on the split path)
+enum { PTMI_OP_MH = 0, PTMI_OP_EVAL = 1, PTMI_OP_PROPOSE = 2, PTMI_OP_ACCEPT = 3, PTMI_OP_MH_GJ = 4 };
+// jump types the SCAM / AM / DE kernels count (the gradient jumps have their own fused kernel, ptmi_gj.inc.h)
 enum { PTMI_J_FUSED = 3 };
 typedef int (*ptmi_shape_fn)(int op, ptmi_engine *h, KArgs &a, int grid, bool full);
 #define PTMI_SHAPE_LIST(X) X(4, 2) X(4, 5) X(4, 8) X(4, 14) X(4, 20) X(4, 26) X(16, 7) X(16, 13) X(16, 26) X(64, 8) X(64, 16) X(64, 32)

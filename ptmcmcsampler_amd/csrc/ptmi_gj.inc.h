@@ -9,6 +9,10 @@
 #include "ptmi_common.h"
 
 
+// the three whitening tables of the block, staged once per launch ([3][d][d], 9.6 KB at d = 20)
+extern __shared__ __attribute__((aligned(16))) double gj_lds[];
+enum { GJT_BACKWARD = 0, GJT_FORWARD = 1, GJT_GRADIENT = 2 };
+
 template <int G, int EPL, int LOGL>
 struct GradJump {
     const KArgs &a;
@@ -73,9 +77,12 @@ struct GradJump {
         for (int e = 0; e < EPL; ++e) p = __builtin_fma(x[e], y[e], p);
         return group_sum<G>(p);
     }
-    // out[i] = sum_k T[k][i] v[k], k ascending, one fma per term
-    __device__ __forceinline__ void tab_vec(const double *T, const double (&v)[EPL], double (&out)[EPL]) const
+    // out[i] = sum_k T[k][i] v[k], k ascending, one fma per term.  WHICH >= 0: a whitening table in LDS (the pointer
+    // is formed from the LDS symbol here so that the reads are ds_read, not flat); WHICH < 0: the global table Tg.
+    template <int WHICH>
+    __device__ __forceinline__ void tab_vec(const double *Tg, const double (&v)[EPL], double (&out)[EPL]) const
     {
+        const double *T = WHICH >= 0 ? gj_lds + (size_t)WHICH * d * d : Tg;
         double acc[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = 0.0;
@@ -113,7 +120,7 @@ struct GradJump {
                 const int i = gl + G * e;
                 r[e] = i < d ? x[e] - mu[i] : 0.0;
             }
-            tab_vec(Pt, r, v);
+            tab_vec<-1>(Pt, r, v);
 #pragma unroll
             for (int e = 0; e < EPL; ++e) g[e] = -v[e];
             return -0.5 * dot(r, v);
@@ -168,12 +175,12 @@ struct GradJump {
     __device__ __forceinline__ double func_grad_white(const double (&q)[EPL], double (&gradw)[EPL]) const
     {
         double x[EPL], g[EPL];
-        tab_vec(a.gj_tab, q, x);                                         // backward: x = L^T q
+        tab_vec<GJT_BACKWARD>(nullptr, q, x);                                         // backward: x = L^T q
         const double ll = logl_grad(x, g);
         const double lp = logp(x);                                       // the built-in priors have zero gradient
 #pragma unroll
         for (int e = 0; e < EPL; ++e) g[e] = beta * g[e] + 0.0;
-        tab_vec(a.gj_tab + 2 * (size_t)d * d, g, gradw);
+        tab_vec<GJT_GRADIENT>(nullptr, g, gradw);
         return beta * ll + lp;
     }
     __device__ __forceinline__ double joint_of(double logl, const double (&r)[EPL]) const { return logl - 0.5 * dot(r, r); }
@@ -216,7 +223,7 @@ struct GradJump {
     {
         double q[EPL], p[EPL], grad[EPL];
         st[GJ_HITER] += 1.0;
-        tab_vec(a.gj_tab + (size_t)d * d, x, q);                         // forward
+        tab_vec<GJT_FORWARD>(nullptr, x, q);                         // forward
         const double logp0 = func_grad_white(q, grad);
         momenta(p);
         const double joint0 = joint_of(logp0, p);
@@ -227,7 +234,7 @@ struct GradJump {
             joint1 = joint_of(logp1, p);
             if (joint1 - 1000.0 < joint0) break;                         // NJ:284-286
         }
-        tab_vec(a.gj_tab, q, qout);
+        tab_vec<GJT_BACKWARD>(nullptr, q, qout);
         return joint1 - joint0;
     }
 
@@ -334,7 +341,7 @@ struct GradJump {
     {
         double q[EPL], grad[EPL], r0[EPL];
         st[GJ_NITER] += 1.0;
-        tab_vec(a.gj_tab + (size_t)d * d, x, q);
+        tab_vec<GJT_FORWARD>(nullptr, x, q);
         const double logp0 = func_grad_white(q, grad);
         if (st[GJ_HAVE_EPS] == 0.0) {
             st[GJ_EPS] = find_reasonable_epsilon(q, grad, logp0);
@@ -389,72 +396,119 @@ struct GradJump {
         }
         double sample[EPL];
         vload(GJV_SAMPLE, sample);
-        tab_vec(a.gj_tab, sample, qout);
+        tab_vec<GJT_BACKWARD>(nullptr, sample, qout);
         return logp0 - lnprob;                                           // undoes the outer Hastings ratio (NJ:838)
     }
 };
 
-// One iteration's gradient-jump proposals: chains whose cycle pick (propose_kernel, qaux[1]) is NUTS or HMC get their
-// proposal q in Q and qxy in qaux[0]; the others are left alone.
+// Fused MH steps with the gradient jumps in the cycle: the non-staged full kernel (ptmi_mh.inc.h) plus the NUTS / HMC
+// branch.  Every chain group runs its nsteps iterations on its own, so a long NUTS tree delays only its wave for that
+// iteration and the launch costs the longest SUM over iterations, not the sum of the per-iteration maxima.
+// One wave per block: there is no block-level cooperation, and single-wave blocks let the dispatcher backfill the
+// SIMDs as soon as a wave's chains are through their (very unequal) trees.
+constexpr int GJ_BLOCK = 64;
 template <int G, int EPL, int LOGL>
-__global__ __launch_bounds__(256) void gradjump_kernel(const KArgs a)
+__global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
 {
-    constexpr int CPB = 256 / G;
+    constexpr int CPB = GJ_BLOCK / G;
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
+    for (int i = (int)threadIdx.x; i < 3 * d * d; i += GJ_BLOCK) gj_lds[i] = a.gj_tab[i];
+    __syncthreads();
     const long long ch = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
-    if (ch >= nch) return;
-    const int jt = (int)a.qaux[ch * 4 + 1];
-    if (jt != PTMI_J_NUTS && jt != PTMI_J_HMC) return;
+    if (ch >= nch) return;                       // no block-wide synchronisation below: whole chain groups may leave
     const int gl = (int)(threadIdx.x % G);
     const int w = (int)(ch / nt);
     const int t = a.temp_of[ch];
-    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)(a.temp0 + t));
-    GradJump<G, EPL, LOGL> gj(a, gl, ch, a.beta[t], a.iter0, sid);
-    double x[EPL], q[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = gl + G * e;
-        x[e] = i < d ? a.X[(size_t)ch * d + i] : 0.0;
-    }
+    const int tg = a.temp0 + t;
+    const double beta = a.beta[t];
+    const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
+    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)tg);
+    const size_t wc = a.per_walker ? (size_t)w : 0;
+    const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
+    const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
+    const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr;
+    double *xrow = a.X + (size_t)ch * d;
     double *stg = a.gj + ((size_t)w * nt + t) * GJ_NSTATE;
-    double st[GJ_NSTATE];
-#pragma unroll
-    for (int k = 0; k < GJ_NSTATE; ++k) st[k] = stg[k];
-    const double qxy = jt == PTMI_J_NUTS ? gj.nuts(st, x, q) : gj.hmc(st, x, q);
+
+    double x[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int i = gl + G * e;
-        if (i < d) a.Q[(size_t)ch * d + i] = q[e];
+        x[e] = i < d ? xrow[i] : 0.0;
+    }
+    double lnL = a.lnL[ch], lp = a.lp[ch];
+    u32 nacc = 0, jp[PTMI_J_NTYPES] = {0, 0, 0, 0, 0}, ja[PTMI_J_NTYPES] = {0, 0, 0, 0, 0};
+    const bool cold = tg == 0 && a.AM != nullptr;
+    int am_row = a.am_row0;
+
+    for (int k = 0; k < a.nsteps; ++k) {
+        const long long it = a.iter0 + k;
+        double log_u, u_acc, q[EPL], qxy = 0.0;
+        const int jt = propose<G, EPL, true, false, false, true>(a, it, sid, gl, cc, Ut, false, S, DE, q, log_u, u_acc);
+        if (jt == PTMI_J_NUTS || jt == PTMI_J_HMC) {
+            GradJump<G, EPL, LOGL> gj(a, gl, ch, beta, it, sid);
+            double st[GJ_NSTATE];
+#pragma unroll
+            for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stg[j];
+            qxy = jt == PTMI_J_NUTS ? gj.nuts(st, x, q) : gj.hmc(st, x, q);
+            if (gl == 0) {
+#pragma unroll
+                for (int j = 0; j < GJ_NSTATE; ++j) stg[j] = st[j];
+            }
+            __threadfence_block();               // the chain's other lanes read the state at its next gradient jump
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) q[e] = x[e] + q[e];            // propose() returned the increment
+        }
+#pragma unroll
+        for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
+        // PT:605-612
+        const double nlp = eval_logp<G, EPL, false>(a, q, gl);
+        const double nlnL = eval_logl<G, EPL, LOGL, false>(a, q, gl, PtG);
+        const double nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
+        // PT:615-622
+        const double lnprob0 = beta * lnL + lp;
+        const double diff = nlnprob - lnprob0 + qxy;
+        if (diff > log_u) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) x[e] = q[e];
+            lnL = nlnL;
+            lp = nlp;
+            nacc += 1;
+#pragma unroll
+            for (int j = 0; j < PTMI_J_NTYPES; ++j) ja[j] += (jt == j);
+        }
+        // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
+        if (cold && !(a.swap_last && k == a.nsteps - 1)) {
+            double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e;
+                if (i < d) am[i] = x[e];
+            }
+            if (a.AMaux && gl == 0) {
+                double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
+                ax[0] = lnL;
+                ax[1] = lp;
+            }
+        }
+        am_row = am_row + 1 == a.cov_update ? 0 : am_row + 1;
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = gl + G * e;
+        if (i < d) xrow[i] = x[e];
     }
     if (gl == 0) {
+        a.lnL[ch] = lnL;
+        a.lp[ch] = lp;
+        const size_t r = (size_t)w * nt + t;
+        a.nacc[r] += nacc;
 #pragma unroll
-        for (int k = 0; k < GJ_NSTATE; ++k) stg[k] = st[k];
-        a.qaux[ch * 4 + 0] = qxy;
-    }
-}
-
-// logp / logl of the proposals Q (the device likelihood in the place of the host callbacks of the split path)
-template <int G, int EPL, int LOGL>
-__global__ __launch_bounds__(256) void eval_q_kernel(const KArgs a, double *newlnL, double *newlp)
-{
-    constexpr int CPB = 256 / G;
-    const int d = a.d;
-    const long long nch = (long long)a.W * a.nt;
-    long long ch = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
-    const bool live = ch < nch;
-    if (!live) ch = nch - 1;
-    const int gl = (int)(threadIdx.x % G);
-    double q[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int i = gl + G * e;
-        q[e] = i < d ? a.Q[(size_t)ch * d + i] : 0.0;
-    }
-    const double lp = eval_logp<G, EPL, false>(a, q, gl);
-    const double lnL = eval_logl<G, EPL, LOGL, false>(a, q, gl, LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr);
-    if (live && gl == 0) {
-        newlp[ch] = lp;
-        newlnL[ch] = lnL;
+        for (int j = 0; j < PTMI_J_NTYPES; ++j) {
+            a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 0] += jp[j];
+            a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 1] += ja[j];
+        }
     }
 }

@@ -225,8 +225,8 @@ constexpr int safe_slots(int G, int EPL)
 // STR: strided lane layout (see "lane groups"); then Ut is the zero-padded LDS copy when ut_padded, and the AM
 // product runs on the matrix cores for all 16 chains of the wave at once.
 // GRP: parameter groups (compile-time: with one group every bound below is the wave-uniform d).
-// GJ: the cycle also holds the gradient jumps (split path only): such a pick hands the state back unchanged and
-// gradjump_kernel fills in the proposal.
+// GJ: the cycle also holds the gradient jumps: such a pick hands the state back unchanged and the caller
+// (mh_steps_gj_kernel, ptmi_gj.inc.h) builds the proposal.
 template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 }
 
 // split path: proposal only / accept only, one iteration (host likelihood callbacks)
-template <int G, int EPL, bool GRP, bool GJ>
+template <int G, int EPL, bool GRP>
 __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
 {
     constexpr int CPB = 256 / G;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double log_u, u_acc;
-    const int jt = propose<G, EPL, true, false, GRP, GJ>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
+    const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {

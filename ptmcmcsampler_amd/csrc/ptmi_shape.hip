@@ -16,17 +16,17 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
     case PTMI_OP_EVAL: hipLaunchKernelGGL((eval_state_kernel<G, E, L>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
 #if PTMI_L == 0
     case PTMI_OP_PROPOSE:
-        if (h->cfg.ngroups > 1) hipLaunchKernelGGL((propose_kernel<G, E, true, false>), dim3(grid), dim3(256), 0, h->stream, a);
-        else if (h->cfg.w_nuts + h->cfg.w_hmc > 0) hipLaunchKernelGGL((propose_kernel<G, E, false, true>), dim3(grid), dim3(256), 0, h->stream, a);
-        else hipLaunchKernelGGL((propose_kernel<G, E, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
+        if (h->cfg.ngroups > 1) hipLaunchKernelGGL((propose_kernel<G, E, true>), dim3(grid), dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL((propose_kernel<G, E, false>), dim3(grid), dim3(256), 0, h->stream, a);
         return PTMI_OK;
     case PTMI_OP_ACCEPT: hipLaunchKernelGGL((accept_kernel<G, E>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
 #endif
-    case PTMI_OP_GRADJUMP:
-    case PTMI_OP_EVALQ:
+    case PTMI_OP_MH_GJ:
         if constexpr (E <= 8) {                 // the tree build keeps seven chain vectors in registers
-            if (op == PTMI_OP_GRADJUMP) hipLaunchKernelGGL((gradjump_kernel<G, E, L>), dim3(grid), dim3(256), 0, h->stream, a);
-            else hipLaunchKernelGGL((eval_q_kernel<G, E, L>), dim3(grid), dim3(256), 0, h->stream, a, h->d_gj_lnL, h->d_gj_lp);
+            const long long nch = (long long)h->cfg.nwalkers * h->cfg.ntemps;
+            const int cpb = GJ_BLOCK / G;
+            hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK),
+                               sizeof(double) * 3 * (size_t)h->cfg.ndim * h->cfg.ndim, h->stream, a);
             return PTMI_OK;
         } else {
             return fail(PTMI_EUNSUPPORTED, "gradient jumps are built for kernel shapes with at most 8 register slots per lane");

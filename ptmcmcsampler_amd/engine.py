@@ -106,7 +106,7 @@ class PTEngine(object):
             nacc=z((W, nt), i64), jstat=z((W, nt, _lib.J_NTYPES, 2), i64), nswap=z((W, self.ntg), i64),
             mu=z((W, d)) if self.owns_cold else None, M2=z((W, d, d)) if self.owns_cold else None,
             cov=z((Wc, d, d)),
-            Q=z((W, nt, d)) if (split or has_gj) else None, qaux=z((W, nt, 4)) if (split or has_gj) else None,
+            Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
             AMaux=z((W, self.cov_update, 2)) if (keep_lnl and self.owns_cold) else None,
             gj=z((W, nt, _lib.GJ_NSTATE)) if has_gj else None,
         )
