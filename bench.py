@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
     ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
+    ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
+                    help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
+                         "walkers = every GPU holds whole ladders of its own walkers (no data-path collective)")
     ap.add_argument("--sharded", action="store_true", help="use the sharded engine even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10000, help="iterations per host core of the CPU baseline (10-30 s of CPU work)")
@@ -114,9 +117,9 @@ def main():
         cov0, p0 = np.eye(d), np.array([-0.1, -0.5] * (d // 2) + [0.0] * (d % 2))
     if a.mix == "nuts":
         kw.update(grad_weights=(10, 0))
-    if world == 1 and not a.sharded:
+    if (world == 1 and not a.sharded) or a.partition == "walkers":
         from ptmcmcsampler_amd.engine import PTEngine
-        eng = PTEngine(d, nt, W, cov0, **kw)
+        eng = PTEngine(d, nt, W, cov0, walker0=rank * W, **kw)       # distinct RNG streams per GPU
     else:
         from ptmcmcsampler_amd.sharded import ShardedPTEngine
         eng = ShardedPTEngine(d, nt * world, W, cov0, group=dist.group.WORLD, **kw)
@@ -181,7 +184,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %d-d %s Gaussian logl, %d temps x %d walkers per GPU, %s cycle, "
                                "Tskip=100 (%s), covUpdate=1000, cov_mode=%s" % (d, a.logl, nt, W, a.mix, a.swap_mode, a.cov_mode),
-                   "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "parallelism": "temperature blocks x%d" % world},
+                   "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "parallelism": ("temperature blocks x%d" if a.partition == "temps" else "walker blocks x%d") % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "mh_steps_kernel", "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,

@@ -885,8 +885,8 @@ ORC_API void orc_swap_apply(const orc_cfg *c, orc_state *st, const int32_t *map,
 /* ------------------------------------------------------------- Welford */
 /* PT:769-794 for one walker: mem buffered rows in buffer order.  fused = 0 is the
  * reference's arithmetic (one product, one sum); fused = 1 accumulates with one fma per
- * element and advances the mean by diff * (1/it) (the pooled mode of the engine, which is not a
- * replica of a reference run). */
+ * element, the upper triangle only (the lower one is its mirror image), and advances the mean by
+ * diff * (1/it) (the pooled mode of the engine, which is not a replica of a reference run). */
 ORC_API void orc_welford2(int d, int mem, int64_t iter, const double *AM, double *mu, double *M2, double *cov, int fused)
 {
     int64_t it = iter - mem;
@@ -903,11 +903,14 @@ ORC_API void orc_welford2(int d, int mem, int64_t iter, const double *AM, double
         }
         for (int j = 0; j < d; ++j) e[j] = row[j] - mu[j];
         for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) {
+            for (int j = fused ? i : 0; j < d; ++j) {       /* fused: the upper triangle only ... */
                 if (fused) M2[(size_t)i * d + j] = fma(diff[i], e[j], M2[(size_t)i * d + j]);
                 else M2[(size_t)i * d + j] += diff[i] * e[j];
             }
     }
+    if (fused)                                              /* ... mirrored: M2 is symmetric by construction */
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < i; ++j) M2[(size_t)i * d + j] = M2[(size_t)j * d + i];
     if (cov) for (int i = 0; i < d * d; ++i) cov[i] = M2[i] / (double)(it - 1);
     free(diff);
 }

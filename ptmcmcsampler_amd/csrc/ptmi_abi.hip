@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
     constexpr int PF = 8;       // rows fetched ahead by the carrier threads (one HBM latency per PF rows)
     constexpr int RB = 4;       // rows handed to the tile per barrier
     __shared__ double sh[2][RB][2][WTILE];  // [buf][row][diff|e][WTILE]
+    if (FUSED && blockIdx.y > blockIdx.x) return;       // pooled definition: the lower triangle is mirrored afterwards
     const int w = (int)blockIdx.z;
     const int ti0 = (int)blockIdx.y * WTILE, tj0 = (int)blockIdx.x * WTILE;
     const int tx = (int)(threadIdx.x & 15), ty = (int)(threadIdx.x >> 4);
@@ -258,16 +259,26 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
 // Pooled-mode Welford on the matrix cores (d <= 112: one block per walker).  The rank-1 updates of RC buffered rows
 // are one [d x RC] . [RC x d] product: v_mfma_f64_16x16x4_f64 accumulates it as a row-ascending fma chain, which is
 // exactly the fused scalar definition (orc_welford2 with fused = 1), so the result is bit-identical.
-// The 49 tiles of 16x16 are dealt round-robin over the four waves (12/12/12/13: the f64 matrix pipe retires one
-// instruction per 64 cycles per SIMD, so the balance across SIMDs is what matters; the waves that also carry the
-// mean recurrence get the lighter share).  The first 112 threads are the carriers: they run the mean recurrence of
-// their column one chunk ahead and hand the diff / e rows over through a double-buffered LDS chunk.  The
-// reciprocals 1/(it+1+r) are the same for every column and walker: computed once per block into LDS.
+// The pooled definition keeps the upper triangle and mirrors it, so only the 28 tiles with ti <= tj are computed,
+// dealt round-robin over the four waves (7 each: the f64 matrix pipe retires one instruction per 64 cycles per SIMD,
+// so the balance across SIMDs is what matters).  The first 112 threads are the carriers: they run the mean
+// recurrence of their column one chunk ahead and hand the diff / e rows over through a double-buffered LDS chunk.
+// The reciprocals 1/(it+1+r) are the same for every column and walker: computed once per block into LDS.
 typedef double wf_d4 __attribute__((ext_vector_type(4)));
 constexpr int WRC = 16;                                     // rows per chunk (4 matrix instructions deep)
-constexpr int WF_NT = (WT * WT + 3) / 4;                    // tiles per wave (13)
+constexpr int WF_TILES = WT * (WT + 1) / 2;                 // upper-triangle tiles (28)
+constexpr int WF_NT = WF_TILES / 4;                         // tiles per wave (7)
+static_assert(WF_TILES % 4 == 0, "the tile deal assumes four equal shares");
 constexpr int WF_THREADS = 256;
 constexpr int WF_MAXMEM = 2048;                             // reciprocal table (cov_update rows)
+// t-th upper-triangle tile in row-major order -> (ti, tj)
+__device__ __forceinline__ void wf_tile(int t, int &ti, int &tj)
+{
+    ti = 0;
+    int row = WT;
+    while (t >= row) { t -= row; ++ti; --row; }
+    tj = ti + t;
+}
 __global__ __launch_bounds__(WF_THREADS, 2) void welford_mfma_kernel(const double *AM, double *mu, double *M2, int d, int mem, long long iter)
 {
     __shared__ double Dl[2][WRC][WTILE], El[2][WRC][WTILE];
@@ -285,20 +296,18 @@ __global__ __launch_bounds__(WF_THREADS, 2) void welford_mfma_kernel(const doubl
     double m = incol && !reset ? muw[col] : 0.0;
     for (int r = (int)threadIdx.x; r < mem; r += WF_THREADS) rcp[r] = 1.0 / (double)(it0 + 1 + r);
 
-    const int res = (wave + 1) & 3;                         // wave 3 takes the 13-tile share
     wf_d4 acc[WF_NT];
     int offa[WF_NT], offb[WF_NT];                           // column offsets of the tile's D and E fragments
 #pragma unroll
     for (int n = 0; n < WF_NT; ++n) {
-        const int t = res + 4 * n;
-        const bool live = t < WT * WT;
-        const int ti = live ? t / WT : 0, tj = live ? t % WT : 0;
+        int ti, tj;
+        wf_tile(wave + 4 * n, ti, tj);
         offa[n] = __builtin_amdgcn_readfirstlane(ti * 16);   // wave-uniform: scalar registers
         offb[n] = __builtin_amdgcn_readfirstlane(tj * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
-            acc[n][r] = (live && !reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
+            acc[n][r] = (!reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
         }
     }
     // The AM rows of the following chunk are requested as soon as the current ones are consumed, so the HBM latency
@@ -334,24 +343,34 @@ __global__ __launch_bounds__(WF_THREADS, 2) void welford_mfma_kernel(const doubl
         for (int k0 = 0; k0 < WRC; k0 += 4)
 #pragma unroll
             for (int n = 0; n < WF_NT; ++n)
-                if (n < WF_NT - 1 || res == 0)
-                    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Db[k0 * WTILE + offa[n]], Eb[k0 * WTILE + offb[n]], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Db[k0 * WTILE + offa[n]], Eb[k0 * WTILE + offb[n]], acc[n], 0, 0, 0);
         __syncthreads();
         buf ^= 1;
     }
 #pragma unroll
     for (int n = 0; n < WF_NT; ++n) {
-        const int t = res + 4 * n;
-        if (t < WT * WT) {
-            const int ti = t / WT, tj = t % WT;
+        int ti, tj;
+        wf_tile(wave + 4 * n, ti, tj);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
-                if (i < d && j < d) M2w[(size_t)i * d + j] = acc[n][r];
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
+            if (i < d && j < d && i <= j) {                 // a diagonal tile also computed its lower half: dropped
+                M2w[(size_t)i * d + j] = acc[n][r];
+                M2w[(size_t)j * d + i] = acc[n][r];
             }
         }
     }
     if (incol) muw[col] = m;
+}
+
+// pooled definition for the tiled kernel (d > 112): the lower triangle is the mirror image of the upper one
+__global__ void symmetrize_kernel(double *M2, int d)
+{
+    double *M = M2 + (size_t)blockIdx.y * d * d;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)d * d) return;
+    const int i = (int)(idx / d), j = (int)(idx % d);
+    if (j < i) M[idx] = M[(size_t)j * d + i];
 }
 
 __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem, long long iter, int fused)
@@ -945,8 +964,12 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
         hipLaunchKernelGGL(welford_mfma_kernel, dim3(c.nwalkers), dim3(WF_THREADS), 0, h->stream, (const double *)h->buf.AM, h->buf.mu,
                            h->buf.M2, d, c.cov_update, (long long)iter);
     else
+    {
         hipLaunchKernelGGL(welford_kernel<true>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
                            h->buf.mu, h->buf.M2, (double *)nullptr, d, c.cov_update, (long long)iter, 0);
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)(((long long)d * d + 255) / 256), c.nwalkers), dim3(256), 0, h->stream,
+                           h->buf.M2, d);
+    }
     if (nt > 1)
         hipLaunchKernelGGL(welford_mean_kernel, dim3((d + 63) / 64, c.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.AM,
                            h->buf.mu, d, c.cov_update, (long long)iter, per ? 0 : 1);
