@@ -182,12 +182,15 @@ def main():
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %d-d %s Gaussian logl, %d temps x %d walkers per GPU, %s cycle, "
-                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s" % (d, a.logl, nt, W, a.mix, a.swap_mode, a.cov_mode),
+        "config": {"workload": "BASELINE configs[%d]: %d-d %s logl, %d temps x %d walkers per GPU, %s cycle, "
+                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s" % (
+                                   {"iso": 3 if d >= 1000 else 1, "dense": 2, "curved": 4}[a.logl], d,
+                                   {"iso": "isotropic Gaussian", "dense": "dense Gaussian", "curved": "curved-likelihood"}[a.logl],
+                                   nt, W, a.mix, a.swap_mode, a.cov_mode),
                    "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "parallelism": ("temperature blocks x%d" if a.partition == "temps" else "walker blocks x%d") % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "mh_steps_kernel", "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,
+                     "kernel": "mh_steps_gj_kernel" if a.mix == "nuts" else "mh_steps_kernel", "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,
                      "algorithmic_bytes_per_update": bytes_per_update, "kernel_time_share_of_wall": kern_ms * 1e-3 / wall},
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
@@ -207,7 +210,6 @@ def main():
         tf = flops * nt * W * avg_steps / (avg_launch_ms * 1e-3) / 1e12
         out["roofline"].update({"bound": "mfma", "achieved": tf, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": tf / F64_MATRIX_PEAK_TFLOPS, "algorithmic_flops_per_update": flops})
-        out["config"]["workload"] = out["config"]["workload"].replace("BASELINE configs[1]", "BASELINE configs[2]")
     if rank == 0:
         acc = eng.get("nacc").astype(np.float64)
         out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / (a.steps + a.warmup))
