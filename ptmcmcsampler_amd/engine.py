@@ -145,11 +145,16 @@ class PTEngine(object):
         self.iter = 0
         self.swap_proposed = 0
         self.eig_epochs = 0
-        for w in range(Wc):
-            self._eig_host(w, cov0)
+        self._eig_host(0, cov0)                                       # every walker starts from the same covariance
+        if Wc > 1:
+            self.t["Ut"][1:] = self.t["Ut"][0]
+            self.t["S"][1:] = self.t["S"][0]
 
     def __del__(self):
         try:
+            if getattr(self, "_eig_pool", None) is not None:
+                self._eig_pool.terminate()
+                self._eig_pool = None
             if getattr(self, "h", None) is not None and self.h:
                 self.lib.ptmi_destroy(self.h)
                 self.h = None
@@ -181,6 +186,28 @@ class PTEngine(object):
             with _blas_single_thread():                               # a small SVD gains nothing from a 256-thread pool
                 U, S, _ = np.linalg.svd(cov[np.ix_(g, g)] if self.ngr > 1 or len(g) != self.d else cov)
             self.put_eig(U, S, w, gi)
+
+    def _eig_host_all(self, cov):
+        """Per-walker mode: the W independent factorizations, one upload for all.  From 64 walkers on they run on a
+        pool of spawned host processes (numpy only; every LAPACK call single-threaded, so each walker's bits are those
+        of a lone reference run); PTMI_EIG_WORKERS sets the pool size (0 = in this process)."""
+        import os
+        from . import _eigworker
+        torch = _torch()
+        whole = self.ngr == 1 and len(self.groups[0]) == self.d
+        groups = None if whole else self.groups
+        nwork = int(os.environ.get("PTMI_EIG_WORKERS", min(64, os.cpu_count() or 1)))
+        if self.Wc < 64 or nwork <= 1:
+            Ut, Sv = _eigworker.svd_chunk((cov, groups))
+        else:
+            if getattr(self, "_eig_pool", None) is None:
+                import multiprocessing as mp
+                self._eig_pool = mp.get_context("spawn").Pool(nwork)       # spawn: no fork of a process that holds HIP state
+            bounds = np.linspace(0, self.Wc, min(self.Wc, 4 * nwork) + 1).astype(int)
+            parts = self._eig_pool.map(_eigworker.svd_chunk, [(cov[a:b], groups) for a, b in zip(bounds[:-1], bounds[1:]) if b > a])
+            Ut, Sv = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        self.t["Ut"].copy_(torch.from_numpy(Ut))
+        self.t["S"].copy_(torch.from_numpy(Sv))
 
     def put_eig(self, U, S, w=0, gi=0):
         """Upload a group's eigenvectors (columns of U) embedded in the full space, one per row."""
@@ -220,8 +247,10 @@ class PTEngine(object):
             return
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
         cov = self.get("cov")
-        for w in range(self.Wc):
-            self._eig_host(w, cov[w])
+        if self.Wc == 1:
+            self._eig_host(0, cov[0])
+        else:
+            self._eig_host_all(cov)
         self.eig_epochs += 1
 
     def update_de(self):
