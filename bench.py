@@ -80,7 +80,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     weights = {"scam": (20, 0, 0), "default": (20, 20, 20), "nuts": (10, 0, 10)}[a.mix]
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl != "curved":   # the NumPy port covers the Gaussian configs
+    # the CPU baseline is timed on rank 0 of the single-GPU run only; the NumPy port covers the Gaussian configs
+    if rank == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl != "curved":
         cpu = cpu_baseline(a, weights)
         log("cpu baseline %.3g updates/s on %d cores" % (cpu["value"], cpu["cores"]))
     import numpy as np
