@@ -65,7 +65,7 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
 // the carried state is always position k+1's own and the recurrence degenerates into independent pair tests.
 __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *pre, const int32_t *prow,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
-                                  int parity)
+                                  int parity, int32_t *inv /* with map: inv[w][map[w][j]] = j */)
 {
     const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (w >= W) return;
@@ -76,33 +76,54 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
     int c = n - 1;                         // position whose state is carried at k+1
     int crow = fused ? prow[(size_t)(n - 1) * W + w] : 0;
     double Lc = pre[nW + (size_t)(n - 1) * W + w];
-    for (int k = n - 2; k >= 0; --k) {
-        const size_t o = (size_t)k * W + w;
-        const double u = pre[o], La = pre[nW + o];
-        const int krow = fused ? prow[o] : 0;
-        const double Tk = ladder[k], Tk1 = ladder[k + 1];
-        double la = pre[2 * nW + o];       // -L[k] / T[k]
-        la += -Lc / Tk1;
-        la += Lc / Tk;
-        la += pre[3 * nW + o];             //  L[k] / T[k+1]
-        const bool acc = (parity < 0 || (k & 1) == parity) && u <= det_exp(la);
-        // position k+1 is final: it keeps the carried state, or takes position k's
-        const int fin = acc ? k : c;
-        if (map) map[(size_t)w * n + k + 1] = fin;
-        if (fused) {
-            const int frow = acc ? krow : crow;
-            so[k + 1] = frow;
-            to[frow] = k + 1;
-            if (!acc) crow = krow;
+    // Only Lc is carried from pair to pair: the scratch of SW pairs is fetched at once (independent loads, one HBM / L2
+    // latency per SW pairs instead of one per pair), then the SW dependent steps run from registers.
+    constexpr int SW = 8;
+    for (int k0 = n - 2; k0 >= 0; k0 -= SW) {
+        double pu[SW], pL[SW], pa[SW], pb[SW], pT[SW + 1];
+        int pr[SW];
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            const int kk = k0 - j;
+            if (kk >= 0) {
+                const size_t oo = (size_t)kk * W + w;
+                pu[j] = pre[oo]; pL[j] = pre[nW + oo]; pa[j] = pre[2 * nW + oo]; pb[j] = pre[3 * nW + oo];
+                pr[j] = fused ? prow[oo] : 0;
+                pT[j + 1] = ladder[kk];
+            }
         }
-        if (acc) {
-            if (k >= local0 && k < local0 + nlocal) nswap[(size_t)w * n + k] += 1;
-        } else {
-            c = k;
-            Lc = La;
+        pT[0] = ladder[k0 + 1];
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            const int k = k0 - j;
+            if (k < 0) break;
+            const double u = pu[j], La = pL[j];
+            const int krow = pr[j];
+            const double Tk = pT[j + 1], Tk1 = pT[j];
+            double la = pa[j];                 // -L[k] / T[k]
+            la += -Lc / Tk1;
+            la += Lc / Tk;
+            la += pb[j];                       //  L[k] / T[k+1]
+            const bool acc = (parity < 0 || (k & 1) == parity) && u <= det_exp(la);
+            // position k+1 is final: it keeps the carried state, or takes position k's
+            const int fin = acc ? k : c;
+            if (map) { map[(size_t)w * n + k + 1] = fin; inv[(size_t)w * n + fin] = k + 1; }
+            if (fused) {
+                const int frow = acc ? krow : crow;
+                so[k + 1] = frow;
+                to[frow] = k + 1;
+                if (!acc) crow = krow;
+            }
+            if (acc) {
+                // a no-return atomic: the recurrence must not wait for a load of the counter
+                if (k >= local0 && k < local0 + nlocal) atomicAdd((unsigned long long *)&nswap[(size_t)w * n + k], 1ull);
+            } else {
+                c = k;
+                Lc = La;
+            }
         }
     }
-    if (map) map[(size_t)w * n] = c;
+    if (map) { map[(size_t)w * n] = c; inv[(size_t)w * n + c] = 0; }
     if (fused) {
         so[0] = crow;
         to[crow] = 0;
@@ -793,7 +814,7 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
                        (long long)iter, c.seed, c.walker0, 0);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps, h->d_ladder,
                        (const double *)h->d_pre, (const int32_t *)h->d_prow, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr,
-                       (u64 *)h->buf.nswap, 0, c.ntemps, -1);
+                       (u64 *)h->buf.nswap, 0, c.ntemps, -1, (int32_t *)nullptr);
     HIPCHK(hipGetLastError());
     return ptmi_swap_write_am(h, iter);
 }
@@ -808,6 +829,20 @@ int ptmi_swap_gather_lnl(ptmi_handle h, double *out)
     return PTMI_OK;
 }
 
+// exchange scratch: inv[W][ntg] (written by the sweep), newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
+static size_t xint_count(const ptmi_config &c)
+{
+    const size_t W = (size_t)c.nwalkers, nr = (size_t)((c.ntemps_global + c.ntemps - 1) / c.ntemps);
+    return W * c.ntemps_global + W * c.ntemps + nr * W + 4 * W + 1;
+}
+static int ensure_xint(ptmi_engine *h)
+{
+    if (h->d_xint) return PTMI_OK;
+    HIPCHK(hipMalloc((void **)&h->d_xint, sizeof(int32_t) * xint_count(h->cfg)));
+    HIPCHK(hipMemsetAsync(h->d_xint, 0, sizeof(int32_t) * xint_count(h->cfg), h->stream));
+    return PTMI_OK;
+}
+
 static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t *map, int block_nt)
 {
     if (!h || !lnL || !map) return fail(PTMI_EINVAL, "NULL argument");
@@ -815,12 +850,14 @@ static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t 
     const ptmi_config &c = h->cfg;
     const int W = c.nwalkers;
     const long long tot = (long long)W * c.ntemps_global;
+    if (int rc = ensure_xint(h)) return rc;
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global,
                        h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, h->d_pre, h->d_prow,
                        (long long)iter, c.seed, c.walker0, block_nt);
     hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps_global, h->d_ladder,
                        (const double *)h->d_pre, (const int32_t *)h->d_prow, (int32_t *)nullptr, (int32_t *)nullptr, map,
-                       (u64 *)h->buf.nswap, c.temp0, c.ntemps, c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1);
+                       (u64 *)h->buf.nswap, c.temp0, c.ntemps, c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1,
+                       h->d_xint /* inv[W][ntemps_global] */);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -835,49 +872,86 @@ int ptmi_swap_sweep_blocks(ptmi_handle h, int64_t iter, const double *lnL_blocks
 }
 
 // ---- device-side exchange of the rows that cross a block edge --------------------------------------------------
-// One thread per walker.  From the global map it (1) inverts it, (2) lists this block's leaving rows (local
-// source, remote destination) and arriving rows (local destination, remote source), both in ascending local
-// position -- the k-th arrival takes the slot the k-th departure frees, the rule of sharded.py's plan_exchange --
-// and (3) rewrites slot_of / temp_of.  A hot -> cold sweep moves at most one row of a walker down out of a block
-// (the carried state) and at most one up (displaced by one level), hence the fixed [2][W] / [nranks][W] tables.
-__global__ void exchange_plan_kernel(int W, int nt, int ntg, int temp0, int nranks, const int32_t *map, int32_t *slot_of,
-                                     int32_t *temp_of, int32_t *inv, int32_t *newslot, int32_t *arr_slot, int32_t *lv_slot,
-                                     int32_t *lv_rank, int32_t *err)
+// One wave per walker, one lane per local position.  From the global map and its inverse (both written by the sweep)
+// it (1) lists this block's leaving rows (local source, remote destination) and arriving rows (local destination,
+// remote source), both in ascending local position -- the k-th arrival takes the slot the k-th departure frees, the
+// rule of sharded.py's plan_exchange -- and (2) rewrites slot_of / temp_of.  A hot -> cold sweep moves at most one
+// row of a walker down out of a block (the carried state) and at most one up (displaced by one level), hence the
+// fixed [2][W] / [nranks][W] tables.  The work is O(local ranks), whatever the length of the whole ladder.
+__global__ __launch_bounds__(256) void exchange_plan_kernel(int W, int nt, int ntg, int temp0, int nranks, const int32_t *map,
+                                                            int32_t *slot_of, int32_t *temp_of, const int32_t *inv, int32_t *newslot,
+                                                            int32_t *arr_slot, int32_t *lv_slot, int32_t *lv_rank, int32_t *err)
 {
-    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (w >= W) return;
     const int me = temp0 / nt;
-    const int32_t *m = map + (size_t)w * ntg;
-    int32_t *iv = inv + (size_t)w * ntg, *so = slot_of + (size_t)w * nt, *to = temp_of + (size_t)w * nt, *ns = newslot + (size_t)w * nt;
-    for (int j = 0; j < ntg; ++j) iv[m[j]] = j;
-    for (int q = 0; q < nranks; ++q) arr_slot[(size_t)q * W + w] = -1;
-    int nlv = 0, freed[2] = {-1, -1};
-    lv_slot[w] = lv_slot[W + w] = -1;
-    lv_rank[w] = lv_rank[W + w] = -1;
-    for (int p = 0; p < nt; ++p) {
-        const int q = iv[temp0 + p] / nt;
-        if (q != me) {
-            if (nlv < 2) { freed[nlv] = so[p]; lv_slot[(size_t)nlv * W + w] = so[p]; lv_rank[(size_t)nlv * W + w] = q; }
-            else atomicAdd(err, 1);
+    const int32_t *m = map + (size_t)w * ntg + temp0, *iv = inv + (size_t)w * ntg + temp0;
+    int32_t *so = slot_of + (size_t)w * nt, *to = temp_of + (size_t)w * nt, *ns = newslot + (size_t)w * nt;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));            // lanes below this one
+    for (int q = lane; q < nranks; q += 64) arr_slot[(size_t)q * W + w] = -1;
+    // departures, ascending local position
+    int nlv = 0, freed0 = -1, freed1 = -1, lq0 = -1, lq1 = -1;
+    for (int base = 0; base < nt; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < nt;
+        const int q = valid ? iv[p] / nt : me;
+        const int slot = valid ? so[p] : -1;
+        const bool leaving = valid && q != me;
+        u64 mask = __ballot(leaving);
+        while (mask) {
+            const int l = __builtin_ctzll(mask);
+            const int fs = __shfl(slot, l, 64), fq = __shfl(q, l, 64);
+            if (nlv == 0) { freed0 = fs; lq0 = fq; }
+            else if (nlv == 1) { freed1 = fs; lq1 = fq; }
             ++nlv;
+            mask &= mask - 1;
         }
     }
-    int narr = 0;
-    for (int j = 0; j < nt; ++j) {
-        const int src = m[temp0 + j], q = src / nt;
-        if (q == me) ns[j] = so[src - temp0];
-        else {
-            const int slot = narr < 2 ? freed[narr] : -1;
-            if (slot < 0 || arr_slot[(size_t)q * W + w] >= 0) atomicAdd(err, 1);
-            else arr_slot[(size_t)q * W + w] = slot;
-            ns[j] = slot < 0 ? 0 : slot;
-            ++narr;
+    // arrivals, ascending local position; rows that stay keep their slot
+    int narr = 0, aq0 = -1;
+    bool bad = nlv > 2 || (nlv == 2 && lq0 == lq1);                       // two destinations on one GPU would collide in send[q][w]
+    for (int base = 0; base < nt; base += 64) {
+        const int j = base + lane;
+        const bool valid = j < nt;
+        const int src = valid ? m[j] : temp0;
+        const int q = src / nt;
+        const bool arriving = valid && q != me;
+        const u64 mask = __ballot(arriving);
+        const int rank = narr + __builtin_popcountll(mask & lt);
+        if (valid) {
+            int slot;
+            if (!arriving) slot = so[src - temp0];
+            else {
+                slot = rank == 0 ? freed0 : (rank == 1 ? freed1 : -1);
+                if (slot >= 0) arr_slot[(size_t)q * W + w] = slot;
+                else { bad = true; slot = 0; }
+            }
+            ns[j] = slot;
         }
+        if (mask) {                                                       // two arrivals from one GPU would collide in recv[q][w]
+            const int l0 = __builtin_ctzll(mask);
+            const int q0 = __shfl(q, l0, 64);
+            if (narr == 0) aq0 = q0;
+            else if (q0 == aq0) bad = true;
+            const u64 rest = mask & (mask - 1);
+            if (rest) {
+                const int q1 = __shfl(q, __builtin_ctzll(rest), 64);
+                if (q1 == aq0) bad = true;
+            }
+        }
+        narr += __builtin_popcountll(mask);
     }
-    if (narr != nlv) atomicAdd(err, 1);
-    // two destinations on one GPU would collide in send[q][w]
-    if (nlv == 2 && lv_rank[w] == lv_rank[W + w]) atomicAdd(err, 1);
-    for (int j = 0; j < nt; ++j) { so[j] = ns[j]; to[ns[j]] = j; }
+    if (narr != nlv) bad = true;
+    if (lane == 0) {                                                      // -1 = no such departure
+        lv_slot[w] = freed0; lv_rank[w] = lq0;
+        lv_slot[W + w] = freed1; lv_rank[W + w] = lq1;
+    }
+    if (__any(bad) && lane == 0) atomicAdd(err, 1);
+    for (int base = 0; base < nt; base += 64) {
+        const int j = base + lane;
+        if (j < nt) { const int sl = ns[j]; so[j] = sl; to[sl] = j; }
+    }
 }
 __global__ void exchange_pack_kernel(int W, int nt, int d, const double *X, const double *lnL, const double *lp,
                                      const int32_t *lv_slot, const int32_t *lv_rank, double *send)
@@ -902,25 +976,18 @@ __global__ void exchange_apply_kernel(int W, int nt, int d, double *X, double *l
     if (threadIdx.x == 0) { lnL[r] = src[d]; lp[r] = src[d + 1]; }
 }
 
-static size_t xint_count(const ptmi_config &c)
-{
-    const size_t W = (size_t)c.nwalkers, nr = (size_t)(c.ntemps_global / c.ntemps);
-    return W * c.ntemps_global + W * c.ntemps + nr * W + 4 * W + 1;
-}
+
 int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send)
 {
     if (!h || !map || !send) return fail(PTMI_EINVAL, "NULL argument");
     const ptmi_config &c = h->cfg;
     if (c.ntemps_global % c.ntemps) return fail(PTMI_EINVAL, "the ladder is not a whole number of blocks");
     const int W = c.nwalkers, nr = c.ntemps_global / c.ntemps;
-    if (!h->d_xint) {
-        HIPCHK(hipMalloc((void **)&h->d_xint, sizeof(int32_t) * xint_count(c)));
-        HIPCHK(hipMemsetAsync(h->d_xint, 0, sizeof(int32_t) * xint_count(c), h->stream));
-    }
+    if (int rc = ensure_xint(h)) return rc;
     int32_t *inv = h->d_xint, *newslot = inv + (size_t)W * c.ntemps_global, *arr = newslot + (size_t)W * c.ntemps;
     int32_t *lvs = arr + (size_t)nr * W, *lvr = lvs + 2 * (size_t)W, *err = lvr + 2 * (size_t)W;
-    hipLaunchKernelGGL(exchange_plan_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps, c.ntemps_global, c.temp0, nr,
-                       map, h->buf.slot_of, h->buf.temp_of, inv, newslot, arr, lvs, lvr, err);
+    hipLaunchKernelGGL(exchange_plan_kernel, dim3((W + 3) / 4), dim3(256), 0, h->stream, W, c.ntemps, c.ntemps_global, c.temp0, nr,
+                       map, h->buf.slot_of, h->buf.temp_of, (const int32_t *)inv, newslot, arr, lvs, lvr, err);
     hipLaunchKernelGGL(exchange_pack_kernel, dim3(W, 2), dim3(64), 0, h->stream, W, c.ntemps, c.ndim, (const double *)h->buf.X,
                        (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)lvs, (const int32_t *)lvr, send);
     HIPCHK(hipGetLastError());

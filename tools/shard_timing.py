@@ -1,0 +1,49 @@
+"""Device time of one swap epoch of a sharded ladder as one of N GPUs sees it (developer tool, one GPU):
+block 0 of an N x 64-rank ladder, likelihoods of the other blocks made up.  usage: shard_timing.py [N ...]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ptmcmcsampler_amd.engine import PTEngine
+
+d, nt, W = 100, 64, 4096
+for N in [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8]:
+    ntg = nt * N
+    e = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=1000, burn=10000, tskip=100, seed=1, cov_mode="pooled",
+                 use_de_buffer=False, ntemps_global=ntg, temp0=0)
+    e.init_state(np.zeros(d))
+    e.mh_steps(1, 99)
+    dev = e.device
+    lnl_loc = torch.empty((W, nt), dtype=torch.float64, device=dev)
+    parts = torch.randn((N, W, nt), dtype=torch.float64, device=dev) * 5 - 50
+    mp = torch.empty((W, ntg), dtype=torch.int32, device=dev)
+    send = torch.zeros((N, W, d + 2), dtype=torch.float64, device=dev)
+    recv = torch.zeros((N, W, d + 2), dtype=torch.float64, device=dev)
+
+    def epoch(it):
+        e.gather_lnl(lnl_loc)
+        parts[0].copy_(lnl_loc)
+        e.sweep_blocks(it, parts, mp)
+        e.exchange_pack(mp, send)
+        e.exchange_apply(recv)
+        e.write_am(it)
+
+    def timed(f, n=5):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        ev[0].record(e.stream)
+        for k in range(n):
+            f(100 * (k + 1))
+        ev[1].record(e.stream)
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / n
+
+    epoch(100)
+    ms = timed(epoch)
+    mh = timed(lambda it: e.mh_steps(it + 1, 99))
+    print("N=%d (ladder of %d): swap epoch %.3f ms on the device, 100 MH steps %.3f ms -> %.1f %% of the MH time" % (N, ntg, ms, mh, 100 * ms / mh), flush=True)
+    del e
+    torch.cuda.empty_cache()
