@@ -54,8 +54,8 @@ def test_sharded_world1_equals_single_engine_and_oracle(world1, cov_mode):
     assert s.swap_proposed == g.swap_proposed == n // 10
 
 
-@pytest.mark.parametrize("nranks,cov_mode", [(2, "per_walker"), (4, "pooled"), (8, "per_walker")])
-def test_device_exchange_with_emulated_ranks(nranks, cov_mode):
+@pytest.mark.parametrize("nranks,cov_mode,ntb", [(2, "per_walker", 3), (4, "pooled", 3), (8, "per_walker", 3), (2, "pooled", 70)])
+def test_device_exchange_with_emulated_ranks(nranks, cov_mode, ntb):
     """Several temperature blocks on ONE GPU (one thread per rank, in-process communicator): the device-side
     exchange (ptmi_swap_sweep_blocks / ptmi_exchange_pack / ptmi_exchange_apply) must reproduce the single-engine
     run and the oracle bit for bit, with rows really crossing block edges."""
@@ -66,7 +66,7 @@ def test_device_exchange_with_emulated_ranks(nranks, cov_mode):
     from oracle import oracle as orc
     from ptmcmcsampler_amd.engine import PTEngine
     from ptmcmcsampler_amd.sharded import ShardedPTEngine
-    d, ntb, W, n = 10, 3, 33, 330
+    d, W, n = (10, 33, 330) if ntb < 64 else (4, 7, 130)       # ntb > 64: more local ranks than lanes in the plan kernel
     ntg = ntb * nranks
     kw = dict(weights=(20, 20, 20), cov_update=50, burn=100, tskip=10, seed=5, cov_mode=cov_mode)
     cov0 = np.eye(d) * 0.05
