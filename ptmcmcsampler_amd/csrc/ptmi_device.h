@@ -107,11 +107,12 @@ __device__ __forceinline__ double det_log(double x)
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
-__device__ __forceinline__ double det_exp(double x)
+// Straight-line: the special cases are selected at the end (a chain per wave lane that branches on them costs more
+// in exec-mask bookkeeping than the few extra instructions); same results as the oracle's early returns.
+__device__ __forceinline__ double det_exp(double xin)
 {
-    if (x != x) return x;
-    if (x > 7.09782712893383973096e+02) return __builtin_inf();
-    if (x < -7.45133219101941108420e+02) return 0.0;
+    const bool isnan = xin != xin, over = xin > 7.09782712893383973096e+02, under = xin < -7.45133219101941108420e+02;
+    const double x = (isnan || over || under) ? 0.0 : xin;           // the main path runs on a harmless argument then
     const int k = (int)(1.44269504088896338700e+00 * x + (x < 0.0 ? -0.5 : 0.5));
     const double dk = (double)k;
     const double hi = x - dk * 6.93147180369123816490e-01;
@@ -121,11 +122,15 @@ __device__ __forceinline__ double det_exp(double x)
     const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 +
                      t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
     const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-    if (k == 0) return y;
-    if (k == 1024) return y * 2.0 * 0x1.0p1023;
     const u64 yb = (u64)__double_as_longlong(y);
-    if (k >= -1021) return __longlong_as_double((long long)(yb + ((u64)(long long)k << 52)));
-    return __longlong_as_double((long long)(yb + ((u64)(long long)(k + 1000) << 52))) * 0x1.0p-1000;
+    const double normal = __longlong_as_double((long long)(yb + ((u64)(long long)k << 52)));                 // k = 0: y itself
+    const double tiny = __longlong_as_double((long long)(yb + ((u64)(long long)(k + 1000) << 52))) * 0x1.0p-1000;
+    const double huge = y * 2.0 * 0x1.0p1023;
+    double res = k >= -1021 ? normal : tiny;
+    res = k == 1024 ? huge : res;
+    res = under ? 0.0 : res;
+    res = over ? __builtin_inf() : res;
+    return isnan ? xin : res;
 }
 
 // p*z + c with the constant c held in a scalar register pair: keeps the 21 Taylor coefficients out of the vector
