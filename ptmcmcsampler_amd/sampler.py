@@ -12,7 +12,12 @@ the reference runs unchanged as ONE process driving one GPU.  Differences, all a
   kernels, one launch pair per iteration) **or** a tuple naming a device likelihood --
   ``("iso",)``, ``("dense", mu, P)``, ``("curved",)`` -- and ``logp`` a callable or
   ``("flat",)`` / ``("box", lo, hi)``; with device likelihoods and no host-side jumps the
-  fused K-step kernel runs.
+  fused K-step kernel runs;
+* ``logl_grad`` / ``logp_grad`` are the reference's gradient callbacks (HMC / NUTS / MALA then run on the host,
+  ``gradjump.py``) or, with a device likelihood, ``True`` for its built-in analytic gradient (NUTS / HMC then run
+  inside the kernel, PTMCMCSampler.py:225-258 with the same weights and step-size keywords);
+* engine options: ``cov_mode="pooled"`` (one covariance adapted from all walkers instead of one per walker),
+  ``swap_mode="oddeven"`` (disjoint swap pairs instead of the reference's hot -> cold sweep), ``keep_walkers``.
 
 Attributes ``_chain, _lnlike, _lnprob, naccepted, nswap_accepted, swapProposed, jumpDict, cov,
 U, S, ladder, temp`` describe walker 0's T = 1 chain, as rank 0's do in the reference.
