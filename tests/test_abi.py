@@ -71,3 +71,44 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("oracle/", "").lower() or f == "_lib.py" or "import oracle" not in src, f
                 assert "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_create_rejects_bad_configurations(lib):
+    """Argument validation of ptmi_create happens before any device is touched: error code and message, no crash."""
+    import ctypes as C
+    import numpy as np
+    L = lib.load()
+    d = 4
+    ladder = np.array([1.0, 2.0])
+    one = np.zeros(8)
+    keep = dict(ladder=ladder, temps=ladder.copy(), tab=np.zeros(3 * d * d))
+
+    def cfg(**over):
+        kw = dict(ndim=d, ntemps=2, nwalkers=2, ntemps_global=2, w_scam=20, cov_update=10, de_size=10, tskip=10, cov_per_walker=1,
+                  ladder=keep["ladder"].ctypes.data_as(lib._dp), temps_mh=keep["temps"].ctypes.data_as(lib._dp))
+        kw.update(over)
+        return lib.Config(**kw)
+
+    buf = lib.Buffers(**{k: C.c_void_p(one.ctypes.data) for k in ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "nacc", "jstat")})
+    h = C.c_void_p()
+
+    def err(c, b=buf):
+        rc = L.ptmi_create(C.byref(c), C.byref(b), C.byref(h))
+        assert rc != 0 and not h
+        return rc, L.ptmi_last_error().decode()
+
+    assert "No jump proposals" in err(cfg(w_scam=0))[1]
+    assert "swap_mode" in err(cfg(swap_mode=7))[1]
+    assert "outside ladder" in err(cfg(temp0=1))[1]
+    assert "cov_update" in err(cfg(cov_update=0))[1]
+    assert "whitening tables" in err(cfg(w_nuts=5))[1]
+    tab = keep["tab"].ctypes.data_as(lib._dp)
+    assert "gj buffer" in err(cfg(w_nuts=5, gj_tab=tab))[1]
+    gbuf = lib.Buffers(**{k: C.c_void_p(one.ctypes.data) for k in ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "nacc", "jstat", "gj")})
+    rc, msg = err(cfg(ndim=40, w_nuts=5, gj_tab=tab), gbuf)
+    assert rc == -3 and "ndim <= 32" in msg                                      # PTMI_EUNSUPPORTED
+    assert "hmc_min" in err(cfg(w_hmc=5, gj_tab=tab, hmc_min=3, hmc_max=3), gbuf)[1]
+    assert "required device buffer" in err(cfg(), lib.Buffers())[1]
+    # a valid configuration gets as far as looking for a device
+    rc, msg = err(cfg()) if lib.device_count() == 0 else (-4, "no HIP device")
+    assert rc == -4 and "no HIP device" in msg
