@@ -80,7 +80,8 @@ typedef struct ptmi_config {
     int32_t ngroups;         /* parameter groups (PTMCMCSampler.py:129-145); 0 or 1 = one group of all parameters */
     int32_t swap_mode;       /* PTMI_SWAP_SWEEP (the reference's hot -> cold sweep, :666-686) or PTMI_SWAP_ODDEVEN */
     /* Gradient jumps on the built-in likelihoods (the reference adds them when logl_grad / logp_grad are given,
-     * :225-258; nutsjump.py): cycle += [NUTS]*w_nuts + [HMC]*w_hmc.  ndim <= 32 in this version. */
+     * :225-258; nutsjump.py): cycle += [NUTS]*w_nuts + [HMC]*w_hmc.  ndim <= 512; the engine then shares a chain among
+     * ptmi_lanes_for_grad(ndim) lanes (at most 8 register slots per lane), which fixes the summation orders. */
     int32_t w_nuts, w_hmc;
     int32_t gj_nburn;        /* nburn of the jump objects (= burn, :227,238,251) */
     int32_t hmc_min, hmc_max;/* HMC takes randint(hmc_min, hmc_max) leapfrogs (:240-241: 2, HMCsteps) */
@@ -140,6 +141,8 @@ int ptmi_version(void);
 int ptmi_device_count(int *count);
 /* lanes of a wavefront that share one chain for a given ndim (fixes the summation order) */
 int ptmi_lanes_for(int ndim);
+/* the same with gradient jumps in the cycle (w_nuts + w_hmc > 0); 0 = not supported */
+int ptmi_lanes_for_grad(int ndim);
 
 int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out);
 int ptmi_destroy(ptmi_handle h);

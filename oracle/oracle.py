@@ -100,8 +100,10 @@ def _p(a, t=_dp):
     return a.ctypes.data_as(t)
 
 
-def lanes_for(ndim):
-    """Lanes that share one chain in the HIP kernels (fixes the summation order)."""
+def lanes_for(ndim, grad=False):
+    """Lanes that share one chain in the HIP kernels (fixes the summation order); grad: with NUTS / HMC in the cycle."""
+    if grad:
+        return 4 if ndim <= 32 else (16 if ndim <= 112 else 64)
     return 4 if ndim <= 104 else (16 if ndim <= 416 else 64)
 
 
@@ -248,7 +250,7 @@ class OracleEngine(object):
         self.cov_update, self.burn, self.tskip, self.seed = cov_update, burn, tskip, seed
         self.per_walker = cov_mode == "per_walker"
         self.Wc = nwalkers if self.per_walker else 1
-        self.lanes = lanes_for(ndim) if lanes is None else lanes
+        self.lanes = lanes_for(ndim, grad=sum(grad_weights) > 0) if lanes is None else lanes
         d, nt, W = ndim, ntemps, nwalkers
         self.X = np.zeros((W, nt, d))
         self.lnL = np.zeros((W, nt))

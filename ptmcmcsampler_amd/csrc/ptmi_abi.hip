@@ -484,14 +484,14 @@ __global__ void selftest_philox_kernel(const u32 *ck, u32 *out, long long n)
 
 // ------------------------------------------------------------------- engine
 struct Shape { int G, EPL; };
-static bool pick_shape(int d, Shape *s)
+static bool pick_shape(int d, bool grad, Shape *s)
 {
     static const Shape table[] = {
 #define PTMI_TABLE_ENTRY(G_, E_) {G_, E_},
         PTMI_SHAPE_LIST(PTMI_TABLE_ENTRY)};
-    const int G = ptmi_lanes_for(d);
+    const int G = grad ? ptmi_lanes_for_grad(d) : ptmi_lanes_for(d);
     for (const Shape &c : table)
-        if (c.G == G && c.G * c.EPL >= d) { *s = c; return true; }
+        if (c.G == G && c.G * c.EPL >= d && (!grad || c.EPL <= 8)) { *s = c; return true; }
     return false;
 }
 
@@ -561,6 +561,8 @@ extern "C" {
 const char *ptmi_last_error(void) { return g_err; }
 int ptmi_version(void) { return PTMI_VERSION; }
 int ptmi_lanes_for(int ndim) { return ndim <= 104 ? 4 : (ndim <= 416 ? 16 : 64); }
+// gradient jumps keep seven chain vectors in registers: at most 8 slots per lane (shapes (4,8), (16,7), (64,8))
+int ptmi_lanes_for_grad(int ndim) { return ndim <= 32 ? 4 : (ndim <= 112 ? 16 : (ndim <= 512 ? 64 : 0)); }
 
 int ptmi_device_count(int *count)
 {
@@ -611,7 +613,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (gj) {
         if (!c.gj_tab) return fail(PTMI_EINVAL, "gradient jumps need the whitening tables (gj_tab)");
         if (!buf->gj) return fail(PTMI_EINVAL, "gradient jumps need the gj buffer");
-        if (c.ndim > 32) return fail(PTMI_EUNSUPPORTED, "gradient jumps on the device are built for ndim <= 32 (got %d)", c.ndim);
+        if (c.ndim > 512) return fail(PTMI_EUNSUPPORTED, "gradient jumps on the device are built for ndim <= 512 (got %d)", c.ndim);
         if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "gradient jumps with parameter groups are not built");
         if (c.w_host > 0) return fail(PTMI_EUNSUPPORTED, "gradient jumps on the device cannot be mixed with host-served jumps");
         if (c.nuts_maxdepth < 0 || c.nuts_maxdepth > 24) return fail(PTMI_EINVAL, "nuts_maxdepth out of range");
@@ -622,7 +624,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (c.w_de > 0 && !buf->DE) return fail(PTMI_EINVAL, "DE weight > 0 but no DE buffer");
     if ((unsigned long long)c.nwalkers * (unsigned)c.ntemps_global > 0xFFFFFFFFull) return fail(PTMI_EINVAL, "too many RNG streams");
     Shape s;
-    if (!pick_shape(c.ndim, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported (max 2048)", c.ndim);
+    if (!pick_shape(c.ndim, gj, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported (max 2048)", c.ndim);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(PTMI_ENODEVICE, "no HIP device visible: libptmi has no CPU fallback");

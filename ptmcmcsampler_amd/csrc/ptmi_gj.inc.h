@@ -82,7 +82,8 @@ struct GradJump {
     template <int WHICH>
     __device__ __forceinline__ void tab_vec(const double *Tg, const double (&v)[EPL], double (&out)[EPL]) const
     {
-        const double *T = WHICH >= 0 ? gj_lds + (size_t)WHICH * d * d : Tg;
+        // quads (ndim <= 32) find the tables in LDS; the wider layouts read them through L2
+        const double *T = WHICH < 0 ? Tg : (G == 4 ? gj_lds + (size_t)WHICH * d * d : a.gj_tab + (size_t)WHICH * d * d);
         double acc[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = 0.0;
@@ -413,8 +414,10 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
     constexpr int CPB = GJ_BLOCK / G;
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
-    for (int i = (int)threadIdx.x; i < 3 * d * d; i += GJ_BLOCK) gj_lds[i] = a.gj_tab[i];
-    __syncthreads();
+    if (G == 4) {
+        for (int i = (int)threadIdx.x; i < 3 * d * d; i += GJ_BLOCK) gj_lds[i] = a.gj_tab[i];
+        __syncthreads();
+    }
     const long long ch = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
     if (ch >= nch) return;                       // no block-wide synchronisation below: whole chain groups may leave
     const int gl = (int)(threadIdx.x % G);

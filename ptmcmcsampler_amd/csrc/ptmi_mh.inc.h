@@ -213,11 +213,12 @@ constexpr int safe_slots(int G, int EPL)
          : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
 }
 // element i = gl + G*e of a table row
-#define PTMI_ROW_LOAD(dst, row, e)                                         \
+#define PTMI_ROW_LOAD_S(SAFE, dst, row, e)                                 \
     do {                                                                   \
-        if ((e) < safe_slots(G, EPL)) dst = (row)[gl + G * (e)];           \
+        if ((e) < (SAFE)) dst = (row)[gl + G * (e)];                       \
         else dst = (gl + G * (e)) < d ? (row)[gl + G * (e)] : 0.0;         \
     } while (0)
+#define PTMI_ROW_LOAD(dst, row, e) PTMI_ROW_LOAD_S(safe_slots(G, EPL), dst, row, e)
 
 // One proposal for the caller's chain (PT:1048-1067, 820-985): writes the increment dq
 // (q = x + dq) and returns the jump type.  log_u = log(accept uniform), evaluated in the
@@ -233,6 +234,8 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
                                        double (&dq)[EPL], double &log_u, double &u_acc)
 {
     const int d = a.d;
+    // with gradient jumps a shape serves every ndim up to G*EPL (ptmi_lanes_for_grad), so no slot is exempt from the bounds check
+    constexpr int PSAFE = GJ ? 0 : safe_slots(G, EPL);
     const int uld = (STR && ut_padded) ? mfma_ld(EPL) : d;   // leading dimension of the Ut table
     // the four lanes of a quad evaluate slots A..D of this chain in one pass
     u64 w0, w1;
@@ -286,7 +289,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         // the direction lands in dq (issued before the normal is computed, so its latency is covered) and
         // is scaled in place
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], col, e);
+        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD_S(PSAFE, dq[e], col, e);
         const double sk = S[k];
         const double z = det_sqrt(-2.0 * ln1) * det_cos2pi(w2uniform(D1));
         const double cd = br == 0 ? cc.cd_scam[0] : (br == 1 ? cc.cd_scam[1] : cc.cd_scam[2]);
@@ -305,8 +308,8 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             double vm, vn;
-            PTMI_ROW_LOAD(vm, rm, e);
-            PTMI_ROW_LOAD(vn, rn, e);
+            PTMI_ROW_LOAD_S(PSAFE, vm, rm, e);
+            PTMI_ROW_LOAD_S(PSAFE, vn, rn, e);
             dq[e] = scale * (vm - vn);
             if (GRP) {                                 // only the group's parameters move (PT:978-983)
                 const int i = gl + G * e;
@@ -361,7 +364,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
 #pragma unroll
                         for (int e = 0; e < EPL; ++e) {
                             double r;
-                            PTMI_ROW_LOAD(r, row, e);
+                            PTMI_ROW_LOAD_S(PSAFE, r, row, e);
                             dq[e] = __builtin_fma(r, wv, dq[e]);
                         }
                     }

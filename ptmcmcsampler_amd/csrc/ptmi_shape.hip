@@ -26,7 +26,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
             const long long nch = (long long)h->cfg.nwalkers * h->cfg.ntemps;
             const int cpb = GJ_BLOCK / G;
             hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK),
-                               sizeof(double) * 3 * (size_t)h->cfg.ndim * h->cfg.ndim, h->stream, a);
+                               G == 4 ? sizeof(double) * 3 * (size_t)h->cfg.ndim * h->cfg.ndim : 0, h->stream, a);
             return PTMI_OK;
         } else {
             return fail(PTMI_EUNSUPPORTED, "gradient jumps are built for kernel shapes with at most 8 register slots per lane");

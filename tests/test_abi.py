@@ -48,7 +48,9 @@ def test_struct_layouts_match_the_header(lib):
     assert got == [C.sizeof(lib.Config), lib.Config.swap_mode.offset, lib.Config.seed.offset, lib.Config.group_mask.offset,
                    C.sizeof(lib.Buffers), lib.Buffers.AMaux.offset, lib.Config.hmc_eps.offset, lib.Config.gj_tab.offset,
                    lib.Buffers.gj.offset]
-    assert [lib.lanes_for(d) for d in (2, 32, 33, 100, 104, 105, 256, 416, 417, 640, 641, 1024, 1025, 2048)] == [lib.load().ptmi_lanes_for(d) for d in (2, 32, 33, 100, 104, 105, 256, 416, 417, 640, 641, 1024, 1025, 2048)]
+    dims = (2, 32, 33, 100, 104, 105, 112, 113, 256, 416, 417, 512, 513, 640, 641, 1024, 1025, 2048)
+    assert [lib.lanes_for(d) for d in dims] == [lib.load().ptmi_lanes_for(d) for d in dims]
+    assert [lib.lanes_for(d, grad=True) for d in dims] == [lib.load().ptmi_lanes_for_grad(d) for d in dims]
 
 
 def test_no_cpu_fallback(lib):
@@ -105,8 +107,8 @@ def test_create_rejects_bad_configurations(lib):
     tab = keep["tab"].ctypes.data_as(lib._dp)
     assert "gj buffer" in err(cfg(w_nuts=5, gj_tab=tab))[1]
     gbuf = lib.Buffers(**{k: C.c_void_p(one.ctypes.data) for k in ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "nacc", "jstat", "gj")})
-    rc, msg = err(cfg(ndim=40, w_nuts=5, gj_tab=tab), gbuf)
-    assert rc == -3 and "ndim <= 32" in msg                                      # PTMI_EUNSUPPORTED
+    rc, msg = err(cfg(ndim=600, w_nuts=5, gj_tab=tab), gbuf)
+    assert rc == -3 and "ndim <= 512" in msg                                     # PTMI_EUNSUPPORTED
     assert "hmc_min" in err(cfg(w_hmc=5, gj_tab=tab, hmc_min=3, hmc_max=3), gbuf)[1]
     assert "required device buffer" in err(cfg(), lib.Buffers())[1]
     # a valid configuration gets as far as looking for a device

@@ -30,6 +30,11 @@ CASES = [
     dict(d=8, nt=2, W=4, logl=("dense",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0)),
     dict(d=32, nt=2, W=3, logl=("iso",), logp=("box", -3.0, 3.0), grad_weights=(5, 20), weights=(10, 0, 10)),
     dict(d=2, nt=3, W=7, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.08, 2, 50)),
+    # wider lane layouts: 16 lanes per chain (33 <= d <= 112), 64 lanes (d <= 512)
+    dict(d=40, nt=2, W=3, logl=("dense",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10)),
+    dict(d=100, nt=2, W=2, logl=("iso",), logp=("box", -4.0, 4.0), grad_weights=(10, 5), weights=(10, 0, 10)),
+    dict(d=150, nt=2, W=2, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0)),
+    dict(d=34, nt=2, W=3, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 0, 10), hmc=(0.08, 2, 50)),
 ]
 
 
