@@ -89,6 +89,8 @@ def lib():
         L.orc_eval_state.argtypes = [C.POINTER(Cfg), C.POINTER(State)]
         L.orc_gradjump.argtypes = [C.POINTER(Cfg), C.c_int, _dp, C.c_int64, C.c_double, _dp, C.c_uint64,
                                    C.POINTER(Replay), _dp, _dp, C.POINTER(C.c_int64)]
+        L.orc_logl_grad.restype = C.c_double
+        L.orc_logl_grad.argtypes = [C.POINTER(Cfg), _dp, _dp]
         L.orc_logl.restype = C.c_double
         L.orc_logl.argtypes = [C.POINTER(Cfg), _dp]
         assert L.orc_sizeof_cfg() == C.sizeof(Cfg)

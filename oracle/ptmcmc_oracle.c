@@ -1003,4 +1003,13 @@ ORC_API double orc_logl(const orc_cfg *c, const double *x)
     return v;
 }
 
+/* value and gradient of a built-in likelihood (what the gradient jumps see) */
+ORC_API double orc_logl_grad(const orc_cfg *c, const double *x, double *g)
+{
+    double *tmp = (double *)malloc(sizeof(double) * 2 * (size_t)c->ndim);
+    double v = eval_logl_grad(c, x, tmp, g);
+    free(tmp);
+    return v;
+}
+
 ORC_API int orc_sizeof_cfg(void) { return (int)sizeof(orc_cfg); }

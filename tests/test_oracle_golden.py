@@ -189,3 +189,44 @@ def test_full_trajectory_matches_reference(golden, name):
         assert np.allclose(M2, g["ep_M2_%d" % i], rtol=1e-9, atol=1e-12)
         assert np.allclose(cov, g["ep_cov_%d" % i], rtol=1e-9, atol=1e-12)
         assert np.allclose(S, g["ep_S_%d" % i], rtol=1e-8, atol=1e-14)
+
+
+def test_builtin_likelihood_gradients():
+    """The analytic gradients the device NUTS / HMC use: the curved likelihood against the formulas of the reference's
+    examples/curved_likelihood.ipynb (cell 1, lnlikefn / lnlikefn_grad, written out here), the Gaussians against their
+    closed forms and all three against central differences."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+
+    def oracle(kind, x, par=None):
+        d = len(x)
+        par_l = np.zeros(1) if par is None else par
+        cfg = orc.Cfg(ndim=d, ntemps=1, nwalkers=1, lanes=4, logl_kind=orc.LOGL[kind], logp_kind=0, logl_par=orc._p(par_l))
+        g = np.zeros(d)
+        v = orc.lib().orc_logl_grad(C.byref(cfg), orc._p(np.ascontiguousarray(x)), orc._p(g))
+        return v, g
+
+    def curved_nb(x):                                   # one 2-d block of the notebook's likelihood
+        l0 = -x[0] ** 2 - (9 + 4 * x[0] ** 2 + 9 * x[1]) ** 2
+        l1 = -8 * x[0] ** 2 - 8 * (x[1] - 2) ** 2
+        g0 = np.array([-2.0 * x[0] - 2.0 * (9 + 4 * x[0] ** 2 + 9 * x[1]) * (8 * x[0]), -18.0 * (9 + 4 * x[0] ** 2 + 9 * x[1])])
+        g1 = np.array([-16 * x[0], -16 * (x[1] - 2)])
+        lik = np.exp(l0) + 0.5 * np.exp(l1)
+        return np.log(lik), (np.exp(l0) * g0 + 0.5 * np.exp(l1) * g1) / lik
+
+    for _ in range(20):
+        x = np.concatenate([np.array([-0.1, -0.5]) + rng.normal(size=2) * 0.3 for _ in range(3)])
+        v, g = oracle("curved", x)
+        ref = [curved_nb(x[i:i + 2]) for i in range(0, 6, 2)]
+        assert abs(v - sum(r[0] for r in ref)) < 1e-12 * max(1.0, abs(v))
+        np.testing.assert_allclose(g, np.concatenate([r[1] for r in ref]), rtol=1e-11, atol=1e-12)
+    d = 6
+    A = rng.normal(size=(d, d))
+    P, mu = A @ A.T / d + np.eye(d), rng.normal(size=d)
+    par = np.concatenate([mu, np.ascontiguousarray(P.T).ravel()])
+    for kind, p, f in (("iso", None, lambda x: -0.5 * x @ x), ("dense", par, lambda x: -0.5 * (x - mu) @ P @ (x - mu))):
+        x = rng.normal(size=d)
+        v, g = oracle(kind, x, p)
+        assert abs(v - f(x)) < 1e-12 * max(1.0, abs(v))
+        num = np.array([(f(x + h) - f(x - h)) / 2e-6 for h in np.eye(d) * 1e-6])
+        np.testing.assert_allclose(g, num, rtol=1e-6, atol=1e-6)
