@@ -308,17 +308,24 @@ class OracleEngine(object):
                      _p(self.jstat, _up), _p(self.gj))
 
     def _svd(self, w):
-        # LAPACK results depend on the BLAS thread count in the last bits; the product pins one thread
-        # for these small factorizations (engine._blas_single_thread) and the checker must do the same
+        # LAPACK results depend on the BLAS thread count in the last bits, so the checker uses the product's rule:
+        # per-walker mode = the reference's np.linalg.svd on one thread (PTMCMCSampler.py:145, 803); pooled mode (not a
+        # replica of a reference run) = np.linalg.eigh, eigenvalues by decreasing size and in absolute value, on one
+        # thread up to 256 parameters and on 8 beyond
         try:
             from threadpoolctl import threadpool_limits
-            ctx = threadpool_limits(limits=1)
         except ImportError:
             import contextlib
-            ctx = contextlib.nullcontext()
-        for gi, g in enumerate(self.groups):               # per-group SVD, PTMCMCSampler.py:139-145, 797-803
-            with ctx:
-                U, S, _ = np.linalg.svd(self.cov[w][np.ix_(g, g)])
+            threadpool_limits = lambda limits: contextlib.nullcontext()   # noqa: E731
+        for gi, g in enumerate(self.groups):               # per group, PTMCMCSampler.py:139-145, 797-803
+            c = self.cov[w][np.ix_(g, g)]
+            if self.per_walker:
+                with threadpool_limits(limits=1):
+                    U, S, _ = np.linalg.svd(c)
+            else:
+                with threadpool_limits(limits=1 if len(c) <= 256 else 8):
+                    ev, V = np.linalg.eigh(c)
+                U, S = np.ascontiguousarray(V[:, ::-1]), np.abs(ev[::-1])
             self.set_eig(U, S, w, gi)
 
     def set_eig(self, U, S, w=0, gi=0):

@@ -182,10 +182,13 @@ def test_curved_likelihood(mods):
     _compare(g, o, "curved ")
 
 
-def test_pooled_covariance_mode(mods):
-    g, o = _pair(mods, 12, 3, 9, cov_mode="pooled", weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=21)
-    g.run(250)
-    o.run(250)
+@pytest.mark.parametrize("d,W,n", [(12, 9, 250), (100, 70, 130), (300, 5, 130)])
+def test_pooled_covariance_mode(mods, d, W, n):
+    """One covariance from all walkers: fused Welford (matrix cores up to d = 112, tiles beyond), two-level pooling,
+    symmetric eigen-decomposition on the host (8 BLAS threads beyond 256 parameters)."""
+    g, o = _pair(mods, d, 3, W, cov_mode="pooled", weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=21)
+    g.run(n)
+    o.run(n)
     _compare(g, o, "pooled ")
     assert_same(g.get("cov"), o.cov, "pooled cov")
     assert_same(g.get("Ut"), o.Ut, "pooled Ut")
