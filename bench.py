@@ -42,7 +42,7 @@ def parse():
                          "walkers = every GPU holds whole ladders of its own walkers (no data-path collective)")
     ap.add_argument("--sharded", action="store_true", help="use the sharded engine even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=10000, help="iterations per host core of the CPU baseline (10-30 s of CPU work)")
+    ap.add_argument("--cpu-iters", type=int, default=100000, help="iterations per usable host core of the CPU baseline (10-30 s)")
     ap.add_argument("--ess-walkers", type=int, default=32)
     return ap.parse_args()
 

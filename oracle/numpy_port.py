@@ -153,18 +153,42 @@ def _worker(args):
     return time.perf_counter() - t0
 
 
-def time_baseline(ndim=100, niter=6000, covUpdate=1000, burn=10000, weights=(20, 0, 0), cores=None, ladder=None):
-    """One chain per process on ``cores`` host cores (the reference's one-chain-per-rank model);
-    returns (updates per second over all cores, cores, description)."""
-    import multiprocessing as mp
+def usable_cores():
+    """Cores this process may actually use: the smaller of the visible CPUs, the affinity mask and the cgroup CPU quota
+    (a container can show 256 CPUs and be throttled to 16)."""
     import os
-    cores = cores or os.cpu_count() or 1
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def time_baseline(ndim=100, niter=6000, covUpdate=1000, burn=10000, weights=(20, 0, 0), cores=None, ladder=None):
+    """One chain per process on ``cores`` host cores (the reference's one-chain-per-rank model; default: every core
+    this process may use); returns (updates per second over all cores, cores, description)."""
+    import multiprocessing as mp
+    cores = cores or usable_cores()
     if ladder is None:
         ladder = (1 + np.sqrt(2 / ndim)) ** np.arange(cores)
     jobs = [(ndim, float(ladder[r % len(ladder)]), niter, covUpdate, burn, weights, 100 + r) for r in range(cores)]
-    t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(_worker, jobs)
-    wall = time.perf_counter() - t0
-    return cores * niter / wall, cores, "%d chains (one per core) x %d iterations, ndim=%d, covUpdate=%d" % (
-        cores, niter, ndim, covUpdate)
+        times = pool.map(_worker, jobs, chunksize=1)
+    # the chains run side by side; the slowest one's own loop time is the wall time of the sampling itself (process
+    # start-up and imports, which a long reference run amortizes, are left out)
+    wall = max(times)
+    return cores * niter / wall, cores, "%d chains (one per core) x %d iterations, ndim=%d, covUpdate=%d; slowest chain %.1f s" % (
+        cores, niter, ndim, covUpdate, wall)

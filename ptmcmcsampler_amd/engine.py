@@ -34,6 +34,23 @@ def _blas_single_thread():
     return _blas_threads(1)
 
 
+def _usable_cores():
+    """Visible CPUs, capped by the affinity mask and the cgroup CPU quota."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def factorize(cov, per_walker):
     """Eigen-directions U (columns) and variances S of a jump covariance.
 
@@ -216,7 +233,7 @@ class PTEngine(object):
         torch = _torch()
         whole = self.ngr == 1 and len(self.groups[0]) == self.d
         groups = None if whole else self.groups
-        nwork = int(os.environ.get("PTMI_EIG_WORKERS", min(64, os.cpu_count() or 1)))
+        nwork = int(os.environ.get("PTMI_EIG_WORKERS", min(64, _usable_cores())))
         if self.Wc < 64 or nwork <= 1:
             Ut, Sv = _eigworker.svd_chunk((cov, groups))
         else:
