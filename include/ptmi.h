@@ -144,6 +144,11 @@ int ptmi_lanes_for(int ndim);
 /* the same with gradient jumps in the cycle (w_nuts + w_hmc > 0); 0 = not supported */
 int ptmi_lanes_for_grad(int ndim);
 
+/* temperatureLadder (PTMCMCSampler.py:699-720), host arithmetic: out[i] = Tmin * tstep^i, i < nchain, with
+ * tstep = the argument if > 0, else exp(log(Tmax/Tmin)/(nchain-1)) if Tmax > 0, else 1 + sqrt(2/ndim); a single chain
+ * gets {1}.  `out` is HOST memory [nchain]. */
+int ptmi_temperature_ladder(int nchain, int ndim, double Tmin, double Tmax, double tstep, double *out);
+
 int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out);
 int ptmi_destroy(ptmi_handle h);
 int ptmi_sync(ptmi_handle h);
@@ -194,7 +199,7 @@ int ptmi_exchange_status(ptmi_handle h, int32_t *violations);
 /* _updateRecursive (:769-794) for every walker at iteration `iter` (= the multiple of
  * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 the
  * walkers' statistics are pooled into cov[0].  The eigendecomposition (:797-803) is a
- * separate step: the host (LAPACK, as the reference) or ptmi_eig_jacobi. */
+ * separate step on the host (LAPACK, as the reference). */
 int ptmi_update_cov(ptmi_handle h, int64_t iter);
 
 /* _updateDEbuffer (:806-817): drop the oldest cov_update rows of each DE history and

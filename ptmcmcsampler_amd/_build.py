@@ -12,8 +12,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 OUT = os.path.join(HERE, "libptmi.so")
-DEPS = [os.path.join(CSRC, f) for f in ("ptmi_abi.hip", "ptmi_shape.hip", "ptmi_mh.inc.h", "ptmi_common.h", "ptmi_device.h")] + [
-    os.path.join(os.path.dirname(HERE), "include", "ptmi.h")]
+
+
+def deps():
+    """Every source the library is built from: all of csrc/*.hip, csrc/*.h and the public header."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [
+        os.path.join(os.path.dirname(HERE), "include", "ptmi.h")]
+
+
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
@@ -31,7 +38,7 @@ def stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in DEPS)
+    return any(os.path.getmtime(p) > t for p in deps())
 
 
 def _compile(job):

@@ -564,6 +564,17 @@ int ptmi_lanes_for(int ndim) { return ndim <= 104 ? 4 : (ndim <= 416 ? 16 : 64);
 // gradient jumps keep seven chain vectors in registers: at most 8 slots per lane (shapes (4,8), (16,7), (64,8))
 int ptmi_lanes_for_grad(int ndim) { return ndim <= 32 ? 4 : (ndim <= 112 ? 16 : (ndim <= 512 ? 64 : 0)); }
 
+// PT:699-720: geometric ladder T_i = Tmin * tstep^i; the spacing is 1 + sqrt(2/ndim) unless Tmax (> 0) or tstep (> 0)
+// fixes it.  Host arithmetic in the reference's operation order (libm pow / exp / log, as NumPy's scalar path).
+int ptmi_temperature_ladder(int nchain, int ndim, double Tmin, double Tmax, double tstep, double *out)
+{
+    if (!out || nchain < 1 || ndim < 1) return fail(PTMI_EINVAL, "ladder: bad argument");
+    double step = tstep;
+    if (!(step > 0.0)) step = Tmax > 0.0 ? exp(log(Tmax / Tmin) / (double)(nchain - 1)) : 1.0 + sqrt(2.0 / (double)ndim);
+    for (int i = 0; i < nchain; ++i) out[i] = nchain > 1 ? Tmin * pow(step, (double)i) : 1.0;
+    return PTMI_OK;
+}
+
 int ptmi_device_count(int *count)
 {
     if (!count) return fail(PTMI_EINVAL, "count is NULL");

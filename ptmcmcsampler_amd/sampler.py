@@ -13,7 +13,7 @@ the reference runs unchanged as ONE process driving one GPU.  Differences, all a
   ``("iso",)``, ``("dense", mu, P)``, ``("curved",)`` -- and ``logp`` a callable or
   ``("flat",)`` / ``("box", lo, hi)``; with device likelihoods and no host-side jumps the
   fused K-step kernel runs;
-* ``logl_grad`` / ``logp_grad`` are the reference's gradient callbacks (HMC / NUTS / MALA then run on the host,
+* ``logl_grad`` / ``logp_grad`` are the reference's gradient callbacks (HMC / NUTS then run on the host,
   ``gradjump.py``) or, with a device likelihood, ``True`` for its built-in analytic gradient (NUTS / HMC then run
   inside the kernel, PTMCMCSampler.py:225-258 with the same weights and step-size keywords);
 * engine options: ``cov_mode="pooled"`` (one covariance adapted from all walkers instead of one per walker),
@@ -206,11 +206,11 @@ class PTSampler(object):
         self.ind_next_write = 0
         self.naccepted = self.swapProposed = self.nswap_accepted = 0
         if self.logl_grad is not None and self.logp_grad is not None:                  # :226-258, same order
-            from .gradjump import HMCJump, MALAJump, NUTSJump
+            from .gradjump import HMCJump, NUTSJump
             lg, pg, cov, nb = self.logl_grad, self.logp_grad, self.cov, self.burn
-            if MALAweight > 0:
-                self.addProposalToCycle(_PerRankJump(self, lambda: MALAJump(lg, pg, cov, nb)), MALAweight)
-                print("WARNING: MALA jumps are not working properly yet")
+            if MALAweight > 0 and self.verbose:                                        # :229-235
+                print("WARNING: MALA jumps are not provided (the reference flags them as not working properly, "
+                      "PTMCMCSampler.py:230-231): MALAweight ignored")
             if HMCweight > 0:
                 self.addProposalToCycle(_PerRankJump(self, lambda: HMCJump(lg, pg, cov, nb, stepsize=HMCstepsize, nminsteps=2,
                                                                           nmaxsteps=HMCsteps)), HMCweight)

@@ -114,3 +114,18 @@ def test_create_rejects_bad_configurations(lib):
     # a valid configuration gets as far as looking for a device
     rc, msg = err(cfg()) if lib.device_count() == 0 else (-4, "no HIP device")
     assert rc == -4 and "no HIP device" in msg
+
+
+def test_product_ladder_matches_the_reference_fixture(lib, golden):
+    """ptmi_temperature_ladder (host arithmetic behind the C ABI) against the reference's temperatureLadder outputs
+    (PTMCMCSampler.py:699-720; fixture written by tests/golden/make_golden.py), bit for bit, incl. the integer lone chain."""
+    import numpy as np
+    from ptmcmcsampler_amd.ladder import temperature_ladder
+    g = golden("ladder")
+    for i, (n, d, Tmin, Tmax) in enumerate(g["cases"]):
+        got = temperature_ladder(int(n), int(d), Tmin, None if Tmax < 0 else Tmax)
+        assert np.array_equal(np.asarray(got, dtype=np.float64), g["ladder_%d" % i]), i
+    one = temperature_ladder(1, 7)
+    assert one.dtype.kind == "i" and "chain_{0}.txt".format(one[0]) == "chain_1.txt"      # PTMCMCSampler.py:285, :718
+    assert "chain_{0}.txt".format(temperature_ladder(2, 2)[0]) == "chain_1.0.txt"
+    assert np.allclose(temperature_ladder(4, 10, 1, None, 2.0), [1, 2, 4, 8])
