@@ -1,19 +1,27 @@
 #!/usr/bin/env python
-"""bench.py -- MH updates/sec of the fused Metropolis-Hastings hot path on MI355X.
+"""bench.py -- MH updates/sec (+ ESS/sec) of the fused Metropolis-Hastings hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): 100-d isotropic Gaussian logl,
-flat prior, 64 temperatures x 4096 walkers per GPU, p0 = 0, cov0 = 0.01 I, SCAM proposal
-cycle ("SCAM + accept kernel"), Tskip = 100, covUpdate = 1000, burn = 10000, seed 1234,
-pooled covariance.  One "step" = one MH iteration of every chain (swap and covariance
-epochs included in the wall time).  With --gpus N the ladder is sharded by temperature
-block (64 ranks per GPU, 64*N in the ladder) and rows cross block edges over RCCL.
+Workload (BASELINE.json configs[1], SURVEY 8d "C2"): 100-d isotropic Gaussian logl, flat prior, 64 temperatures x 4096
+walkers per GPU, p0 = 0, cov0 = 0.01 I, SCAM proposal cycle ("SCAM + accept kernel"), Tskip = 100, covUpdate = 1000,
+burn = 10000, seed 1234, pooled covariance.
 
-Prints ONE JSON line (rank 0).  `value` = whole-job MH updates per second with the state
-resident in HBM before the timed region.
+One "step" = one Tskip cycle of the hot path over the whole batch: 100 Metropolis-Hastings iterations of every chain, the
+PT swap that closes the cycle, and whatever covariance / DE epochs fall inside (one covariance epoch every 10 steps).
+`--steps K --warmup W` therefore time K*100 iterations after W*100 untimed ones; swap and covariance epochs are inside the
+wall time whatever K is (K >= 10 contains at least one covariance epoch).  `value` = chains x iterations / wall, whole job,
+with the state resident in HBM before the timed region.
+
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one per GPU, RCCL); under an external
+`python -m torch.distributed.run ... bench.py --gpus N` it uses the ranks it is given.  The ladder is then sharded by
+temperature block (64 ranks per GPU, 64*N in the ladder) and rows cross block edges over RCCL.
+
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,21 +29,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix = FP64 vector
+F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector = FP64 matrix peak
+TSKIP = 100                    # iterations per step
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=200, help="timed Tskip cycles (100 MH iterations + swap each)")
+    ap.add_argument("--warmup", type=int, default=100, help="untimed Tskip cycles before them")
     ap.add_argument("--ndim", type=int, default=100)
     ap.add_argument("--ntemps", type=int, default=64, help="temperature ranks per GPU")
     ap.add_argument("--nwalkers", type=int, default=4096)
     ap.add_argument("--mix", default="scam", choices=["scam", "default", "nuts"],
                     help="scam: SCAM-only; default: SCAM/AM/DE 20/20/20; nuts: SCAM/DE/NUTS 10/10/10 (BASELINE configs[4])")
+    ap.add_argument("--pick", default="chain", choices=["chain", "walker"],
+                    help="chain: every chain picks its proposal from its own stream (a replica of the reference); "
+                         "walker: one pick per walker and iteration (wave-uniform proposal type)")
     ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
-    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker"])
+    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker", "per_walker_device"])
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
@@ -43,8 +55,11 @@ def parse():
     ap.add_argument("--sharded", action="store_true", help="use the sharded engine even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100000, help="iterations per usable host core of the CPU baseline (10-30 s)")
-    ap.add_argument("--ess-walkers", type=int, default=32)
+    ap.add_argument("--ess-walkers", type=int, default=64)
     return ap.parse_args()
+
+
+T0 = time.perf_counter()
 
 
 def log(msg):
@@ -52,12 +67,21 @@ def log(msg):
         print("[bench %7.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
 
 
-T0 = time.perf_counter()
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, and hand their exit
+    code on.  Rank 0 of the children prints the JSON line on the inherited stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="1")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(a, weights):
     """Timed in a fresh interpreter BEFORE this process touches the GPU (no fork after HIP init)."""
-    import subprocess
     code = ("import json,sys; sys.path.insert(0, %r); from oracle import numpy_port as p; "
             "v,c,w = p.time_baseline(ndim=%d, niter=%d, covUpdate=1000, burn=10000, weights=%r); "
             "print(json.dumps([v,c,w]))" % (ROOT, a.ndim, a.cpu_iters, tuple(weights)))
@@ -67,33 +91,65 @@ def cpu_baseline(a, weights):
         raise RuntimeError("cpu baseline failed: " + r.stderr[-500:])
     v, cores, what = json.loads(r.stdout.strip().splitlines()[-1])
     return {"value": v, "unit": "updates/s", "cores": cores, "kind": "port",
-            "sample": "reference-equivalent NumPy port (oracle/numpy_port.py), " + what}
+            "sample": "reference-equivalent NumPy port (oracle/numpy_port.py; per-core rate within 10 % of the reference itself, "
+                      "oracle/baseline_calibration.json), one chain per core at the ladder's first temperatures, no swaps: " + what}
+
+
+class ColdSamples(object):
+    """T = 1 samples of a few walkers over the timed region, copied on the device from the AM ring (which holds the last
+    covUpdate cold samples of every walker, row = iteration % covUpdate) whenever the ring is about to wrap."""
+
+    def __init__(self, eng, nw):
+        self.eng, self.nw, self.snaps = eng, nw, []
+
+    def snap(self, it_done):
+        if self.nw:
+            self.snaps.append((it_done, self.eng.t["AM"][:self.nw].clone()))
+
+    def series(self, first, last):
+        """[nw][last - first + 1][d], iterations first..last in time order."""
+        import numpy as np
+        cu = self.eng.cov_update
+        out = None
+        have = np.zeros(last - first + 1, dtype=bool)
+        for it_done, ring in self.snaps:
+            ring = ring.cpu().numpy()
+            if out is None:
+                out = np.zeros((ring.shape[0], last - first + 1, ring.shape[2]))
+            its = np.arange(max(first, it_done - cu + 1), min(last, it_done) + 1)
+            if len(its):
+                out[:, its - first] = ring[:, its % cu]
+                have[its - first] = True
+        return out[:, have] if out is not None else None
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "LOCAL_RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     # stdout must carry exactly one JSON line: park everything else the process (and RCCL's C-level banner)
     # prints on stderr, and keep the real stdout for the result
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (a.gpus, world))
     weights = {"scam": (20, 0, 0), "default": (20, 20, 20), "nuts": (10, 0, 10)}[a.mix]
     cpu = None
     # the CPU baseline is timed on rank 0 of the single-GPU run only; the NumPy port covers the Gaussian configs
-    if rank == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl != "curved":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl == "iso":
         cpu = cpu_baseline(a, weights)
         log("cpu baseline %.3g updates/s on %d cores" % (cpu["value"], cpu["cores"]))
     import numpy as np
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
     backend = os.environ.get("PTMI_DIST_BACKEND", "nccl")          # "gloo" only to rehearse N ranks on a one-GPU box
-    if backend != "nccl":
-        local %= torch.cuda.device_count()
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but only %d GPUs are visible (PTMI_DIST_BACKEND=gloo rehearses several ranks on one GPU)"
+                         % (world, torch.cuda.device_count()))
+    local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or a.sharded:
@@ -110,8 +166,8 @@ def main():
     if a.logl == "dense":
         A = np.random.default_rng(0).standard_normal((d, d))
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
-    kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=100, seed=1234, cov_mode=a.cov_mode, logl=logl,
-              device=local, swap_mode=a.swap_mode)
+    kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, cov_mode=a.cov_mode, logl=logl,
+              device=local, swap_mode=a.swap_mode, pick_mode=a.pick)
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.logl == "curved":                      # examples/curved_likelihood.ipynb: box prior [-10, 10], cov = I, start near the mode
         kw.update(logl=("curved",), logp=("box", np.full(d, -10.0), np.full(d, 10.0)))
@@ -133,11 +189,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    eng.run(a.warmup)
+    it_warm, it_timed = a.warmup * TSKIP, a.steps * TSKIP
+    eng.run(it_warm)
     fence()
-    log("warmup done")
-    # timed region: exactly --steps iterations; each fused-MH launch is bracketed by HIP events on the
-    # engine's stream (= torch's current stream, the one the kernels are launched on)
+    log("warmup done (%d iterations)" % it_warm)
+    # timed region: exactly --steps Tskip cycles; each fused-MH launch is bracketed by HIP events on the engine's
+    # stream (= torch's current stream, the one the kernels are launched on)
     events = []
     orig = eng.mh_steps
 
@@ -149,89 +206,103 @@ def main():
         events.append((e0, e1, nsteps))
 
     eng.mh_steps = timed_mh
-    ess_keep = []
-    nw_ess = min(a.ess_walkers, W) if eng.owns_cold else 0
+    cold = ColdSamples(eng, min(a.ess_walkers, W) if eng.owns_cold else 0)
     orig_cov = eng.update_cov
+    n_cov = [0]
 
     def cov_and_keep(it_done):
-        if nw_ess:
-            ess_keep.append(eng.t["AM"][:nw_ess].clone())       # device-side copy of the cold samples of a few walkers
+        cold.snap(it_done)                      # device-side copy of a few walkers' cold samples, before the ring wraps
+        n_cov[0] += 1
         orig_cov(it_done)
 
     eng.update_cov = cov_and_keep
     t0 = time.perf_counter()
-    eng.run(a.steps)
+    eng.run(it_timed)
     fence()
     wall = time.perf_counter() - t0
     eng.mh_steps, eng.update_cov = orig, orig_cov
+    cold.snap(it_warm + it_timed)
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
-    log("timed region %.3f s" % wall)
+    log("timed region %.3f s (%d iterations, %d covariance epochs)" % (wall, it_timed, n_cov[0]))
 
     nchains_total = nt * world * W
-    value = nchains_total * a.steps / wall
+    value = nchains_total * it_timed / wall
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
     kern_steps = sum(n for _, _, n in events)
-    bytes_per_update = 16 * d + 32
     avg_launch_ms = kern_ms / max(1, len(events))
     avg_steps = kern_steps / max(1, len(events))
-    achieved = bytes_per_update * nt * W * avg_steps / (avg_launch_ms * 1e-3) / 1e9
+    upd_per_launch = nt * W * avg_steps
+    bytes_per_update = 16 * d + 32
+    flops_per_update = 4 * d
+    hbm_view = bytes_per_update * upd_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    tf = flops_per_update * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12
+    kernel = "mh_steps_gj_kernel" if a.mix == "nuts" else "mh_steps_kernel"
     out = {
-        "metric": "MH updates/sec (whole node), 100-d Gaussian, 64 temps x 4096 walkers per GPU",
+        "metric": "MH updates/sec (whole node) + ESS/sec, 100-d Gaussian, 64 temps x 4096 walkers per GPU",
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[%d]: %d-d %s logl, %d temps x %d walkers per GPU, %s cycle, "
-                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s" % (
+        "config": {"workload": "BASELINE configs[%d]: %d-d %s logl, %d temps x %d walkers per GPU, %s cycle (pick per %s), "
+                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s; one step = 100 MH iterations of every chain + the PT swap "
+                               "(+ a covariance epoch every 10 steps)" % (
                                    {"iso": 3 if d >= 1000 else 1, "dense": 2, "curved": 4}[a.logl], d,
                                    {"iso": "isotropic Gaussian", "dense": "dense Gaussian", "curved": "curved-likelihood"}[a.logl],
-                                   nt, W, a.mix, a.swap_mode, a.cov_mode),
-                   "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "parallelism": ("temperature blocks x%d" if a.partition == "temps" else "walker blocks x%d") % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "mh_steps_gj_kernel" if a.mix == "nuts" else "mh_steps_kernel", "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,
-                     "algorithmic_bytes_per_update": bytes_per_update, "kernel_time_share_of_wall": kern_ms * 1e-3 / wall},
+                                   nt, W, a.mix, a.pick, a.swap_mode, a.cov_mode),
+                   "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "iterations_per_step": TSKIP,
+                   "parallelism": ("temperature blocks x%d" if a.partition == "temps" else "walker blocks x%d") % world},
+        "iterations_timed": it_timed, "swap_epochs_timed": it_timed // TSKIP if nt * world > 1 else 0, "cov_epochs_timed": n_cov[0],
+        "rccl_ranks": world if (dist is not None and backend == "nccl") else (0 if dist is not None else 1),
+        # The fused K-step kernel keeps a chain's state in registers, so it is bounded by f64 vector issue, not by HBM:
+        # achieved = SURVEY 8(d)'s 4d flop per update x updates per launch / the launch's HIP-event time.
+        "roofline": {"bound": "f64_valu", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
+                     "traffic": None, "kernel": kernel, "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,
+                     "algorithmic_flops_per_update": flops_per_update, "algorithmic_bytes_per_update": bytes_per_update,
+                     "algorithmic_hbm_gbs": hbm_view, "algorithmic_hbm_ratio": hbm_view / HBM_PEAK_GBS,
+                     "kernel_time_share_of_wall": kern_ms * 1e-3 / wall},
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
-    # summary applies only to the exact workload it was measured on
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        key = "ndim=%d ntemps=%d nwalkers=%d mix=%s logl=%s steps_per_launch=%d" % (d, nt, W, a.mix, a.logl, int(round(avg_steps)))
-        if tr.get("workload") == key:
-            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, " + ", ".join(tr["source"])
-            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_update * nt * W * avg_steps
-    except (OSError, ValueError):
-        pass
+    # summary is per launch of 100 steps on one named workload
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        key = "ndim=%d ntemps=%d nwalkers=%d mix=%s logl=%s" % (d, nt, W, a.mix, a.logl)
+        if tr.get("workload", "").startswith(key) and (tr.get("pick", "chain") == a.pick):
+            per_launch = tr["traffic_bytes_per_launch"] * avg_steps / float(tr.get("steps_per_launch", 100))
+            out["roofline"]["traffic"] = per_launch
+            out["roofline"]["traffic_note"] = ("HBM bytes per launch from rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                                               + ", ".join(tr["source"]))
+            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_update * upd_per_launch
+            break
     if a.logl == "dense":
         # config 3: the dense contraction bounds the kernel: 2d^2+3d flop per likelihood, +2d^2 per AM proposal
         flops = 2 * d * d + 3 * d + (2 * d * d * weights[1] / float(sum(weights)) if weights[1] else 0.0)
-        tf = flops * nt * W * avg_steps / (avg_launch_ms * 1e-3) / 1e12
-        out["roofline"].update({"bound": "mfma", "achieved": tf, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tf / F64_MATRIX_PEAK_TFLOPS, "algorithmic_flops_per_update": flops})
+        tfd = flops * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12
+        out["roofline"].update({"bound": "mfma", "achieved": tfd, "frac": tfd / F64_PEAK_TFLOPS, "algorithmic_flops_per_update": flops})
     if rank == 0:
         acc = eng.get("nacc").astype(np.float64)
-        out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / (a.steps + a.warmup))
+        out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / (it_timed + it_warm))
         out["swap_accept_rate_pair0"] = float(eng.get("nswap")[:, 0].mean() / max(1, eng.swap_proposed))
-        if ess_keep:
+        chain = cold.series(it_warm + 1, it_warm + it_timed)
+        if chain is not None and chain.shape[1] >= 16:
             from ptmcmcsampler_amd.ess import ess
-            blocks = [b.cpu().numpy() for b in ess_keep]
-            cu = blocks[0].shape[1]
-            # AM rows are in ring order (row 0 = newest); restore time order before concatenating
-            chain = np.concatenate([np.concatenate([b[:, 1:], b[:, :1]], axis=1) for b in blocks], axis=1)
             per_walker = [ess(chain[w]) for w in range(chain.shape[0])]
-            covered = cu * len(blocks)
-            out["ess_per_sec"] = float(np.mean(per_walker) / covered * a.steps * W / wall)
-            out["ess_note"] = "Sokal-window ESS (min over dims) of the T=1 chain, mean over %d walkers x %d samples, scaled to %d walkers" % (
-                len(per_walker), covered, W)
+            covered = chain.shape[1]
+            out["ess_per_sec"] = float(np.mean(per_walker) / covered * it_timed * W / wall)
+            out["ess_note"] = ("Sokal-window ESS (min over dims) of the T=1 chains: mean over %d walkers x %d timed samples, scaled to "
+                               "the %d walkers of the batch" % (len(per_walker), covered, W))
+        else:
+            out["ess_per_sec"] = None
         if cpu is not None:
             out["cpu_baseline"] = cpu
             # the C oracle on one core, for scale (a compiled scalar port; not what a reference user gets)
             from oracle import oracle as orc
             o = orc.OracleEngine(d, 8, 8, np.eye(d) * 0.01, weights=weights, cov_update=1000, burn=10000, tskip=100,
-                                 seed=1234, cov_mode=a.cov_mode)
+                                 seed=1234, cov_mode="pooled" if a.cov_mode == "pooled" else "per_walker")
             o.init_state(np.zeros(d))
             t1 = time.perf_counter()
             o.run(1000)

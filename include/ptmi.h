@@ -61,6 +61,15 @@ enum { PTMI_J_SCAM = 0, PTMI_J_AM = 1, PTMI_J_DE = 2, PTMI_J_NUTS = 3, PTMI_J_HM
  * reference run. */
 enum { PTMI_SWAP_SWEEP = 0, PTMI_SWAP_ODDEVEN = 1 };
 
+/* ptmi_config.pick_mode: who draws the entry of the proposal cycle (_jump, PTMCMCSampler.py:1058).  CHAIN: every chain
+ * draws its own from its rank's stream, as every MPI rank of the reference does -- a walker is then a replica of a
+ * reference run.  WALKER: one draw per (walker, iteration), taken from the stream of the walker's rank 0, decides the
+ * proposal TYPE for all temperature ranks of the walker (everything else -- group, scale branch, direction, normals,
+ * accept uniform -- stays per chain).  The choice is independent of the state, so every chain still runs a valid
+ * Metropolis-Hastings kernel with the same mixture weights; on the device the proposal type becomes wave-uniform
+ * (no divergence, the matrix-core AM product runs only on AM steps).  Not a replica of a reference run. */
+enum { PTMI_PICK_CHAIN = 0, PTMI_PICK_WALKER = 1 };
+
 typedef struct ptmi_config {
     int32_t ndim;            /* parameters per chain */
     int32_t ntemps;          /* temperature ranks held by THIS handle (a contiguous block) */
@@ -86,7 +95,7 @@ typedef struct ptmi_config {
     int32_t gj_nburn;        /* nburn of the jump objects (= burn, :227,238,251) */
     int32_t hmc_min, hmc_max;/* HMC takes randint(hmc_min, hmc_max) leapfrogs (:240-241: 2, HMCsteps) */
     int32_t nuts_maxdepth;   /* tree heights 0..nuts_maxdepth per call (the reference has no cap); <= 24 */
-    int32_t pad0_;
+    int32_t pick_mode;       /* PTMI_PICK_CHAIN or PTMI_PICK_WALKER (below) */
     double hmc_eps;          /* HMCstepsize (:239) */
     double nuts_delta;       /* target acceptance of NUTS' dual averaging (0.6, :256) */
     uint64_t seed;
@@ -165,6 +174,17 @@ int ptmi_set_de_active(ptmi_handle h, int on);
  * updateChains (:327-328).  The caller splits the run at swap / covariance / DE
  * epochs (none may fall strictly inside the range). */
 int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps);
+
+/* Which instantiation of the fused kernel the most recent ptmi_mh_steps launched (the parity tests assert that they
+ * reached the one they mean to test): a combination of the flags below, plus lanes per chain in bits 8-15 and register
+ * slots per lane in bits 16-23. */
+enum { PTMI_VAR_STAGED = 1,    /* strided lane layout, tables in LDS, products on the f64 matrix cores */
+       PTMI_VAR_FULL = 2,      /* the cycle holds AM and / or an active DE (else SCAM only) */
+       PTMI_VAR_LDS_UT = 4,    /* staged: the eigenvector table is in LDS too */
+       PTMI_VAR_GROUPS = 8,    /* parameter groups */
+       PTMI_VAR_GRADJUMP = 16, /* the kernel with the NUTS / HMC branch */
+       PTMI_VAR_UNIFORM = 32   /* wave-uniform cycle pick (pick_mode = PTMI_PICK_WALKER) */ };
+int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant);
 
 /* PTswap (:631-697) for iteration `iter` when the whole ladder is on this GPU. */
 int ptmi_swap(ptmi_handle h, int64_t iter);

@@ -14,84 +14,118 @@ import time
 import numpy as np
 
 
+class _Comm(object):
+    """The reference pays for two communicator calls per iteration even on one rank (:501, :523)."""
+
+    def barrier(self):
+        pass
+
+    def bcast(self, obj, root=0):
+        return obj
+
+
+class _Bound(object):
+    """logl / logp reach the sampler through a wrapper object that splices args and kwargs in (:1072-1086)."""
+
+    def __init__(self, f, args, kwargs):
+        self.f, self.args, self.kwargs = f, args, kwargs
+
+    def __call__(self, x):
+        return self.f(x, *self.args, **self.kwargs)
+
+
 class ChainPort(object):
+    """One chain with the reference's call graph: run -> one_step -> _jump -> proposal(x, iter, beta) -> wrapped
+    callbacks -> update_chains, every piece paying the interpreter costs its counterpart pays."""
+
     def __init__(self, ndim, logl, logp, cov, temp=1.0, covUpdate=1000, burn=10000, weights=(20, 20, 20), seed=0):
-        self.ndim, self.logl, self.logp, self.temp = ndim, logl, logp, temp
+        self.ndim, self.logl, self.logp = ndim, _Bound(logl, [], {}), _Bound(logp, [], {})
+        self.temp = np.float64(temp)                 # a ladder entry, i.e. a NumPy scalar (:278)
         self.cov = np.array(cov, dtype=float)
-        self.U, self.S, _ = np.linalg.svd(self.cov)
+        self.groups = [np.arange(0, ndim)]           # parameters move through an index array (:129-131)
+        self.U, self.S = [[]], [[]]
+        self.U[0], self.S[0], _ = np.linalg.svd(self.cov)
         self.M2, self.mu = np.zeros((ndim, ndim)), np.zeros(ndim)
-        self.covUpdate, self.burn = covUpdate, burn
+        self.covUpdate, self.burn, self.rank, self.nchain = covUpdate, burn, 0, 1
         self.AM = np.zeros((covUpdate, ndim))
         self.DE = np.zeros((burn, ndim))
-        self.rng = np.random.default_rng(seed)
-        self.cycle = ["scam"] * weights[0] + ["am"] * weights[1]
+        self.stream = np.random.default_rng(seed)
+        self.comm = _Comm()
+        self.cycle, self.aux, self.stats = [], [], {}
         self.wde = weights[2]
         self.naccepted = 0
-        self.jumps = dict(scam=[0, 0], am=[0, 0], de=[0, 0])
+        for f, w in ((self.scam, weights[0]), (self.am, weights[1])):
+            self.add(f, w)
 
-    # the reference also pays for these every iteration / every isave (:321-339, :501, :523, :741-745, :1085)
-    def _call(self, f, x, *args, **kwargs):
-        return f(x, *args, **kwargs)
+    def add(self, f, weight):
+        self.cycle += [f] * weight
+        if weight:
+            self.stats.setdefault(f.__name__, [0, 0])
 
-    def _noop(self, *a, **k):
-        return a[0] if a else None
-
-    def _store(self, x, lnl, lnp, it, thin, isave, sink):
-        if it % thin == 0:
-            ind = int(it / thin)
-            self._chain[ind, :] = x
-            self._lnlike[ind] = lnl
-            self._lnprob[ind] = lnp
-        if it % isave == 0 and it > 0:
-            for ind in range((it - isave) // thin + 1, it // thin + 1):
-                sink.write("\t".join(["%22.22f" % (self._chain[ind, kk]) for kk in range(self.ndim)]))
-                sink.write("\t%f\t%f\t%f\t%f\n" % (self._lnprob[ind], self._lnlike[ind], self.naccepted / it, 1))
-
-    def _scale(self):
-        prob = self.rng.random()
-        scale = 10 if prob > 0.97 else (0.2 if prob > 0.9 else 1.0)
+    def _size(self):
+        """(group index, size, jump scale): the common head of SCAM and AM (:838-862, :896-920)."""
+        gi = self.stream.integers(0, len(self.groups))
+        nd = len(self.groups[gi])
+        prob = self.stream.random()
+        if prob > 0.97:
+            scale = 10
+        elif prob > 0.9:
+            scale = 0.2
+        else:
+            scale = 1.0
         if self.temp <= 100:
             scale *= np.sqrt(self.temp)
-        return scale
+        return gi, nd, scale
 
-    def scam(self, x):
-        q = x.copy()
-        self.rng.integers(0, 1)
-        scale = self._scale()
-        ind = np.unique(self.rng.integers(0, self.ndim, 1))
+    def scam(self, x, iter, beta):
+        q, qxy = x.copy(), 0
+        gi, nd, scale = self._size()
+        ind = np.unique(self.stream.integers(0, nd, 1))
         cd = 2.4 / np.sqrt(2 * len(ind)) * scale
-        q += self.rng.standard_normal() * cd * np.sqrt(self.S[ind]) * self.U[:, ind].flatten()
-        return q
+        q[self.groups[gi]] += self.stream.standard_normal() * cd * np.sqrt(self.S[gi][ind]) * self.U[gi][:, ind].flatten()
+        return q, qxy
 
-    def am(self, x):
-        self.rng.integers(0, 1)
-        scale = self._scale()
-        y = np.dot(self.U.T, x)
-        cd = 2.4 / np.sqrt(2 * self.ndim) * scale
-        y = y + self.rng.standard_normal(self.ndim) * cd * np.sqrt(self.S)
-        return np.dot(self.U, y)
+    def am(self, x, iter, beta):
+        q, qxy = x.copy(), 0
+        gi, nd, scale = self._size()
+        y = np.dot(self.U[gi].T, x[self.groups[gi]])
+        ind = np.arange(len(self.groups[gi]))
+        cd = 2.4 / np.sqrt(2 * len(ind)) * scale
+        y[ind] = y[ind] + self.stream.standard_normal(len(ind)) * cd * np.sqrt(self.S[gi][ind])
+        q[self.groups[gi]] = np.dot(self.U[gi], y)
+        return q, qxy
 
-    def de(self, x):
-        q = x.copy()
-        self.rng.integers(0, 1)
+    def de(self, x, iter, beta):
+        q, qxy = x.copy(), 0
+        gi = self.stream.integers(0, len(self.groups))
+        nd = len(self.groups[gi])
         n = len(self.DE)
-        mm, nn = self.rng.integers(0, n), self.rng.integers(0, n)
+        mm, nn = self.stream.integers(0, n), self.stream.integers(0, n)
         while mm == nn:
-            nn = self.rng.integers(0, n)
-        if self.rng.random() > 0.5:
+            nn = self.stream.integers(0, n)
+        if self.stream.random() > 0.5:
             scale = 1.0
         else:
-            scale = self.rng.random() * 2.4 / np.sqrt(2 * self.ndim) * np.sqrt(self.temp)
-        for ii in range(self.ndim):
-            q[ii] += scale * (self.DE[mm, ii] - self.DE[nn, ii])
-        return q
+            scale = self.stream.random() * 2.4 / np.sqrt(2 * nd) * np.sqrt(1 / beta)
+        for ii in range(nd):
+            q[self.groups[gi][ii]] += scale * (self.DE[mm, self.groups[gi][ii]] - self.DE[nn, self.groups[gi][ii]])
+        return q, qxy
 
-    def update_recursive(self, it_done):
-        it = it_done - self.covUpdate
+    def _jump(self, x, iter):
+        k = self.stream.integers(0, len(self.cycle))
+        q, qxy = self.cycle[k](x, iter, 1 / self.temp)
+        if len(self.aux) > 0:
+            for aux in self.aux:
+                q, extra = aux(x, q, iter, 1 / self.temp)
+                qxy += extra
+        return q, qxy, self.cycle[k].__name__
+
+    def update_recursive(self, it_done, mem):
+        it = it_done - mem
         if it == 0:
-            self.M2[:] = 0
-            self.mu[:] = 0
-        for ii in range(self.covUpdate):
+            self.M2 = np.zeros((self.ndim, self.ndim))
+            self.mu = np.zeros(self.ndim)
+        for ii in range(mem):
             diff = np.zeros(self.ndim)
             it += 1
             for jj in range(self.ndim):
@@ -99,41 +133,69 @@ class ChainPort(object):
                 self.mu[jj] += diff[jj] / it
             self.M2 += np.outer(diff, (self.AM[ii, :] - self.mu))
         self.cov[:, :] = self.M2 / (it - 1)
-        self.U, self.S, _ = np.linalg.svd(self.cov)
+        for ct, group in enumerate(self.groups):
+            covgroup = np.zeros((len(group), len(group)))
+            for ii in range(len(group)):
+                for jj in range(len(group)):
+                    covgroup[ii, jj] = self.cov[group[ii], group[jj]]
+            self.U[ct], self.S[ct], _ = np.linalg.svd(covgroup)
+
+    def update_chains(self, x, lnl, lnp, it):
+        if self.rank == 0:
+            self.AM[it % self.covUpdate, :] = x
+        if it % self.thin == 0:
+            ind = int(it / self.thin)
+            self._chain[ind, :] = x
+            self._lnlike[ind] = lnl
+            self._lnprob[ind] = lnp
+        if it % self.isave == 0 and it > 0:
+            for ind in range((it - self.isave) // self.thin + 1, it // self.thin + 1):
+                self.sink.write("\t".join(["%22.22f" % (self._chain[ind, kk]) for kk in range(self.ndim)]))
+                self.sink.write("\t%f\t%f\t%f\t%f\n" % (self._lnprob[ind], self._lnlike[ind], self.naccepted / it, 1))
+
+    def one_step(self, x, lnl, lnp, it):
+        """PTMCMCOneStep (:530-629) for a lone rank."""
+        if self.rank == 0 and (it - 1) % self.covUpdate == 0 and (it - 1) != 0:
+            self.update_recursive(it - 1, self.covUpdate)
+        if self.rank == 0 and (it - 1) % self.burn == 0 and (it - 1) != 0:
+            self.DE = np.concatenate([self.DE[self.covUpdate:], self.AM])
+        if self.rank == 0 and (it - 1) == self.burn and self.wde:
+            self.add(self.de, self.wde)
+        y, qxy, name = self._jump(x, it)
+        self.stats[name][0] += 1
+        lp = self.logp(y)
+        if lp == float(-np.inf):
+            newp = -np.inf
+        else:
+            newl = self.logl(y)
+            newp = 1 / self.temp * newl + lp
+        diff = newp - lnp + qxy
+        if diff > np.log(self.stream.random()):
+            x, lnl, lnp = y, newl, newp
+            self.naccepted += 1
+            self.stats[name][1] += 1
+        if self.nchain > 1 and it % 100 == 0:
+            pass
+        self.update_chains(x, lnl, lnp, it)
+        return x, lnl, lnp
 
     def run(self, p0, niter, thin=10, isave=1000):
         import io
+        self.thin, self.isave, self.sink = thin, isave, io.StringIO()
         x = np.array(p0, dtype=float)
+        lp = self.logp(x)
         lnl = self.logl(x)
-        lnp = lnl / self.temp + self.logp(x)
-        fn = dict(scam=self.scam, am=self.am, de=self.de)
+        lnp = 1 / self.temp * lnl + lp
         N = int(niter / thin) + 1
         self._chain, self._lnlike, self._lnprob = np.zeros((N, self.ndim)), np.zeros(N), np.zeros(N)
-        sink = io.StringIO()
-        for it in range(1, niter + 1):
-            self._noop()                                   # comm.barrier(), :501
-            if (it - 1) % self.covUpdate == 0 and it - 1 != 0:
-                self.update_recursive(it - 1)
-            if (it - 1) % self.burn == 0 and it - 1 != 0:
-                self.DE = np.concatenate([self.DE[self.covUpdate:], self.AM])
-            if it - 1 == self.burn and self.wde:
-                self.cycle = self.cycle + ["de"] * self.wde
-            name = self.cycle[self.rng.integers(0, len(self.cycle))]
-            y = fn[name](x)
-            self.jumps[name][0] += 1
-            lp = self._call(self.logp, y)
-            if lp == -np.inf:
-                newp = -np.inf
-            else:
-                newl = self._call(self.logl, y)
-                newp = 1 / self.temp * newl + lp
-            if newp - lnp + 0 > np.log(self.rng.random()):
-                x, lnl, lnp = y, newl, newp
-                self.naccepted += 1
-                self.jumps[name][1] += 1
-            self.AM[it % self.covUpdate, :] = x
-            self._store(x, lnl, lnp, it, thin, isave, sink)
-            self._noop(it >= niter)                        # comm.bcast(runComplete), :523
+        it, done = 0, False
+        while not done:
+            it += 1
+            self.comm.barrier()                            # :501
+            x, lnl, lnp = self.one_step(x, lnl, lnp, it)
+            if self.rank == 0 and it >= niter:
+                done = True
+            done = self.comm.bcast(done, root=0)           # :523
         return x
 
 

@@ -21,13 +21,15 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "ndim", "ntemps", "nwalkers", "ntemps_global", "temp0", "walker0", "logl_kind", "logp_kind",
         "w_host", "w_scam", "w_am", "w_de", "de_size", "cov_update", "tskip", "cov_per_walker", "device", "ngroups", "swap_mode",
-        "w_nuts", "w_hmc", "gj_nburn", "hmc_min", "hmc_max", "nuts_maxdepth", "pad0_")] + [
+        "w_nuts", "w_hmc", "gj_nburn", "hmc_min", "hmc_max", "nuts_maxdepth", "pick_mode")] + [
         ("hmc_eps", C.c_double), ("nuts_delta", C.c_double), ("seed", C.c_uint64), ("stream", C.c_void_p), ("ladder", _dp), ("temps_mh", _dp),
         ("logl_par", _dp), ("logl_par_len", C.c_int64), ("logp_par", _dp), ("logp_par_len", C.c_int64),
         ("group_size", C.POINTER(C.c_int32)), ("group_mask", _dp), ("gj_tab", _dp)]
 
 
-SWAP_MODES = {"sweep": 0, "oddeven": 1}      # PTMI_SWAP_SWEEP, PTMI_SWAP_ODDEVEN
+VAR_STAGED, VAR_FULL, VAR_LDS_UT, VAR_GROUPS, VAR_GRADJUMP, VAR_UNIFORM = 1, 2, 4, 8, 16, 32   # ptmi_last_mh_variant
+SWAP_MODES = {"sweep": 0, "oddeven": 1}
+PICK_MODES = {"chain": 0, "walker": 1}        # PTMI_PICK_CHAIN, PTMI_PICK_WALKER      # PTMI_SWAP_SWEEP, PTMI_SWAP_ODDEVEN
 
 BUFFER_FIELDS = ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "DE", "AM", "nacc", "jstat", "nswap",
                  "mu", "M2", "cov", "Q", "qaux", "AMaux", "gj")
@@ -40,7 +42,7 @@ class Buffers(C.Structure):
 # every symbol include/ptmi.h declares
 SYMBOLS = (
     "ptmi_last_error", "ptmi_version", "ptmi_device_count", "ptmi_lanes_for", "ptmi_lanes_for_grad", "ptmi_temperature_ladder", "ptmi_create", "ptmi_destroy",
-    "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_swap", "ptmi_swap_gather_lnl",
+    "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_last_mh_variant", "ptmi_swap", "ptmi_swap_gather_lnl",
     "ptmi_swap_sweep", "ptmi_swap_sweep_blocks", "ptmi_exchange_pack", "ptmi_exchange_apply", "ptmi_exchange_status",
     "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept",
     "ptmi_selftest_math", "ptmi_selftest_philox", "ptmi_malloc", "ptmi_free", "ptmi_memcpy_h2d", "ptmi_memcpy_d2h",
@@ -83,6 +85,7 @@ def load():
     L.ptmi_set_de_active.argtypes = [H, C.c_int]
     L.ptmi_set_de_head.argtypes = [H, C.c_int32]
     L.ptmi_mh_steps.argtypes = [H, C.c_int64, C.c_int32]
+    L.ptmi_last_mh_variant.argtypes = [H, C.POINTER(C.c_int32)]
     L.ptmi_swap.argtypes = [H, C.c_int64]
     L.ptmi_swap_gather_lnl.argtypes = [H, C.c_void_p]
     L.ptmi_swap_sweep.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]

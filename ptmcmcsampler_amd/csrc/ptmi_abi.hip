@@ -614,6 +614,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (!c.ladder || !c.temps_mh) return fail(PTMI_EINVAL, "ladder / temps_mh missing");
     if (c.ngroups < 0 || c.ngroups > 1024) return fail(PTMI_EINVAL, "ngroups out of range");
     if (c.swap_mode != PTMI_SWAP_SWEEP && c.swap_mode != PTMI_SWAP_ODDEVEN) return fail(PTMI_EINVAL, "unknown swap_mode %d", c.swap_mode);
+    if (c.pick_mode != PTMI_PICK_CHAIN && c.pick_mode != PTMI_PICK_WALKER) return fail(PTMI_EINVAL, "unknown pick_mode %d", c.pick_mode);
     if (c.ngroups > 1) {
         if (!c.group_size || !c.group_mask) return fail(PTMI_EINVAL, "group_size / group_mask missing");
         for (int g = 0; g < c.ngroups; ++g)
@@ -749,6 +750,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     if (h->cfg.w_host > 0) return fail(PTMI_EINVAL, "host-served jumps need the split path (ptmi_propose / ptmi_accept)");
     if (h->cfg.w_nuts + h->cfg.w_hmc > 0) {      // the fused kernel with the NUTS / HMC branch (csrc/ptmi_gj.inc.h)
         if (int rc = run_shape(h, PTMI_OP_MH_GJ, a, chains_grid(h), true)) return rc;
+        h->last_variant = PTMI_VAR_GRADJUMP | PTMI_VAR_FULL;
         HIPCHK(hipGetLastError());
         return PTMI_OK;
     }
@@ -757,6 +759,13 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     const int grid = chains_grid(h);
     if (int rc = run_shape(h, PTMI_OP_MH, a, grid, full)) return rc;
     HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant)
+{
+    if (!h || !variant) return fail(PTMI_EINVAL, "NULL argument");
+    *variant = h->last_variant | (h->G << 8) | (h->EPL << 16);
     return PTMI_OK;
 }
 

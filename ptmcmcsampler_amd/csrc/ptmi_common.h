@@ -82,6 +82,7 @@ struct ptmi_engine {
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
     int G, EPL;
     int de_on, de_head;
+    int last_variant;   // PTMI_VAR_* flags of the most recent fused-MH launch (ptmi_last_mh_variant)
     hipEvent_t ev0, ev1;
 };
 

@@ -428,10 +428,13 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
                 PTMI_PL[i] = (r < d && c < d) ? PtG[(size_t)r * d + c] : 0.0;
             }
         }
-        // all chains of the block belong to one walker (or the table is pooled): the first chain's table
-        const long long ch0 = (long long)logical_block() * CPB;
-        const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
-        UtBlock = a.Ut + w0 * d * d;
+        // FULL: all chains of the block belong to one walker (or the table is pooled; the host checks, launch_mh_k): the
+        // first chain's table serves the block.  SCAM-only cycles read one row per step from the chain's OWN table.
+        if (FULL) {
+            const long long ch0 = (long long)logical_block() * CPB;
+            const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
+            UtBlock = a.Ut + w0 * d * d;
+        }
         if (FULL && (UT_ALWAYS_LDS || a.lds_u)) {
             for (int i = (int)threadIdx.x; i < tab_n; i += 256) {
                 const int r = i / LD, c = i % LD;
@@ -660,11 +663,13 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, h->stream, a);
+            h->last_variant = PTMI_VAR_STAGED | (FULL ? PTMI_VAR_FULL : 0) | (a.lds_u ? PTMI_VAR_LDS_UT : 0);
             return PTMI_OK;
         }
     }
     if (c.ngroups > 1) hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, true>), dim3(grid), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
+    h->last_variant = (FULL ? PTMI_VAR_FULL : 0) | (c.ngroups > 1 ? PTMI_VAR_GROUPS : 0);
     return PTMI_OK;
 }
 template <int G, int EPL, int LOGL>

@@ -79,7 +79,9 @@ class PTEngine(object):
     covariance from all walkers' rank-0 samples.  ``logl`` / ``logp`` select the built-in
     device likelihood / prior: ("iso",), ("dense", mu, P), ("curved",); ("flat",),
     ("box", lo, hi).  ``swap_mode``: ``"sweep"`` is the reference's hot -> cold PTswap; ``"oddeven"`` tries
-    the disjoint pairs (k, k+1), k = swap epoch (mod 2), all at once (see include/ptmi.h).
+    the disjoint pairs (k, k+1), k = swap epoch (mod 2), all at once (see include/ptmi.h).  ``pick_mode``: ``"chain"`` =
+    every chain draws its own entry of the proposal cycle (the reference's ``_jump``); ``"walker"`` = one draw per walker
+    and iteration fixes the proposal type of all its temperature ranks (wave-uniform on the device, include/ptmi.h).
     """
 
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
@@ -87,7 +89,7 @@ class PTEngine(object):
                  cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
                  w_host=0, keep_lnl=False, groups=None, swap_mode="sweep",
-                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10):
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain"):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -107,6 +109,9 @@ class PTEngine(object):
         self.per_walker = cov_mode == "per_walker"
         if cov_mode not in ("per_walker", "pooled"):
             raise ValueError("cov_mode must be 'per_walker' or 'pooled'")
+        if pick_mode not in _lib.PICK_MODES:
+            raise ValueError("pick_mode must be 'chain' or 'walker'")
+        self.pick_mode = pick_mode
         self.Wc = self.W if self.per_walker else 1
         # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
         self.groups = [np.arange(self.d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
@@ -166,7 +171,7 @@ class PTEngine(object):
             logl_kind=_lib.LOGL[logl[0]], logp_kind=_lib.LOGP[logp[0]], w_host=int(w_host), w_scam=self.weights[0], w_am=self.weights[1],
             w_de=self.weights[2] if has_de else 0, de_size=self.burn, cov_update=self.cov_update, tskip=self.tskip,
             cov_per_walker=int(self.per_walker), device=device, ngroups=self.ngr if self.ngr > 1 else 0,
-            swap_mode=_lib.SWAP_MODES[swap_mode], seed=self.seed,
+            swap_mode=_lib.SWAP_MODES[swap_mode], pick_mode=_lib.PICK_MODES[pick_mode], seed=self.seed,
             w_nuts=self.grad_weights[0], w_hmc=self.grad_weights[1], gj_nburn=self.burn, hmc_eps=float(hmc[0]),
             hmc_min=int(hmc[1]), hmc_max=int(hmc[2]), nuts_maxdepth=int(nuts_maxdepth), nuts_delta=float(nuts_delta),
             gj_tab=self.gj_tab.ctypes.data_as(_lib._dp) if has_gj else None,
@@ -372,6 +377,12 @@ class PTEngine(object):
     # ------------------------------------------------------------------ stepping
     def mh_steps(self, iter0, nsteps):
         _lib.check(self.lib.ptmi_mh_steps(self.h, iter0, nsteps))
+
+    def last_variant(self):
+        """Flags of the fused-kernel instantiation the last ``mh_steps`` launched (``_lib.VAR_*``), lanes, slots."""
+        v = C.c_int32(0)
+        _lib.check(self.lib.ptmi_last_mh_variant(self.h, C.byref(v)))
+        return v.value & 0xFF, (v.value >> 8) & 0xFF, (v.value >> 16) & 0xFF
 
     def swap(self, it):
         """PT swap of iteration ``it`` with the whole ladder on this GPU (:631-697)."""

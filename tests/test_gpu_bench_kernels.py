@@ -1,0 +1,209 @@
+"""Parity of the kernel instantiations and sizes that bench.py times (BASELINE configs[1..4]), HIP vs oracle, bit for bit.
+
+Every test asserts through ptmi_last_mh_variant that the instantiation it means to test is the one that launched.
+Run on the GPU box: ``python -m pytest tests -m gpu``.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare, _pair, assert_same, mods  # noqa: F401  (mods is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense(d, seed=0):
+    """The dense Gaussian of bench.py --logl dense (BASELINE configs[2]; tests/test_simple.py:27-30 in the reference)."""
+    A = np.random.default_rng(seed).standard_normal((d, d))
+    return ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
+
+
+@pytest.mark.parametrize("cov_mode,nt,W", [("pooled", 4, 9), ("per_walker", 3, 5), ("per_walker", 64, 2)])
+def test_dense_scam_only_runs_staged_and_matches(mods, cov_mode, nt, W):
+    """Dense likelihood, SCAM-only cycle: the staged (matrix-core likelihood) kernel with the eigenvectors read per chain.
+    per_walker with nt = 3 puts several walkers in one block: each chain must use ITS walker's table after the first
+    covariance epoch (PTMCMCSampler.py:820-876 with the walker's own U, S)."""
+    orc, _lib, _ = mods
+    d = 100
+    g, o = _pair(mods, d, nt, W, logl=_dense(d), cov0=np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=25, burn=1000,
+                 tskip=10, seed=5, cov_mode=cov_mode)
+    g.run(80)
+    o.run(80)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL and (G, E) == (4, 26)
+    _compare(g, o, "dense scam %s " % cov_mode)
+    assert_same(g.get("Ut"), o.Ut, "Ut")
+    if cov_mode == "per_walker":
+        assert not np.array_equal(o.Ut[0], o.Ut[1])            # the walkers' tables did diverge
+
+
+@pytest.mark.parametrize("cov_mode,nt,W,weights", [("pooled", 4, 7, (20, 20, 0)), ("pooled", 3, 6, (20, 20, 20)),
+                                                    ("per_walker", 64, 2, (20, 20, 20)), ("pooled", 5, 4, (0, 20, 0))])
+def test_dense_with_am_runs_on_the_matrix_cores_and_matches(mods, cov_mode, nt, W, weights):
+    """BASELINE configs[2] as benchmarked: dense likelihood AND AM proposal as f64-MFMA table products
+    (mh_steps_kernel<4,26,1,true,true,false>), PTMCMCSampler.py:605-612, 879-933."""
+    orc, _lib, _ = mods
+    d = 100
+    g, o = _pair(mods, d, nt, W, logl=_dense(d), cov0=np.eye(d) * 0.01, weights=weights, cov_update=30, burn=60,
+                 tskip=10, seed=11, cov_mode=cov_mode)
+    g.run(130)
+    o.run(130)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and (G, E) == (4, 26)
+    _compare(g, o, "dense am %s " % cov_mode)
+    assert_same(g.get("cov"), o.cov, "cov")
+    assert_same(g.get("Ut"), o.Ut, "Ut")
+    assert o.jstat[..., 1, 1].sum() > 0                        # AM proposals were accepted
+
+
+def test_iso_default_mix_pooled_runs_staged(mods):
+    """The default-mix kernel of bench.py --mix default (iso likelihood: the eigenvector table in LDS)."""
+    orc, _lib, _ = mods
+    g, o = _pair(mods, 100, 64, 3, cov0=np.eye(100) * 0.01, weights=(20, 20, 20), cov_update=40, burn=80, tskip=20,
+                 seed=3, cov_mode="pooled")
+    g.run(170)
+    o.run(170)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and flags & _lib.VAR_LDS_UT
+    _compare(g, o, "mix ")
+    assert o.jstat[..., 2, 0].sum() > 0
+
+
+class _Subset(object):
+    """A few walkers of a big pooled run on the oracle.  Pooled tables depend on every walker, so the epochs are driven
+    from outside: the covariance / DE inputs are the device's AM buffers, run through the ORACLE's Welford, pooling,
+    factorization and DE update; the chains then continue on the oracle with those tables."""
+
+    def __init__(self, orc, walkers, d, nt, W, cov0, **kw):
+        self.orc, self.walkers, self.d, self.W = orc, walkers, d, W
+        self.subs = []
+        for w0 in walkers:
+            o = orc.OracleEngine(d, nt, 1, cov0, cov_mode="pooled", walker0=w0, **kw)
+            o._epochs = lambda it: None
+            self.subs.append(o)
+        self.cu, self.burn = kw["cov_update"], kw["burn"]
+        self.mu, self.M2 = np.zeros((W, d)), np.zeros((W, d, d))
+        self.DE = np.zeros((self.burn, d))
+
+    def epoch(self, AM, it_done):
+        """PTMCMCSampler.py:545-585 for iteration it_done + 1, from all walkers' AM rows."""
+        orc, d, W = self.orc, self.d, self.W
+        if it_done % self.cu == 0:
+            for w in range(W):
+                orc.welford(AM[w], self.mu[w], self.M2[w], it_done, fused=True)
+            mu_o, cov_o = np.zeros(d), np.zeros((d, d))
+            orc.lib().orc_pool_cov(d, W, it_done, orc._p(self.mu), orc._p(self.M2), orc._p(mu_o), orc._p(cov_o))
+            for o in self.subs:
+                o.cov[0] = cov_o
+                o._svd(0)
+        if it_done % self.burn == 0:
+            AMc = np.ascontiguousarray(AM)
+            orc.lib().orc_de_update_pooled(d, self.burn, self.cu, W, orc._p(self.DE), orc._p(AMc))
+            for o in self.subs:
+                o.DE[0] = self.DE
+        if it_done == self.burn:
+            for o in self.subs:
+                o.cfg.de_on = 1
+
+
+def _check_subset(g, sub, what):
+    X, lnL, so = g.get("X"), g.get("lnL"), g.get("slot_of")
+    nsw, nacc, js = g.get("nswap"), g.get("nacc"), g.get("jstat")
+    for w0, o in zip(sub.walkers, sub.subs):
+        assert_same(X[w0], o.X[0], "%s walker %d X" % (what, w0))
+        assert_same(lnL[w0], o.lnL[0], "%s walker %d lnL" % (what, w0))
+        assert_same(so[w0], o.slot_of[0], "%s walker %d slot_of" % (what, w0))
+        assert_same(nsw[w0], o.nswap[0], "%s walker %d nswap" % (what, w0))
+        assert_same(nacc[w0], o.nacc[0], "%s walker %d nacc" % (what, w0))
+        assert_same(js[w0], o.jstat[0], "%s walker %d jstat" % (what, w0))
+
+
+def test_full_size_default_mix_with_covariance_and_de_epochs(mods):
+    """BASELINE configs[1] size (64 temps x 4096 walkers x 100-d), default SCAM/AM/DE mix, pooled covariance with
+    covUpdate = 100 and burn = 200, 400 iterations: three covariance epochs (matrix-core Welford over 4096 walkers +
+    two-level pooling), a DE epoch and DE activation, four swap epochs.  Device covariance / eigenvectors / DE ring
+    equal the oracle's on the same AM rows, and three walkers' chains match the oracle bit for bit throughout."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    cov0 = np.eye(d) * 0.01
+    kw = dict(weights=(20, 20, 20), cov_update=100, burn=200, tskip=100, seed=1234)
+    g = PTEngine(d, nt, W, cov0, cov_mode="pooled", **kw)
+    g.init_state(np.zeros(d))
+    sub = _Subset(orc, (0, 1777, 4095), d, nt, W, cov0, **kw)
+    for o in sub.subs:
+        o.init_state(np.zeros(d))
+    cu = kw["cov_update"]
+    seen = 0
+    for k in range(4):
+        if k > 0:
+            g.sync()
+            sub.epoch(g.get("AM"), k * cu)
+        g.run(cu)                                   # starts with the device's own epoch
+        for o in sub.subs:
+            o.run(cu)
+        flags, G, E = g.last_variant()
+        assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and flags & _lib.VAR_LDS_UT and (G, E) == (4, 26)
+        if k > 0:
+            assert_same(g.get("cov")[0], sub.subs[0].cov[0], "pooled cov after epoch %d" % k)
+            assert_same(g.get("Ut")[0], sub.subs[0].Ut[0], "Ut after epoch %d" % k)
+            assert_same(g.get("S")[0], sub.subs[0].S[0], "S after epoch %d" % k)
+        if k * cu >= kw["burn"]:
+            ring = g.get("DE")[0]
+            assert_same(np.roll(ring, -g.de_head, axis=0), sub.DE, "DE history")
+            seen += 1
+        _check_subset(g, sub, "segment %d" % k)
+    assert seen == 2 and g.de_on
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., :3, 0].sum(-1) == 400).all() and js[..., 2, 0].sum() > 0 and js[..., 1, 1].sum() > 0
+    so = g.get("slot_of")
+    assert (np.sort(so, axis=1) == np.arange(nt)).all()
+    assert g.get("nswap").sum() > 0 and g.swap_proposed == 4
+
+
+def test_config4_slice_1000d_64_temps(mods):
+    """BASELINE configs[3], one GPU's share: 1000-d isotropic Gaussian, 64 ranks x 512 walkers, default mix (64 lanes per
+    chain); invariants on the batch and bit parity on two walkers, through a swap epoch."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, n = 1000, 64, 512, 100
+    cov0 = np.eye(d) * 0.01
+    kw = dict(weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=50, seed=99)
+    g = PTEngine(d, nt, W, cov0, cov_mode="pooled", **kw)
+    g.init_state(np.zeros(d))
+    g.run(n)
+    g.sync()
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_FULL and G == 64
+    X, lnL = g.get("X"), g.get("lnL")
+    assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12)
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., :2, 0].sum(-1) == n).all() and js[..., 1, 0].sum() > 0
+    sub = _Subset(orc, (3, 511), d, nt, W, cov0, **kw)
+    for o in sub.subs:
+        o.init_state(np.zeros(d))
+        o.run(n)
+    _check_subset(g, sub, "config 4")
+    assert g.get("nswap").sum() > 0
+
+
+def test_config5_slice_curved_nuts_16_temps(mods):
+    """BASELINE configs[4], one GPU's share: 20-d curved likelihood, 16 ranks x 4096 walkers, SCAM + DE + NUTS cycle
+    (DE still waiting for burn), box prior; bit parity on three walkers incl. their NUTS step-size state."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, n = 20, 16, 4096, 120
+    cov0 = np.eye(d)
+    p0 = np.array([-0.1, -0.5] * (d // 2))
+    kw = dict(logl=("curved",), logp=("box", np.full(d, -10.0), np.full(d, 10.0)), weights=(10, 0, 10), grad_weights=(10, 0),
+              cov_update=1000, burn=10000, tskip=50, seed=7)
+    g = PTEngine(d, nt, W, cov0, cov_mode="pooled", **kw)
+    g.init_state(p0)
+    g.run(n)
+    g.sync()
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_GRADJUMP
+    sub = _Subset(orc, (0, 2048, 4095), d, nt, W, cov0, **kw)
+    for o in sub.subs:
+        o.init_state(p0)
+        o.run(n)
+    _check_subset(g, sub, "config 5")
+    gj = g.get("gj")
+    for w0, o in zip(sub.walkers, sub.subs):
+        assert_same(gj[w0], o.gj[0], "walker %d NUTS state" % w0)
+    assert g.get("jstat").astype(np.int64)[..., 3, 0].sum() > 0
