@@ -37,7 +37,7 @@ class Cfg(C.Structure):
         "de_on", "de_size", "cov_update", "tskip", "cov_per_walker", "ntemps_global", "temp0", "walker0", "ngroups")] + [
         ("seed", C.c_uint64), ("logl_par", _dp), ("logp_par", _dp), ("temps_mh", _dp), ("beta", _dp),
         ("gsize", _ip), ("gmask", _dp)] + [(n, C.c_int32) for n in (
-        "w_nuts", "w_hmc", "gj_nburn", "hmc_min", "hmc_max", "nuts_maxdepth")] + [
+        "w_nuts", "w_hmc", "gj_nburn", "hmc_min", "hmc_max", "nuts_maxdepth", "pick_mode")] + [
         ("hmc_eps", C.c_double), ("nuts_delta", C.c_double), ("gj_tab", _dp)]
 
 
@@ -237,8 +237,9 @@ class OracleEngine(object):
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep",
-                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10):
-        assert swap_mode in ("sweep", "oddeven")
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain"):
+        assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker")
+        self.pick_mode = pick_mode
         self.swap_mode = swap_mode
         self.d, self.nt, self.W = ndim, ntemps, nwalkers
         self.ntg = ntemps if ntemps_global is None else ntemps_global
@@ -298,7 +299,7 @@ class OracleEngine(object):
                        beta=_p(self.beta), gsize=_p(self.gsize, _ip), gmask=_p(self.gmask),
                        w_nuts=self.grad_weights[0], w_hmc=self.grad_weights[1], gj_nburn=burn, hmc_eps=hmc[0],
                        hmc_min=hmc[1], hmc_max=hmc[2], nuts_maxdepth=nuts_maxdepth, nuts_delta=nuts_delta,
-                       gj_tab=_p(self.gj_tab))
+                       gj_tab=_p(self.gj_tab), pick_mode={"chain": 0, "walker": 1}[pick_mode])
         self.iter = 0
 
     # -- helpers

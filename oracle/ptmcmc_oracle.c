@@ -61,14 +61,24 @@ static void philox_words(uint64_t seed, uint64_t iter, uint32_t stream, uint32_t
     w[1] = ((uint64_t)o[3] << 32) | o[2];
 }
 
-/* slot numbers of the counter-based schedule (DESIGN.md "RNG schedule"):
- *   A: w0 cycle pick, w1 scale-branch uniform     B: w0 accept uniform, w1 SCAM direction / DE row mm
- *   C: w0 DE row nn offset, w1 DE scale uniform    D: (w0,w1) SCAM normal
+/* slot numbers of the counter-based schedule (DESIGN.md "RNG schedule").  One iteration of one chain consumes two
+ * Philox calls of its rank's stream, every bit of which has a use:
+ *   slot 0 (P): w0 = [ hi32: cycle pick | lo32: scale-branch uniform ],  w1 = accept uniform
+ *   slot 1 (Q): SCAM: w0 = Box-Muller u1, w1 = [ hi32: eigen-direction | lo32: Box-Muller angle ]
+ *               DE:   w0 = [ hi32: row mm | lo32: offset of row nn ],     w1 = DE scale uniform
+ *   slot 2 (G): w0 hi32 = parameter group (only drawn with more than one group)
  *   SWAP+k: w0 uniform of pair (k,k+1), stream of rank 0
- *   AM+k: (w0,w1) Box-Muller pair: cos branch -> eigen-direction k, sin branch -> direction k+lanes, (k/lanes) even */
-enum { SLOT_A = 0, SLOT_B = 1, SLOT_C = 2, SLOT_D = 3, SLOT_SWAP = 0x10000, SLOT_AM = 0x1000000,
+ *   AM+k: (w0,w1) Box-Muller pair: cos branch -> eigen-direction k, sin branch -> direction k+lanes, (k/lanes) even
+ * 64-bit words give 53-bit uniforms, 32-bit halves give 32-bit uniforms h * 2^-32 and indices (h * n) >> 32.
+ * pick_mode WALKER takes the cycle pick from slot 0 of the stream of the walker's rank 0 instead of the chain's own. */
+enum { SLOT_P = 0, SLOT_Q = 1, SLOT_G = 2, SLOT_SWAP = 0x10000, SLOT_AM = 0x1000000,
        SLOT_GJ = 0x2000000 /* + 4096 * (momenta draw of the call) + direction */, SLOT_GJS = 0x3000000 /* + scalar draw of the call */ };
+enum { PICK_CHAIN = 0, PICK_WALKER = 1 };
 
+static inline uint32_t hi32(uint64_t w) { return (uint32_t)(w >> 32); }
+static inline uint32_t lo32(uint64_t w) { return (uint32_t)w; }
+static inline double h2uniform(uint32_t h) { return (double)h * 0x1.0p-32; }                     /* [0,1), 32 bits */
+static inline uint32_t h2index(uint32_t h, uint32_t n) { return (uint32_t)(((uint64_t)h * n) >> 32); }
 static inline double w2uniform(uint64_t w) { return (double)(w >> 11) * 0x1.0p-53; }        /* [0,1) */
 static inline double w2uniform_open(uint64_t w) { return (double)((w >> 11) + 1) * 0x1.0p-53; } /* (0,1] */
 static inline uint64_t w2index(uint64_t w, uint64_t n) { return (uint64_t)(((unsigned __int128)w * n) >> 64); }
@@ -235,6 +245,7 @@ typedef struct {
     int32_t gj_nburn;                 /* nburn of the jump objects (= burn, PT:227,238,251) */
     int32_t hmc_min, hmc_max;         /* HMC: randint(hmc_min, hmc_max) leapfrogs (PT:240-241: 2, HMCsteps) */
     int32_t nuts_maxdepth;            /* tree heights built per call are 0..nuts_maxdepth (the reference has no cap) */
+    int32_t pick_mode;                /* PICK_CHAIN (the reference: every rank draws its own cycle entry) or PICK_WALKER */
     double hmc_eps;                   /* HMCstepsize */
     double nuts_delta;                /* target acceptance of the dual averaging (0.6, PT:256) */
     const double *gj_tab;             /* [3][d][d] whitening tables from L = cholesky(cov0) (NJ:53-54), each used as
@@ -679,24 +690,31 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
     const int ngr = c->ngroups > 1 ? c->ngroups : 1;
     const uint32_t sid = (uint32_t)((uint64_t)(c->walker0 + w) * (uint32_t)c->ntemps_global + (uint32_t)(c->temp0 + t));
     orc_replay *r = rp ? rp + t : NULL;
-    uint64_t A[2], B[2], C[2], D[2];
-    if (!r) { philox_words(c->seed, (uint64_t)it, sid, SLOT_A, A); philox_words(c->seed, (uint64_t)it, sid, SLOT_B, B); }
+    uint64_t P[2] = {0, 0}, Q[2] = {0, 0};
+    if (!r) { philox_words(c->seed, (uint64_t)it, sid, SLOT_P, P); philox_words(c->seed, (uint64_t)it, sid, SLOT_Q, Q); }
 
-    /* pick from the weighted cycle (PT:1058) */
+    /* pick from the weighted cycle (PT:1058); pick_mode WALKER: the draw of the walker's rank 0 serves all its ranks */
     const int w_de = c->de_on ? c->w_de : 0;
     const int L = c->w_scam + c->w_am + w_de + c->w_nuts + c->w_hmc;
-    const int ind = r ? (int)rp_next(r, K_INT, L) : (int)w2index(A[0], (uint64_t)L);
+    uint32_t pickw = hi32(P[0]);
+    if (!r && c->pick_mode == PICK_WALKER) {
+        uint64_t P0[2];
+        philox_words(c->seed, (uint64_t)it, (uint32_t)((uint64_t)(c->walker0 + w) * (uint32_t)c->ntemps_global), SLOT_P, P0);
+        pickw = hi32(P0[0]);
+    }
+    const int ind = r ? (int)rp_next(r, K_INT, L) : (int)h2index(pickw, (uint32_t)L);
     const int jt = ind < c->w_scam ? J_SCAM : (ind < c->w_scam + c->w_am ? J_AM : (ind < c->w_scam + c->w_am + w_de ? J_DE :
                    (ind < c->w_scam + c->w_am + w_de + c->w_nuts ? J_NUTS : J_HMC)));
     double qxy = 0.0;
 
-    /* group pick (PT:839,897,955); counter mode: word C0 for SCAM / AM, D0 for DE (the words those jumps leave unused) */
+    /* group pick (PT:839,897,955); counter mode: its own Philox call, drawn only when there is a choice */
     int g = 0;
     if (jt >= J_NUTS) g = 0;                                        /* the gradient jumps move all parameters */
     else if (r) g = (int)rp_next(r, K_INT, ngr);
     else if (ngr > 1) {
-        if (jt == J_DE) { philox_words(c->seed, (uint64_t)it, sid, SLOT_D, D); g = (int)w2index(D[0], (uint64_t)ngr); }
-        else { philox_words(c->seed, (uint64_t)it, sid, SLOT_C, C); g = (int)w2index(C[0], (uint64_t)ngr); }
+        uint64_t Gw[2];
+        philox_words(c->seed, (uint64_t)it, sid, SLOT_G, Gw);
+        g = (int)h2index(hi32(Gw[0]), (uint32_t)ngr);
     }
     const int ng = (c->ngroups > 1) ? c->gsize[g] : d;
     const double *Ut = st->Ut + (wc * ngr + g) * (size_t)d * d, *S = st->S + (wc * ngr + g) * (size_t)d;
@@ -710,7 +728,7 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
         else hmc_call(&G, &rng, gst, x, q, &qxy);
         free(G.w);
     } else if (jt == J_SCAM || jt == J_AM) {
-        const double prob = r ? rp_next(r, K_UNI, 0) : w2uniform(A[1]);
+        const double prob = r ? rp_next(r, K_UNI, 0) : h2uniform(lo32(P[0]));
         double scale = prob > 0.97 ? 10.0 : (prob > 0.9 ? 0.2 : 1.0);
         if (temp <= 100.0) scale *= sqrt(temp);                         /* PT:861-862 */
         if (jt == J_SCAM) {
@@ -718,9 +736,8 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             double z;
             if (r) { k = (int)rp_next(r, K_INT, ng); z = rp_next(r, K_NRM, 0); }
             else {
-                philox_words(c->seed, (uint64_t)it, sid, SLOT_D, D);
-                k = (int)w2index(B[1], (uint64_t)ng);
-                z = orc_normal(D[0], D[1]);
+                k = (int)h2index(hi32(Q[1]), (uint32_t)ng);
+                z = sqrt(-2.0 * orc_log(w2uniform_open(Q[0]))) * orc_cos2pi(h2uniform(lo32(Q[1])));   /* Box-Muller, 32-bit angle */
             }
             const double cd = 2.4 / sqrt(2.0 * 1.0) * scale;            /* PT:870, neff = 1 */
             const double a = z * cd * sqrt(S[k]);                       /* PT:873 */
@@ -754,16 +771,15 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             while (mm == nn) nn = (int)rp_next(r, K_INT, Bn);           /* PT:965-966 */
             prob = rp_next(r, K_UNI, 0);
         } else {
-            philox_words(c->seed, (uint64_t)it, sid, SLOT_C, C);
-            mm = (int)w2index(B[1], (uint64_t)Bn);
-            nn = (int)(((uint64_t)mm + 1 + w2index(C[0], (uint64_t)(Bn - 1))) % (uint64_t)Bn);
-            prob = w2uniform(A[1]);
+            mm = (int)h2index(hi32(Q[0]), (uint32_t)Bn);
+            nn = (int)(((uint32_t)mm + 1u + h2index(lo32(Q[0]), (uint32_t)(Bn - 1))) % (uint32_t)Bn);
+            prob = h2uniform(lo32(P[0]));
         }
         if (prob > 0.5) scale = 1.0;
         else {
             double rr;
             if (r) rr = rp_next(r, K_UNI, 0);
-            else rr = w2uniform(C[1]);
+            else rr = w2uniform(Q[1]);
             scale = rr * 2.4 / sqrt(2.0 * (double)ng) * sqrt(1.0 / beta); /* PT:976 */
         }
         const double *DE = st->DE + wc * (size_t)Bn * d;
@@ -780,7 +796,7 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
 
     /* Hastings test (PT:615-622); lnprob0 is always 1/T*lnL + logp(x) of the held state */
     const double lnprob0 = beta * st->lnL[ch] + st->lp[ch];
-    const double u = r ? rp_next(r, K_UNI, 0) : w2uniform(B[0]);
+    const double u = r ? rp_next(r, K_UNI, 0) : w2uniform(P[1]);
     const double diff = newlnprob - lnprob0 + qxy;                  /* qxy = 0 for SCAM / AM / DE */
     if (diff > orc_log(u)) {
         memcpy(x, q, sizeof(double) * d);

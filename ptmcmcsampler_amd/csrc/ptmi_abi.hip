@@ -511,6 +511,7 @@ static KArgs make_args(ptmi_engine *h)
     a.d = c.ndim; a.nt = c.ntemps; a.W = c.nwalkers; a.ntg = c.ntemps_global; a.temp0 = c.temp0; a.walker0 = c.walker0;
     a.w_host = c.w_host; a.w_scam = c.w_scam; a.w_am = c.w_am; a.w_de = c.w_de; a.de_on = h->de_on; a.de_size = c.de_size; a.de_head = h->de_head;
     a.cov_update = c.cov_update; a.tskip = c.tskip; a.per_walker = c.cov_per_walker; a.logp_kind = c.logp_kind;
+    a.pick_walker = c.pick_mode == PTMI_PICK_WALKER;
     a.w_nuts = c.w_nuts; a.w_hmc = c.w_hmc; a.gj_nburn = c.gj_nburn; a.hmc_min = c.hmc_min; a.hmc_max = c.hmc_max;
     a.nuts_maxdepth = c.nuts_maxdepth; a.hmc_eps = c.hmc_eps; a.nuts_delta = c.nuts_delta;
     a.gj_tab = h->d_gj_tab; a.gj = b.gj; a.gj_scr = h->d_gj_scr; a.gj_scal = h->d_gj_scal;
@@ -765,7 +766,8 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
 int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant)
 {
     if (!h || !variant) return fail(PTMI_EINVAL, "NULL argument");
-    *variant = h->last_variant | (h->G << 8) | (h->EPL << 16);
+    *variant = h->last_variant | ((h->cfg.pick_mode == PTMI_PICK_WALKER && (h->last_variant & PTMI_VAR_FULL)) ? PTMI_VAR_UNIFORM : 0) |
+               (h->G << 8) | (h->EPL << 16);
     return PTMI_OK;
 }
 

@@ -426,7 +426,9 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
     const int tg = a.temp0 + t;
     const double beta = a.beta[t];
     const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
-    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)tg);
+    const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
+    const u32 sid = sid0 + (u32)tg;
+    DrawBatch<false> batch;
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
     const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
@@ -447,8 +449,11 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
 
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
-        double log_u, u_acc, q[EPL], qxy = 0.0;
-        const int jt = propose<G, EPL, true, false, false, true>(a, it, sid, gl, cc, Ut, false, S, DE, q, log_u, u_acc);
+        double q[EPL], qxy = 0.0;
+        Draws dr;
+        draws_for_step<false, true>(batch, dr, a, k, sid, sid0, gl);
+        const double log_u = dr.log_u;
+        const int jt = propose<G, EPL, true, false, false, true>(a, it, sid, gl, cc, dr, Ut, false, S, DE, q);
         if (jt == PTMI_J_NUTS || jt == PTMI_J_HMC) {
             GradJump<G, EPL, LOGL> gj(a, gl, ch, beta, it, sid);
             double st[GJ_NSTATE];

@@ -184,21 +184,33 @@ __device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EP
 // order as the reference: scale in {10, 0.2, 1.0}; scale *= sqrt(temp) if temp <= 100
 // (PT:846-862); cd = 2.4 / sqrt(2 neff) * scale (PT:870, 928).
 struct ChainConst {
-    double cd_scam[3], sc[3];      // by scale branch: prob > 0.97, prob > 0.9, else; sc = scale (AM: cd = 2.4/sqrt(2 n_g) * sc)
+    // by scale branch (prob > 0.97, prob > 0.9, else): SCAM's cd and the bare scale (AM: cd = 2.4/sqrt(2 n_g) * sc).
+    // Scalars on purpose: arrays selected by the branch index were lowered to a table in scratch memory.
+    double cd0, cd1, cd2, sc0, sc1, sc2;
     double de_mul;                 // DE: rr * 2.4 / sqrt(2 n_g) * de_mul  (PT:976)
+    // every member is read before the selects: a conditional read would be folded into a read through a selected address
+    static __device__ __forceinline__ double pick3(int br, double v0, double v1, double v2)
+    {
+        double r = v2;
+        r = br == 1 ? v1 : r;
+        r = br == 0 ? v0 : r;
+        return r;
+    }
+    __device__ __forceinline__ double cd_scam(int br) const { return pick3(br, cd0, cd1, cd2); }
+    __device__ __forceinline__ double sc(int br) const { return pick3(br, sc0, sc1, sc2); }
 };
 __device__ __forceinline__ ChainConst chain_const(double temp, double beta, int d)
 {
     ChainConst c;
-    const double sT = temp <= 100.0 ? det_sqrt(temp) : 1.0;
-    const double base[3] = {10.0, 0.2, 1.0};
+    const bool warm = temp <= 100.0;
+    const double sT = warm ? det_sqrt(temp) : 1.0;
     const double c1 = 2.4 / det_sqrt(2.0 * 1.0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double sc = temp <= 100.0 ? base[j] * sT : base[j];
-        c.cd_scam[j] = c1 * sc;
-        c.sc[j] = sc;
-    }
+    c.sc0 = warm ? 10.0 * sT : 10.0;
+    c.sc1 = warm ? 0.2 * sT : 0.2;
+    c.sc2 = warm ? 1.0 * sT : 1.0;
+    c.cd0 = c1 * c.sc0;
+    c.cd1 = c1 * c.sc1;
+    c.cd2 = c1 * c.sc2;
     c.de_mul = det_sqrt(1.0 / beta);
     return c;
 }
@@ -220,39 +232,101 @@ constexpr int safe_slots(int G, int EPL)
     } while (0)
 #define PTMI_ROW_LOAD(dst, row, e) PTMI_ROW_LOAD_S(safe_slots(G, EPL), dst, row, e)
 
-// One proposal for the caller's chain (PT:1048-1067, 820-985): writes the increment dq
-// (q = x + dq) and returns the jump type.  log_u = log(accept uniform), evaluated in the
-// same instruction stream as the Box-Muller log, on another lane of each quad.
+// ------------------------------------------------------------------ draws
+// RNG schedule (oracle/ptmcmc_oracle.c "slot numbers"): an iteration of a chain consumes Philox slots
+// 0 (P) and 1 (Q) of its rank's stream.  The first four lanes of a chain evaluate them for TWO consecutive iterations in
+// one instruction stream: lane j -> slot (j & 1) of iteration it + (j >> 1); the same pass takes the logarithms both
+// iterations need (accept uniform on the even lanes, Box-Muller radius on the odd ones) and finishes the SCAM normal on
+// the odd lanes.  A step reads its values from lanes 0 / 1; after the first of the two steps the batch is rotated by two
+// lanes.  With pick_mode WALKER the word that picks the cycle entry comes from slot 0 of the stream of the walker's
+// rank 0, evaluated for four iterations at a time (lane j -> iteration it + j) and rotated by one lane per step.
+struct Draws {
+    u64 P0, Q0, Q1;       // P0 = [pick | scale-branch uniform]; Q0, Q1: SCAM (u1 | direction, angle) or DE (rows | scale)
+    double log_u;         // log(accept uniform)
+    double z;             // the SCAM normal (PT:873)
+    u32 pickw;            // the word that picks the cycle entry
+};
+__device__ __forceinline__ u32 h2index(u32 h, u32 n) { return __umulhi(h, n); }
+__device__ __forceinline__ double h2uniform(u32 h) { return (double)h * 0x1.0p-32; }
+template <bool STR>
+struct DrawBatch {
+    u64 w0, w1;           // this lane's Philox words
+    double lg, z;         // log of this lane's uniform; odd lanes: the SCAM normal
+    u32 pw;               // pick_mode WALKER: this lane's pick word
+    template <typename T>
+    static __device__ __forceinline__ T rot(T v, int by)   // value of the chain's lane (gl + by) & 3
+    {
+        if constexpr (STR) return __shfl(v, (int)((threadIdx.x + 16 * by) & 63), 64);
+        else if constexpr (sizeof(T) == 8) return (T)(by == 2 ? dpp64<0x4E>((u64)v) : dpp64<0x39>((u64)v));   // quad_perm [2,3,0,1] / [1,2,3,0]
+        else return (T)(by == 2 ? dpp32<0x4E>((u32)v) : dpp32<0x39>((u32)v));
+    }
+    __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl)
+    {
+        const int j = gl & 3;
+        philox_words(a.seed, (u64)(it + (j >> 1)), sid, (u32)(j & 1), w0, w1);
+        lg = det_log((j & 1) ? w2uniform_open(w0) : w2uniform(w1));
+        z = det_sqrt(-2.0 * lg) * det_cos2pi(h2uniform((u32)w1));                // meaningful on the odd lanes
+    }
+    __device__ __forceinline__ void advance()
+    {
+        w0 = rot(w0, 2); w1 = rot(w1, 2);
+        lg = __longlong_as_double((long long)rot((u64)__double_as_longlong(lg), 2));
+        z = __longlong_as_double((long long)rot((u64)__double_as_longlong(z), 2));
+    }
+    __device__ __forceinline__ void refill_pick(const KArgs &a, long long it, u32 sid0, int gl)
+    {
+        u64 p0, p1;
+        philox_words(a.seed, (u64)(it + (gl & 3)), sid0, 0u, p0, p1);
+        pw = (u32)(p0 >> 32);
+    }
+    __device__ __forceinline__ void advance_pick() { pw = rot(pw, 1); }
+    __device__ __forceinline__ u64 P1() const { return grp_bcast<STR, 0>(w1); }   // accept-uniform word (split path)
+    __device__ __forceinline__ void take(Draws &d, bool walker) const
+    {
+        d.P0 = grp_bcast<STR, 0>(w0);
+        d.log_u = grp_bcastf<STR, 0>(lg);
+        d.Q0 = grp_bcast<STR, 1>(w0);
+        d.Q1 = grp_bcast<STR, 1>(w1);
+        d.z = grp_bcastf<STR, 1>(z);
+        d.pickw = walker ? (u32)grp_bcast<STR, 0>((u64)pw) : (u32)(d.P0 >> 32);
+    }
+};
+// Steps k = 0, 1, ... of a launch that starts at iteration iter0: keep the batch current for step k.
+template <bool STR, bool FULL>
+__device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, const KArgs &a, int k, u32 sid, u32 sid0, int gl)
+{
+    if ((k & 1) == 0) b.refill(a, a.iter0 + k, sid, gl);
+    else b.advance();
+    const bool walker = FULL && a.pick_walker;
+    if (walker) {
+        if ((k & 3) == 0) b.refill_pick(a, a.iter0 + k, sid0, gl);
+        else b.advance_pick();
+    }
+    b.take(dr, walker);
+}
+
+// One proposal for the caller's chain (PT:1048-1067, 820-985) from the iteration's draws: writes the increment dq
+// (q = x + dq) and returns the jump type.
 // STR: strided lane layout (see "lane groups"); then Ut is the zero-padded LDS copy when ut_padded, and the AM
 // product runs on the matrix cores for all 16 chains of the wave at once.
 // GRP: parameter groups (compile-time: with one group every bound below is the wave-uniform d).
 // GJ: the cycle also holds the gradient jumps: such a pick hands the state back unchanged and the caller
 // (mh_steps_gj_kernel, ptmi_gj.inc.h) builds the proposal.
 template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
-__device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc,
+__device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, const Draws &dr,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
-                                       double (&dq)[EPL], double &log_u, double &u_acc)
+                                       double (&dq)[EPL])
 {
     const int d = a.d;
     // with gradient jumps a shape serves every ndim up to G*EPL (ptmi_lanes_for_grad), so no slot is exempt from the bounds check
     constexpr int PSAFE = GJ ? 0 : safe_slots(G, EPL);
     const int uld = (STR && ut_padded) ? mfma_ld(EPL) : d;   // leading dimension of the Ut table
-    // the four lanes of a quad evaluate slots A..D of this chain in one pass
-    u64 w0, w1;
-    philox_words(a.seed, (u64)it, sid, (u32)(gl & 3), w0, w1);
-    const u64 A0 = grp_bcast<STR, 0>(w0), A1 = grp_bcast<STR, 0>(w1);
-    const u64 B0 = grp_bcast<STR, 1>(w0), B1 = grp_bcast<STR, 1>(w1);
-    // one log stream: lane B -> log(accept uniform), lane D -> log(u1) of the SCAM normal
-    const double larg = (gl & 3) == 1 ? w2uniform(w0) : w2uniform_open(w0);
-    const double lg = det_log(larg);
-    log_u = grp_bcastf<STR, 1>(lg);
-    u_acc = w2uniform(B0);
 
     int jt = PTMI_J_SCAM;
     if (FULL) {
         const int w_de = a.de_on ? a.w_de : 0;
         const int L = a.w_host + a.w_scam + a.w_am + w_de + (GJ ? a.w_nuts + a.w_hmc : 0);
-        const int pick = (int)w2index(A0, (u64)L);
+        const int pick = (int)h2index(dr.pickw, (u32)L);
         const int ind = pick - a.w_host;
         jt = ind < a.w_scam ? PTMI_J_SCAM : (ind < a.w_scam + a.w_am ? PTMI_J_AM : PTMI_J_DE);
         if (GJ && ind >= a.w_scam + a.w_am + w_de) {
@@ -266,45 +340,42 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
             jt = PTMI_J_NTYPES + pick;
         }
     }
-    const double prob = w2uniform(A1);
-    const int br = prob > 0.97 ? 0 : (prob > 0.9 ? 1 : 2);
-    // the words of slots C and D are fetched outside the divergent branches (cross-lane reads need their source active)
-    const u64 C0 = grp_bcast<STR, 2>(w0), C1 = FULL ? grp_bcast<STR, 2>(w1) : 0;
-    const u64 D1 = grp_bcast<STR, 3>(w1);
-    const double ln1 = grp_bcastf<STR, 3>(lg);
-    // parameter group (PT:839,897,955): word C0 for SCAM / AM, D0 for DE -- the words those jumps leave unused.
+    // scale branch (PT:846-858): prob = lo32 * 2^-32 against 0.97, 0.9 and (DE) 0.5, as exact integer thresholds:
+    // lo * 2^-32 > c  <=>  lo > floor(c * 2^32)  (c * 2^32 is no integer for 0.97 and 0.9, and exactly 2^31 for 0.5)
+    const u32 plo = (u32)dr.P0;
+    constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0), T50 = 0x80000000u;
+    const int br = plo > T97 ? 0 : (plo > T90 ? 1 : 2);
+    // parameter group (PT:839,897,955): its own Philox call, only with more than one group.
     // A group's eigenvectors are embedded in the full space, so the jumps below only change the table they read.
     int g = 0, ng = d;
     if (GRP) {
-        const u64 D0 = grp_bcast<STR, 3>(w0);
-        g = (int)w2index(jt == PTMI_J_DE ? D0 : C0, (u64)a.ngroups);
+        u64 g0, g1;
+        philox_words(a.seed, (u64)it, sid, 2u, g0, g1);
+        g = (int)h2index((u32)(g0 >> 32), (u32)a.ngroups);
         ng = a.gsize[g];
         Ut += (size_t)g * d * d;
         S += (size_t)g * d;
     }
 
     if (jt == PTMI_J_SCAM) {
-        const int k = (int)w2index(B1, (u64)ng);
+        const int k = (int)h2index((u32)(dr.Q1 >> 32), (u32)ng);
         const double *col = Ut + (size_t)k * uld;
-        // the direction lands in dq (issued before the normal is computed, so its latency is covered) and
-        // is scaled in place
+        // the direction lands in dq and is scaled in place
 #pragma unroll
         for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD_S(PSAFE, dq[e], col, e);
         const double sk = S[k];
-        const double z = det_sqrt(-2.0 * ln1) * det_cos2pi(w2uniform(D1));
-        const double cd = br == 0 ? cc.cd_scam[0] : (br == 1 ? cc.cd_scam[1] : cc.cd_scam[2]);
-        const double amp = z * cd * det_sqrt(sk);             // PT:873
+        const double amp = dr.z * cc.cd_scam(br) * det_sqrt(sk);             // PT:873
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dq[e] = amp * dq[e];
     } else if (FULL && jt == PTMI_J_DE) {
-        const int Bn = a.de_size;
-        const int mm = (int)w2index(B1, (u64)Bn);
-        const int nn = (int)(((u64)mm + 1ull + w2index(C0, (u64)(Bn - 1))) % (u64)Bn);
+        const u32 Bn = (u32)a.de_size;
+        const u32 mm = h2index((u32)(dr.Q0 >> 32), Bn);
+        const u32 nn = (mm + 1u + h2index((u32)dr.Q0, Bn - 1u)) % Bn;
         double scale;
-        if (prob > 0.5) scale = 1.0;
-        else scale = w2uniform(C1) * 2.4 / a.gdiv[g] * cc.de_mul;  // PT:976
-        const double *rm = DE + (size_t)((mm + a.de_head) % Bn) * d;
-        const double *rn = DE + (size_t)((nn + a.de_head) % Bn) * d;
+        if (plo > T50) scale = 1.0;
+        else scale = w2uniform(dr.Q1) * 2.4 / a.gdiv[g] * cc.de_mul;  // PT:976
+        const double *rm = DE + (size_t)((mm + (u32)a.de_head) % Bn) * d;
+        const double *rn = DE + (size_t)((nn + (u32)a.de_head) % Bn) * d;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             double vm, vn;
@@ -321,7 +392,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         // AM (PT:879-933): q = x + U (cd sqrt(S) z).  Weights per chain (divergent), product per wave.
         const bool is_am = jt == PTMI_J_AM;
         if (!STR ? is_am : __any(is_am)) {
-            const double cd = a.gcn[g] * (br == 0 ? cc.sc[0] : (br == 1 ? cc.sc[1] : cc.sc[2]));   // PT:928
+            const double cd = a.gcn[g] * cc.sc(br);   // PT:928
             double wk[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) wk[e] = 0.0;
@@ -405,11 +476,13 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     const int tg = a.temp0 + t;
     const double beta = a.beta[t];
     const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
-    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)tg);
+    const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);                 // stream of the walker's rank 0
+    const u32 sid = sid0 + (u32)tg;
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * a.ngroups * d * d, *S = a.S + wc * a.ngroups * d;
     const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * d : nullptr;
     double *xrow = a.X + (size_t)ch * d;
+    DrawBatch<STR> batch;
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = mfma_ld(EPL);
@@ -454,10 +527,12 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
-        double log_u, u_acc;
+        Draws dr;
+        draws_for_step<STR, FULL>(batch, dr, a, k, sid, sid0, gl);
+        const double log_u = dr.log_u;
         int jt;
-        if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, PTMI_UL, true, S, DE, dq, log_u, u_acc);
-        else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, UtBlock, false, S, DE, dq, log_u, u_acc);
+        if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, S, DE, dq);
+        else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
         if (FULL) {
 #pragma unroll
             for (int j = 0; j < PTMI_J_FUSED; ++j) jp[j] += (jt == j);
@@ -546,7 +621,8 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     const int t = a.temp_of[ch];
     const double beta = a.beta[t];
     const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
-    const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg + (u32)(a.temp0 + t));
+    const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
+    const u32 sid = sid0 + (u32)(a.temp0 + t);
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * a.ngroups * d * d, *S = a.S + wc * a.ngroups * d;
     const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
@@ -554,8 +630,11 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     double x[EPL], dq[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
-    double log_u, u_acc;
-    const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, Ut, false, S, DE, dq, log_u, u_acc);
+    DrawBatch<false> batch;
+    Draws dr;
+    draws_for_step<false, true>(batch, dr, a, 0, sid, sid0, gl);
+    const double log_u = dr.log_u, u_acc = w2uniform(batch.P1());
+    const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, dr, Ut, false, S, DE, dq);
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {

@@ -207,3 +207,37 @@ def test_config5_slice_curved_nuts_16_temps(mods):
     for w0, o in zip(sub.walkers, sub.subs):
         assert_same(gj[w0], o.gj[0], "walker %d NUTS state" % w0)
     assert g.get("jstat").astype(np.int64)[..., 3, 0].sum() > 0
+
+
+@pytest.mark.parametrize("nt,W,cov_mode,logl", [(64, 3, "pooled", "iso"), (16, 5, "per_walker", "iso"), (3, 7, "pooled", "iso"),
+                                                (64, 2, "pooled", "dense"), (5, 3, "per_walker", "dense")])
+def test_walker_pick_mode_matches_oracle_and_is_uniform(mods, nt, W, cov_mode, logl):
+    """pick_mode="walker" (include/ptmi.h): one cycle draw per walker and iteration, from the stream of its rank 0,
+    fixes the proposal TYPE of all its ranks; everything else stays per chain.  HIP == oracle bit for bit, and the
+    per-type proposal counts are identical across the ranks of a walker."""
+    orc, _lib, _ = mods
+    d = 100
+    g, o = _pair(mods, d, nt, W, logl=_dense(d) if logl == "dense" else ("iso",), cov0=np.eye(d) * 0.01, weights=(20, 20, 20),
+                 cov_update=30, burn=60, tskip=10, seed=17, cov_mode=cov_mode, pick_mode="walker")
+    g.run(150)
+    o.run(150)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_UNIFORM and flags & _lib.VAR_FULL
+    _compare(g, o, "walker pick ")
+    js = g.get("jstat").astype(np.int64)[..., :3, 0]                      # [W][nt][type] proposals
+    assert (js == js[:, :1]).all() and (js.sum(-1) == 150).all()
+    assert (js[:, 0] > 0).all()                                           # every type was drawn
+    if W > 1:
+        assert not (js[0, 0] == js[1:, 0]).all()                          # walkers draw independently
+
+
+def test_walker_pick_mode_with_gradient_jumps(mods):
+    g, o = _pair(mods, 20, 4, 5, logl=("curved",), logp=("box", -10 * np.ones(20), 10 * np.ones(20)), cov0=np.eye(20),
+                 p0=np.tile(np.array([-0.1, -0.5] * 10), (5, 4, 1)), weights=(10, 0, 10), grad_weights=(10, 5),
+                 cov_update=50, burn=60, tskip=10, seed=23, pick_mode="walker")
+    g.run(130)
+    o.run(130)
+    _compare(g, o, "walker pick + NUTS ")
+    assert_same(g.get("gj"), o.gj, "gj")
+    js = g.get("jstat").astype(np.int64)[..., 0]
+    assert (js == js[:, :1]).all() and js[..., 3].sum() > 0 and js[..., 4].sum() > 0
