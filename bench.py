@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--nwalkers", type=int, default=4096)
     ap.add_argument("--mix", default="scam", choices=["scam", "default", "nuts"],
                     help="scam: SCAM-only; default: SCAM/AM/DE 20/20/20; nuts: SCAM/DE/NUTS 10/10/10 (BASELINE configs[4])")
+    ap.add_argument("--weights", default=None, help="SCAM,AM,DE weights overriding --mix (kernel experiments)")
     ap.add_argument("--pick", default="chain", choices=["chain", "walker"],
                     help="chain: every chain picks its proposal from its own stream (a replica of the reference); "
                          "walker: one pick per walker and iteration (wave-uniform proposal type)")
@@ -138,6 +139,9 @@ def main():
     if world != a.gpus:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (a.gpus, world))
     weights = {"scam": (20, 0, 0), "default": (20, 20, 20), "nuts": (10, 0, 10)}[a.mix]
+    if a.weights:
+        weights = tuple(int(v) for v in a.weights.split(","))
+        a.mix = "w" + a.weights.replace(",", "-")
     cpu = None
     # the CPU baseline is timed on rank 0 of the single-GPU run only; the NumPy port covers the Gaussian configs
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl == "iso":

@@ -2,6 +2,8 @@
 // Included by ptmi_shape.hip once per shape.  Reference behaviour cited as PT:<lines> =
 // PTMCMCSampler/PTMCMCSampler.py of nanograv/PTMCMCSampler.
 #pragma once
+#include <stdlib.h>
+
 #include "ptmi_common.h"
 
 // ------------------------------------------------------------- lane groups
@@ -315,8 +317,10 @@ __device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, con
 template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, const Draws &dr,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
-                                       double (&dq)[EPL])
+                                       double (&dq)[EPL], bool s_sqrt = false)
 {
+    // s_sqrt: S holds sqrt(eigenvalue) already (the block's LDS copy; sqrt is correctly rounded, so the bits are the same)
+    auto root_s = [&](int k) { const double v = S[k]; return s_sqrt ? v : det_sqrt(v); };
     const int d = a.d;
     // with gradient jumps a shape serves every ndim up to G*EPL (ptmi_lanes_for_grad), so no slot is exempt from the bounds check
     constexpr int PSAFE = GJ ? 0 : safe_slots(G, EPL);
@@ -357,17 +361,17 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         S += (size_t)g * d;
     }
 
-    if (jt == PTMI_J_SCAM) {
+    auto scam_body = [&]() {
         const int k = (int)h2index((u32)(dr.Q1 >> 32), (u32)ng);
         const double *col = Ut + (size_t)k * uld;
         // the direction lands in dq and is scaled in place
 #pragma unroll
         for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD_S(PSAFE, dq[e], col, e);
-        const double sk = S[k];
-        const double amp = dr.z * cc.cd_scam(br) * det_sqrt(sk);             // PT:873
+        const double amp = dr.z * cc.cd_scam(br) * root_s(k);                // PT:873
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dq[e] = amp * dq[e];
-    } else if (FULL && jt == PTMI_J_DE) {
+    };
+    auto de_body = [&]() {
         const u32 Bn = (u32)a.de_size;
         const u32 mm = h2index((u32)(dr.Q0 >> 32), Bn);
         const u32 nn = (mm + 1u + h2index((u32)dr.Q0, Bn - 1u)) % Bn;
@@ -387,41 +391,75 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
                 if (i < d && a.gmask[(size_t)g * d + i] == 0.0) dq[e] = 0.0;
             }
         }
-    }
-    if (FULL) {
-        // AM (PT:879-933): q = x + U (cd sqrt(S) z).  Weights per chain (divergent), product per wave.
-        const bool is_am = jt == PTMI_J_AM;
-        if (!STR ? is_am : __any(is_am)) {
+    };
+    // AM (PT:879-933): q = x + U (cd sqrt(S) z).  Weights per chain (divergent), product per wave.
+    const bool is_am = FULL && jt == PTMI_J_AM;
+    auto am_body = [&]() {
+        {
             const double cd = a.gcn[g] * cc.sc(br);   // PT:928
-            double wk[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) wk[e] = 0.0;
-            if (is_am) {
-                // directions k = gl + G*e and k + G (slots e even / odd) are the cos and sin branches of ONE Box-Muller
-#pragma unroll
-                for (int e = 0; e < EPL; e += 2) {
-                    const int k = gl + G * e;
-                    if (k < ng) {
-                        u64 e0, e1;
-                        philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
-                        const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
-                        double sn, cs;
-                        det_sincos2pi(w2uniform(e1), sn, cs);
-                        wk[e] = (r * cs) * cd * det_sqrt(S[k]);                        // PT:930
-                        if (e + 1 < EPL && k + G < ng) wk[e + 1] = (r * sn) * cd * det_sqrt(S[k + G]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);     // one Box-Muller at a time: interleaving them only costs registers
+            // directions k = gl + G*e and k + G (slots e even / odd) are the cos and sin branches of ONE Box-Muller
+            auto weights = [&](int e, double &wa, double &wb) {
+                wa = 0.0;
+                wb = 0.0;
+                const int k = gl + G * e;
+                if (is_am && k < ng) {
+                    u64 e0, e1;
+                    philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
+                    const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
+                    double sn, cs;
+                    det_sincos2pi(w2uniform(e1), sn, cs);
+                    wa = (r * cs) * cd * root_s(k);                             // PT:930
+                    if (e + 1 < EPL && k + G < ng) wb = (r * sn) * cd * root_s(k + G);
                 }
-            }
+            };
             if (STR) {
+                // Matrix cores: the weights of two k-steps come out of one Box-Muller and go straight into the two
+                // accumulation steps -- no weight array is kept, and the matrix pipe works on pair e while the vector
+                // pipe draws pair e + 2.  The accumulation order (k ascending) is that of mfma_tab_vec.
+                constexpr int NT = MfmaAcc<EPL>::NT;
                 MfmaAcc<EPL> acc;
-                if (ut_padded) mfma_tab_vec<EPL, true>(Ut, uld, d, wk, acc);
-                else mfma_tab_vec<EPL, false>(Ut, uld, d, wk, acc);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc.t[t] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
+                const int c16 = (int)(threadIdx.x & 15), g4 = (int)((threadIdx.x & 63) >> 4);
+                // a ROLLED loop over the pairs: unrolled, the thirteen Box-Muller bodies alone are half of the kernel's code and
+                // the kernel outgrows the instruction cache
+                const int esteps = (d + 3) / 4 < EPL ? (d + 3) / 4 : EPL;     // k-steps that hold a table row
+#pragma unroll 1
+                for (int e = 0; e < esteps; e += 2) {
+                    double ta[NT], wa, wb;
+                    const bool second = e + 1 < esteps;
+                    auto rows = [&](int k) {                           // table row block of one k-step
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int col = 16 * t + c16;
+                            if (ut_padded) ta[t] = Ut[(size_t)k * uld + col];
+                            else ta[t] = (k < d && col < d) ? Ut[(size_t)k * uld + col] : 0.0;
+                        }
+                    };
+                    rows(4 * e + g4);                                  // in flight during the draw
+                    weights(e, wa, wb);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wa, acc.t[t], 0, 0, 0);
+                    if (second) {
+                        rows(4 * e + 4 + g4);                          // behind the seven products above
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wb, acc.t[t], 0, 0, 0);
+                    }
+                }
                 if (is_am) {
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) dq[e] = acc.at(e);
                 }
             } else {
+                double wk[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; e += 2) {
+                    double wa, wb;
+                    weights(e, wa, wb);
+                    wk[e] = wa;
+                    if (e + 1 < EPL) wk[e + 1] = wb;
+                    __builtin_amdgcn_sched_barrier(0);     // one Box-Muller at a time: interleaving them only costs registers
+                }
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) dq[e] = 0.0;
 #pragma unroll
@@ -442,7 +480,10 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
                 }
             }
         }
-    }
+    };
+    if (jt == PTMI_J_SCAM) scam_body();
+    else if (FULL && jt == PTMI_J_DE) de_body();
+    if (FULL && (!STR ? is_am : __any(is_am))) am_body();
     return jt;
 }
 
@@ -458,10 +499,14 @@ __device__ __forceinline__ int logical_block()
 // STAGE (G = 4 shapes, chosen by the host when all chains of a block share their tables): strided lane layout,
 // the dense precision matrix and -- if it still fits -- the block's Ut are copied to LDS zero-padded, and the
 // table-times-vector products of the AM proposal and of the dense likelihood run on the matrix cores.
-template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP>
+// ULDS (SCAM-only cycles whose block shares one eigenvector table that fits LDS twice per CU): contiguous lane layout,
+// the table copied to LDS unpadded, so the one row a step reads comes at LDS latency instead of L2 latency.
+template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false>
 __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
 {
-    constexpr int CPB = 256 / G;
+    static_assert(!ULDS || (!STAGE && !FULL && !GRP), "ULDS is the SCAM-only contiguous-layout kernel");
+    constexpr int BLK = 256;
+    constexpr int CPB = BLK / G;
     constexpr bool STR = STAGE;
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
@@ -491,12 +536,14 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     // LDS pointers are derived from smem at their use so that they stay LDS (ds_read) accesses
 #define PTMI_PL (smem)
 #define PTMI_UL (smem + (LOGL == PTMI_LOGL_DENSE ? (size_t)tab_n : 0))
+    // FULL staged kernels: sqrt of the block's eigenvalues, behind the tables (d doubles)
+#define PTMI_SQ (smem + (size_t)tab_n * ((LOGL == PTMI_LOGL_DENSE ? 1 : 0) + ((UT_ALWAYS_LDS || a.lds_u) ? 1 : 0)))
     // with the dense likelihood both tables may not fit: then Ut stays in global memory (host decides, a.lds_u)
     constexpr bool UT_ALWAYS_LDS = LOGL != PTMI_LOGL_DENSE;
     const double *UtBlock = Ut;
     if (STAGE) {
         if (LOGL == PTMI_LOGL_DENSE) {
-            for (int i = (int)threadIdx.x; i < tab_n; i += 256) {
+            for (int i = (int)threadIdx.x; i < tab_n; i += BLK) {
                 const int r = i / LD, c = i % LD;
                 PTMI_PL[i] = (r < d && c < d) ? PtG[(size_t)r * d + c] : 0.0;
             }
@@ -508,12 +555,24 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
             UtBlock = a.Ut + w0 * d * d;
         }
+        if (FULL) {
+            const double *Sb = a.S + (size_t)((UtBlock - a.Ut) / ((size_t)d * d)) * d;     // the eigenvalues that go with UtBlock
+            for (int i = (int)threadIdx.x; i < d; i += BLK) PTMI_SQ[i] = det_sqrt(Sb[i]);
+        }
         if (FULL && (UT_ALWAYS_LDS || a.lds_u)) {
-            for (int i = (int)threadIdx.x; i < tab_n; i += 256) {
+            for (int i = (int)threadIdx.x; i < tab_n; i += BLK) {
                 const int r = i / LD, c = i % LD;
                 PTMI_UL[i] = (r < d && c < d) ? UtBlock[(size_t)r * d + c] : 0.0;
             }
         }
+        __syncthreads();
+    }
+    if (ULDS) {
+        const long long ch0 = (long long)logical_block() * CPB;
+        const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
+        const double *src = a.Ut + w0 * d * d, *srcS = a.S + w0 * d;
+        for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = src[i];
+        for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
         __syncthreads();
     }
 
@@ -531,7 +590,9 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         draws_for_step<STR, FULL>(batch, dr, a, k, sid, sid0, gl);
         const double log_u = dr.log_u;
         int jt;
-        if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, S, DE, dq);
+        if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
+        else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true);
+        else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true);
         else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
         if (FULL) {
 #pragma unroll
@@ -730,19 +791,37 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     const ptmi_config &c = h->cfg;
     constexpr bool WANTS = G == 4 && (FULL || LOGL == PTMI_LOGL_DENSE);   // the tables fit only for the small-ndim shapes
     a.lds_u = 0;
-    if (WANTS) {
+    if constexpr (WANTS) {
         const size_t tab = sizeof(double) * (size_t)(4 * ((c.ndim + 3) / 4)) * mfma_ld(EPL);   // zero-padded copy
+        // SCAM-only cycles read one row of the chain's own table per step; with AM the block needs ONE table
         const bool one_table_per_block = c.ngroups <= 1 && (!FULL || !c.cov_per_walker || c.ntemps % (256 / G) == 0);
         size_t lds = LOGL == PTMI_LOGL_DENSE ? tab : 0;
-        if (FULL && lds + tab <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
+        if (FULL && lds + tab + sizeof(double) * c.ndim <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
+        if (FULL) lds += sizeof(double) * c.ndim;                               // sqrt(eigenvalues)
         if (lds <= 160 * 1024 && one_table_per_block) {
-            auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, WANTS, false>;
+            auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, true, false>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, h->stream, a);
             h->last_variant = PTMI_VAR_STAGED | (FULL ? PTMI_VAR_FULL : 0) | (a.lds_u ? PTMI_VAR_LDS_UT : 0);
+            return PTMI_OK;
+        }
+    }
+    // SCAM-only cycle, one eigenvector table per block, two blocks' tables fit the CU's LDS: read the direction from LDS
+    if constexpr (!FULL && LOGL != PTMI_LOGL_DENSE) {
+        const size_t tab = sizeof(double) * ((size_t)c.ndim * c.ndim + c.ndim);
+        const bool one_table = c.ngroups <= 1 && (!c.cov_per_walker || c.ntemps % (256 / G) == 0);
+        static const bool off = getenv("PTMI_NO_ULDS") != nullptr;      // measurement switch: same results either way
+        if (one_table && 2 * tab <= 160 * 1024 && !off) {
+            auto kern = mh_steps_kernel<G, EPL, LOGL, false, false, false, true>;
+            if (tab > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab);
+                if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", tab, hipGetErrorString(e));
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), tab, h->stream, a);
+            h->last_variant = PTMI_VAR_LDS_UT;
             return PTMI_OK;
         }
     }
