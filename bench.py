@@ -48,7 +48,9 @@ def parse():
                     help="chain: every chain picks its proposal from its own stream (a replica of the reference); "
                          "walker: one pick per walker and iteration (wave-uniform proposal type)")
     ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
-    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "per_walker", "per_walker_device"])
+    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "per_walker", "per_walker_device"],
+                    help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
+                         "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK")
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
@@ -170,8 +172,9 @@ def main():
     if a.logl == "dense":
         A = np.random.default_rng(0).standard_normal((d, d))
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
-    kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, cov_mode=a.cov_mode, logl=logl,
-              device=local, swap_mode=a.swap_mode, pick_mode=a.pick)
+    kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
+              pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled",
+              eig_mode="jacobi" if a.cov_mode.endswith("_device") else "lapack")
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.logl == "curved":                      # examples/curved_likelihood.ipynb: box prior [-10, 10], cov = I, start near the mode
         kw.update(logl=("curved",), logp=("box", np.full(d, -10.0), np.full(d, 10.0)))

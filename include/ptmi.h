@@ -219,8 +219,15 @@ int ptmi_exchange_status(ptmi_handle h, int32_t *violations);
 /* _updateRecursive (:769-794) for every walker at iteration `iter` (= the multiple of
  * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 the
  * walkers' statistics are pooled into cov[0].  The eigendecomposition (:797-803) is a
- * separate step on the host (LAPACK, as the reference). */
+ * separate step: on the host (LAPACK, as the reference) or ptmi_eig_jacobi. */
 int ptmi_update_cov(ptmi_handle h, int64_t iter);
+
+/* The eigendecomposition of _updateRecursive (:797-803, np.linalg.svd of the covariance) for every covariance the handle
+ * holds (Wc matrices), on the device: Ut and S are overwritten from cov.  One-sided Jacobi, one block per matrix, both
+ * tables in LDS (ndim <= 101, one parameter group); eigenvalues descending, every eigenvector (a row of Ut) with its
+ * largest component positive.  Same subspaces as LAPACK, but not its column signs: a run adapted this way is not a
+ * bit-replica of one adapted through the host.  Asynchronous on the handle's stream. */
+int ptmi_eig_jacobi(ptmi_handle h);
 
 /* _updateDEbuffer (:806-817): drop the oldest cov_update rows of each DE history and
  * append the AM buffer (pooled mode: row r comes from walker r mod W). */

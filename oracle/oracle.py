@@ -93,6 +93,7 @@ def lib():
         L.orc_logl_grad.argtypes = [C.POINTER(Cfg), _dp, _dp]
         L.orc_logl.restype = C.c_double
         L.orc_logl.argtypes = [C.POINTER(Cfg), _dp]
+        L.orc_eig_jacobi.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int]
         assert L.orc_sizeof_cfg() == C.sizeof(Cfg)
         _lib = L
     return _lib
@@ -127,6 +128,19 @@ def temperature_ladder(nchain, ndim, Tmin=1, Tmax=None):
             ladder[ii] = Tmin * tstep**ii
         return ladder
     return np.array([1])
+
+
+JACOBI_MAX_SWEEPS = 30
+
+
+def eig_jacobi(cov, max_sweeps=JACOBI_MAX_SWEEPS):
+    """(Ut, S, sweeps) of a symmetric positive semi-definite matrix by the engine's Jacobi definition: eigenvectors as
+    ROWS of Ut, eigenvalues descending."""
+    cov = np.ascontiguousarray(cov, dtype=np.float64)
+    d = len(cov)
+    Ut, S = np.zeros((d, d)), np.zeros(d)
+    n = lib().orc_eig_jacobi(d, _p(cov), _p(Ut), _p(S), max_sweeps)
+    return Ut, S, n
 
 
 def welford(AM, mu, M2, it, fused=False):
@@ -237,8 +251,10 @@ class OracleEngine(object):
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep",
-                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain"):
-        assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker")
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain",
+                 eig_mode="lapack"):
+        assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi")
+        self.eig_mode = eig_mode
         self.pick_mode = pick_mode
         self.swap_mode = swap_mode
         self.d, self.nt, self.W = ndim, ntemps, nwalkers
@@ -271,6 +287,7 @@ class OracleEngine(object):
         self.S = np.zeros((self.Wc, self.ngr, d))
         for w in range(self.Wc):
             self._svd(w)
+        self._initial_done = True                          # the initial factorization is the host's in every mode (PT:139-145)
         self.mu = np.zeros((W, d))
         self.M2 = np.zeros((W, d, d))
         self.DE = np.zeros((self.Wc, burn, d))
@@ -318,6 +335,10 @@ class OracleEngine(object):
         except ImportError:
             import contextlib
             threadpool_limits = lambda limits: contextlib.nullcontext()   # noqa: E731
+        if self.eig_mode == "jacobi" and getattr(self, "_initial_done", False):
+            Ut, S, _ = eig_jacobi(self.cov[w])           # the engine's device eigensolver (covariance epochs only)
+            self.Ut[w, 0], self.S[w, 0] = Ut, S
+            return
         for gi, g in enumerate(self.groups):               # per group, PTMCMCSampler.py:139-145, 797-803
             c = self.cov[w][np.ix_(g, g)]
             if self.per_walker:

@@ -1028,4 +1028,73 @@ ORC_API double orc_logl_grad(const orc_cfg *c, const double *x, double *g)
     return v;
 }
 
+
+/* ------------------------------------------------ batched Jacobi eigensolver */
+/* The engine's device eigensolver (eig_mode "jacobi", csrc/ptmi_abi.hip eig_jacobi_kernel), restated operation for
+ * operation: it replaces np.linalg.svd(cov) of _updateRecursive (PT:797-803) where thousands of per-walker covariances
+ * have to be factorized per epoch.  One-sided (Hestenes) Jacobi on the rows of W = V^T A, A symmetric positive
+ * semi-definite: rotations of row pairs (p, q) in the round-robin order of the circle method, applied to W and to the
+ * accumulated V^T alike, until the rows of W are mutually orthogonal; then W W^T = V^T A^2 V is diagonal, row k of V^T is
+ * an eigenvector and ||row k of W|| its eigenvalue.  Each row pair is worked on by `lanes` (4) lanes: lane l sums the
+ * elements l, l + lanes, ... with fma in ascending order and the lanes combine as (s0 + s2) + (s1 + s3).
+ * Output: eigenvalues descending (ties by ascending row), eigenvectors as ROWS of Ut, each with its largest-magnitude
+ * component (first of equals) made positive.  Returns the number of sweeps run. */
+static double jac_dot(const double *a, const double *b, int d)
+{
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int l = 0; l < 4; ++l)
+        for (int i = l; i < d; i += 4) s[l] = fma(a[i], b[i], s[l]);
+    return (s[0] + s[2]) + (s[1] + s[3]);
+}
+ORC_API int orc_eig_jacobi(int d, const double *cov, double *Ut, double *S, int max_sweeps)
+{
+    const int n = d + (d & 1), P = n / 2, rounds = n - 1;
+    double *W = (double *)malloc(sizeof(double) * 2 * (size_t)d * d), *V = W + (size_t)d * d;
+    memcpy(W, cov, sizeof(double) * (size_t)d * d);
+    for (int i = 0; i < d * d; ++i) V[i] = 0.0;
+    for (int i = 0; i < d; ++i) V[(size_t)i * d + i] = 1.0;
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        int rotated = 0;
+        for (int r = 0; r < rounds; ++r) {
+            for (int k = 0; k < P; ++k) {            /* the pairs of a round are disjoint: any order */
+                int a = k == 0 ? n - 1 : (r + k) % (n - 1);
+                int b = k == 0 ? r : (r - k + (n - 1)) % (n - 1);
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                if (q >= d) continue;                /* the bye of an odd dimension */
+                double *wp = W + (size_t)p * d, *wq = W + (size_t)q * d, *vp = V + (size_t)p * d, *vq = V + (size_t)q * d;
+                const double al = jac_dot(wp, wp, d), be = jac_dot(wq, wq, d), ga = jac_dot(wp, wq, d);
+                if (!(fabs(ga) > 0x1.0p-50 * sqrt(al * be))) continue;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < d; ++i) {
+                    const double x = wp[i], y = wq[i];
+                    wp[i] = c * x - sn * y;
+                    wq[i] = sn * x + c * y;
+                    const double u = vp[i], v = vq[i];
+                    vp[i] = c * u - sn * v;
+                    vq[i] = sn * u + c * v;
+                }
+                rotated = 1;
+            }
+        }
+        if (!rotated) break;
+    }
+    double *nrm = (double *)malloc(sizeof(double) * (size_t)d);
+    for (int k = 0; k < d; ++k) nrm[k] = sqrt(jac_dot(W + (size_t)k * d, W + (size_t)k * d, d));
+    for (int k = 0; k < d; ++k) {
+        int rank = 0;
+        for (int j = 0; j < d; ++j) rank += (nrm[j] > nrm[k]) || (nrm[j] == nrm[k] && j < k);
+        const double *vk = V + (size_t)k * d;
+        int im = 0;
+        for (int i = 1; i < d; ++i) if (fabs(vk[i]) > fabs(vk[im])) im = i;
+        const double sg = vk[im] < 0.0 ? -1.0 : 1.0;
+        for (int i = 0; i < d; ++i) Ut[(size_t)rank * d + i] = sg * vk[i];
+        S[rank] = nrm[k];
+    }
+    free(nrm); free(W);
+    return sweep;
+}
+
 ORC_API int orc_sizeof_cfg(void) { return (int)sizeof(orc_cfg); }

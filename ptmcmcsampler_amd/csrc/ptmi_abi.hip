@@ -453,6 +453,117 @@ __global__ void de_update_kernel(double *DE, const double *AM, int d, int de_siz
     for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) dst[i] = src[i];
 }
 
+
+// ---------------------------------------------------------- eigensolver
+// Batched symmetric eigensolver for the per-walker covariances (PT:797-803 calls LAPACK's SVD once per epoch; a batch of
+// thousands of walkers would queue thousands of host factorizations).  One block per matrix, one-sided (Hestenes) Jacobi
+// on the rows of W = V^T A with W and V^T both in LDS: in every round of the circle-method schedule the n/2 disjoint row
+// pairs are rotated at once, four lanes per pair (lane l owns elements l, l+4, ... of both rows: conflict-free LDS
+// accesses, quad reductions by DPP); one barrier per round.  Operation order = oracle/ptmcmc_oracle.c orc_eig_jacobi,
+// so the results are bit-identical to it.  Eigenvalues descending, eigenvectors as rows, largest component positive.
+constexpr int JAC_THREADS = 256;
+constexpr int JAC_MAX_SWEEPS = 30;
+__device__ __forceinline__ double jac_quad_sum(double p)
+{
+    p = p + dppf64<0x4E>(p);     // xor 2: (s0 + s2), (s1 + s3)
+    p = p + dppf64<0xB1>(p);     // xor 1
+    return p;
+}
+__global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *cov, double *Ut, double *S, int d, int ut_stride, int s_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double jsm[];     // W[d][d], V[d][d]: all of the CU's LDS at d = 101
+    double *W = jsm, *V = jsm + (size_t)d * d;
+    constexpr int NE = 26;                                           // elements of a row per lane: l, l + 4, ... < 104
+    const int tid = (int)threadIdx.x;
+    const double *A = cov + (size_t)blockIdx.x * d * d;
+    for (int i = tid; i < d * d; i += JAC_THREADS) {
+        W[i] = A[i];
+        V[i] = (i / d == i % d) ? 1.0 : 0.0;
+    }
+    const int n = d + (d & 1), P = n / 2, rounds = n - 1;
+    const int pr = tid >> 2, l = tid & 3;
+    __syncthreads();
+    for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
+        int rotated = 0;
+        for (int r = 0; r < rounds; ++r) {
+            if (pr < P) {                                            // P <= 51 pairs: one quad each
+                const int k = pr;
+                const int a = k == 0 ? n - 1 : (r + k) % (n - 1);
+                const int b = k == 0 ? r : (r - k + (n - 1)) % (n - 1);
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                const bool real = q < d;                             // the bye of an odd dimension
+                double *wp = W + (size_t)p * d, *wq = W + (size_t)(real ? q : p) * d;
+                // both rows into registers once (zeros beyond the row: fma(0, 0, s) = s leaves the sums untouched)
+                double xp[NE], xq[NE];
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int i = l + 4 * j;
+                    xp[j] = i < d ? wp[i] : 0.0;
+                    xq[j] = i < d ? wq[i] : 0.0;
+                }
+                double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    al = __builtin_fma(xp[j], xp[j], al);
+                    be = __builtin_fma(xq[j], xq[j], be);
+                    ga = __builtin_fma(xp[j], xq[j], ga);
+                }
+                al = jac_quad_sum(al); be = jac_quad_sum(be); ga = jac_quad_sum(ga);
+                if (real && __builtin_fabs(ga) > 0x1.0p-50 * det_sqrt(al * be)) {      // quad-uniform
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + det_sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / det_sqrt(1.0 + t * t), sn = c * t;
+                    double *vp = V + (size_t)p * d, *vq = V + (size_t)q * d;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const int i = l + 4 * j;
+                        if (i < d) {
+                            const double u = vp[i], v = vq[i];
+                            wp[i] = c * xp[j] - sn * xq[j];
+                            wq[i] = sn * xp[j] + c * xq[j];
+                            vp[i] = c * u - sn * v;
+                            vq[i] = sn * u + c * v;
+                        }
+                    }
+                    rotated = 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(rotated)) break;
+    }
+    // norms (a quad per row, same summation as above): first in registers, then -- W is dead -- in W[0..d)
+    double mynorm[2] = {0.0, 0.0};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int k = pass * (JAC_THREADS / 4) + pr;
+        double al = 0.0;
+        if (k < d)
+            for (int j = 0; j < NE; ++j) { const int i = l + 4 * j; const double x = i < d ? W[(size_t)k * d + i] : 0.0; al = __builtin_fma(x, x, al); }
+        mynorm[pass] = det_sqrt(jac_quad_sum(al));
+    }
+    __syncthreads();                                                 // every row of W has been read: W[0..d) now holds the norms
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int k = pass * (JAC_THREADS / 4) + pr;
+        if (k < d && l == 0) W[k] = mynorm[pass];
+    }
+    __syncthreads();
+    const double *nrm = W;
+    double *Uo = Ut + (size_t)blockIdx.x * ut_stride, *So = S + (size_t)blockIdx.x * s_stride;
+    for (int k = pr; k < d; k += JAC_THREADS / 4) {
+        const double mine = nrm[k];
+        int rank = 0;
+        for (int j = 0; j < d; ++j) rank += (nrm[j] > mine) || (nrm[j] == mine && j < k);
+        const double *vk = V + (size_t)k * d;
+        int im = 0;
+        for (int i = 1; i < d; ++i) if (__builtin_fabs(vk[i]) > __builtin_fabs(vk[im])) im = i;
+        const double sg = vk[im] < 0.0 ? -1.0 : 1.0;
+        for (int i = l; i < d; i += 4) Uo[(size_t)rank * d + i] = sg * vk[i];
+        if (l == 0) So[rank] = mine;
+    }
+}
+
 // ----------------------------------------------------------------- selftest
 __global__ void selftest_math_kernel(int op, const double *in, const double *in2, double *out, long long n)
 {
@@ -1074,6 +1185,23 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
                            (const double *)h->d_pool_M2, (double *)nullptr, h->buf.cov, d, ng, ng, (double)POOL_GS * n_per,
                            (double)(W - (ng - 1) * POOL_GS) * n_per, (double)W * n_per - 1.0);
     }
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_eig_jacobi(ptmi_handle h)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    const ptmi_config &c = h->cfg;
+    if (!h->buf.cov || !h->buf.Ut || !h->buf.S) return fail(PTMI_EINVAL, "cov / Ut / S buffers missing");
+    if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "the device eigensolver factorizes the full covariance (no parameter groups)");
+    const int d = c.ndim;
+    const size_t lds = sizeof(double) * 2 * (size_t)d * d;
+    if (lds > 160 * 1024 || d > 101) return fail(PTMI_EUNSUPPORTED, "the device eigensolver keeps two %d x %d tables in LDS: ndim <= 101", d, d);
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eig_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nmat = c.cov_per_walker ? c.nwalkers : 1;
+    hipLaunchKernelGGL(eig_jacobi_kernel, dim3(nmat), dim3(JAC_THREADS), lds, h->stream, (const double *)h->buf.cov, h->buf.Ut, h->buf.S,
+                       d, d * d, d);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

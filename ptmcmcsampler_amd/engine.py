@@ -82,6 +82,9 @@ class PTEngine(object):
     the disjoint pairs (k, k+1), k = swap epoch (mod 2), all at once (see include/ptmi.h).  ``pick_mode``: ``"chain"`` =
     every chain draws its own entry of the proposal cycle (the reference's ``_jump``); ``"walker"`` = one draw per walker
     and iteration fixes the proposal type of all its temperature ranks (wave-uniform on the device, include/ptmi.h).
+    ``eig_mode``: who factorizes the adapted covariance at a covariance epoch (PTMCMCSampler.py:797-803): ``"lapack"`` = the
+    host, exactly as the reference (``np.linalg.svd`` per walker); ``"jacobi"`` = ``ptmi_eig_jacobi`` on the device, one
+    block per walker, no host round trip (ndim <= 101, one parameter group; same subspaces, its own sign rule).
     """
 
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
@@ -89,7 +92,8 @@ class PTEngine(object):
                  cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
                  w_host=0, keep_lnl=False, groups=None, swap_mode="sweep",
-                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain"):
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain",
+                 eig_mode="lapack"):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -112,6 +116,9 @@ class PTEngine(object):
         if pick_mode not in _lib.PICK_MODES:
             raise ValueError("pick_mode must be 'chain' or 'walker'")
         self.pick_mode = pick_mode
+        if eig_mode not in ("lapack", "jacobi"):
+            raise ValueError("eig_mode must be 'lapack' or 'jacobi'")
+        self.eig_mode = eig_mode
         self.Wc = self.W if self.per_walker else 1
         # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
         self.groups = [np.arange(self.d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
@@ -288,6 +295,10 @@ class PTEngine(object):
         if not self.owns_cold:
             return
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
+        if self.eig_mode == "jacobi":
+            _lib.check(self.lib.ptmi_eig_jacobi(self.h))              # stays on the stream: no host synchronisation
+            self.eig_epochs += 1
+            return
         cov = self.get("cov")
         if self.Wc == 1:
             self._eig_host(0, cov[0])

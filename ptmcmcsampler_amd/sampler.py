@@ -17,7 +17,9 @@ the reference runs unchanged as ONE process driving one GPU.  Differences, all a
   ``gradjump.py``) or, with a device likelihood, ``True`` for its built-in analytic gradient (NUTS / HMC then run
   inside the kernel, PTMCMCSampler.py:225-258 with the same weights and step-size keywords);
 * engine options: ``cov_mode="pooled"`` (one covariance adapted from all walkers instead of one per walker),
-  ``swap_mode="oddeven"`` (disjoint swap pairs instead of the reference's hot -> cold sweep), ``keep_walkers``.
+  ``swap_mode="oddeven"`` (disjoint swap pairs instead of the reference's hot -> cold sweep), ``pick_mode="walker"`` (one
+  proposal-type draw per walker and iteration), ``eig_mode="jacobi"`` (covariance epochs factorized on the device),
+  ``keep_walkers``.
 
 Attributes ``_chain, _lnlike, _lnprob, naccepted, nswap_accepted, swapProposed, jumpDict, cov,
 U, S, ladder, temp`` describe walker 0's T = 1 chain, as rank 0's do in the reference.
@@ -102,7 +104,8 @@ class _PerRankJump(object):
 class PTSampler(object):
     def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
                  logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
-                 nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1, swap_mode="sweep"):
+                 nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1, swap_mode="sweep",
+                 pick_mode="chain", eig_mode="lapack"):
         self.comm = comm if comm is not None else _DummyComm()
         if self.comm.Get_size() != 1:
             raise NotImplementedError(
@@ -110,6 +113,7 @@ class PTSampler(object):
         self.MPIrank, self.nchain = 0, int(ntemps) if ntemps else 1
         self.nwalkers, self.device_index, self.cov_mode = int(nwalkers), device, cov_mode
         self.swap_mode = swap_mode                          # "sweep" = PTswap as the reference; "oddeven" see PTEngine
+        self.pick_mode, self.eig_mode = pick_mode, eig_mode # engine options, see PTEngine
         self.keep_walkers = max(1, min(int(keep_walkers), self.nwalkers))
         self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
         self.stream = np.random.default_rng(self.seed)      # for host-side custom jumps that want a generator
@@ -266,7 +270,7 @@ class PTSampler(object):
             logl=self.logl_spec or ("iso",), logp=self.logp_spec or ("flat",),
             weights=(self.SCAMweight, self.AMweight, self.DEweight), cov_update=covUpdate, burn=burn, tskip=Tskip,
             seed=self.seed, cov_mode=self.cov_mode, hot_chain=hotChain, device=self.device_index, split=self.split,
-            swap_mode=self.swap_mode, grad_weights=self._grad_weights, hmc=(HMCstepsize, 2, HMCsteps),
+            swap_mode=self.swap_mode, pick_mode=self.pick_mode, eig_mode=self.eig_mode, grad_weights=self._grad_weights, hmc=(HMCstepsize, 2, HMCsteps),
             w_host=len(self.host_jumps), keep_lnl=True, groups=None if len(self.groups) == 1 and len(self.groups[0]) == self.ndim and np.array_equal(np.asarray(self.groups[0]), np.arange(self.ndim)) else self.groups)
 
     # ------------------------------------------------------------------ sample (:374-528)

@@ -1,0 +1,87 @@
+"""The engine's device eigensolver (eig_mode="jacobi", include/ptmi.h ptmi_eig_jacobi) replaces np.linalg.svd of the
+adapted covariance (PTMCMCSampler.py:797-803).  CPU: the oracle's restatement of the algorithm against LAPACK.  GPU: the
+kernel against the oracle, bit for bit, alone and inside a sampling run."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def _spd(d, rs, floor=0.1):
+    A = rs.randn(d, d)
+    c = A @ A.T / d + floor * np.eye(d)
+    return (c + c.T) / 2
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 33, 99, 100])
+def test_oracle_jacobi_factorizes_like_lapack(d):
+    rs = np.random.RandomState(d)
+    cov = _spd(d, rs) * 10.0 ** rs.uniform(-6, 3)
+    Ut, S, sweeps = orc.eig_jacobi(cov)
+    assert 0 < sweeps + (d == 1) < orc.JACOBI_MAX_SWEEPS
+    scale = np.abs(cov).max()
+    assert np.abs(Ut.T @ np.diag(S) @ Ut - cov).max() <= 1e-12 * scale        # U diag(S) U^T = cov
+    assert np.abs(Ut @ Ut.T - np.eye(d)).max() <= 1e-12
+    assert (np.diff(S) <= 0).all() and (S >= 0).all()
+    w = np.linalg.svd(cov, compute_uv=False)                                    # what the reference's call returns
+    assert np.abs(S - w).max() <= 1e-12 * w.max()
+    big = np.abs(Ut).argmax(axis=1)
+    assert (Ut[np.arange(d), big] > 0).all()                                    # the sign rule
+    # same subspaces as LAPACK: |cos| of matching eigenvectors is 1 (the spectrum of a random SPD matrix is simple)
+    U, _, _ = np.linalg.svd(cov)
+    assert np.abs(np.abs(np.einsum("ki,ik->k", Ut, U)) - 1).max() <= 1e-8
+
+
+def test_oracle_jacobi_degenerate_inputs():
+    Ut, S, n = orc.eig_jacobi(np.eye(6) * 0.01)               # the sampler's usual start: nothing to rotate
+    assert n == 0 and np.array_equal(Ut, np.eye(6)) and np.array_equal(S, np.full(6, 0.01))
+    Ut, S, n = orc.eig_jacobi(np.zeros((4, 4)))
+    assert np.array_equal(Ut, np.eye(4)) and not S.any()
+    rs = np.random.RandomState(1)
+    cov = _spd(7, rs)
+    cov[:, 2] = 0
+    cov[2, :] = 0                                              # a parameter that never moved: one zero eigenvalue
+    Ut, S, _ = orc.eig_jacobi(cov)
+    assert S[-1] == 0.0 and abs(abs(Ut[-1, 2]) - 1) < 1e-15
+    assert np.abs(Ut.T @ np.diag(S) @ Ut - cov).max() <= 1e-13
+    v = rs.randn(5)
+    Ut, S, _ = orc.eig_jacobi(np.outer(v, v))                  # rank one
+    assert abs(S[0] - v @ v) <= 1e-13 * (v @ v) and np.abs(S[1:]).max() <= 1e-13 * (v @ v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2, 7, 50, 99, 100, 101])
+def test_device_jacobi_is_bit_identical_to_the_oracle(d):
+    from ptmcmcsampler_amd import _lib
+    from ptmcmcsampler_amd.engine import PTEngine
+    rs = np.random.RandomState(100 + d)
+    W = 5
+    g = PTEngine(d, 1, W, np.eye(d), weights=(1, 0, 0), cov_update=4, burn=4, tskip=0, eig_mode="jacobi")
+    covs = np.stack([_spd(d, rs) * 10.0 ** rs.uniform(-4, 2) for _ in range(W - 2)] + [np.eye(d) * 0.01, np.zeros((d, d))])
+    g.put("cov", covs)
+    _lib.check(g.lib.ptmi_eig_jacobi(g.h))
+    g.sync()
+    Ut, S = g.get("Ut")[:, 0], g.get("S")[:, 0]
+    for w in range(W):
+        oUt, oS, _ = orc.eig_jacobi(covs[w])
+        assert np.array_equal(Ut[w].view(np.uint64), oUt.view(np.uint64)), (d, w)
+        assert np.array_equal(S[w].view(np.uint64), oS.view(np.uint64)), (d, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cov_mode,d,nt,W", [("per_walker", 100, 4, 6), ("per_walker", 12, 64, 3), ("pooled", 100, 3, 40)])
+def test_sampling_with_device_eigensolver_matches_oracle(cov_mode, d, nt, W):
+    """A whole run adapted through ptmi_eig_jacobi: every array equals the oracle's run adapted through orc_eig_jacobi."""
+    from ptmcmcsampler_amd.engine import PTEngine
+    kw = dict(weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=5, cov_mode=cov_mode, eig_mode="jacobi")
+    rs = np.random.RandomState(3)
+    cov0, p0 = _spd(d, rs) * 0.01, rs.randn(W, nt, d) * 0.3
+    g, o = PTEngine(d, nt, W, cov0, **kw), orc.OracleEngine(d, nt, W, cov0, **kw)
+    for e in (g, o):
+        e.init_state(p0)
+        e.run(170)
+    g.sync()
+    for name in ("X", "lnL", "slot_of", "nacc", "jstat", "nswap", "AM", "cov", "Ut", "S"):
+        a, b = g.get(name), getattr(o, name)
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), name
+    assert g.eig_epochs == 4 and o.jstat[..., 1, 1].sum() > 0
