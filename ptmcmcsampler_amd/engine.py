@@ -269,25 +269,27 @@ class PTEngine(object):
         self.t["Ut"][w, gi].copy_(torch.from_numpy(Ut))
         self.t["S"][w, gi].copy_(torch.from_numpy(Sv))
 
-    def init_state(self, p0):
-        """Initial point(s): ``p0`` of shape [d] (broadcast) or [W][nt][d] (by slot)."""
+    def init_state(self, p0, i0=0):
+        """Point(s) the chains hold at iteration ``i0``: ``p0`` of shape [d] (broadcast) or [W][nt][d] (by slot)."""
         torch = _torch()
         p0 = np.asarray(p0, dtype=np.float64)
-        full = p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d))
-        self.t["X"].copy_(torch.from_numpy(np.ascontiguousarray(full)))
+        full = np.array(p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d)))
+        self.t["X"].copy_(torch.from_numpy(full))
         _lib.check(self.lib.ptmi_eval_state(self.h))                 # :479-487
-        self._store_initial()
+        self._store_initial(i0)
+        self.iter = int(i0)
 
-    def _store_initial(self):
-        """updateChains(p0, lnlike0, lnprob0, i0=0), :491: row 0 of the AM ring holds the start point."""
+    def _store_initial(self, i0=0):
+        """updateChains(p0, lnlike0, lnprob0, i0), :491: row i0 % covUpdate of the AM ring holds the point."""
         torch = _torch()
         if self.owns_cold:
             ar = torch.arange(self.W, device=self.device)
             idx = self.t["slot_of"][:, 0].long()
-            self.t["AM"][:, 0, :] = self.t["X"][ar, idx]
+            row = int(i0) % self.cov_update
+            self.t["AM"][:, row, :] = self.t["X"][ar, idx]
             if self.t["AMaux"] is not None:
-                self.t["AMaux"][:, 0, 0] = self.t["lnL"][ar, idx]
-                self.t["AMaux"][:, 0, 1] = self.t["lp"][ar, idx]
+                self.t["AMaux"][:, row, 0] = self.t["lnL"][ar, idx]
+                self.t["AMaux"][:, row, 1] = self.t["lp"][ar, idx]
 
     # ------------------------------------------------------------------ epochs
     def update_cov(self, it_done):

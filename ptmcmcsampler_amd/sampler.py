@@ -105,7 +105,7 @@ class PTSampler(object):
     def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
                  logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
                  nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1, swap_mode="sweep",
-                 pick_mode="chain", eig_mode="lapack"):
+                 pick_mode="chain", eig_mode="lapack", checkpoint=None):
         self.comm = comm if comm is not None else _DummyComm()
         if self.comm.Get_size() != 1:
             raise NotImplementedError(
@@ -114,6 +114,9 @@ class PTSampler(object):
         self.nwalkers, self.device_index, self.cov_mode = int(nwalkers), device, cov_mode
         self.swap_mode = swap_mode                          # "sweep" = PTswap as the reference; "oddeven" see PTEngine
         self.pick_mode, self.eig_mode = pick_mode, eig_mode # engine options, see PTEngine
+        # device checkpoints (ptmi_checkpoint.npz beside the chain file) are written at every save when the run may be
+        # resumed: checkpoint=True, or -- by default -- when it was itself started with resume=True
+        self.checkpoint = bool(resume) if checkpoint is None else bool(checkpoint)
         self.keep_walkers = max(1, min(int(keep_walkers), self.nwalkers))
         self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
         self.stream = np.random.default_rng(self.seed)      # for host-side custom jumps that want a generator
@@ -252,11 +255,34 @@ class PTSampler(object):
                 self._hot_names.append(self.outDir + ("/chain_hot.txt" if last_hot else "/chain_{0}.txt".format(self.ladder[r])))
         self.resumeLength = 0
         self._ckpt = os.path.join(self.outDir, "ptmi_checkpoint.npz")
-        self._resuming = bool(self.resume) and os.path.isfile(self._ckpt) and os.path.isfile(self.fname)
-        if self._resuming:
+        have_file = bool(self.resume) and os.path.isfile(self.fname)
+        self._resuming = have_file and os.path.isfile(self._ckpt)          # continue from the device checkpoint
+        self._replaying = have_file and not self._resuming                 # the reference's way: replay the chain file
+        self.resumechain = None
+        if self._resuming or self._replaying:
             if self.verbose:
                 print("Resuming run from chain file {0}".format(self.fname))
-        else:
+        if self._replaying:
+            # PTMCMCSampler.py:290-313: the text rows are all there is (a chain the reference wrote, or a run of ours
+            # without checkpoints).  One chain only: a file holds one rank of one walker.
+            if self.nchain != 1 or self.nwalkers != 1:
+                raise Exception("Couldn't resume: {0} exists but the device checkpoint {1} does not, and a chain file alone can "
+                                "only be replayed for one chain (ntemps = nwalkers = 1).  Refusing to overwrite it.".format(
+                                    self.fname, self._ckpt))
+            try:
+                self.resumechain = np.loadtxt(self.fname, ndmin=2)
+            except ValueError as error:
+                print("Reading old chain files failed with error", error)
+                raise Exception("Couldn't read old chain to resume")
+            self.resumeLength = self.resumechain.shape[0]
+            if self.resumechain.shape[1] != self.ndim + 4:
+                raise Exception("Old chain has {0} columns, expected ndim + 4 = {1}".format(self.resumechain.shape[1], self.ndim + 4))
+            if self.isave != self.thin and self.resumeLength % (self.isave / self.thin) != 1:
+                raise Exception("Old chain has {0} rows, which is not the initial sample plus a multiple of isave/thin = {1}".format(
+                    self.resumeLength, self.isave // self.thin))
+            print("Resuming with", self.resumeLength, "samples from file representing", (self.resumeLength - 1) * self.thin + 1,
+                  "original samples")
+        if not (self._resuming or self._replaying):
             open(self.fname, "w").close()
             for f in self._hot_names:
                 open(f, "w").close()
@@ -292,15 +318,21 @@ class PTSampler(object):
                             HMCsteps=HMCsteps, maxIter=maxIter, thin=thin, i0=i0, neff=neff,
                             writeHotChains=writeHotChains, hotChain=hotChain)
         eng = self.engine
+        if eng is None:
+            raise RuntimeError("sample(..., i0 != 0) continues an initialised sampler: call sample() with i0 = 0 first")
         p0 = np.asarray(p0, dtype=np.float64)
         self.tstart = time.time()
+        if i0 != 0:
+            self.Niter = Niter                                 # the chains take p0 as their state at iteration i0 (:479-491)
         if i0 == 0 and self._resuming:
             i0 = self._load_checkpoint()                       # continue where the last complete save stopped
+        elif i0 == 0 and self._replaying:
+            i0 = self._replay_chain_file()                     # rebuild the adaptive state from the rows, as the reference does
         else:
             if self.split:
-                self._init_split(p0)
+                self._init_split(p0, i0)
             else:
-                eng.init_state(p0)
+                eng.init_state(p0, i0)
             self._harvest([i0])
             if self._hot_names:
                 self._harvest_hot(i0)
@@ -355,7 +387,8 @@ class PTSampler(object):
     def _save_checkpoint(self, iter):
         st = self.engine.checkpoint()
         st["iter"] = iter
-        st.update(f_chains=self._chains, f_lnlikes=self._lnlikes, f_lnprobs=self._lnprobs,
+        n = self.ind_next_write                                # the stored part of the sample arrays only
+        st.update(f_chains=self._chains[:, :n], f_lnlikes=self._lnlikes[:, :n], f_lnprobs=self._lnprobs[:, :n],
                   f_ind_next_write=self.ind_next_write,
                   f_jump_names=np.asarray(list(self.jumpDict), dtype=str),
                   f_jump_counts=np.asarray([self.jumpDict[k] for k in self.jumpDict], dtype=np.int64).reshape(-1, 2),
@@ -376,9 +409,65 @@ class PTSampler(object):
             self.jumpDict[str(name)] = [int(cnt[0]), int(cnt[1])]
         self._mirror_cov()
         self.resumeLength = self.ind_next_write
+        # the chain files must end where the checkpoint does: a run killed between the file write and the checkpoint
+        # leaves rows the resumed run is about to write again
+        for k in range(self.keep_walkers):
+            fname = self.fname if k == 0 else self.fname[:-4] + "_w%d.txt" % k
+            if os.path.isfile(fname):
+                rows = open(fname).read().splitlines(True)
+                if len(rows) < self.ind_next_write:
+                    raise Exception("{0} has {1} rows but the checkpoint was written after {2}".format(fname, len(rows), self.ind_next_write))
+                if len(rows) > self.ind_next_write:
+                    open(fname, "w").writelines(rows[:self.ind_next_write])
         i0 = int(st["iter"])
         print("Resuming with", self.resumeLength, "samples from file representing", i0 + 1, "original samples")
         return i0
+
+    def _replay_chain_file(self):
+        """Resume as the reference does (PTMCMCSampler.py:591-599): for iterations below resumeLength * thin the chain
+        does not jump but takes row iter // thin of the old file as its state, so the AM buffer, the covariance epochs
+        (:545-560) and the DE history (:563-571) are rebuilt from the file.  Returns the last replayed iteration."""
+        import torch
+        eng, rows, thin, cu = self.engine, self.resumechain, self.thin, self.covUpdate
+        d = self.ndim
+        last = self.resumeLength * thin - 1                         # iterations 1 .. last are replayed
+        X, lnl, lnp = rows[:, :d], rows[:, -3], rows[:, -4]
+        beta0 = 1.0 / eng.temps_mh[0]
+        # iteration 0: the first row (:474-476, :491)
+        eng.t["AM"][0, 0] = torch.from_numpy(X[0].copy())
+        eng.t["AMaux"][0, 0, 0], eng.t["AMaux"][0, 0, 1] = float(lnl[0]), float(lnp[0] - beta0 * lnl[0])
+        self._chains[0, 0], self._lnlikes[0, 0], self._lnprobs[0, 0] = X[0], lnl[0], lnp[0]
+        it = 1
+        while it <= last:
+            before = eng.eig_epochs
+            eng._epochs(it)                                         # covariance / DE epochs see the replayed AM rows
+            if eng.eig_epochs != before:
+                self._mirror_cov()
+            if (it - 1) == self.burn and self.DEweight and self.DEJump not in self.propCycle:
+                self.addProposalToCycle(self.DEJump, self.DEweight)
+                self.randomizeProposalCycle()
+            end = min(eng._segment_end(it, last), last)
+            its = np.arange(it, end + 1)
+            src = its // thin
+            eng.t["AM"][0, torch.from_numpy(its % cu).to(eng.device)] = torch.from_numpy(X[src]).to(eng.device)
+            aux = np.stack([lnl[src], lnp[src] - beta0 * lnl[src]], 1)
+            eng.t["AMaux"][0, torch.from_numpy(its % cu).to(eng.device)] = torch.from_numpy(aux).to(eng.device)
+            keep = its[its % thin == 0]
+            self._chains[0, keep // thin], self._lnlikes[0, keep // thin], self._lnprobs[0, keep // thin] = (
+                X[keep // thin], lnl[keep // thin], lnp[keep // thin])
+            it = end + 1
+        # the chain's state after the replay, its acceptance counter (:597-599), and what is on file already
+        k = last // thin
+        state = np.broadcast_to(X[k], (eng.W, eng.nt, d)).copy()
+        eng.t["X"].copy_(torch.from_numpy(state))
+        eng.put("lnL", np.full((eng.W, eng.nt), lnl[k]))
+        eng.put("lp", np.full((eng.W, eng.nt), lnp[k] - beta0 * lnl[k]))
+        nacc = eng.get("nacc")
+        nacc[0, 0] = int(round(last * rows[k, -2]))
+        eng.put("nacc", nacc.astype(np.int64))
+        self.ind_next_write = self.resumeLength
+        eng.iter = last
+        return last
 
     # ------------------------------------------------------------------ bookkeeping
     def _mirror_cov(self):
@@ -446,7 +535,7 @@ class PTSampler(object):
                     ll[w, s] = self.logl(Q[w, s])
         return ll, lp
 
-    def _init_split(self, p0):
+    def _init_split(self, p0, i0=0):
         import torch
         eng = self.engine
         full = p0 if p0.ndim == 3 else np.broadcast_to(p0, (eng.W, eng.nt, eng.d)).copy()
@@ -455,7 +544,8 @@ class PTSampler(object):
         ll[lp == -np.inf] = -np.inf                               # :481-483
         eng.put("lnL", ll)
         eng.put("lp", lp)
-        eng._store_initial()
+        eng._store_initial(i0)
+        eng.iter = int(i0)
 
     def _split_step(self, it):
         import torch
@@ -504,7 +594,8 @@ class PTSampler(object):
             if iter > 0:
                 np.save(self.outDir + "/cov.npy", self.cov)
                 self.engine.iter = iter
-                self._save_checkpoint(iter)
+                if self.checkpoint:
+                    self._save_checkpoint(iter)
             if self.verbose:
                 if iter > 0:
                     sys.stdout.write("\r")

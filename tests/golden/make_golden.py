@@ -317,7 +317,7 @@ def gen_ptswap(PT, out, tmp):
     rs = np.random.RandomState(8)
     res, meta = {}, []
     ci = 0
-    for n, d, spread in ((2, 3, 1.0), (4, 6, 3.0), (64, 100, 8.0), (64, 100, 60.0), (16, 5, 0.0), (8, 2, np.inf)):
+    for n, d, spread in ((2, 3, 1.0), (4, 6, 3.0), (64, 100, 8.0), (64, 100, 60.0), (16, 5, 0.0), (8, 2, np.inf), (512, 4, 40.0)):
         for rep in range(3):
             if np.isinf(spread):  # -inf likelihoods (out-of-prior starts) among the ranks
                 lnL = -np.abs(rs.randn(n)) * 5
@@ -505,6 +505,85 @@ def gen_gradjump(out):
     np.savez_compressed(os.path.join(out, "gradjump.npz"), **res)
 
 
+
+def gen_config1(PT, out):
+    """BASELINE configs[0]: the workload of the reference's examples/simple.py:52-122 -- 20-d dense Gaussian
+    built from the global NumPy state, box prior [0, 10], cov0 = 0.01 I, the UniformJump custom proposal with weight 5,
+    sample(p0, 10000, burn=500, thin=1, covUpdate=500, SCAM = AM = DE = 20) -- run by the reference with fixed seeds.
+    Stored: the target, the start, and the statistics of the reference's chain."""
+    tmp = tempfile.mkdtemp()
+    np.random.seed(20240501)
+    ndim, pmin, pmax = 20, 0.0, 10.0
+    mu, icov = make_dense(np.random, ndim, pmin, pmax)
+    logl, logp = Dense(mu, icov), Box(np.ones(ndim) * pmin, np.ones(ndim) * pmax)
+    p0 = np.random.uniform(pmin, pmax, ndim)
+    cov0 = np.eye(ndim) * 0.1**2
+    s = PT.PTSampler(ndim, logl, logp, np.copy(cov0), outDir=tmp, verbose=False, seed=42)
+
+    def jump(x, it, beta):
+        return np.random.uniform(pmin, pmax, len(x)), 0
+
+    s.addProposalToCycle(jump, 5)
+    s.sample(np.copy(p0), 10000, burn=500, thin=1, covUpdate=500, SCAMweight=20, AMweight=20, DEweight=20)
+    chain = s._chain[2500:10001]
+    res = dict(mu=mu, icov=icov, p0=p0, cov0=cov0, ndim=ndim, pmin=pmin, pmax=pmax,
+               ref_mean=chain.mean(0), ref_cov=np.cov(chain, rowvar=False), ref_acc=s.naccepted / 10000.0,
+               ref_lnlike_mean=s._lnlike[2500:10001].mean(),
+               jnames=np.asarray(sorted(s.jumpDict)), jstats=np.asarray([s.jumpDict[n] for n in sorted(s.jumpDict)], dtype=np.int64),
+               jumps_txt=np.asarray(open(os.path.join(tmp, "jumps.txt")).read().splitlines()),
+               nrows=len(open(s.fname).read().splitlines()), chainfile_name=os.path.basename(s.fname))
+    np.savez_compressed(os.path.join(out, "config1.npz"), **res)
+
+
+def gen_resume(PT, out):
+    """A chain file the reference wrote (600 iterations, thin 2, isave 100), and what the reference does when it resumes
+    from it (PTMCMCSampler.py:290-319, 591-599): the file rows are replayed as the chain's states, so the adaptive
+    covariance and the DE history are rebuilt from them.  Stored: the file, the adaptation snapshots of the replay, the
+    state at the iteration where sampling resumes."""
+    tmp = tempfile.mkdtemp()
+    d = 4
+    rs = np.random.RandomState(9)
+    mu, icov = make_dense(rs, d, 0.0, 10.0)
+    logl, logp = Dense(mu, icov), Box(np.zeros(d), 10 * np.ones(d))
+    p0, cov0 = rs.uniform(2, 8, d), np.eye(d) * 0.25
+    kw = dict(thin=2, isave=100, covUpdate=100, burn=200, SCAMweight=20, AMweight=20, DEweight=20)
+    s = PT.PTSampler(d, logl, logp, np.copy(cov0), outDir=tmp, verbose=False, seed=3)
+    s.sample(np.copy(p0), 600, **kw)
+    text = open(s.fname).read()
+    s2 = PT.PTSampler(d, logl, logp, np.copy(cov0), outDir=tmp, verbose=False, seed=4, resume=True)
+    epochs, orig = [], s2._updateRecursive
+
+    def snap(it, mem):
+        orig(it, mem)
+        epochs.append((it, s2.mu.copy(), s2.M2.copy(), s2.cov.copy()))
+
+    s2._updateRecursive = snap
+    state = {}
+    step = s2.PTMCMCOneStep
+
+    def one(p, lnl, lnp, it):
+        r = step(p, lnl, lnp, it)
+        if it == s2.resumeLength * s2.thin - 1:            # the last replayed iteration
+            state.update(x=np.array(r[0]), lnl=float(r[1]), lnp=float(r[2]), nacc=float(s2.naccepted), de=s2._DEbuffer.copy(),
+                         am=s2._AMbuffer.copy())
+        return r
+
+    s2.PTMCMCOneStep = one
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        s2.sample(np.copy(p0), 1000, **kw)
+    final = open(s2.fname).read().splitlines()
+    res = dict(mu=mu, icov=icov, p0=p0, cov0=cov0, ndim=d, chainfile=np.asarray(text.splitlines()), chainfile_name=os.path.basename(s.fname),
+               resume_length=s2.resumeLength, final_rows=len(final), replay_x=state["x"], replay_lnl=state["lnl"], replay_lnp=state["lnp"],
+               replay_nacc=state["nacc"], replay_de=state["de"], replay_am=state["am"], nepochs=len(epochs))
+    for k, v in kw.items():
+        res["kw_" + k] = v
+    for i, (it, m, M2, cov) in enumerate(epochs):
+        res["ep_it_%d" % i], res["ep_mu_%d" % i], res["ep_M2_%d" % i], res["ep_cov_%d" % i] = it, m, M2, cov
+    np.savez_compressed(os.path.join(out, "resume.npz"), **res)
+
+
 def main():
     PT = import_reference()
     tmp = tempfile.mkdtemp()
@@ -515,6 +594,8 @@ def main():
     gen_ptswap(PT, HERE, tmp)
     gen_trajectories(PT, HERE)
     gen_gradjump(HERE)
+    gen_config1(PT, HERE)
+    gen_resume(PT, HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d B" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -162,7 +162,7 @@ def test_resume_continues_bit_identically(tmp_path):
 
     def make(out, resume=False):
         return PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(out), verbose=False, seed=77, ntemps=3,
-                         nwalkers=4, keep_walkers=2, resume=resume)
+                         nwalkers=4, keep_walkers=2, resume=resume, checkpoint=True)
     a = make(tmp_path / "a")
     a.sample(p0, 1200, **kw)
     b1 = make(tmp_path / "b")
@@ -198,3 +198,159 @@ def test_write_hot_chains_and_groups(tmp_path):
     assert np.all(hot[:, d] == 0.0) or np.allclose(hot[1:, d], hot[1:, d + 1] / 1e80, atol=1e-6)   # lnprob = lnlike / 1e80
     assert len(s.U) == 2 and s.U[0].shape == (3, 3) and s.S[1].shape == (3,)
     assert np.abs(s.cov[0, 3]) < np.abs(s.cov[0, 0])          # adapted, and the facade mirrors the device covariance
+
+
+def test_resume_without_checkpoint_refuses_to_truncate(tmp_path):
+    """resume=True on a ladder whose device checkpoint is missing: the chain files must survive and the call must fail
+    loudly (a text file can only be replayed for a single chain)."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 3
+    kw = dict(burn=100, thin=1, covUpdate=50, isave=100, Tskip=10)
+    a = PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path), verbose=False, seed=1, ntemps=2)
+    a.sample(np.zeros(d), 200, **kw)
+    assert not os.path.exists(tmp_path / "ptmi_checkpoint.npz")                 # checkpoints are opt-in
+    before = open(tmp_path / "chain_1.0.txt").read()
+    b = PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path), verbose=False, seed=1, ntemps=2, resume=True)
+    with pytest.raises(Exception, match="Couldn't resume"):
+        b.sample(np.zeros(d), 400, **kw)
+    assert open(tmp_path / "chain_1.0.txt").read() == before
+
+
+def test_resume_from_a_chain_file_the_reference_wrote(tmp_path, golden, capsys):
+    """PTMCMCSampler.py:290-319, 591-599: resume=True with nothing but the reference's chain_1.txt.  The rows are
+    replayed as the chain's states; the covariance epochs and the DE history rebuilt from them equal the reference's own
+    (its mu / M2 / cov snapshots and its DE buffer during its resumed run), bit for bit; sampling then continues and
+    appends to the file."""
+    from ptmcmcsampler_amd import PTSampler
+    g = golden("resume")
+    d = int(g["ndim"])
+    open(tmp_path / str(g["chainfile_name"]), "w").write("\n".join(str(r) for r in g["chainfile"]) + "\n")
+    kw = {k[3:]: int(g[k]) for k in g.files if k.startswith("kw_")}
+    s = PTSampler(d, ("dense", g["mu"], g["icov"]), ("box", np.zeros(d), 10 * np.ones(d)), np.copy(g["cov0"]), outDir=str(tmp_path),
+                  verbose=False, seed=8, resume=True)
+    snaps = []
+    replay = s._replay_chain_file
+
+    def watched():
+        eng = s.engine
+        upd = eng.update_cov
+
+        def update_cov(it_done):
+            upd(it_done)
+            snaps.append((it_done, eng.get("mu")[0].copy(), eng.get("M2")[0].copy(), eng.get("cov")[0].copy()))
+
+        eng.update_cov = update_cov
+        last = replay()
+        eng.update_cov = upd
+        snaps.append(("end", last, np.roll(eng.get("DE")[0], -eng.de_head, axis=0), eng.get("AM")[0].copy(), eng.get("X")[0, 0].copy(),
+                      eng.get("lnL")[0, 0], int(eng.get("nacc")[0, 0])))
+        return last
+
+    s._replay_chain_file = watched
+    s.sample(g["p0"], 1000, **kw)
+    assert "Resuming with 301 samples from file representing 601 original samples" in capsys.readouterr().out
+    end = snaps.pop()
+    assert int(g["resume_length"]) == 301 and end[1] == 601
+    nrep = sum(1 for i in range(int(g["nepochs"])) if int(g["ep_it_%d" % i]) <= 600)
+    assert nrep == 6 and [sn[0] for sn in snaps] == [100, 200, 300, 400, 500, 600]
+    for i, (it, mu, M2, cov) in enumerate(snaps):
+        assert it == int(g["ep_it_%d" % i])
+        for name, mine in (("mu", mu), ("M2", M2), ("cov", cov)):
+            assert np.array_equal(mine.view(np.uint64), g["ep_%s_%d" % (name, i)].view(np.uint64)), (name, it)
+    assert np.array_equal(end[2], g["replay_de"]) and np.array_equal(end[3], g["replay_am"])
+    assert np.array_equal(end[4], g["replay_x"]) and end[5] == float(g["replay_lnl"])
+    assert abs(end[6] - float(g["replay_nacc"])) <= 1.0
+    rows = open(tmp_path / str(g["chainfile_name"])).read().splitlines()
+    assert len(rows) == int(g["final_rows"]) == 501
+    assert rows[:301] == [str(r) for r in g["chainfile"]]                          # the old rows are kept as they were
+    new = np.loadtxt(tmp_path / str(g["chainfile_name"]))[301:]
+    assert np.all(new[:, :d] >= 0) and np.all(new[:, :d] <= 10) and len(np.unique(new[:, 0])) > 20
+    assert s.DEJump in s.propCycle and s.jumpDict["DEJump"][0] > 0
+
+
+def test_neff_stops_the_run_early(tmp_path, capsys):
+    """neff (PTMCMCSampler.py:510-521): every 1000 iterations past 2 * burn the effective sample size of the cold chain
+    is estimated, and the run ends once it reaches the request; the partial block is written."""
+    from ptmcmcsampler_amd import PTSampler
+    from ptmcmcsampler_amd.ess import integrated_time
+    d = 3
+    s = PTSampler(d, ("iso",), ("flat",), np.eye(d), outDir=str(tmp_path), verbose=True, seed=2)
+    s.sample(np.zeros(d), 200000, burn=300, thin=1, covUpdate=300, isave=1000, neff=150)
+    out = capsys.readouterr().out
+    assert s.Niter < 200000 and s.Niter % 1000 == 0 and s.Niter > 600
+    m = re.search(r"Run Complete with (\d+) effective samples", out)
+    assert m and int(m.group(1)) >= 150
+    tau = max(integrated_time(s._chain[300:s.Niter, i]) for i in range(d))
+    assert (s.Niter - 300) / tau >= 150                                            # the criterion, recomputed
+    assert (s.Niter - 1000 - 300) / tau < 150 * 1.5                                # and it did stop about as early as it could
+    assert len(open(tmp_path / "chain_1.txt").read().splitlines()) == s.Niter + 1
+    # without neff the same run goes on to the end
+    s2 = PTSampler(d, ("iso",), ("flat",), np.eye(d), outDir=str(tmp_path / "b"), verbose=False, seed=2)
+    s2.sample(np.zeros(d), 3000, burn=300, thin=1, covUpdate=300, isave=1000)
+    assert s2.Niter == 3000
+
+
+def test_continue_with_i0(tmp_path):
+    """sample(p0, Niter, i0 = k), k != 0 (PTMCMCSampler.py:443-491): no re-initialisation; the chains take p0 as their
+    state at iteration k (AM row k % covUpdate, sample k / thin) and run on to Niter."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 4
+    s = PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.1, outDir=str(tmp_path), verbose=False, seed=6, ntemps=2)
+    with pytest.raises(RuntimeError, match="i0 = 0 first"):
+        s.sample(np.zeros(d), 100, i0=50)
+    kw = dict(burn=100, thin=5, covUpdate=40, isave=100, Tskip=10, maxIter=400)
+    s.sample(np.zeros(d), 200, **kw)
+    assert s.engine.iter == 200 and s.ind_next_write == 41
+    p1 = np.full(d, 0.25)
+    s.sample(p1, 400, i0=200, **kw)
+    assert s.engine.iter == 400 and s.ind_next_write == 81
+    assert np.array_equal(s._chain[40], p1) and np.isclose(s._lnlike[40], -0.5 * (p1 ** 2).sum())
+    assert not np.array_equal(s._chain[41], p1) or not np.array_equal(s._chain[45], p1)
+    assert len(open(tmp_path / "chain_1.0.txt").read().splitlines()) == 81
+
+
+def test_config1_examples_simple_parameters(tmp_path, golden):
+    """BASELINE configs[0] at exactly the parameters of the reference's examples/simple.py:52-122: 20-d dense Gaussian,
+    box prior [0, 10], cov0 = 0.01 I, UniformJump with weight 5, sample(p0, 10000, burn=500, thin=1, covUpdate=500,
+    SCAM = AM = DE = 20), Python callbacks.  The reference's own run on the same target (fixture config1.npz, written by
+    tests/golden/make_golden.py) is the yardstick: same files, same cycle fractions, and two chains that agree within their
+    Monte-Carlo error (different RNGs, so no closer)."""
+    from ptmcmcsampler_amd import PTSampler
+    from ptmcmcsampler_amd.ess import ess
+    g = golden("config1")
+    ndim, pmin, pmax = int(g["ndim"]), float(g["pmin"]), float(g["pmax"])
+    mu, icov = g["mu"], g["icov"]
+
+    def lnlikefn(x):
+        diff = x - mu
+        return -np.dot(diff, np.dot(icov, diff)) / 2.0
+
+    def lnpriorfn(x):
+        return 0.0 if np.all(pmin <= x) and np.all(pmax >= x) else -np.inf
+
+    s = PTSampler(ndim, lnlikefn, lnpriorfn, np.copy(g["cov0"]), outDir=str(tmp_path), verbose=False, seed=42)
+    rs = np.random.RandomState(7)
+
+    def jump(x, it, beta):
+        return rs.uniform(pmin, pmax, len(x)), 0
+
+    s.addProposalToCycle(jump, 5)
+    s.sample(np.copy(g["p0"]), 10000, burn=500, thin=1, covUpdate=500, SCAMweight=20, AMweight=20, DEweight=20)
+    assert str(g["chainfile_name"]) == "chain_1.txt"
+    rows = open(tmp_path / "chain_1.txt").read().splitlines()
+    assert len(rows) == int(g["nrows"]) == 10001
+    assert sorted(open(tmp_path / "jumps.txt").read().splitlines()) == sorted(str(l) for l in g["jumps_txt"])
+    assert sorted(s.jumpDict) == [str(n) for n in g["jnames"]]
+    ref = {str(n): v for n, v in zip(g["jnames"], g["jstats"])}
+    for name, (prop, acc) in s.jumpDict.items():
+        assert abs(prop - ref[name][0]) < 5 * np.sqrt(ref[name][0]), name          # cycle shares (binomial error)
+    assert sum(v[0] for v in s.jumpDict.values()) == 10000
+    assert abs(s.naccepted / 10000.0 - float(g["ref_acc"])) < 0.06
+    x = s._chain[2500:10001]
+    sd = np.sqrt(np.diag(g["ref_cov"]))
+    n_eff = ess(x)                       # min over the 20 dimensions: a few thousand strongly correlated samples
+    assert n_eff > 3
+    # two independent estimates of the same posterior mean: allow 5 standard errors of their difference
+    assert np.all(np.abs(x.mean(0) - g["ref_mean"]) < 5 * sd * np.sqrt(2.0 / n_eff))
+    assert np.all(np.abs(np.sqrt(np.diag(np.cov(x, rowvar=False))) / sd - 1) < 0.5)
+    assert abs(s._lnlike[2500:10001].mean() - float(g["ref_lnlike_mean"])) < 2.0
