@@ -215,6 +215,11 @@ int ptmi_swap_sweep_blocks(ptmi_handle h, int64_t iter, const double *lnL_blocks
 int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send /* dev [nranks][W][d+2] */);
 int ptmi_exchange_apply(ptmi_handle h, const double *recv /* dev [nranks][W][d+2] */);
 int ptmi_exchange_status(ptmi_handle h, int32_t *violations);
+/* After ptmi_exchange_pack: 1 if some row of the sweep moves further than to a neighbouring block (possible only when the
+ * carried state wins every pair of a whole block), else 0 -- the same answer on every GPU, computed from the global map.
+ * With 0 only send[rank-1] and send[rank+1] hold rows: the caller exchanges those two segments with its neighbours
+ * (RCCL send/recv over one xGMI link each way) and skips the all-to-all.  Synchronises the stream (4 bytes come back). */
+int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag);
 
 /* _updateRecursive (:769-794) for every walker at iteration `iter` (= the multiple of
  * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 the

@@ -43,7 +43,7 @@ class Buffers(C.Structure):
 SYMBOLS = (
     "ptmi_last_error", "ptmi_version", "ptmi_device_count", "ptmi_lanes_for", "ptmi_lanes_for_grad", "ptmi_temperature_ladder", "ptmi_create", "ptmi_destroy",
     "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_last_mh_variant", "ptmi_swap", "ptmi_swap_gather_lnl",
-    "ptmi_swap_sweep", "ptmi_swap_sweep_blocks", "ptmi_exchange_pack", "ptmi_exchange_apply", "ptmi_exchange_status",
+    "ptmi_swap_sweep", "ptmi_swap_sweep_blocks", "ptmi_exchange_pack", "ptmi_exchange_apply", "ptmi_exchange_status", "ptmi_exchange_multihop",
     "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_eig_jacobi", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept",
     "ptmi_selftest_math", "ptmi_selftest_philox", "ptmi_malloc", "ptmi_free", "ptmi_memcpy_h2d", "ptmi_memcpy_d2h",
     "ptmi_memset", "ptmi_timer_start", "ptmi_timer_stop_ms",
@@ -94,6 +94,7 @@ def load():
     L.ptmi_exchange_pack.argtypes = [H, C.c_void_p, C.c_void_p]
     L.ptmi_exchange_apply.argtypes = [H, C.c_void_p]
     L.ptmi_exchange_status.argtypes = [H, C.POINTER(C.c_int32)]
+    L.ptmi_exchange_multihop.argtypes = [H, C.POINTER(C.c_int32)]
     L.ptmi_update_cov.argtypes = [H, C.c_int64]
     L.ptmi_propose.argtypes = [H, C.c_int64]
     L.ptmi_accept.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]

@@ -816,7 +816,7 @@ int ptmi_destroy(ptmi_handle h)
 {
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
-    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_xint);
+    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -975,6 +975,8 @@ static int ensure_xint(ptmi_engine *h)
     if (h->d_xint) return PTMI_OK;
     HIPCHK(hipMalloc((void **)&h->d_xint, sizeof(int32_t) * xint_count(h->cfg)));
     HIPCHK(hipMemsetAsync(h->d_xint, 0, sizeof(int32_t) * xint_count(h->cfg), h->stream));
+    HIPCHK(hipMalloc((void **)&h->d_hop, sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
     return PTMI_OK;
 }
 
@@ -1112,6 +1114,17 @@ __global__ void exchange_apply_kernel(int W, int nt, int d, double *X, double *l
 }
 
 
+// A row travels further than to a neighbouring block when the carried state of the sweep wins every pair of a whole
+// block.  Every GPU scans the whole map (identical everywhere), so all of them take the same decision on the transport.
+__global__ void exchange_multihop_kernel(int W, int ntg, int nt, const int32_t *map, int32_t *flag)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)W * ntg) return;
+    const int j = (int)(idx % ntg);
+    const int hop = map[idx] / nt - j / nt;
+    if (hop > 1 || hop < -1) atomicOr(flag, 1);
+}
+
 int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send)
 {
     if (!h || !map || !send) return fail(PTMI_EINVAL, "NULL argument");
@@ -1125,7 +1138,20 @@ int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send)
                        map, h->buf.slot_of, h->buf.temp_of, (const int32_t *)inv, newslot, arr, lvs, lvr, err);
     hipLaunchKernelGGL(exchange_pack_kernel, dim3(W, 2), dim3(64), 0, h->stream, W, c.ntemps, c.ndim, (const double *)h->buf.X,
                        (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)lvs, (const int32_t *)lvr, send);
+    HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
+    const long long tot = (long long)W * c.ntemps_global;
+    hipLaunchKernelGGL(exchange_multihop_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global, c.ntemps,
+                       map, h->d_hop);
     HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag)
+{
+    if (!h || !flag) return fail(PTMI_EINVAL, "NULL argument");
+    *flag = 0;
+    if (!h->d_hop) return PTMI_OK;
+    HIPCHK(hipMemcpyAsync(flag, h->d_hop, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PTMI_OK;
 }
 int ptmi_exchange_apply(ptmi_handle h, const double *recv)

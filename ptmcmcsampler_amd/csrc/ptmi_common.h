@@ -78,6 +78,7 @@ struct ptmi_engine {
     int32_t *d_gsize;
     double *d_pre;      // [4][ntg][W] scratch of the swap (uniforms, likelihoods, own-likelihood terms)
     int32_t *d_prow;    // [ntg][W] rows by position (fused swap)
+    int32_t *d_hop;     // set by ptmi_exchange_pack when a row of the last sweep travels beyond a neighbouring block
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance

@@ -363,6 +363,12 @@ class PTEngine(object):
     def exchange_apply(self, recv):
         _lib.check(self.lib.ptmi_exchange_apply(self.h, recv.data_ptr()))
 
+    def exchange_multihop(self):
+        """After exchange_pack: does any row of this sweep travel beyond a neighbouring block? (same answer on every GPU)"""
+        v = C.c_int32(0)
+        _lib.check(self.lib.ptmi_exchange_multihop(self.h, C.byref(v)))
+        return bool(v.value)
+
     def exchange_violations(self):
         v = C.c_int32(0)
         _lib.check(self.lib.ptmi_exchange_status(self.h, C.byref(v)))

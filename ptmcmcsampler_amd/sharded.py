@@ -6,9 +6,10 @@ walker (state ``[W][nt][d]`` on its GPU).  Chains only interact at
 * swap epochs (every Tskip, PTMCMCSampler/PTMCMCSampler.py:631-697): lnL is
   all-gathered (``W * ntemps * 8`` bytes), every GPU runs the identical hot->cold sweep
   (same Philox uniforms, same data -> same map), and only rows whose new position is in
-  another block travel, by one all-to-all over RCCL/xGMI;
-* covariance / DE epochs (:545-576): the GPU holding rank 0 adapts and broadcasts
-  ``cov, Ut, S`` and the new DE rows.
+  another block travel: by grouped send/recv with the two neighbouring blocks (RCCL over one xGMI
+  link each way), and by an all-to-all only in the rare epoch where a row crosses a whole block;
+* covariance / DE epochs (:545-576): the GPU holding rank 0 adapts and broadcasts the
+  factorization ``Ut, S`` (not the covariance: only the owner reads it) and the new DE rows.
 
 The exchange below is written with torch tensor ops so it runs unchanged on CUDA tensors
 over RCCL ("nccl") and on CPU tensors over gloo (the CPU tests drive it with an
@@ -86,6 +87,29 @@ class DistComm(object):
     def broadcast(self, t):
         self.dist.broadcast(t, src=self.root, group=self.group)
 
+    def neighbour_exchange(self, send, recv):
+        """send[q] -> rank q and recv[q] <- rank q for q = rank - 1, rank + 1 only: one grouped send/recv pair per block
+        edge (RCCL: ncclSend / ncclRecv inside one group, i.e. one xGMI link each way).  Over gloo (CPU tests, one-GPU
+        rehearsals) device tensors are staged through the host."""
+        import torch
+        dist = self.dist
+        peers = [q for q in (self.rank - 1, self.rank + 1) if 0 <= q < self.world]
+        if not peers:
+            return
+        gr = (lambda q: dist.get_global_rank(self.group, q)) if self.group is not None else (lambda q: q)
+        staged = send.is_cuda and dist.get_backend(self.group) != "nccl"
+        sbuf = {q: (send[q].cpu() if staged else send[q]) for q in peers}
+        rbuf = {q: (torch.empty_like(sbuf[q]) if staged else recv[q]) for q in peers}
+        ops = []
+        for q in peers:
+            ops.append(dist.P2POp(dist.isend, sbuf[q], gr(q), group=self.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf[q], gr(q), group=self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if staged:
+            for q in peers:
+                recv[q].copy_(rbuf[q])
+
 
 class ShardedPTEngine(object):
     """One ladder of ``ntemps_global`` ranks sharded over ``group``; same interface as PTEngine."""
@@ -113,6 +137,7 @@ class ShardedPTEngine(object):
         self._map = torch.zeros((self.W, self.ntg), dtype=torch.int32, device=self.device)
         self._parts = torch.empty((self.world * self.W, self.nt), dtype=torch.float64, device=self.device)
         self.rows_moved = 0
+        self.neighbour_swaps = 0                                                 # swap epochs served by the two neighbour links alone
         # device-side exchange (HIP engines): fixed [world][W][d+2] buffers, no host synchronisation per swap
         self.device_exchange = hasattr(L, "exchange_pack")
         if self.device_exchange:
@@ -144,7 +169,13 @@ class ShardedPTEngine(object):
         if self.device_exchange:
             L.sweep_blocks(it, self._parts, self._map)                        # identical on every rank
             L.exchange_pack(self._map, self._send)                            # tables rewritten, leaving rows packed
-            self.comm.all_to_all(self._recv, self._send)                      # equal splits: send[q] -> rank q
+            # A sweep moves a walker's rows between NEIGHBOURING blocks unless its carried state wins every pair of a
+            # whole block: then (and only then) the all-to-all is needed; every rank reads the same flag off the map.
+            if hasattr(self.comm, "neighbour_exchange") and not L.exchange_multihop():
+                self.comm.neighbour_exchange(self._send, self._recv)
+                self.neighbour_swaps += 1
+            else:
+                self.comm.all_to_all(self._recv, self._send)                  # equal splits: send[q] -> rank q
             L.exchange_apply(self._recv)
             L.write_am(it)
             self.swap_proposed += 1
@@ -178,7 +209,9 @@ class ShardedPTEngine(object):
         L = self.local
         if self.owns_cold:
             L.update_cov(it_done)
-        for name in ("cov", "Ut", "S"):
+        # the other blocks only ever read the factorization: the covariance itself stays where it is adapted
+        # (pooled: 80 KB of eigenvectors per epoch at ndim = 100; per walker: a third less than with cov)
+        for name in ("Ut", "S"):
             self.comm.broadcast(L.t[name])
 
     def update_de(self):

@@ -518,17 +518,24 @@ def gen_config1(PT, out):
     logl, logp = Dense(mu, icov), Box(np.ones(ndim) * pmin, np.ones(ndim) * pmax)
     p0 = np.random.uniform(pmin, pmax, ndim)
     cov0 = np.eye(ndim) * 0.1**2
-    s = PT.PTSampler(ndim, logl, logp, np.copy(cov0), outDir=tmp, verbose=False, seed=42)
-
     def jump(x, it, beta):
         return np.random.uniform(pmin, pmax, len(x)), 0
 
-    s.addProposalToCycle(jump, 5)
-    s.sample(np.copy(p0), 10000, burn=500, thin=1, covUpdate=500, SCAMweight=20, AMweight=20, DEweight=20)
-    chain = s._chain[2500:10001]
+    # 10000 iterations do not bring this 20-d truncated Gaussian to equilibrium (the mean log-likelihood is still rising):
+    # runs of the reference itself differ by several posterior standard deviations.  Four of them give the yardstick.
+    means, covs, accs, lls = [], [], [], []
+    for seed in (42, 43, 44, 45):
+        np.random.seed(seed)
+        s = PT.PTSampler(ndim, logl, logp, np.copy(cov0), outDir=tmp, verbose=False, seed=seed)
+        s.addProposalToCycle(jump, 5)
+        s.sample(np.copy(p0), 10000, burn=500, thin=1, covUpdate=500, SCAMweight=20, AMweight=20, DEweight=20)
+        chain = s._chain[2500:10001]
+        means.append(chain.mean(0))
+        covs.append(np.cov(chain, rowvar=False))
+        accs.append(s.naccepted / 10000.0)
+        lls.append(s._lnlike[2500:10001].mean())
     res = dict(mu=mu, icov=icov, p0=p0, cov0=cov0, ndim=ndim, pmin=pmin, pmax=pmax,
-               ref_mean=chain.mean(0), ref_cov=np.cov(chain, rowvar=False), ref_acc=s.naccepted / 10000.0,
-               ref_lnlike_mean=s._lnlike[2500:10001].mean(),
+               ref_means=np.asarray(means), ref_covs=np.asarray(covs), ref_accs=np.asarray(accs), ref_lnlike_means=np.asarray(lls),
                jnames=np.asarray(sorted(s.jumpDict)), jstats=np.asarray([s.jumpDict[n] for n in sorted(s.jumpDict)], dtype=np.int64),
                jumps_txt=np.asarray(open(os.path.join(tmp, "jumps.txt")).read().splitlines()),
                nrows=len(open(s.fname).read().splitlines()), chainfile_name=os.path.basename(s.fname))

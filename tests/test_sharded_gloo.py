@@ -84,3 +84,34 @@ def test_plan_exchange_is_a_permutation():
         assert (np.sort(ns, axis=1) == np.arange(nt)).all()
         for q in range(world):
             assert plans[r]["send_counts"][q] == plans[q]["recv_counts"][r]
+
+
+def _p2p_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ptmcmcsampler_amd.sharded import DistComm
+        comm = DistComm(dist.group.WORLD)
+        W, k = 5, 4
+        send = torch.full((world, W, k), -1.0, dtype=torch.float64)
+        for q in range(world):
+            send[q] = 100.0 * rank + q + torch.arange(W * k, dtype=torch.float64).reshape(W, k) / 1000.0
+        recv = torch.full((world, W, k), -7.0, dtype=torch.float64)
+        comm.neighbour_exchange(send, recv)
+        for q in range(world):
+            if abs(q - rank) == 1:
+                want = 100.0 * q + rank + torch.arange(W * k, dtype=torch.float64).reshape(W, k) / 1000.0
+                assert torch.equal(recv[q], want), (rank, q)
+            else:
+                assert bool((recv[q] == -7.0).all()), (rank, q)          # nothing arrives from anyone but the neighbours
+        open(os.path.join(out_dir, "p2p_%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_neighbour_exchange_moves_only_the_two_edge_segments(tmp_path, world):
+    """DistComm.neighbour_exchange = the grouped send/recv of the block-edge rows (what runs as ncclSend/ncclRecv on RCCL)."""
+    mp.spawn(_p2p_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["p2p_%d" % r for r in range(world)]

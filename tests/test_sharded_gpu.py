@@ -109,6 +109,14 @@ def test_device_exchange_with_emulated_ranks(nranks, cov_mode, ntb):
         # rows that are not where they started prove that states crossed block edges
         moved += int((np.abs(L.by_temp("X") - p0[:, sl]).sum(-1) > 0).sum())
     assert ref.nswap[:, ntb - 1].sum() > 0, "no swap was ever accepted across the first block edge"
+    # transport: every rank took the same decision at every swap epoch; the neighbour links alone served some epochs, and
+    # with three-rank blocks some sweep carried a row across a whole block (the all-to-all fallback)
+    hops = {e.neighbour_swaps for e in engines}
+    assert len(hops) == 1 and 0 <= engines[0].neighbour_swaps <= n // 10
+    if nranks == 2 or ntb >= 64:
+        assert engines[0].neighbour_swaps == n // 10          # two blocks have no one but each other; 70 ranks are never crossed whole
+    if ntb == 3 and nranks >= 4:
+        assert engines[0].neighbour_swaps < n // 10           # 33 walkers on three-rank blocks: some sweep always crosses one
 
 
 def test_two_real_processes_share_the_gpu_over_gloo():
@@ -121,3 +129,28 @@ def test_two_real_processes_share_the_gpu_over_gloo():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "two_proc_one_gpu.py"), "2"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "all ranks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver calls it: the script starts its two ranks itself.  A one-GPU box cannot give
+    RCCL two devices, so the rehearsal runs over gloo with both ranks on cuda:0 (PTMI_DIST_BACKEND=gloo); the sharded
+    engine, the neighbour send/recv at the block edge and the JSON contract are the ones of the RCCL run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PTMI_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--nwalkers", "128",
+                        "--ntemps", "16", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["rccl_ranks"] == 0                       # gloo rehearsal: no RCCL ranks
+    assert out["config"]["parallelism"] == "temperature blocks x2" and out["config"]["ntemps_per_gpu"] == 16
+    assert out["swap_epochs_timed"] == 12 and out["cov_epochs_timed"] == 1 and out["swap_accept_rate_pair0"] > 0
+    assert out["ess_per_sec"] is not None and out["roofline"]["frac"] <= 1.0

@@ -44,3 +44,12 @@ class ThreadComm(object):
         if self.rank != 0:
             t.copy_(self.w.slots[0])
         self._sync()
+
+    def neighbour_exchange(self, send, recv):
+        """send[q] -> rank q, recv[q] <- rank q for the two neighbouring ranks only."""
+        self.w.slots[self.rank] = send
+        self._sync()
+        for q in (self.rank - 1, self.rank + 1):
+            if 0 <= q < self.world:
+                recv[q].copy_(self.w.slots[q][self.rank])
+        self._sync()
