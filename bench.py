@@ -56,6 +56,9 @@ def parse():
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
                          "walkers = every GPU holds whole ladders of its own walkers (no data-path collective)")
     ap.add_argument("--sharded", action="store_true", help="use the sharded engine even with one rank (testing)")
+    ap.add_argument("--callback", action="store_true",
+                    help="evaluate the likelihood in a batched torch callback between ptmi_propose and ptmi_accept (one launch pair per "
+                         "iteration) instead of inside the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100000, help="iterations per usable host core of the CPU baseline (10-30 s)")
     ap.add_argument("--ess-walkers", type=int, default=64)
@@ -183,11 +186,19 @@ def main():
         kw.update(grad_weights=(10, 0))
     if (world == 1 and not a.sharded) or a.partition == "walkers":
         from ptmcmcsampler_amd.engine import PTEngine
-        eng = PTEngine(d, nt, W, cov0, walker0=rank * W, **kw)       # distinct RNG streams per GPU
+        eng = PTEngine(d, nt, W, cov0, walker0=rank * W, split=a.callback, **kw)       # distinct RNG streams per GPU
     else:
         from ptmcmcsampler_amd.sharded import ShardedPTEngine
         eng = ShardedPTEngine(d, nt * world, W, cov0, group=dist.group.WORLD, **kw)
-    eng.init_state(p0)
+    if a.callback:
+        if a.logl != "iso" or world != 1:
+            raise SystemExit("--callback times the iso-Gaussian through a torch callback on one GPU")
+        cb_l = lambda X: -0.5 * (X * X).sum(-1)                      # noqa: E731
+        cb_p = lambda X: torch.zeros(X.shape[0], dtype=torch.float64, device=X.device)   # noqa: E731
+        eng.init_state_callback(p0, cb_l, cb_p)
+        eng.run = lambda n: eng.run_callback(n, cb_l, cb_p)
+    else:
+        eng.init_state(p0)
     log("engine ready")
 
     def fence():
@@ -203,16 +214,17 @@ def main():
     # timed region: exactly --steps Tskip cycles; each fused-MH launch is bracketed by HIP events on the engine's
     # stream (= torch's current stream, the one the kernels are launched on)
     events = []
-    orig = eng.mh_steps
+    hot = "split_step" if a.callback else "mh_steps"                # the launch (pair) that is the dominant kernel
+    orig = getattr(eng, hot)
 
-    def timed_mh(iter0, nsteps):
+    def timed_mh(iter0, *rest):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(eng.stream)
-        orig(iter0, nsteps)
+        orig(iter0, *rest)
         e1.record(eng.stream)
-        events.append((e0, e1, nsteps))
+        events.append((e0, e1, 1 if a.callback else rest[0]))
 
-    eng.mh_steps = timed_mh
+    setattr(eng, hot, timed_mh)
     cold = ColdSamples(eng, min(a.ess_walkers, W) if eng.owns_cold else 0)
     orig_cov = eng.update_cov
     n_cov = [0]
@@ -227,7 +239,8 @@ def main():
     eng.run(it_timed)
     fence()
     wall = time.perf_counter() - t0
-    eng.mh_steps, eng.update_cov = orig, orig_cov
+    setattr(eng, hot, orig)
+    eng.update_cov = orig_cov
     cold.snap(it_warm + it_timed)
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -246,7 +259,7 @@ def main():
     flops_per_update = 4 * d
     hbm_view = bytes_per_update * upd_per_launch / (avg_launch_ms * 1e-3) / 1e9
     tf = flops_per_update * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12
-    kernel = "mh_steps_gj_kernel" if a.mix == "nuts" else "mh_steps_kernel"
+    kernel = "mh_steps_gj_kernel" if a.mix == "nuts" else ("propose_kernel + torch callback + accept_kernel" if a.callback else "mh_steps_kernel")
     out = {
         "metric": "MH updates/sec (whole node) + ESS/sec, 100-d Gaussian, 64 temps x 4096 walkers per GPU",
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

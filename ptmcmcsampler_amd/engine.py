@@ -421,6 +421,50 @@ class PTEngine(object):
             it = end + 1
         self.iter = last
 
+    # ------------------------------------------------------------------ batched callbacks
+    def eval_callback(self, X, logl, logp):
+        """logp then logl of every row of the device tensor X [W][nt][d] through BATCHED callbacks
+        ``f(X[n, d]) -> [n]`` (torch tensors on this GPU in, the same out): the device-side form of the reference's
+        ``_function_wrapper`` boundary (PTMCMCSampler.py:1072-1086, called at :605-611).  Nothing is copied to the host.
+        Where the prior is -inf the likelihood value is not used (the reference does not even call it, :607-608)."""
+        torch = _torch()
+        flat = X.reshape(-1, self.d)
+        lp = torch.as_tensor(logp(flat), dtype=torch.float64, device=self.device).reshape(self.W, self.nt).contiguous()
+        ll = torch.as_tensor(logl(flat), dtype=torch.float64, device=self.device).reshape(self.W, self.nt)
+        ll = torch.where(torch.isneginf(lp), torch.zeros_like(ll), ll).contiguous()
+        return ll, lp
+
+    def init_state_callback(self, p0, logl, logp, i0=0):
+        """init_state for a likelihood that lives in a batched callback (:479-487)."""
+        torch = _torch()
+        p0 = np.asarray(p0, dtype=np.float64)
+        full = np.array(p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d)))
+        self.t["X"].copy_(torch.from_numpy(full))
+        ll, lp = self.eval_callback(self.t["X"], logl, logp)
+        self.t["lnL"].copy_(torch.where(torch.isneginf(lp), lp, ll))               # :481-483
+        self.t["lp"].copy_(lp)
+        self._store_initial(i0)
+        self.iter = int(i0)
+
+    def split_step(self, it, logl, logp):
+        """One iteration of every chain with batched callbacks: ptmi_propose -> callbacks on the device tensor of
+        proposals -> ptmi_accept.  All on the engine's stream; no host copy of the proposals."""
+        if self.t["Q"] is None:
+            raise _lib.PtmiError("the callback path needs the engine built with split=True")
+        _lib.check(self.lib.ptmi_propose(self.h, it))
+        ll, lp = self.eval_callback(self.t["Q"], logl, logp)
+        _lib.check(self.lib.ptmi_accept(self.h, it, ll.data_ptr(), lp.data_ptr()))
+
+    def run_callback(self, niter, logl, logp):
+        """``run`` with the likelihood and the prior in batched callbacks (epochs and swaps as in ``run``)."""
+        last = self.iter + niter
+        for it in range(self.iter + 1, last + 1):
+            self._epochs(it)
+            self.split_step(it, logl, logp)
+            if self.tskip > 0 and self.ntg > 1 and it % self.tskip == 0:
+                self.swap(it)
+        self.iter = last
+
     # ------------------------------------------------------------------ timing
     def timer_start(self):
         _lib.check(self.lib.ptmi_timer_start(self.h))

@@ -16,6 +16,10 @@ the reference runs unchanged as ONE process driving one GPU.  Differences, all a
 * ``logl_grad`` / ``logp_grad`` are the reference's gradient callbacks (HMC / NUTS then run on the host,
   ``gradjump.py``) or, with a device likelihood, ``True`` for its built-in analytic gradient (NUTS / HMC then run
   inside the kernel, PTMCMCSampler.py:225-258 with the same weights and step-size keywords);
+* ``batched=True``: ``logl`` / ``logp`` are called once per iteration with the device tensor of all proposals,
+  ``f(X[n, ndim]) -> [n]`` (torch in, torch out; loglargs / loglkwargs still apply) -- the same boundary as the reference's
+  ``_function_wrapper`` (PTMCMCSampler.py:1072-1086), one call per batch instead of one per chain, nothing copied to the
+  host; custom Python jumps cannot be mixed in;
 * engine options: ``cov_mode="pooled"`` (one covariance adapted from all walkers instead of one per walker),
   ``swap_mode="oddeven"`` (disjoint swap pairs instead of the reference's hot -> cold sweep), ``pick_mode="walker"`` (one
   proposal-type draw per walker and iteration), ``eig_mode="jacobi"`` (covariance epochs factorized on the device),
@@ -105,7 +109,7 @@ class PTSampler(object):
     def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
                  logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
                  nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1, swap_mode="sweep",
-                 pick_mode="chain", eig_mode="lapack", checkpoint=None):
+                 pick_mode="chain", eig_mode="lapack", checkpoint=None, batched=False):
         self.comm = comm if comm is not None else _DummyComm()
         if self.comm.Get_size() != 1:
             raise NotImplementedError(
@@ -117,6 +121,8 @@ class PTSampler(object):
         # device checkpoints (ptmi_checkpoint.npz beside the chain file) are written at every save when the run may be
         # resumed: checkpoint=True, or -- by default -- when it was itself started with resume=True
         self.checkpoint = bool(resume) if checkpoint is None else bool(checkpoint)
+        # batched=True: logl / logp take ALL proposals at once, f(X[n, ndim]) -> [n], as torch tensors on the GPU
+        self.batched = bool(batched)
         self.keep_walkers = max(1, min(int(keep_walkers), self.nwalkers))
         self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
         self.stream = np.random.default_rng(self.seed)      # for host-side custom jumps that want a generator
@@ -291,6 +297,9 @@ class PTSampler(object):
         self.split = self.logl is not None or bool(self.host_jumps) or bool(self.aux)
         if self.split and self.logl is None:
             raise NotImplementedError("host-side jumps need Python logl/logp callbacks")
+        if self.batched and (self.logl is None or self.host_jumps or self.aux):
+            raise NotImplementedError("batched=True takes callable logl/logp and no per-chain Python jumps "
+                                      "(they would need every proposal on the host)")
         self.engine = PTEngine(
             self.ndim, self.nchain, self.nwalkers, np.asarray(self.cov, dtype=np.float64), ladder=self.ladder,
             logl=self.logl_spec or ("iso",), logp=self.logp_spec or ("flat",),
@@ -538,6 +547,9 @@ class PTSampler(object):
     def _init_split(self, p0, i0=0):
         import torch
         eng = self.engine
+        if self.batched:
+            eng.init_state_callback(p0, self.logl, self.logp, i0)
+            return
         full = p0 if p0.ndim == 3 else np.broadcast_to(p0, (eng.W, eng.nt, eng.d)).copy()
         eng.t["X"].copy_(torch.from_numpy(np.ascontiguousarray(full)))
         ll, lp = self._eval_host(full)
@@ -550,6 +562,9 @@ class PTSampler(object):
     def _split_step(self, it):
         import torch
         eng = self.engine
+        if self.batched:
+            eng.split_step(it, self.logl, self.logp)
+            return
         _lib.check(eng.lib.ptmi_propose(eng.h, it))
         Q, qa = eng.t["Q"].cpu().numpy(), eng.t["qaux"].cpu().numpy()
         temp_of = eng.get("temp_of")

@@ -356,3 +356,39 @@ def test_config1_examples_simple_parameters(tmp_path, golden):
     assert dist < spread, (dist, spread)                                             # as close to one of them as they are to each other
     assert lls.min() - 15.0 < s._lnlike[2500:10001].mean() < 0.0
     assert np.all(x >= pmin) and np.all(x <= pmax)
+
+
+def test_batched_device_callbacks_equal_the_fused_kernel(tmp_path):
+    """batched=True: logl / logp are called once per iteration with the device tensor of all proposals (the reference's
+    callback boundary, PTMCMCSampler.py:1072-1086 / :605-611, per batch).  With a callback that returns the bits of the
+    built-in likelihood (2-d: one element per lane, so the sum has one order) the run equals the fused-kernel run."""
+    import torch
+    from ptmcmcsampler_amd import PTSampler
+    d = 2
+    kw = dict(burn=100, thin=1, covUpdate=50, isave=100, Tskip=10, SCAMweight=20, AMweight=20, DEweight=20)
+    calls = []
+
+    def logl(X, scale=1.0):
+        assert X.is_cuda and X.dtype == torch.float64 and X.shape == (15, d)       # all chains of 5 walkers x 3 ranks at once
+        calls.append(1)
+        return -0.5 * scale * (X * X).sum(-1)
+
+    def logp(X):
+        return torch.where(((X >= -3.0) & (X <= 3.0)).all(-1), 0.0, -float("inf")).to(torch.float64)
+
+    a = PTSampler(d, logl, logp, np.eye(d) * 0.5, loglkwargs=dict(scale=1.0), outDir=str(tmp_path / "a"), verbose=False, seed=4,
+                  ntemps=3, nwalkers=5, keep_walkers=5, batched=True)
+    a.sample(np.zeros(d), 300, **kw)
+    b = PTSampler(d, ("iso",), ("box", -3.0 * np.ones(d), 3.0 * np.ones(d)), np.eye(d) * 0.5, outDir=str(tmp_path / "b"), verbose=False,
+                  seed=4, ntemps=3, nwalkers=5, keep_walkers=5)
+    b.sample(np.zeros(d), 300, **kw)
+    assert len(calls) == 301                                                         # the start point + one call per iteration
+    for name in ("X", "lnL", "lp", "slot_of", "nacc", "jstat", "nswap", "Ut"):
+        assert np.array_equal(a.engine.get(name), b.engine.get(name)), name
+    assert np.array_equal(a._chains, b._chains) and np.array_equal(a._lnlikes, b._lnlikes)
+    assert (a.engine.get("jstat")[..., 0].sum(-1) > a.engine.get("jstat")[..., 1].sum(-1)).all()     # the prior rejected some
+    assert open(tmp_path / "a" / "chain_1.0.txt").read() == open(tmp_path / "b" / "chain_1.0.txt").read()
+    with pytest.raises(NotImplementedError, match="batched=True"):
+        c = PTSampler(d, logl, logp, np.eye(d), outDir=str(tmp_path / "c"), verbose=False, batched=True)
+        c.addProposalToCycle(lambda x, it, beta: (x, 0), 3)
+        c.sample(np.zeros(d), 10)
