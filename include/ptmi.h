@@ -139,7 +139,7 @@ typedef struct ptmi_buffers {
     double *AMaux;      /* [W][cov_update][2]  lnL and lp of the rank-0 chain beside each AM row: the
                          *              _lnlike/_lnprob columns of updateChains (:331-335) (optional) */
     double *gj;         /* [W][T][8]   by RANK: the attributes of a rank's NUTSJump / HMCJump object (nutsjump.py:379-433):
-                         *              epsilon, mu, Hbar, epsilonbar (starts at 1), NUTS calls, HMC calls, have-epsilon flag, -
+                         *              epsilon, mu, Hbar, epsilonbar (starts at 1), NUTS calls, HMC calls, have-epsilon flag, leapfrogs taken so far
                          *              (needed with w_nuts + w_hmc > 0) */
 } ptmi_buffers;
 

@@ -223,7 +223,7 @@ enum { LOGP_FLAT = 0, LOGP_BOX = 1 };
 enum { J_SCAM = 0, J_AM = 1, J_DE = 2, J_NUTS = 3, J_HMC = 4, J_NTYPES = 5 };
 enum { K_INT = 0, K_UNI = 1, K_NRM = 2, K_SHUF = 3, K_EXP = 4 };
 /* per-rank state of the gradient jumps (the attributes of a rank's NUTSJump / HMCJump object, NJ:379-433) */
-enum { GJ_EPS = 0, GJ_MU = 1, GJ_HBAR = 2, GJ_EPSBAR = 3, GJ_NITER = 4, GJ_HITER = 5, GJ_HAVE_EPS = 6, GJ_NSTATE = 8 };
+enum { GJ_EPS = 0, GJ_MU = 1, GJ_HBAR = 2, GJ_EPSBAR = 3, GJ_NITER = 4, GJ_HITER = 5, GJ_HAVE_EPS = 6, GJ_NLEAP = 7 /* leapfrogs so far */, GJ_NSTATE = 8 };
 
 typedef struct {
     int32_t ndim, ntemps, nwalkers, lanes;
@@ -726,6 +726,7 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
         double *gst = st->gj + ((size_t)w * nt + t) * GJ_NSTATE;
         if (jt == J_NUTS) nuts_call(&G, &rng, gst, x, it, q, &qxy);
         else hmc_call(&G, &rng, gst, x, q, &qxy);
+        gst[GJ_NLEAP] += (double)G.nleap;
         free(G.w);
     } else if (jt == J_SCAM || jt == J_AM) {
         const double prob = r ? rp_next(r, K_UNI, 0) : h2uniform(lo32(P[0]));

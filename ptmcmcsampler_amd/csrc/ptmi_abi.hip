@@ -1,6 +1,7 @@
 // ptmi_abi.hip -- the C ABI of libptmi.so, the engine object and the kernels that are not per-chain templates
 // (swap sweep, Welford / pooling, DE ring, self-tests).  See include/ptmi.h for the boundary and DESIGN.md.
 #include <math.h>
+#include <stdlib.h>
 
 #include <new>
 #include <vector>
@@ -564,6 +565,44 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
     }
 }
 
+
+// ------------------------------------------------ launch order of the gradient-jump kernel
+// Counting sort of the chains by the NUTS step size of their rank (half-octave classes, smallest first = longest
+// trees first; a rank that has no step size yet is in class 0: its first call searches for one), then dealt across the
+// waves like cards.  The order only decides which chains share a wave; it is not stable and need not be.
+__device__ __forceinline__ int gj_class(const double *gj, size_t r)
+{
+    const double eps = gj[r * GJ_NSTATE + GJ_EPS];
+    if (gj[r * GJ_NSTATE + GJ_HAVE_EPS] == 0.0 || !(eps > 0.0)) return 0;
+    const int ex = (int)((__double_as_longlong(eps) >> 52) & 0x7FF) - 1023;          // floor(log2 eps)
+    const int half = (int)((__double_as_longlong(eps) >> 51) & 1);                   // upper half of the octave
+    const int c = 2 * (ex + 24) + half + 1;                                          // eps = 2^-24 -> class 1
+    return c < 1 ? 1 : (c > GJ_BUCKETS - 1 ? GJ_BUCKETS - 1 : c);
+}
+__global__ void gj_order_count_kernel(const double *gj, const int32_t *temp_of, long long nch, int nt, int32_t *bucket)
+{
+    const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nch) return;
+    atomicAdd(&bucket[gj_class(gj, (size_t)(ch / nt) * nt + temp_of[ch])], 1);
+}
+__global__ void gj_order_scan_kernel(int32_t *bucket)
+{
+    if (threadIdx.x != 0) return;
+    int32_t run = 0;
+    for (int b = 0; b < GJ_BUCKETS; ++b) { bucket[GJ_BUCKETS + b] = run; run += bucket[b]; bucket[2 * GJ_BUCKETS + b] = 0; }
+}
+__global__ void gj_order_fill_kernel(const double *gj, const int32_t *temp_of, long long nch, int nt, int32_t *bucket, int32_t *order, int cpw)
+{
+    const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nch) return;
+    const int b = gj_class(gj, (size_t)(ch / nt) * nt + temp_of[ch]);
+    // rank t in the sorted list (longest trees first) -> chain slot: consecutive ranks go to DIFFERENT waves, so the few
+    // chains with long trees are dealt one per wave and a launch lasts as long as its slowest chain, not the slowest sum
+    const long long t = bucket[GJ_BUCKETS + b] + atomicAdd(&bucket[2 * GJ_BUCKETS + b], 1);
+    const long long nw = nch / cpw, whole = nw * cpw;
+    order[t < whole ? (t % nw) * cpw + t / nw : t] = (int32_t)ch;
+}
+
 // ----------------------------------------------------------------- selftest
 __global__ void selftest_math_kernel(int op, const double *in, const double *in2, double *out, long long n)
 {
@@ -790,6 +829,9 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         const size_t nvec = (size_t)GJV_TOP + (size_t)GJL_VECS * (c.nuts_maxdepth + 1);
         hipError_t e3 = hipMalloc((void **)&h->d_gj_scr, sizeof(double) * nvec * lanes * nch);
         if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_scal, sizeof(double) * (size_t)GJS_SCALARS * (c.nuts_maxdepth + 1) * nch);
+        static const bool unordered = getenv("PTMI_GJ_UNORDERED") != nullptr;        // measurement switch: same results either way
+        if (e3 == hipSuccess && !unordered) e3 = hipMalloc((void **)&h->d_gj_order, sizeof(int32_t) * nch);
+        if (e3 == hipSuccess && !unordered) e3 = hipMalloc((void **)&h->d_gj_bucket, sizeof(int32_t) * 3 * GJ_BUCKETS);
         if (e3 != hipSuccess || (rc = upload(&h->d_gj_tab, c.gj_tab, 3LL * c.ndim * c.ndim))) {
             ptmi_destroy(h);
             return e3 != hipSuccess ? fail(PTMI_EHIP, "gradient-jump scratch: %s", hipGetErrorString(e3)) : rc;
@@ -818,7 +860,7 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
     (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
-    (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal);
+    (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -861,6 +903,17 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     if (int rc = set_step_args(h, &a)) return rc;
     if (h->cfg.w_host > 0) return fail(PTMI_EINVAL, "host-served jumps need the split path (ptmi_propose / ptmi_accept)");
     if (h->cfg.w_nuts + h->cfg.w_hmc > 0) {      // the fused kernel with the NUTS / HMC branch (csrc/ptmi_gj.inc.h)
+        if (h->cfg.w_nuts > 0 && h->d_gj_order) {                                   // chains of similar step size share a wave
+            const long long nch = (long long)h->cfg.nwalkers * h->cfg.ntemps;
+            const unsigned g = (unsigned)((nch + 255) / 256);
+            HIPCHK(hipMemsetAsync(h->d_gj_bucket, 0, sizeof(int32_t) * GJ_BUCKETS, h->stream));
+            hipLaunchKernelGGL(gj_order_count_kernel, dim3(g), dim3(256), 0, h->stream, (const double *)h->buf.gj, (const int32_t *)h->buf.temp_of,
+                               nch, h->cfg.ntemps, h->d_gj_bucket);
+            hipLaunchKernelGGL(gj_order_scan_kernel, dim3(1), dim3(64), 0, h->stream, h->d_gj_bucket);
+            hipLaunchKernelGGL(gj_order_fill_kernel, dim3(g), dim3(256), 0, h->stream, (const double *)h->buf.gj, (const int32_t *)h->buf.temp_of,
+                               nch, h->cfg.ntemps, h->d_gj_bucket, h->d_gj_order, 64 / h->G);
+            a.gj_order = h->d_gj_order;
+        }
         if (int rc = run_shape(h, PTMI_OP_MH_GJ, a, chains_grid(h), true)) return rc;
         h->last_variant = PTMI_VAR_GRADJUMP | PTMI_VAR_FULL;
         HIPCHK(hipGetLastError());

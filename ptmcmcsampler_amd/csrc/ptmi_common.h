@@ -50,10 +50,12 @@ struct KArgs {
     const double *gj_tab;        // [3][d][d] backward, forward, gradient tables
     double *gj;                  // [W][T][8] per-rank jump state
     double *gj_scr, *gj_scal;    // scratch of the tree build: [slot][e][chain][lane], [level][scalar][chain]
+    const int32_t *gj_order;     // chain handled by each chain slot of the launch (chains of similar NUTS step size share a wave)
 };
 
 // gradient jumps (ptmi_gj.inc.h): per-rank state, Philox slots, layout of a chain's tree scratch
-enum { GJ_EPS = 0, GJ_MU = 1, GJ_HBAR = 2, GJ_EPSBAR = 3, GJ_NITER = 4, GJ_HITER = 5, GJ_HAVE_EPS = 6, GJ_NSTATE = 8 };
+enum { GJ_EPS = 0, GJ_MU = 1, GJ_HBAR = 2, GJ_EPSBAR = 3, GJ_NITER = 4, GJ_HITER = 5, GJ_HAVE_EPS = 6, GJ_NLEAP = 7 /* leapfrogs so far */, GJ_NSTATE = 8 };
+constexpr int GJ_BUCKETS = 128;         // step-size classes of the launch order (ptmi_abi.hip gj_order_*)
 constexpr u32 SLOT_GJ = 0x2000000u;    // + 4096 * (momenta draw of the call) + direction
 constexpr u32 SLOT_GJS = 0x3000000u;   // + scalar draw of the call
 // vector slots of a chain's scratch: the two ends and the sample of the outer loop, then 4 per tree level
@@ -81,6 +83,7 @@ struct ptmi_engine {
     int32_t *d_hop;     // set by ptmi_exchange_pack when a row of the last sweep travels beyond a neighbouring block
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
+    int32_t *d_gj_order, *d_gj_bucket;         // launch order of the chains ([nch]) and its counting-sort scratch ([3][GJ_BUCKETS])
     double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
     int G, EPL;
     int de_on, de_head;

@@ -22,6 +22,7 @@ struct GradJump {
     const long long it;
     const u32 sid;
     u32 nm = 0, ns = 0;          // momenta / scalar draws used so far in this call
+    u32 nleap = 0;               // leapfrogs of this call (statistics: gj[..][GJ_NLEAP])
 
     __device__ __forceinline__ GradJump(const KArgs &a_, int gl_, long long ch_, double beta_, long long it_, u32 sid_)
         : a(a_), gl(gl_), d(a_.d), ch(ch_), nch((long long)a_.W * a_.nt), beta(beta_), it(it_), sid(sid_) {}
@@ -188,8 +189,9 @@ struct GradJump {
 
     // NJ:149-169; outputs may alias the inputs
     __device__ __forceinline__ double leapfrog(const double (&theta)[EPL], const double (&r)[EPL], const double (&grad)[EPL], double eps,
-                                               double (&to)[EPL], double (&ro)[EPL], double (&go)[EPL]) const
+                                               double (&to)[EPL], double (&ro)[EPL], double (&go)[EPL])
     {
+        nleap += 1;
         const double he = 0.5 * eps;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -418,8 +420,14 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
         for (int i = (int)threadIdx.x; i < 3 * d * d; i += GJ_BLOCK) gj_lds[i] = a.gj_tab[i];
         __syncthreads();
     }
-    const long long ch = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
-    if (ch >= nch) return;                       // no block-wide synchronisation below: whole chain groups may leave
+    const long long cslot = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
+    if (cslot >= nch) return;                    // no block-wide synchronisation below: whole chain groups may leave
+    // The chains of a wave run in lock step: every iteration costs the wave its longest tree, and the launch ends with its
+    // slowest wave.  On the curved likelihood a per cent of the ranks keep a small NUTS step size (trees of ~100
+    // leapfrogs) while the rest run away to huge ones (one leapfrog): the host deals the chains over the waves by step
+    // size (gj_order_*), longest trees first and one per wave, so that no wave has to add up several long trees per
+    // iteration (tools/gj_census.py).  Which lanes host a chain does not enter its arithmetic.
+    const long long ch = a.gj_order ? (long long)a.gj_order[cslot] : cslot;
     const int gl = (int)(threadIdx.x % G);
     const int w = (int)(ch / nt);
     const int t = a.temp_of[ch];
@@ -460,6 +468,7 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
 #pragma unroll
             for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stg[j];
             qxy = jt == PTMI_J_NUTS ? gj.nuts(st, x, q) : gj.hmc(st, x, q);
+            st[GJ_NLEAP] += (double)gj.nleap;
             if (gl == 0) {
 #pragma unroll
                 for (int j = 0; j < GJ_NSTATE; ++j) stg[j] = st[j];
