@@ -667,6 +667,159 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     }
 }
 
+// Dense Gaussian likelihood, SCAM-only cycle, one eigenvector table for the whole block (pooled covariance, or the ranks of
+// one walker filling the block): BASELINE configs[2] as bench.py --logl dense runs it.  Everything a step reads sits in
+// LDS -- the precision matrix and the eigenvector table UNPADDED side by side, the mean and sqrt(eigenvalues) behind them
+// (161.6 KB at d = 100: the whole CU) -- so one block of 512 threads puts TWO waves on every SIMD over one copy of the
+// tables, and the matrix pipe works on one wave's P.r while the other wave draws, proposes and accepts.  To fit two waves
+// into the register file nothing of row size is kept besides x, dq and the accumulators: r = (x + dq) - mu is formed where
+// it is used (bit-identical both times).  An unpadded table makes the matrix instruction read past a row's end into the
+// next row; those columns only feed the padding outputs i >= d, which are masked.  Strided lane layout as STAGE.
+template <int EPL, int BLK>
+__global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KArgs a)
+{
+    constexpr int G = 4, CPB = BLK / G, NT = MfmaAcc<EPL>::NT;
+    const int d = a.d, nt = a.nt;
+    const long long nch = (long long)a.W * nt;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int cib = wave * 16 + (lane & 15), gl = lane >> 4;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    long long ch = (long long)logical_block() * CPB + cib;
+    const bool live = ch < nch;
+    if (!live) ch = nch - 1;
+    const int w = (int)(ch / nt);
+    const int t = a.temp_of[ch];
+    const int tg = a.temp0 + t;
+    const double beta = a.beta[t];
+    const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
+    const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
+    const u32 sid = sid0 + (u32)tg;
+    double *xrow = a.X + (size_t)ch * d;
+    DrawBatch<true> batch;
+
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+#define PTMI_D_P (smem)
+#define PTMI_D_U (smem + (size_t)d * d)
+#define PTMI_D_MU (smem + 2 * (size_t)d * d)
+#define PTMI_D_SQ (smem + 2 * (size_t)d * d + 4 * EPL)
+    {
+        const long long ch0 = (long long)logical_block() * CPB;
+        const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
+        const double *Pg = a.logl_par + d, *Ug = a.Ut + w0 * d * d, *Sg = a.S + w0 * d, *mug = a.logl_par;
+        for (int i = (int)threadIdx.x; i < d * d; i += BLK) { PTMI_D_P[i] = Pg[i]; PTMI_D_U[i] = Ug[i]; }
+        for (int i = (int)threadIdx.x; i < 4 * EPL; i += BLK) PTMI_D_MU[i] = i < d ? mug[i] : 0.0;
+        for (int i = (int)threadIdx.x; i < d; i += BLK) PTMI_D_SQ[i] = det_sqrt(Sg[i]);
+        __syncthreads();
+    }
+
+    double x[EPL], dq[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
+    double lnL = a.lnL[ch], lp = a.lp[ch];
+    u32 nacc = 0;
+    const bool cold = live && tg == 0 && a.AM != nullptr;
+    int am_row = a.am_row0;
+    const int esteps = (d + 3) / 4 < EPL ? (d + 3) / 4 : EPL;
+
+    for (int k = 0; k < a.nsteps; ++k) {
+        const long long it = a.iter0 + k;
+        Draws dr;
+        draws_for_step<true, false>(batch, dr, a, k, sid, sid0, gl);
+        const double log_u = dr.log_u;
+        propose<G, EPL, false, true, false>(a, it, sid, gl, cc, dr, PTMI_D_U, false, PTMI_D_SQ, nullptr, dq, true);
+        // PT:605-612: prior on q = x + dq, then -1/2 r^T P r with r = q - mu
+        double nlp = 0.0;
+        if (a.logp_kind == PTMI_LOGP_BOX) {
+            const double *lo = a.logp_par, *hi = a.logp_par + d;
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e;
+                const double qe = x[e] + dq[e];
+                if (i < d) ok = ok && (lo[i] <= qe) && (hi[i] >= qe);
+            }
+            nlp = grp_all<G, true>(ok) ? 0.0 : -__builtin_inf();
+        }
+        MfmaAcc<EPL> acc;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc.t[tt] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
+        // software pipeline of depth one (the row block of step e + 1 is in flight while step e multiplies); the scheduling
+        // barrier keeps the compiler from hoisting all 7 * 26 table reads to the top
+        double cur[NT], nxt[NT];
+        auto fetch = [&](int e, double (&dst)[NT]) {
+            const double *row = PTMI_D_P + (size_t)(4 * e + g4) * d + c16;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) dst[tt] = row[16 * tt];
+        };
+        fetch(0, cur);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            if (e < esteps) {                                              // wave-uniform
+                if (e + 1 < EPL && e + 1 < esteps) fetch(e + 1, nxt);
+                const double re = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc.t[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[tt], re, acc.t[tt], 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) cur[tt] = nxt[tt];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        double p = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const double re = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
+            const double ve = (gl + G * e) < d ? acc.at(e) : 0.0;          // outputs past the row are padding
+            p = __builtin_fma(re, ve, p);
+        }
+        const double nlnL = -0.5 * grp_sum<G, true>(p);
+        const double nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
+        // PT:615-622
+        const double lnprob0 = beta * lnL + lp;
+        const double diff = nlnprob - lnprob0 + 0.0;
+        if (diff > log_u) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                double inc = dq[e];
+                asm volatile("" : "+v"(inc));
+                x[e] = x[e] + inc;
+            }
+            lnL = nlnL;
+            lp = nlp;
+            nacc += 1;
+        }
+        // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
+        if (cold && !(a.swap_last && k == a.nsteps - 1)) {
+            double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e;
+                if (e < safe_slots(G, EPL) || i < d) am[i] = x[e];
+            }
+            if (a.AMaux && gl == 0) {
+                double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
+                ax[0] = lnL;
+                ax[1] = lp;
+            }
+        }
+        am_row = am_row + 1 == a.cov_update ? 0 : am_row + 1;
+    }
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = gl + G * e;
+            if (e < safe_slots(G, EPL) || i < d) xrow[i] = x[e];
+        }
+        if (gl == 0) {
+            a.lnL[ch] = lnL;
+            a.lp[ch] = lp;
+            const size_t r = (size_t)w * nt + t;
+            a.nacc[r] += nacc;
+            a.jstat[(r * PTMI_J_NTYPES + PTMI_J_SCAM) * 2 + 0] += (u32)a.nsteps;
+            a.jstat[(r * PTMI_J_NTYPES + PTMI_J_SCAM) * 2 + 1] += nacc;
+        }
+    }
+}
+
 // split path: proposal only / accept only, one iteration (host likelihood callbacks)
 template <int G, int EPL, bool GRP>
 __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
@@ -791,6 +944,27 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     const ptmi_config &c = h->cfg;
     constexpr bool WANTS = G == 4 && (FULL || LOGL == PTMI_LOGL_DENSE);   // the tables fit only for the small-ndim shapes
     a.lds_u = 0;
+    if constexpr (G == 4 && !FULL && LOGL == PTMI_LOGL_DENSE) {
+        // dense likelihood + SCAM-only + one table for the block: all tables unpadded in LDS, 512-thread blocks
+        const size_t lds2 = sizeof(double) * (2 * (size_t)c.ndim * c.ndim + 4 * EPL + c.ndim);
+        static const char *blk = getenv("PTMI_DENSE_BLK");              // measurement switch: 256, 512 (default) or 0 = the older kernel
+        const int want = blk ? atoi(blk) : 512;
+        const bool shared = c.ngroups <= 1 && (!c.cov_per_walker || c.ntemps % (want / G) == 0);
+        if (want && shared && lds2 <= 160 * 1024) {
+            const long long nch = (long long)c.nwalkers * c.ntemps;
+            auto launch = [&](auto kern, int BLKv) -> int {
+                if (lds2 > 64 * 1024) {
+                    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                    if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds2, hipGetErrorString(e));
+                }
+                const int cpb = BLKv / G;
+                hipLaunchKernelGGL(kern, dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(BLKv), lds2, h->stream, a);
+                h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_LDS_UT;
+                return PTMI_OK;
+            };
+            return want == 256 ? launch(mh_dense_scam_kernel<EPL, 256>, 256) : launch(mh_dense_scam_kernel<EPL, 512>, 512);
+        }
+    }
     if constexpr (WANTS) {
         const size_t tab = sizeof(double) * (size_t)(4 * ((c.ndim + 3) / 4)) * mfma_ld(EPL);   // zero-padded copy
         // SCAM-only cycles read one row of the chain's own table per step; with AM the block needs ONE table
