@@ -581,9 +581,14 @@ __device__ __forceinline__ int gj_class(const double *gj, size_t r)
 }
 __global__ void gj_order_count_kernel(const double *gj, const int32_t *temp_of, long long nch, int nt, int32_t *bucket)
 {
+    __shared__ int32_t local[GJ_BUCKETS];                 // most chains fall into two or three classes: count per block first
+    for (int b = (int)threadIdx.x; b < GJ_BUCKETS; b += (int)blockDim.x) local[b] = 0;
+    __syncthreads();
     const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= nch) return;
-    atomicAdd(&bucket[gj_class(gj, (size_t)(ch / nt) * nt + temp_of[ch])], 1);
+    if (ch < nch) atomicAdd(&local[gj_class(gj, (size_t)(ch / nt) * nt + temp_of[ch])], 1);
+    __syncthreads();
+    for (int b = (int)threadIdx.x; b < GJ_BUCKETS; b += (int)blockDim.x)
+        if (local[b]) atomicAdd(&bucket[b], local[b]);
 }
 __global__ void gj_order_scan_kernel(int32_t *bucket)
 {
@@ -593,12 +598,21 @@ __global__ void gj_order_scan_kernel(int32_t *bucket)
 }
 __global__ void gj_order_fill_kernel(const double *gj, const int32_t *temp_of, long long nch, int nt, int32_t *bucket, int32_t *order, int cpw)
 {
+    // a block reserves its share of every class with one atomic per class; inside the block the order is by thread
+    __shared__ int32_t local[GJ_BUCKETS], base[GJ_BUCKETS];
+    for (int b = (int)threadIdx.x; b < GJ_BUCKETS; b += (int)blockDim.x) local[b] = 0;
+    __syncthreads();
     const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = ch < nch ? gj_class(gj, (size_t)(ch / nt) * nt + temp_of[ch]) : 0;
+    const int mine = ch < nch ? atomicAdd(&local[b], 1) : 0;
+    __syncthreads();
+    for (int bb = (int)threadIdx.x; bb < GJ_BUCKETS; bb += (int)blockDim.x)
+        base[bb] = local[bb] ? atomicAdd(&bucket[2 * GJ_BUCKETS + bb], local[bb]) : 0;
+    __syncthreads();
     if (ch >= nch) return;
-    const int b = gj_class(gj, (size_t)(ch / nt) * nt + temp_of[ch]);
     // rank t in the sorted list (longest trees first) -> chain slot: consecutive ranks go to DIFFERENT waves, so the few
     // chains with long trees are dealt one per wave and a launch lasts as long as its slowest chain, not the slowest sum
-    const long long t = bucket[GJ_BUCKETS + b] + atomicAdd(&bucket[2 * GJ_BUCKETS + b], 1);
+    const long long t = bucket[GJ_BUCKETS + b] + base[b] + mine;
     const long long nw = nch / cpw, whole = nw * cpw;
     order[t < whole ? (t % nw) * cpw + t / nw : t] = (int32_t)ch;
 }

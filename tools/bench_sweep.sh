@@ -1,0 +1,38 @@
+#!/bin/bash
+# The bench lines DESIGN.md quotes, one JSON line per workload, into gpurun_out/sweep_<tag>/ (copy the merged file to
+# profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r02'
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/sweep_$TAG
+mkdir -p $OUT
+cd $ROOT
+b() { local name=$1; shift; python bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$?"; }
+b driver --steps 20 --warmup 5                                   # exactly what the driver runs (with the CPU baseline)
+b scam --no-cpu-baseline                                         # config 2, default length (200 steps after 100)
+b mix_chain --no-cpu-baseline --mix default --steps 100 --warmup 110
+b mix_walker --no-cpu-baseline --mix default --pick walker --steps 100 --warmup 110
+b dense --no-cpu-baseline --logl dense --steps 50 --warmup 20    # config 3, SCAM cycle
+b dense_mix_walker --no-cpu-baseline --logl dense --mix default --pick walker --steps 30 --warmup 110
+b per_walker_lapack --no-cpu-baseline --cov-mode per_walker --steps 20 --warmup 10
+b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10
+b callback --no-cpu-baseline --callback --steps 10 --warmup 2
+b c4_share --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 20 --warmup 10
+b c5_share --no-cpu-baseline --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 6 --warmup 4
+b oddeven --no-cpu-baseline --swap-mode oddeven --steps 100 --warmup 20
+python - <<PY
+import json, glob, os
+out = {}
+for f in sorted(glob.glob("$OUT/*.json")):
+    try:
+        out[os.path.basename(f)[:-5]] = json.load(open(f))
+    except Exception as e:
+        out[os.path.basename(f)[:-5]] = {"error": str(e)}
+json.dump(out, open("$OUT/all.json", "w"), indent=1)
+for k, d in out.items():
+    if "value" in d:
+        r = d["roofline"]
+        print("%-20s %.4g upd/s  %.3f ms/step  kernel %.3f ms (%.0f%% of wall)  %s frac %.3f  ess/s %s" % (
+            k, d["value"], d["ms_per_step"], r["avg_launch_ms"], 100 * r["kernel_time_share_of_wall"], r["bound"], r["frac"], d.get("ess_per_sec")))
+    else:
+        print(k, d)
+PY

@@ -1,9 +1,10 @@
 #!/bin/bash
 # rocprofv3 passes for the bench kernels; run on the GPU box through gpurun from the repo root:
-#   gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh r01'
-# Writes rocpd databases + text summaries under gpurun_out/prof_<tag>/ ; the summaries are copied to profiles/.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh r02'
+# Writes text summaries under gpurun_out/prof_<tag>/ ; copy them to profiles/<tag>_*.txt (tracked).
+# One bench "step" = 100 MH iterations + the PT swap (bench.py).  Counter passes never combine with --stats or trace domains.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -17,16 +18,24 @@ run() {  # name, rocprof args..., -- bench args
     python $ROOT/tools/rocpd_summary.py $OUT/$name/${name}_results.db $OUT/$name.txt > /dev/null
     rm -rf $OUT/$name              # the rocpd databases are large; only the text summaries travel back
 }
-# config 2 (the headline): per-kernel times, HBM traffic counters (separate passes), SQ activity
-run scam_stats --stats --        # the default bench command: the line the driver records
-run scam_fetch --pmc FETCH_SIZE -- --steps 1000 --warmup 200
-run scam_write --pmc WRITE_SIZE -- --steps 1000 --warmup 200
-run scam_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU -- --steps 1000 --warmup 200
-# config 3 (dense Gaussian, matrix cores) and the default SCAM/AM/DE mix
-run dense_stats --stats -- --logl dense --steps 400 --warmup 100
-run dense_sq --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -- --logl dense --steps 300 --warmup 100
-run mix_stats --stats -- --mix default --steps 1000 --warmup 100
-# config 5 shape on one GPU (curved likelihood, SCAM / DE / NUTS) and the covariance epoch kernels
-run c5_stats --stats -- --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 300 --warmup 100
-run welford_sq --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES -- --steps 3000 --warmup 200
+SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU"
+MF="SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"
+# config 2 (the headline): the driver's command, per-kernel times, HBM traffic counters (separate passes), SQ activity
+run scam_stats --stats -- --steps 20 --warmup 5
+run scam_fetch --pmc FETCH_SIZE -- --steps 20 --warmup 5
+run scam_write --pmc WRITE_SIZE -- --steps 20 --warmup 5
+run scam_sq --pmc $SQ -- --steps 20 --warmup 5
+# config 3 (dense Gaussian, matrix cores): SCAM cycle and the AM-weighted default mix
+run dense_stats --stats -- --logl dense --steps 20 --warmup 5
+run dense_sq --pmc $MF -- --logl dense --steps 20 --warmup 5
+run densemix_stats --stats -- --logl dense --mix default --pick walker --steps 20 --warmup 105
+# default SCAM/AM/DE mix with DE active (burn = 10000 iterations = 100 steps): per chain pick and per walker pick
+run mix_stats --stats -- --mix default --steps 20 --warmup 105
+run mixw_stats --stats -- --mix default --pick walker --steps 20 --warmup 105
+run mixw_sq --pmc $MF -- --mix default --pick walker --steps 10 --warmup 105
+# per-walker covariance: device Jacobi eigensolver
+run pwd_stats --stats -- --cov-mode per_walker_device --steps 20 --warmup 5
+# config 5 shape on one GPU (curved likelihood, SCAM / DE / NUTS) and config 4's share of one GPU (1000-d, 64 x 512 chains)
+run c5_stats --stats -- --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 4 --warmup 2
+run c4_stats --stats -- --ndim 1000 --nwalkers 512 --mix default --steps 10 --warmup 5
 ls $OUT/*.txt
