@@ -287,12 +287,17 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
 // recurrence of their column one chunk ahead and hand the diff / e rows over through a double-buffered LDS chunk.
 // The reciprocals 1/(it+1+r) are the same for every column and walker: computed once per block into LDS.
 typedef double wf_d4 __attribute__((ext_vector_type(4)));
-constexpr int WRC = 16;                                     // rows per chunk (4 matrix instructions deep)
+constexpr int WRC = 8;                                      // rows per chunk (2 matrix instructions deep): 37 KB of LDS, four blocks per CU
 constexpr int WF_TILES = WT * (WT + 1) / 2;                 // upper-triangle tiles (28)
-constexpr int WF_NT = WF_TILES / 4;                         // tiles per wave (7)
-static_assert(WF_TILES % 4 == 0, "the tile deal assumes four equal shares");
+// Tiles per wave: an equal deal.  (Giving the two carrier waves fewer tiles, 5/5/9/9, gained 7 %; what did pay was
+// occupancy: 8-row chunks need 37 KB of LDS and 115 VGPRs, so four blocks share a CU instead of two: 1.98 -> 1.48 ms per
+// epoch of 4096 walkers x 1000 rows.)  Which wave computes a tile does not enter its arithmetic.
+constexpr int WF_NT = 7;                                    // most tiles any wave holds
+__device__ __forceinline__ int wf_first(int wave) { return 7 * wave; }
+__device__ __forceinline__ int wf_count(int wave) { return 7; }
+static_assert(4 * 7 == WF_TILES, "the tile deal covers the upper triangle");
 constexpr int WF_THREADS = 256;
-constexpr int WF_MAXMEM = 2048;                             // reciprocal table (cov_update rows)
+constexpr int WF_MAXMEM = 1024;                             // reciprocal table (cov_update rows)
 // t-th upper-triangle tile in row-major order -> (ti, tj)
 __device__ __forceinline__ void wf_tile(int t, int &ti, int &tj)
 {
@@ -301,7 +306,7 @@ __device__ __forceinline__ void wf_tile(int t, int &ti, int &tj)
     while (t >= row) { t -= row; ++ti; --row; }
     tj = ti + t;
 }
-__global__ __launch_bounds__(WF_THREADS, 2) void welford_mfma_kernel(const double *AM, double *mu, double *M2, int d, int mem, long long iter)
+__global__ __launch_bounds__(WF_THREADS, 4) void welford_mfma_kernel(const double *AM, double *mu, double *M2, int d, int mem, long long iter)
 {
     __shared__ double Dl[2][WRC][WTILE], El[2][WRC][WTILE];
     __shared__ double rcp[WF_MAXMEM];
@@ -320,28 +325,31 @@ __global__ __launch_bounds__(WF_THREADS, 2) void welford_mfma_kernel(const doubl
 
     wf_d4 acc[WF_NT];
     int offa[WF_NT], offb[WF_NT];                           // column offsets of the tile's D and E fragments
+    const int t0 = wf_first(wave), tn = wf_count(wave);      // wave-uniform
 #pragma unroll
     for (int n = 0; n < WF_NT; ++n) {
         int ti, tj;
-        wf_tile(wave + 4 * n, ti, tj);
+        wf_tile(t0 + (n < tn ? n : 0), ti, tj);
         offa[n] = __builtin_amdgcn_readfirstlane(ti * 16);   // wave-uniform: scalar registers
         offb[n] = __builtin_amdgcn_readfirstlane(tj * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
-            acc[n][r] = (!reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
+            acc[n][r] = (n < tn && !reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
         }
     }
-    // The AM rows of the following chunk are requested as soon as the current ones are consumed, so the HBM latency
-    // of the row reads overlaps the matrix work on the chunk in between.
-    double v[WRC];
-    auto fetch = [&](int r0) {
+    // AM rows are requested TWO chunks before the carriers turn them into diff / e rows (one chunk of matrix work does not
+    // cover an HBM round trip), in two register buffers used alternately; and inside a chunk the carriers' recurrence is
+    // cut into four pieces slipped between the four groups of matrix instructions, so that the matrix pipe of their SIMD
+    // works while they compute.
+    double va[WRC], vb[WRC];
+    auto fetch = [&](int r0, double (&v)[WRC]) {
 #pragma unroll
         for (int u = 0; u < WRC; ++u) v[u] = (incol && r0 + u < mem) ? am[(size_t)(r0 + u) * d + col] : 0.0;
     };
-    auto produce = [&](int r0, int buf) {
+    auto produce4 = [&](int r0, int u0, int buf, const double (&v)[WRC]) {       // rows r0 + u0 .. r0 + u0 + 3 of a chunk
 #pragma unroll
-        for (int u = 0; u < WRC; ++u) {
+        for (int u = u0; u < u0 + 4; ++u) {
             double df = 0.0, ev = 0.0;
             if (incol && r0 + u < mem) {
                 df = v[u] - m;
@@ -351,32 +359,43 @@ __global__ __launch_bounds__(WF_THREADS, 2) void welford_mfma_kernel(const doubl
             Dl[buf][u][col] = df;                           // rows past the end and padded columns carry zeros
             El[buf][u][col] = ev;
         }
-        fetch(r0 + WRC);
     };
-    if (carrier) fetch(0);
-    __syncthreads();                                        // reciprocal table
-    if (carrier) produce(0, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int r0 = 0; r0 < mem; r0 += WRC) {
-        if (carrier && r0 + WRC < mem) produce(r0 + WRC, buf ^ 1);
+    // matrix work of chunk r0 (LDS buffer buf) with the production of chunk r0 + WRC (from v) in its gaps; then v is
+    // refilled with the rows two chunks further on
+    auto body = [&](int r0, int buf, double (&v)[WRC]) {
         const double *Db = &Dl[buf][0][0] + g * WTILE + c, *Eb = &El[buf][0][0] + g * WTILE + c;
+        const bool more = carrier && r0 + WRC < mem;
 #pragma unroll
-        for (int k0 = 0; k0 < WRC; k0 += 4)
+        for (int k0 = 0; k0 < WRC; k0 += 4) {
 #pragma unroll
             for (int n = 0; n < WF_NT; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Db[k0 * WTILE + offa[n]], Eb[k0 * WTILE + offb[n]], acc[n], 0, 0, 0);
+                if (n < tn) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Db[k0 * WTILE + offa[n]], Eb[k0 * WTILE + offb[n]], acc[n], 0, 0, 0);
+            if (more) produce4(r0 + WRC, k0, buf ^ 1, v);
+        }
+        if (more) fetch(r0 + 3 * WRC, v);
         __syncthreads();
-        buf ^= 1;
+    };
+    if (carrier) fetch(0, va);
+    __syncthreads();                                        // reciprocal table
+    if (carrier) {
+#pragma unroll
+        for (int u0 = 0; u0 < WRC; u0 += 4) produce4(0, u0, 0, va);
+        fetch(WRC, va);
+        fetch(2 * WRC, vb);
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < mem; r0 += 2 * WRC) {
+        body(r0, 0, va);
+        if (r0 + WRC < mem) body(r0 + WRC, 1, vb);
     }
 #pragma unroll
     for (int n = 0; n < WF_NT; ++n) {
         int ti, tj;
-        wf_tile(wave + 4 * n, ti, tj);
+        wf_tile(t0 + (n < tn ? n : 0), ti, tj);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
-            if (i < d && j < d && i <= j) {                 // a diagonal tile also computed its lower half: dropped
+            if (n < tn && i < d && j < d && i <= j) {       // a diagonal tile also computed its lower half: dropped
                 M2w[(size_t)i * d + j] = acc[n][r];
                 M2w[(size_t)j * d + i] = acc[n][r];
             }
