@@ -1036,16 +1036,16 @@ ORC_API double orc_logl_grad(const orc_cfg *c, const double *x, double *g)
  * have to be factorized per epoch.  One-sided (Hestenes) Jacobi on the rows of W = V^T A, A symmetric positive
  * semi-definite: rotations of row pairs (p, q) in the round-robin order of the circle method, applied to W and to the
  * accumulated V^T alike, until the rows of W are mutually orthogonal; then W W^T = V^T A^2 V is diagonal, row k of V^T is
- * an eigenvector and ||row k of W|| its eigenvalue.  Each row pair is worked on by `lanes` (4) lanes: lane l sums the
- * elements l, l + lanes, ... with fma in ascending order and the lanes combine as (s0 + s2) + (s1 + s3).
+ * an eigenvector and ||row k of W|| its eigenvalue.  Each row pair is worked on by eight lanes: lane l sums the
+ * elements l, l + 8, ... with fma in ascending order and the lanes combine as ((s0+s4)+(s2+s6)) + ((s1+s5)+(s3+s7)).
  * Output: eigenvalues descending (ties by ascending row), eigenvectors as ROWS of Ut, each with its largest-magnitude
  * component (first of equals) made positive.  Returns the number of sweeps run. */
 static double jac_dot(const double *a, const double *b, int d)
 {
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int l = 0; l < 4; ++l)
-        for (int i = l; i < d; i += 4) s[l] = fma(a[i], b[i], s[l]);
-    return (s[0] + s[2]) + (s[1] + s[3]);
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int l = 0; l < 8; ++l)
+        for (int i = l; i < d; i += 8) s[l] = fma(a[i], b[i], s[l]);
+    return ((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7]));
 }
 ORC_API int orc_eig_jacobi(int d, const double *cov, double *Ut, double *S, int max_sweeps)
 {

@@ -478,14 +478,17 @@ __global__ void de_update_kernel(double *DE, const double *AM, int d, int de_siz
 // Batched symmetric eigensolver for the per-walker covariances (PT:797-803 calls LAPACK's SVD once per epoch; a batch of
 // thousands of walkers would queue thousands of host factorizations).  One block per matrix, one-sided (Hestenes) Jacobi
 // on the rows of W = V^T A with W and V^T both in LDS: in every round of the circle-method schedule the n/2 disjoint row
-// pairs are rotated at once, four lanes per pair (lane l owns elements l, l+4, ... of both rows: conflict-free LDS
-// accesses, quad reductions by DPP); one barrier per round.  Operation order = oracle/ptmcmc_oracle.c orc_eig_jacobi,
+// pairs are rotated at once, eight lanes per pair (lane l owns elements l, l+8, ... of both rows, cached in registers
+// for the three dot products and the rotation); one barrier per round.  Operation order = oracle/ptmcmc_oracle.c orc_eig_jacobi,
 // so the results are bit-identical to it.  Eigenvalues descending, eigenvectors as rows, largest component positive.
-constexpr int JAC_THREADS = 256;
+constexpr int JAC_THREADS = 512;                            // 8 lanes per row pair, up to 64 pairs (ndim <= 101 uses 51)
+constexpr int JAC_L = 8;
 constexpr int JAC_MAX_SWEEPS = 30;
-__device__ __forceinline__ double jac_quad_sum(double p)
+// sum over the eight lanes of a pair: xor 4, xor 2, xor 1 (the oracle's ((s0+s4)+(s2+s6)) + ((s1+s5)+(s3+s7)))
+__device__ __forceinline__ double jac_oct_sum(double p)
 {
-    p = p + dppf64<0x4E>(p);     // xor 2: (s0 + s2), (s1 + s3)
+    p = p + __shfl_xor(p, 4, 64);
+    p = p + dppf64<0x4E>(p);     // xor 2
     p = p + dppf64<0xB1>(p);     // xor 1
     return p;
 }
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
 {
     extern __shared__ __attribute__((aligned(16))) double jsm[];     // W[d][d], V[d][d]: all of the CU's LDS at d = 101
     double *W = jsm, *V = jsm + (size_t)d * d;
-    constexpr int NE = 26;                                           // elements of a row per lane: l, l + 4, ... < 104
+    constexpr int NE = 13;                                           // elements of a row per lane: l, l + 8, ... < 104
     const int tid = (int)threadIdx.x;
     const double *A = cov + (size_t)blockIdx.x * d * d;
     for (int i = tid; i < d * d; i += JAC_THREADS) {
@@ -501,12 +504,12 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
         V[i] = (i / d == i % d) ? 1.0 : 0.0;
     }
     const int n = d + (d & 1), P = n / 2, rounds = n - 1;
-    const int pr = tid >> 2, l = tid & 3;
+    const int pr = tid / JAC_L, l = tid % JAC_L;
     __syncthreads();
     for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
         int rotated = 0;
         for (int r = 0; r < rounds; ++r) {
-            if (pr < P) {                                            // P <= 51 pairs: one quad each
+            if (pr < P) {                                            // P <= 51 pairs: eight lanes each
                 const int k = pr;
                 const int a = k == 0 ? n - 1 : (r + k) % (n - 1);
                 const int b = k == 0 ? r : (r - k + (n - 1)) % (n - 1);
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
                 double xp[NE], xq[NE];
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
-                    const int i = l + 4 * j;
+                    const int i = l + JAC_L * j;
                     xp[j] = i < d ? wp[i] : 0.0;
                     xq[j] = i < d ? wq[i] : 0.0;
                 }
@@ -528,15 +531,15 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
                     be = __builtin_fma(xq[j], xq[j], be);
                     ga = __builtin_fma(xp[j], xq[j], ga);
                 }
-                al = jac_quad_sum(al); be = jac_quad_sum(be); ga = jac_quad_sum(ga);
-                if (real && __builtin_fabs(ga) > 0x1.0p-50 * det_sqrt(al * be)) {      // quad-uniform
+                al = jac_oct_sum(al); be = jac_oct_sum(be); ga = jac_oct_sum(ga);
+                if (real && __builtin_fabs(ga) > 0x1.0p-50 * det_sqrt(al * be)) {      // uniform over the pair's lanes
                     const double zeta = (be - al) / (2.0 * ga);
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + det_sqrt(1.0 + zeta * zeta));
                     const double c = 1.0 / det_sqrt(1.0 + t * t), sn = c * t;
                     double *vp = V + (size_t)p * d, *vq = V + (size_t)q * d;
 #pragma unroll
                     for (int j = 0; j < NE; ++j) {
-                        const int i = l + 4 * j;
+                        const int i = l + JAC_L * j;
                         if (i < d) {
                             const double u = vp[i], v = vq[i];
                             wp[i] = c * xp[j] - sn * xq[j];
@@ -552,26 +555,26 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
         }
         if (!__syncthreads_or(rotated)) break;
     }
-    // norms (a quad per row, same summation as above): first in registers, then -- W is dead -- in W[0..d)
+    // norms (eight lanes per row, same summation as above): first in registers, then -- W is dead -- in W[0..d)
     double mynorm[2] = {0.0, 0.0};
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const int k = pass * (JAC_THREADS / 4) + pr;
+        const int k = pass * (JAC_THREADS / JAC_L) + pr;
         double al = 0.0;
         if (k < d)
-            for (int j = 0; j < NE; ++j) { const int i = l + 4 * j; const double x = i < d ? W[(size_t)k * d + i] : 0.0; al = __builtin_fma(x, x, al); }
-        mynorm[pass] = det_sqrt(jac_quad_sum(al));
+            for (int j = 0; j < NE; ++j) { const int i = l + JAC_L * j; const double x = i < d ? W[(size_t)k * d + i] : 0.0; al = __builtin_fma(x, x, al); }
+        mynorm[pass] = det_sqrt(jac_oct_sum(al));
     }
     __syncthreads();                                                 // every row of W has been read: W[0..d) now holds the norms
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const int k = pass * (JAC_THREADS / 4) + pr;
+        const int k = pass * (JAC_THREADS / JAC_L) + pr;
         if (k < d && l == 0) W[k] = mynorm[pass];
     }
     __syncthreads();
     const double *nrm = W;
     double *Uo = Ut + (size_t)blockIdx.x * ut_stride, *So = S + (size_t)blockIdx.x * s_stride;
-    for (int k = pr; k < d; k += JAC_THREADS / 4) {
+    for (int k = pr; k < d; k += JAC_THREADS / JAC_L) {
         const double mine = nrm[k];
         int rank = 0;
         for (int j = 0; j < d; ++j) rank += (nrm[j] > mine) || (nrm[j] == mine && j < k);
@@ -579,11 +582,10 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
         int im = 0;
         for (int i = 1; i < d; ++i) if (__builtin_fabs(vk[i]) > __builtin_fabs(vk[im])) im = i;
         const double sg = vk[im] < 0.0 ? -1.0 : 1.0;
-        for (int i = l; i < d; i += 4) Uo[(size_t)rank * d + i] = sg * vk[i];
+        for (int i = l; i < d; i += JAC_L) Uo[(size_t)rank * d + i] = sg * vk[i];
         if (l == 0) So[rank] = mine;
     }
 }
-
 
 // ------------------------------------------------ launch order of the gradient-jump kernel
 // Counting sort of the chains by the NUTS step size of their rank (half-octave classes, smallest first = longest
