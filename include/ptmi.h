@@ -125,7 +125,7 @@ typedef struct ptmi_buffers {
                          *              a group's vectors are embedded in the full space (zero outside the group, zero rows
                          *              beyond its size) */
     double *S;          /* [Wc][Ng][d]  eigenvalues (zero beyond the group's size) */
-    double *DE;         /* [Wc][de_size][d]  DE history ring (optional) */
+    double *DE;         /* [Wc][de_size][stride]  DE history ring (optional); row format: ptmi_de_row_stride */
     double *AM;         /* [W][cov_update][d] samples of the rank-0 chain (:327-328); only where temp0 == 0 */
     uint64_t *nacc;     /* [W][T]      accepted MH updates per rank (:621) */
     uint64_t *jstat;    /* [W][T][PTMI_J_NTYPES][2]  proposed, accepted per jump type (:602,622) */
@@ -157,6 +157,11 @@ int ptmi_lanes_for_grad(int ndim);
  * tstep = the argument if > 0, else exp(log(Tmax/Tmin)/(nchain-1)) if Tmax > 0, else 1 + sqrt(2/ndim); a single chain
  * gets {1}.  `out` is HOST memory [nchain]. */
 int ptmi_temperature_ladder(int nchain, int ndim, double Tmin, double Tmax, double tstep, double *out);
+
+/* Row format of the DE buffer for a given ndim (grad != 0: with gradient jumps in the cycle): *stride doubles per row;
+ * *epl == 0: a row holds the parameters in order (stride == ndim); *epl > 0 (4 lanes per chain): the row is lane-major,
+ * row[lane * epl + e] = parameter lane + 4 e (zero past ndim), stride == 4 * epl -- a lane's share of a row is contiguous. */
+int ptmi_de_row_stride(int ndim, int grad, int *stride, int *epl);
 
 int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out);
 int ptmi_destroy(ptmi_handle h);

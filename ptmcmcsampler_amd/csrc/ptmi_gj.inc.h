@@ -439,7 +439,7 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
     DrawBatch<false> batch;
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
-    const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
+    const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * a.de_ld : nullptr;
     const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr;
     double *xrow = a.X + (size_t)ch * d;
     double *stg = a.gj + ((size_t)w * nt + t) * GJ_NSTATE;

@@ -378,13 +378,18 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         double scale;
         if (plo > T50) scale = 1.0;
         else scale = w2uniform(dr.Q1) * 2.4 / a.gdiv[g] * cc.de_mul;  // PT:976
-        const double *rm = DE + (size_t)((mm + (u32)a.de_head) % Bn) * d;
-        const double *rn = DE + (size_t)((nn + (u32)a.de_head) % Bn) * d;
+        const double *rm = DE + (size_t)((mm + (u32)a.de_head) % Bn) * a.de_ld;
+        const double *rn = DE + (size_t)((nn + (u32)a.de_head) % Bn) * a.de_ld;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             double vm, vn;
-            PTMI_ROW_LOAD_S(PSAFE, vm, rm, e);
-            PTMI_ROW_LOAD_S(PSAFE, vn, rn, e);
+            if (G == 4) {                              // lane-major rows: this lane's EPL values are contiguous, pads are stored zeros
+                vm = rm[gl * EPL + e];
+                vn = rn[gl * EPL + e];
+            } else {
+                PTMI_ROW_LOAD_S(PSAFE, vm, rm, e);
+                PTMI_ROW_LOAD_S(PSAFE, vn, rn, e);
+            }
             dq[e] = scale * (vm - vn);
             if (GRP) {                                 // only the group's parameters move (PT:978-983)
                 const int i = gl + G * e;
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     const u32 sid = sid0 + (u32)tg;
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * a.ngroups * d * d, *S = a.S + wc * a.ngroups * d;
-    const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * d : nullptr;
+    const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * a.de_ld : nullptr;
     double *xrow = a.X + (size_t)ch * d;
     DrawBatch<STR> batch;
 
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     const u32 sid = sid0 + (u32)(a.temp0 + t);
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * a.ngroups * d * d, *S = a.S + wc * a.ngroups * d;
-    const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * d : nullptr;
+    const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * a.de_ld : nullptr;
     const double *xrow = a.X + (size_t)ch * d;
     double x[EPL], dq[EPL];
 #pragma unroll

@@ -145,13 +145,16 @@ class PTEngine(object):
         f64, i32, i64 = torch.float64, torch.int32, torch.int64
         z = lambda shape, dt=f64: torch.zeros(shape, dtype=dt, device=self.device)  # noqa: E731
         has_de = self.weights[2] > 0 if use_de_buffer is None else use_de_buffer
+        st, ep = C.c_int(0), C.c_int(0)                                # row format of the DE buffer (include/ptmi.h)
+        _lib.check(self.lib.ptmi_de_row_stride(d, int(has_gj), C.byref(st), C.byref(ep)))
+        self.de_ld, self.de_epl = st.value, ep.value
         self.owns_cold = self.temp0 == 0
         self.t = dict(
             X=z((W, nt, d)), lnL=z((W, nt)), lp=z((W, nt)),
             temp_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
             slot_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
             Ut=z((Wc, self.ngr, d, d)), S=z((Wc, self.ngr, d)),
-            DE=z((Wc, self.burn, d)) if has_de else None,
+            DE=z((Wc, self.burn, self.de_ld)) if has_de else None,
             AM=z((W, self.cov_update, d)) if self.owns_cold else None,
             nacc=z((W, nt), i64), jstat=z((W, nt, _lib.J_NTYPES, 2), i64), nswap=z((W, self.ntg), i64),
             mu=z((W, d)) if self.owns_cold else None, M2=z((W, d, d)) if self.owns_cold else None,
@@ -213,8 +216,11 @@ class PTEngine(object):
 
     # ------------------------------------------------------------------ data access
     def get(self, name):
-        """Device array -> numpy (counters as uint64)."""
+        """Device array -> numpy (counters as uint64; DE rows in parameter order whatever their device format)."""
         a = self.t[name].cpu().numpy()
+        if name == "DE" and self.de_epl:
+            pos = (np.arange(self.d) % 4) * self.de_epl + np.arange(self.d) // 4       # where parameter i sits in a lane-major row
+            return np.ascontiguousarray(a[..., pos])
         return a.view(np.uint64) if name in ("nacc", "jstat", "nswap") else a
 
     def put(self, name, value):

@@ -224,7 +224,7 @@ class ShardedPTEngine(object):
             L.update_de()
             rows = L.t["DE"][:, idx].contiguous()
         else:
-            rows = torch.empty((L.t["DE"].shape[0], mem, self.d), dtype=torch.float64, device=self.device)
+            rows = torch.empty((L.t["DE"].shape[0], mem, L.t["DE"].shape[2]), dtype=torch.float64, device=self.device)
         self.comm.broadcast(rows)
         if not self.owns_cold:
             L.t["DE"][:, idx] = rows
