@@ -21,10 +21,18 @@ def _torch():
     return torch
 
 
+_BLAS_CTL = None
+
+
 def _blas_threads(n):
+    """Context that caps the BLAS thread pools at ``n``.  The controller is built once: discovering the loaded BLAS
+    libraries is what costs (0.2 ms per call, a third of a 100 x 100 factorization)."""
+    global _BLAS_CTL
     try:
-        from threadpoolctl import threadpool_limits
-        return threadpool_limits(limits=n)
+        if _BLAS_CTL is None:
+            from threadpoolctl import ThreadpoolController
+            _BLAS_CTL = ThreadpoolController()
+        return _BLAS_CTL.limit(limits=n)
     except ImportError:
         import contextlib
         return contextlib.nullcontext()
