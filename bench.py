@@ -48,6 +48,8 @@ def parse():
                     help="chain: every chain picks its proposal from its own stream (a replica of the reference); "
                          "walker: one pick per walker and iteration (wave-uniform proposal type)")
     ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
+    ap.add_argument("--prior", default="flat", choices=["flat", "box"],
+                    help="flat: the headline workload; box: uniform on [-10, 10]^d, the usual lnpriorfn of a reference run")
     ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "per_walker", "per_walker_device"],
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
                          "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK")
@@ -179,6 +181,8 @@ def main():
               pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled",
               eig_mode="jacobi" if a.cov_mode.endswith("_device") else "lapack")
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
+    if a.prior == "box":
+        kw.update(logp=("box", np.full(d, -10.0), np.full(d, 10.0)))
     if a.logl == "curved":                      # examples/curved_likelihood.ipynb: box prior [-10, 10], cov = I, start near the mode
         kw.update(logl=("curved",), logp=("box", np.full(d, -10.0), np.full(d, 10.0)))
         cov0, p0 = np.eye(d), np.array([-0.1, -0.5] * (d // 2) + [0.0] * (d % 2))
@@ -265,12 +269,12 @@ def main():
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[%d]: %d-d %s logl, %d temps x %d walkers per GPU, %s cycle (pick per %s), "
+        "config": {"workload": "BASELINE configs[%d]: %d-d %s logl%s, %d temps x %d walkers per GPU, %s cycle (pick per %s), "
                                "Tskip=100 (%s), covUpdate=1000, cov_mode=%s; one step = 100 MH iterations of every chain + the PT swap "
                                "(+ a covariance epoch every 10 steps)" % (
                                    {"iso": 3 if d >= 1000 else 1, "dense": 2, "curved": 4}[a.logl], d,
                                    {"iso": "isotropic Gaussian", "dense": "dense Gaussian", "curved": "curved-likelihood"}[a.logl],
-                                   nt, W, a.mix, a.pick, a.swap_mode, a.cov_mode),
+                                   " + box prior" if a.prior == "box" else "", nt, W, a.mix, a.pick, a.swap_mode, a.cov_mode),
                    "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "iterations_per_step": TSKIP,
                    "parallelism": ("temperature blocks x%d" if a.partition == "temps" else "walker blocks x%d") % world},
         "iterations_timed": it_timed, "swap_epochs_timed": it_timed // TSKIP if nt * world > 1 else 0, "cov_epochs_timed": n_cov[0],

@@ -691,6 +691,7 @@ static KArgs make_args(ptmi_engine *h)
 {
     KArgs a;
     memset(&a, 0, sizeof(a));
+    a.box_off = -1;
     const ptmi_config &c = h->cfg;
     const ptmi_buffers &b = h->buf;
     a.X = b.X; a.lnL = b.lnL; a.lp = b.lp; a.temp_of = b.temp_of; a.slot_of = b.slot_of;

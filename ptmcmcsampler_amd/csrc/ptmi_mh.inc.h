@@ -56,6 +56,7 @@ __device__ __forceinline__ double grp_xor1(double v)
 // 4*ceil(d/4) rows and 16*NT columns, zero filled (the LDS copy); otherwise bounds are checked per lane.
 // Must be called by ALL lanes of the wave (the A operand of a matrix instruction comes from every lane).
 typedef double ptmi_d4 __attribute__((ext_vector_type(4)));
+typedef double ptmi_d2 __attribute__((ext_vector_type(2)));
 template <int EPL>
 struct MfmaAcc {
     static constexpr int NT = (4 * EPL + 15) / 16;
@@ -165,20 +166,112 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
     }
 }
 
-template <int G, int EPL, bool STR>
-__device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EPL], int gl)
+// Kernel shapes: (lanes per chain G, register slots per lane EPL); a shape serves
+// G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
+// lane for every ndim the shape serves and need no bounds check.
+constexpr int safe_slots(int G, int EPL)
+{
+    return G == 4 ? (EPL == 26 ? 20 : EPL == 20 ? 14 : EPL == 14 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
+         : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
+         : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
+}
+
+// Box prior (the reference's usual lnpriorfn: -inf outside [pmin, pmax]): true when every element of the row lies inside.
+// The bounds are read from memory in every step (2*EPL registers to keep them are not there), CH slots at a time: the
+// requests of a chunk go out together and are compared when they arrive.  The empty asm between chunks pins that shape.
+// Left to itself the compiler either turned a short-circuit chain into 2*EPL dependent branches, each waiting for its
+// own memory round trip, or hoisted all the loads out of the step loop and spilled them.
+template <int G, int EPL, class QF>
+__device__ __forceinline__ bool box_inside(const double *lo_, const double *hi_, int d, int gl, QF q)
+{
+    typedef const __attribute__((address_space(1))) double *gptr;
+    constexpr int CH = 7;
+    gptr lo = (gptr)lo_, hi = (gptr)hi_;
+    int ok = 1;
+#pragma unroll
+    for (int e0 = 0; e0 < EPL; e0 += CH) {
+        asm volatile("" : "+s"(lo), "+s"(hi), "+v"(ok));
+        double l[CH], h[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int e = e0 + c, i = gl + G * e;
+            if (e >= EPL) break;
+            const int ii = i < d ? i : 0;       // padding slots read element 0 and are ignored (no slot is exempt: gradient-jump
+                                               // engines run a shape below its usual ndim range)
+            l[c] = lo[ii];
+            h[c] = hi[ii];
+        }
+        bool in = true;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int e = e0 + c, i = gl + G * e;
+            if (e >= EPL) break;
+            const double qe = q(e);
+            const bool in1 = (l[c] <= qe) & (h[c] >= qe);
+            in &= in1 | (i >= d);
+        }
+        ok &= (int)in;
+    }
+    return ok != 0;
+}
+
+// The same test against the block's LDS copy of the bounds (box_table_fill): {lo, hi} pairs in lane order, one 16-byte
+// read per slot, padding slots hold {-inf, +inf}.  A vector-memory read costs the CU's address unit 8+ cycles per wave
+// and the test needs 2*EPL of them per step -- more than the rest of a SCAM step; the LDS pipe does it in a quarter.
+template <int G, int EPL, class QF>
+__device__ __forceinline__ bool box_inside_lds(const double *smem, int off, int gl, QF q)
+{
+    constexpr int CH = 7;
+    int base = off + 2 * EPL * gl, ok = 1;
+#pragma unroll
+    for (int e0 = 0; e0 < EPL; e0 += CH) {
+        asm volatile("" : "+v"(base), "+v"(ok));              // chunk boundary (see box_inside)
+        const ptmi_d2 *tab = (const ptmi_d2 *)(smem + base);
+        ptmi_d2 b[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (e0 + c < EPL) b[c] = tab[e0 + c];
+        bool in = true;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (e0 + c >= EPL) break;
+            const double qe = q(e0 + c);
+            in &= (b[c].x <= qe) & (b[c].y >= qe);
+        }
+        ok &= (int)in;
+    }
+    return ok != 0;
+}
+constexpr int box_table_doubles(int G, int EPL) { return 2 * G * EPL; }
+// Prologue of the step kernels; the caller's __syncthreads follows.
+template <int G, int EPL>
+__device__ __forceinline__ void box_table_fill(const KArgs &a, double *smem, int nthreads)
+{
+    if (a.logp_kind != PTMI_LOGP_BOX || a.box_off < 0) return;
+    const double *lo = a.logp_par, *hi = a.logp_par + a.d;
+    for (int i = (int)threadIdx.x; i < G * EPL; i += nthreads) {
+        const int p = i / EPL + G * (i % EPL);
+        smem[a.box_off + 2 * i] = p < a.d ? lo[p] : -__builtin_inf();
+        smem[a.box_off + 2 * i + 1] = p < a.d ? hi[p] : __builtin_inf();
+    }
+}
+
+// PT:605-606 for the built-in priors; smem: the block's dynamic LDS (bounds table at a.box_off) or nullptr
+template <int G, int EPL, bool STR, class QF>
+__device__ __forceinline__ double eval_logp_q(const KArgs &a, const double *smem, int gl, QF q)
 {
     if (a.logp_kind == PTMI_LOGP_BOX) {
-        const double *lo = a.logp_par, *hi = a.logp_par + a.d;
-        bool ok = true;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int i = gl + G * e;
-            if (i < a.d) ok = ok && (lo[i] <= q[e]) && (hi[i] >= q[e]);
-        }
+        bool ok;
+        if (smem != nullptr && a.box_off >= 0) ok = box_inside_lds<G, EPL>(smem, a.box_off, gl, q);
+        else ok = box_inside<G, EPL>(a.logp_par, a.logp_par + a.d, a.d, gl, q);
         return grp_all<G, STR>(ok) ? 0.0 : -__builtin_inf();
     }
     return 0.0;
+}
+template <int G, int EPL, bool STR>
+__device__ __forceinline__ double eval_logp(const KArgs &a, const double (&q)[EPL], int gl, const double *smem = nullptr)
+{
+    return eval_logp_q<G, EPL, STR>(a, smem, gl, [&](int e) { return q[e]; });
 }
 
 // ---------------------------------------------------------------- proposals
@@ -217,15 +310,6 @@ __device__ __forceinline__ ChainConst chain_const(double temp, double beta, int 
     return c;
 }
 
-// Kernel shapes: (lanes per chain G, register slots per lane EPL); a shape serves
-// G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
-// lane for every ndim the shape serves and need no bounds check.
-constexpr int safe_slots(int G, int EPL)
-{
-    return G == 4 ? (EPL == 26 ? 20 : EPL == 20 ? 14 : EPL == 14 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
-         : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
-         : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
-}
 // element i = gl + G*e of a table row
 #define PTMI_ROW_LOAD_S(SAFE, dst, row, e)                                 \
     do {                                                                   \
@@ -572,14 +656,18 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         }
         __syncthreads();
     }
+    // ULDS with a box prior: the bounds table takes the place of sqrt(S) (both do not fit twice per CU at d = 100)
+    const bool ulds_box = ULDS && a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0 && a.box_off < d * d + d;
     if (ULDS) {
         const long long ch0 = (long long)logical_block() * CPB;
         const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
         const double *src = a.Ut + w0 * d * d, *srcS = a.S + w0 * d;
         for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = src[i];
-        for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
-        __syncthreads();
+        if (!ulds_box)
+            for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
     }
+    box_table_fill<G, EPL>(a, smem, BLK);
+    if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
 
     double x[EPL], dq[EPL];
 #pragma unroll
@@ -595,7 +683,8 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         draws_for_step<STR, FULL>(batch, dr, a, k, sid, sid0, gl);
         const double log_u = dr.log_u;
         int jt;
-        if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
+        if (ULDS && ulds_box) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, S, DE, dq, false);
+        else if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
         else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true);
         else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true);
         else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
@@ -609,7 +698,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             double q[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
-            nlp = eval_logp<G, EPL, STR>(a, q, gl);
+            nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
             // the reference skips logl when the prior is -inf (PT:607-608); the value is unused then, and the
             // matrix-core path needs every lane, so it is evaluated unconditionally
             if (STAGE) nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, PTMI_PL);
@@ -714,6 +803,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         for (int i = (int)threadIdx.x; i < d * d; i += BLK) { PTMI_D_P[i] = Pg[i]; PTMI_D_U[i] = Ug[i]; }
         for (int i = (int)threadIdx.x; i < 4 * EPL; i += BLK) PTMI_D_MU[i] = i < d ? mug[i] : 0.0;
         for (int i = (int)threadIdx.x; i < d; i += BLK) PTMI_D_SQ[i] = det_sqrt(Sg[i]);
+        box_table_fill<G, EPL>(a, smem, BLK);
         __syncthreads();
     }
 
@@ -733,18 +823,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         const double log_u = dr.log_u;
         propose<G, EPL, false, true, false>(a, it, sid, gl, cc, dr, PTMI_D_U, false, PTMI_D_SQ, nullptr, dq, true);
         // PT:605-612: prior on q = x + dq, then -1/2 r^T P r with r = q - mu
-        double nlp = 0.0;
-        if (a.logp_kind == PTMI_LOGP_BOX) {
-            const double *lo = a.logp_par, *hi = a.logp_par + d;
-            bool ok = true;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int i = gl + G * e;
-                const double qe = x[e] + dq[e];
-                if (i < d) ok = ok && (lo[i] <= qe) && (hi[i] >= qe);
-            }
-            nlp = grp_all<G, true>(ok) ? 0.0 : -__builtin_inf();
-        }
+        const double nlp = eval_logp_q<G, EPL, true>(a, smem, gl, [&](int e) { return x[e] + dq[e]; });
         MfmaAcc<EPL> acc;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) acc.t[tt] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
@@ -949,9 +1028,17 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     const ptmi_config &c = h->cfg;
     constexpr bool WANTS = G == 4 && (FULL || LOGL == PTMI_LOGL_DENSE);   // the tables fit only for the small-ndim shapes
     a.lds_u = 0;
+    a.box_off = -1;
+    // box prior: the bounds table goes behind the variant's other LDS tables when it still fits (else global reads)
+    const size_t box_bytes = c.logp_kind == PTMI_LOGP_BOX ? sizeof(double) * box_table_doubles(G, EPL) : 0;
+    auto even = [](size_t doubles) { return (doubles + 1) & ~(size_t)1; };
     if constexpr (G == 4 && !FULL && LOGL == PTMI_LOGL_DENSE) {
         // dense likelihood + SCAM-only + one table for the block: all tables unpadded in LDS, 512-thread blocks
-        const size_t lds2 = sizeof(double) * (2 * (size_t)c.ndim * c.ndim + 4 * EPL + c.ndim);
+        size_t lds2 = sizeof(double) * (2 * (size_t)c.ndim * c.ndim + 4 * EPL + c.ndim);
+        if (box_bytes && sizeof(double) * even(lds2 / sizeof(double)) + box_bytes <= 160 * 1024) {
+            a.box_off = (int)even(lds2 / sizeof(double));
+            lds2 = sizeof(double) * (size_t)a.box_off + box_bytes;
+        }
         static const char *blk = getenv("PTMI_DENSE_BLK");              // measurement switch: 256, 512 (default) or 0 = the older kernel
         const int want = blk ? atoi(blk) : 512;
         const bool shared = c.ngroups <= 1 && (!c.cov_per_walker || c.ntemps % (want / G) == 0);
@@ -978,6 +1065,10 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
         if (FULL && lds + tab + sizeof(double) * c.ndim <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
         if (FULL) lds += sizeof(double) * c.ndim;                               // sqrt(eigenvalues)
         if (lds <= 160 * 1024 && one_table_per_block) {
+            if (box_bytes && sizeof(double) * even(lds / sizeof(double)) + box_bytes <= 160 * 1024) {
+                a.box_off = (int)even(lds / sizeof(double));
+                lds = sizeof(double) * (size_t)a.box_off + box_bytes;
+            }
             auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, true, false>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -990,9 +1081,20 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     }
     // SCAM-only cycle, one eigenvector table per block, two blocks' tables fit the CU's LDS: read the direction from LDS
     if constexpr (!FULL && LOGL != PTMI_LOGL_DENSE) {
-        const size_t tab = sizeof(double) * ((size_t)c.ndim * c.ndim + c.ndim);
+        size_t tab = sizeof(double) * ((size_t)c.ndim * c.ndim + c.ndim);
         const bool one_table = c.ngroups <= 1 && (!c.cov_per_walker || c.ntemps % (256 / G) == 0);
         static const bool off = getenv("PTMI_NO_ULDS") != nullptr;      // measurement switch: same results either way
+        if (box_bytes) {
+            // the bounds table instead of sqrt(S) when both do not fit twice per CU (the kernel then takes the root per step)
+            const size_t ut = sizeof(double) * even((size_t)c.ndim * c.ndim);
+            if (2 * (sizeof(double) * even(tab / sizeof(double)) + box_bytes) <= 160 * 1024) {
+                a.box_off = (int)even(tab / sizeof(double));
+                tab = sizeof(double) * (size_t)a.box_off + box_bytes;
+            } else if (2 * (ut + box_bytes) <= 160 * 1024) {
+                a.box_off = (int)(ut / sizeof(double));
+                tab = ut + box_bytes;
+            }
+        }
         if (one_table && 2 * tab <= 160 * 1024 && !off) {
             auto kern = mh_steps_kernel<G, EPL, LOGL, false, false, false, true>;
             if (tab > 64 * 1024) {
@@ -1004,8 +1106,9 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             return PTMI_OK;
         }
     }
-    if (c.ngroups > 1) hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, true>), dim3(grid), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
+    a.box_off = box_bytes ? 0 : -1;               // no other table in LDS
+    if (c.ngroups > 1) hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, true>), dim3(grid), dim3(256), box_bytes, h->stream, a);
+    else hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, false>), dim3(grid), dim3(256), box_bytes, h->stream, a);
     h->last_variant = (FULL ? PTMI_VAR_FULL : 0) | (c.ngroups > 1 ? PTMI_VAR_GROUPS : 0);
     return PTMI_OK;
 }
