@@ -21,7 +21,7 @@ def deps():
         os.path.join(os.path.dirname(HERE), "include", "ptmi.h")]
 
 
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"] + os.environ.get("PTMI_EXTRA_CXXFLAGS", "").split()
 
 
 def hipcc():

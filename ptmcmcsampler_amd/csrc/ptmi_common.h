@@ -52,6 +52,7 @@ struct KArgs {
     const double *gj_tab;        // [3][d][d] backward, forward, gradient tables
     double *gj;                  // [W][T][8] per-rank jump state
     double *gj_scr, *gj_scal;    // scratch of the tree build: [slot][e][chain][lane], [level][scalar][chain]
+    int gj_stack_off, gj_lds_levels;   // tree stack: offset (doubles) in the block's LDS and how many of the lowest heights live there
     const int32_t *gj_order;     // chain handled by each chain slot of the launch (chains of similar NUTS step size share a wave)
 };
 
@@ -63,7 +64,7 @@ constexpr u32 SLOT_GJS = 0x3000000u;   // + scalar draw of the call
 // vector slots of a chain's scratch: the two ends and the sample of the outer loop, then 4 per tree level
 enum { GJV_TM = 0, GJV_RM = 1, GJV_GM = 2, GJV_TP = 3, GJV_RP = 4, GJV_GP = 5, GJV_SAMPLE = 6, GJV_TOP = 7 };
 enum { GJL_FAR_T = 0, GJL_FAR_R = 1, GJL_CAND_T = 2, GJL_CAND_G = 3, GJL_VECS = 4 };
-enum { GJS_LOGP = 0, GJS_N = 1, GJS_ALPHA = 2, GJS_NALPHA = 3, GJS_H = 4, GJS_SCALARS = 8 };
+enum { GJS_LOGP = 0, GJS_N = 1, GJS_ALPHA = 2, GJS_NALPHA = 3, GJS_SCALARS = 4 };
 
 template <int G>
 __device__ __forceinline__ double group_bcast_lane(double v, int src)

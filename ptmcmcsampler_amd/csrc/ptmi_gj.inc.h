@@ -9,9 +9,13 @@
 #include "ptmi_common.h"
 
 
-// the three whitening tables of the block, staged once per launch ([3][d][d], 9.6 KB at d = 20)
+// The block's LDS (one wave per block): the three whitening tables, staged once per launch ([3][d][d], 9.6 KB at d = 20,
+// 4-lane shapes only); the entries of the lowest heights of the tree stack (KArgs::gj_stack_off, gj_lds_levels); the
+// bounds of a box prior (KArgs::box_off).
 extern __shared__ __attribute__((aligned(16))) double gj_lds[];
 enum { GJT_BACKWARD = 0, GJT_FORWARD = 1, GJT_GRADIENT = 2 };
+// doubles of one stack level in LDS: four chain vectors and four scalars for each of the wave's 64 lanes
+constexpr int gj_level_doubles(int EPL) { return (GJL_VECS * EPL + 4) * 64; }
 
 template <int G, int EPL, int LOGL>
 struct GradJump {
@@ -78,16 +82,21 @@ struct GradJump {
         for (int e = 0; e < EPL; ++e) p = __builtin_fma(x[e], y[e], p);
         return group_sum<G>(p);
     }
-    // out[i] = sum_k T[k][i] v[k], k ascending, one fma per term.  WHICH >= 0: a whitening table in LDS (the pointer
-    // is formed from the LDS symbol here so that the reads are ds_read, not flat); WHICH < 0: the global table Tg.
+    // out[i] = sum_k T[k][i] v[k], k ascending, one fma per term.  WHICH >= 0: a whitening table (read through L2: these
+    // are the layouts of ndim > 32; the 4-lane shapes run GradJumpWide); WHICH < 0: the global table Tg.
     template <int WHICH>
     __device__ __forceinline__ void tab_vec(const double *Tg, const double (&v)[EPL], double (&out)[EPL]) const
     {
-        // quads (ndim <= 32) find the tables in LDS; the wider layouts read them through L2
-        const double *T = WHICH < 0 ? Tg : (G == 4 ? gj_lds + (size_t)WHICH * d * d : a.gj_tab + (size_t)WHICH * d * d);
+        // every table read is unconditional (a padding slot reads element 0 of the row and its sum is dropped at the end):
+        // a read under `if (i < d)` is not speculated, and each term then waited for its own round trip behind a branch
         double acc[EPL];
+        int col[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] = 0.0;
+        for (int e = 0; e < EPL; ++e) {
+            acc[e] = 0.0;
+            col[e] = gl + G * e < d ? gl + G * e : 0;
+        }
+        const double *T = WHICH < 0 ? Tg : a.gj_tab + (size_t)WHICH * d * d;
 #pragma unroll
         for (int e2 = 0; e2 < EPL; ++e2) {
 #pragma unroll 1
@@ -97,14 +106,11 @@ struct GradJump {
                 const double vk = group_bcast_lane<G>(v[e2], src);
                 const double *row = T + (size_t)k * d;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int i = gl + G * e;
-                    if (i < d) acc[e] = __builtin_fma(row[i], vk, acc[e]);
-                }
+                for (int e = 0; e < EPL; ++e) acc[e] = __builtin_fma(row[col[e]], vk, acc[e]);
             }
         }
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) out[e] = acc[e];
+        for (int e = 0; e < EPL; ++e) out[e] = gl + G * e < d ? acc[e] : 0.0;
     }
 
     // logl and its gradient (the value is eval_logl's, operation for operation)
@@ -161,17 +167,7 @@ struct GradJump {
     }
     __device__ __forceinline__ double logp(const double (&x)[EPL]) const
     {
-        if (a.logp_kind == PTMI_LOGP_BOX) {
-            const double *lo = a.logp_par, *hi = a.logp_par + d;
-            bool ok = true;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int i = gl + G * e;
-                if (i < d) ok = ok && (lo[i] <= x[e]) && (hi[i] >= x[e]);
-            }
-            return group_all<G>(ok) ? 0.0 : -__builtin_inf();
-        }
-        return 0.0;
+        return eval_logp_q<G, EPL, false>(a, gj_lds, gl, [&](int e) { return x[e]; });
     }
     // beta*logl + logp and its gradient in the whitened coordinates (NJ:71-90)
     __device__ __forceinline__ double func_grad_white(const double (&q)[EPL], double (&gradw)[EPL]) const
@@ -273,13 +269,69 @@ struct GradJump {
         int s;
     };
 
+    // ---- the stack of pending left subtrees.  Heights decrease strictly from the bottom of the stack to its top (a finished
+    // subtree merges with a pending sibling of its own height before anything is pushed), so there is at most one entry
+    // per height: the entry of height h lives in slot h, and the set of pending heights is a bit mask in a register (the
+    // top of the stack is its lowest bit).  Slots below gj_lds_levels are in LDS -- height h is touched once per 2^h
+    // leaves, so two levels take three quarters of the traffic -- the rest in the global scratch.
+    __device__ __forceinline__ void stack_vec_store(int h, int which, const double (&v)[EPL]) const
+    {
+        if (h < a.gj_lds_levels) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) gj_lds[a.gj_stack_off + (h * (GJL_VECS * EPL + 4) + which * EPL + e) * 64 + (int)threadIdx.x] = v[e];
+        } else {
+            vstore(GJV_TOP + h * GJL_VECS + which, v);
+        }
+    }
+    __device__ __forceinline__ void stack_vec_load(int h, int which, double (&v)[EPL]) const
+    {
+        if (h < a.gj_lds_levels) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = gj_lds[a.gj_stack_off + (h * (GJL_VECS * EPL + 4) + which * EPL + e) * 64 + (int)threadIdx.x];
+        } else {
+            vload(GJV_TOP + h * GJL_VECS + which, v);
+        }
+    }
+    // scalars of an entry: in LDS every lane keeps its own copy; in global memory the chain's lanes share one (hence the fence)
+    __device__ __forceinline__ void stack_scal_store(int h, double logp, double n, double alpha, double nalpha) const
+    {
+        if (h < a.gj_lds_levels) {
+            const int base = a.gj_stack_off + (h * (GJL_VECS * EPL + 4) + GJL_VECS * EPL) * 64 + (int)threadIdx.x;
+            gj_lds[base] = logp;
+            gj_lds[base + 64] = n;
+            gj_lds[base + 128] = alpha;
+            gj_lds[base + 192] = nalpha;
+        } else {
+            scal(h, GJS_LOGP) = logp;                                    // every lane of the chain writes the same values
+            scal(h, GJS_N) = n;
+            scal(h, GJS_ALPHA) = alpha;
+            scal(h, GJS_NALPHA) = nalpha;
+            __threadfence_block();
+        }
+    }
+    __device__ __forceinline__ void stack_scal_load(int h, double &logp, double &n, double &alpha, double &nalpha) const
+    {
+        if (h < a.gj_lds_levels) {
+            const int base = a.gj_stack_off + (h * (GJL_VECS * EPL + 4) + GJL_VECS * EPL) * 64 + (int)threadIdx.x;
+            logp = gj_lds[base];
+            n = gj_lds[base + 64];
+            alpha = gj_lds[base + 128];
+            nalpha = gj_lds[base + 192];
+        } else {
+            logp = scal(h, GJS_LOGP);
+            n = scal(h, GJS_N);
+            alpha = scal(h, GJS_ALPHA);
+            nalpha = scal(h, GJS_NALPHA);
+        }
+    }
+
     // NJ:495-652 as a loop: leaves are generated left to right in direction v from the growth end; a finished subtree
     // is merged with the pending left sibling of the same height on the stack, or waits there for its right sibling.
     // A left subtree that stopped (s = 0) is handed up unchanged to the height of the next pending sibling (or the root).
     __device__ __forceinline__ void build_tree(double (&tg)[EPL], double (&rg)[EPL], double (&gg)[EPL], double logu, int v, int j,
                                                double eps, double joint0, Tree &cur)
     {
-        int sp = 0;
+        u32 pend = 0;                                                    // heights with a pending left subtree
         for (;;) {
             const double logpp = leapfrog(tg, rg, gg, (double)v * eps, tg, rg, gg);
             const double joint = joint_of(logpp, rg);
@@ -293,47 +345,42 @@ struct GradJump {
             cur.nalpha = 1;
             int h = 0;
             for (;;) {
-                const int top_h = sp > 0 ? (int)scal(sp - 1, GJS_H) : -1;
-                if (sp > 0 && top_h == h) {                              // cur is the right sibling of the stack top
-                    --sp;
-                    const int base = GJV_TOP + sp * GJL_VECS;
-                    const long long tn = (long long)scal(sp, GJS_N);
+                const int top_h = pend ? (int)__builtin_ctz(pend) : -1;
+                if (top_h == h) {                                        // cur is the right sibling of the stack top
+                    pend &= pend - 1u;
+                    double t_logp, t_n, t_alpha, t_nalpha;
+                    stack_scal_load(h, t_logp, t_n, t_alpha, t_nalpha);
+                    const long long tn = (long long)t_n;
                     const long long tot = tn + cur.n;
                     const double den = (double)tot > 1.0 ? (double)tot : 1.0;
                     const bool take_u = uniform() < (double)cur.n / den;
                     if (!take_u) {
-                        vload(base + GJL_CAND_T, cur.cand_t);
-                        vload(base + GJL_CAND_G, cur.cand_g);
-                        cur.logp = scal(sp, GJS_LOGP);
+                        stack_vec_load(h, GJL_CAND_T, cur.cand_t);
+                        stack_vec_load(h, GJL_CAND_G, cur.cand_g);
+                        cur.logp = t_logp;
                     }
-                    vload(base + GJL_FAR_T, cur.far_t);
-                    vload(base + GJL_FAR_R, cur.far_r);
+                    stack_vec_load(h, GJL_FAR_T, cur.far_t);
+                    stack_vec_load(h, GJL_FAR_R, cur.far_r);
                     cur.n = tot;
                     const bool go = v == 1 ? keep_going(cur.far_t, tg, cur.far_r, rg) : keep_going(tg, cur.far_t, rg, cur.far_r);
                     cur.s = cur.s && go;                                 // the popped tree has s = 1
-                    cur.alpha = scal(sp, GJS_ALPHA) + cur.alpha;
-                    cur.nalpha = (long long)scal(sp, GJS_NALPHA) + cur.nalpha;
+                    cur.alpha = t_alpha + cur.alpha;
+                    cur.nalpha = (long long)t_nalpha + cur.nalpha;
                     h += 1;
                     continue;
                 }
                 if (h == j) return;
                 if (cur.s == 0) {
-                    if (sp == 0) return;
+                    if (pend == 0) return;
                     h = top_h;
                     continue;
                 }
-                const int base = GJV_TOP + sp * GJL_VECS;                // push: wait for the right sibling
-                vstore(base + GJL_FAR_T, cur.far_t);
-                vstore(base + GJL_FAR_R, cur.far_r);
-                vstore(base + GJL_CAND_T, cur.cand_t);
-                vstore(base + GJL_CAND_G, cur.cand_g);
-                scal(sp, GJS_LOGP) = cur.logp;                           // every lane of the chain writes the same values
-                scal(sp, GJS_N) = (double)cur.n;
-                scal(sp, GJS_ALPHA) = cur.alpha;
-                scal(sp, GJS_NALPHA) = (double)cur.nalpha;
-                scal(sp, GJS_H) = (double)h;
-                __threadfence_block();
-                ++sp;
+                stack_vec_store(h, GJL_FAR_T, cur.far_t);                // push: wait for the right sibling
+                stack_vec_store(h, GJL_FAR_R, cur.far_r);
+                stack_vec_store(h, GJL_CAND_T, cur.cand_t);
+                stack_vec_store(h, GJL_CAND_G, cur.cand_g);
+                stack_scal_store(h, cur.logp, (double)cur.n, cur.alpha, (double)cur.nalpha);
+                pend |= 1u << h;
                 break;
             }
         }
@@ -404,6 +451,401 @@ struct GradJump {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 4-lane shapes (ndim <= 32) run a gradient jump ONE CHAIN AT A TIME ON THE WHOLE WAVE.  A launch ends with its
+// slowest chain (a per cent of the ranks of the curved likelihood build trees of ~100 leapfrogs where the rest take one),
+// and in the 4-lane layout a leapfrog costs ~7 000 issue slots: every lane walks all EPL slots of every vector, the tree's
+// control flow is divergent between the chains of the wave (exec-mask bookkeeping, scalar spills), and the state of the
+// recursion does not fit the registers.  Here element i = g + 4 e of a chain vector sits in lane 16 g + e (row g of the
+// wave holds what lane g of the chain held, in slot order), a vector is ONE register pair, every scalar and all control
+// flow is wave-uniform, the whole tree stack lives in LDS, and a leapfrog is ~700 issue slots.  The arithmetic and its
+// order are those of the 4-lane code above (and of the oracle): a sum over a vector is the lane's chain of fmas over its
+// slots -- here a scan along the row -- followed by (p0 + p2) + (p1 + p3).
+constexpr int gjw_table_doubles(int EPL) { return 3 * (4 * EPL) * (4 * EPL); }          // rows padded to 4 EPL: constant offsets
+constexpr int gjw_level_doubles() { return GJL_VECS * 64 + 4; }
+__device__ __forceinline__ double lane_get(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)b, lane), hi = (u32)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+// -DPTMI_GJ_PROFILE: cycle counts of the pieces of a gradient jump, printed by the first wave (tools/gj_leap_timing.py)
+#ifdef PTMI_GJ_PROFILE
+#define GJP_T0(var) const unsigned long long var = __builtin_readcyclecounter()
+#define GJP_ADD(slot, var) (prof[slot] += __builtin_readcyclecounter() - var)
+#else
+#define GJP_T0(var)
+#define GJP_ADD(slot, var)
+#endif
+enum { GJP_TABVEC = 0, GJP_LOGL = 1, GJP_DOT = 2, GJP_LEAF = 3, GJP_MERGE = 4, GJP_PUSH = 5, GJP_CALL = 6, GJP_DRAW = 7, GJP_N = 8 };
+
+template <int EPL, int LOGL>
+struct GradJumpWide {
+    static constexpr int G = 4, LD = 4 * EPL;
+    const KArgs &a;
+    const int d, L, we, wg, wi;
+    const bool act;                  // this lane holds an element of the chain's vectors
+    const int col;                   // its index (0 on idle lanes: their reads are dropped)
+    const long long ch, nch;
+    const double beta;
+    const long long it;
+    const u32 sid;
+    const int vb;                    // 64 doubles of the block's LDS: the vector of a table product, in element order
+    double blo = 0.0, bhi = 0.0;     // this lane's bounds of a box prior
+    u32 nm = 0, ns = 0, nleap = 0;
+#ifdef PTMI_GJ_PROFILE
+    mutable unsigned long long prof[GJP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    __device__ __forceinline__ GradJumpWide(const KArgs &a_, long long ch_, double beta_, long long it_, u32 sid_, int vb_)
+        : a(a_), d(a_.d), L((int)threadIdx.x), we(L & 15), wg(L >> 4), wi(wg + 4 * we), act(we < EPL && wi < a_.d), col(act ? wi : 0),
+          ch(ch_), nch((long long)a_.W * a_.nt), beta(beta_), it(it_), sid(sid_), vb(vb_)
+    {
+        if (a.logp_kind == PTMI_LOGP_BOX) { blo = a.logp_par[col]; bhi = a.logp_par[d + col]; }
+    }
+
+    // ---- draws
+    __device__ __forceinline__ double momenta()                            // NJ:92-94; directions k and k + 4 share one Box-Muller
+    {
+        const u32 block = nm++;
+        double r = 0.0;
+        if (act) {
+            const int k = wg + 4 * (we & ~1);
+            u64 e0, e1;
+            philox_words(a.seed, (u64)it, sid, SLOT_GJ + 4096u * block + (u32)k, e0, e1);
+            const double rr = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
+            double sn, cs;
+            det_sincos2pi(w2uniform(e1), sn, cs);
+            r = (we & 1) ? rr * sn : rr * cs;
+        }
+        return r;
+    }
+    __device__ __forceinline__ u64 scalar_word()
+    {
+        GJP_T0(t0);
+        u64 w0, w1;
+        philox_words(a.seed, (u64)it, sid, SLOT_GJS + ns++, w0, w1);
+        GJP_ADD(GJP_DRAW, t0);
+        return w0;
+    }
+    __device__ __forceinline__ double uniform() { return w2uniform(scalar_word()); }
+    __device__ __forceinline__ double exponential() { return -det_log(w2uniform_open(scalar_word())); }
+    __device__ __forceinline__ int randint(int lo, int hi) { return lo + (int)w2index(scalar_word(), (u64)(hi - lo)); }
+
+    // ---- linear algebra
+    // Sum over the chain in the 4-lane order: per row the chain p = fma(x_e, y_e, p) over its slots.  Every lane recomputes
+    // its link from its left neighbour's value in each of the EPL steps: lane e is right from step e + 1 on (lane 0 has no
+    // neighbour and starts from 0), so after EPL steps lane EPL - 1 of row g holds the chain of lane group g; then (p0 + p2) + (p1 + p3).
+    __device__ __forceinline__ double row_chain(double x, double y) const
+    {
+        double p = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) p = __builtin_fma(x, y, dppf64<0x111>(p));      // row_shr:1, 0 into lane 0
+        return p;
+    }
+    __device__ __forceinline__ double rows_sum(double p) const
+    {
+        const double p0 = lane_get(p, EPL - 1), p1 = lane_get(p, 16 + EPL - 1), p2 = lane_get(p, 32 + EPL - 1), p3 = lane_get(p, 48 + EPL - 1);
+        return (p0 + p2) + (p1 + p3);
+    }
+    __device__ __forceinline__ double dot(double x, double y) const
+    {
+        GJP_T0(t0);
+        const double r = rows_sum(row_chain(x, y));
+        GJP_ADD(GJP_DOT, t0);
+        return r;
+    }
+    // out[i] = sum_k T[k][i] v[k], k ascending, one fma per term; WHICH >= 0: the LDS copy of a whitening table (rows of LD)
+    template <int WHICH>
+    __device__ __forceinline__ double tab_vec(const double *Tg, double v) const
+    {
+        GJP_T0(t0);
+        double acc = 0.0;
+        // The vector goes through LDS in element order and every lane reads all of it back (same address for the whole wave:
+        // a broadcast); two readlanes per term instead had each fma wait on a fresh scalar pair.  Straight-line on purpose:
+        // with a (wave-uniform) branch around every term each table read waited for its own LDS round trip -- 2 400 cycles
+        // per product, more than half of a gradient jump.  Rows k >= d of the LDS tables are zeros; their terms are computed and dropped.
+        __syncthreads();                                                 // the previous product's readers are through
+        if (act) gj_lds[vb + wi] = v;
+        __syncthreads();
+        // all reads first (the scheduling barrier keeps them there): left to the scheduler they went out two at a time
+        // and the chain of fmas waited for an LDS round trip at every other term
+        double tk[4 * EPL], vk[4 * EPL];
+#pragma unroll
+        for (int k = 0; k < 4 * EPL; ++k) {
+            tk[k] = WHICH >= 0 ? gj_lds[(WHICH * LD + k) * LD + col] : Tg[(size_t)(k < d ? k : 0) * d + col];
+            vk[k] = gj_lds[vb + k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (d == 4 * EPL) {
+#pragma unroll
+            for (int k = 0; k < 4 * EPL; ++k) acc = __builtin_fma(tk[k], vk[k], acc);
+        } else {                                                         // (a uniform branch per term instead of the select is 4x slower)
+#pragma unroll
+            for (int k = 0; k < 4 * EPL; ++k) {
+                const double nxt = __builtin_fma(tk[k], vk[k], acc);
+                acc = k < d ? nxt : acc;
+            }
+        }
+        GJP_ADD(GJP_TABVEC, t0);
+        return act ? acc : 0.0;
+    }
+    __device__ __forceinline__ double logl_grad(double x, double &g) const
+    {
+        GJP_T0(t0);
+        if (LOGL == PTMI_LOGL_ISO) {
+            g = -x;
+            const double r = -0.5 * dot(x, x);
+            GJP_ADD(GJP_LOGL, t0);
+            return r;
+        } else if (LOGL == PTMI_LOGL_DENSE) {
+            const double r = act ? x - a.logl_par[col] : 0.0;
+            const double v = tab_vec<-1>(a.logl_par + d, r);
+            g = -v;
+            const double rr = -0.5 * dot(r, v);
+            GJP_ADD(GJP_LOGL, t0);
+            return rr;
+        } else {
+            const double other = __shfl_xor(x, 16, 64);                    // the pair's other member: lane group g ^ 1, same slot
+            const bool even = !(wg & 1);
+            const bool pair = we < EPL && (even ? wi + 1 < d : wi < d);
+            const double xx = even ? x : other, y = even ? other : x;
+            const double x2 = xx * xx;
+            const double gg = 9.0 + 4.0 * x2 + 9.0 * y;
+            const double l0 = -x2 - gg * gg;
+            const double ym = y - 2.0;
+            const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
+            const double e0 = det_exp(l0), e1 = 0.5 * det_exp(l1);
+            const double sum = e0 + e1;
+            const double tl = det_log(sum);                                // wanted on the even lanes only; same cost for the wave
+            const double d0 = even ? -2.0 * xx - 16.0 * gg * xx : -18.0 * gg;
+            const double d1 = even ? -16.0 * xx : -16.0 * ym;
+            const double gv = (e0 * d0 + e1 * d1) / sum;
+            g = pair ? gv : 0.0;
+            const double r = dot(pair && even ? tl : 0.0, 1.0);
+            GJP_ADD(GJP_LOGL, t0);
+            return r;
+        }
+    }
+    __device__ __forceinline__ double logp(double x) const
+    {
+        if (a.logp_kind == PTMI_LOGP_BOX) {
+            const bool ok = !act || ((blo <= x) & (bhi >= x));
+            return __ballot(ok) == ~0ull ? 0.0 : -__builtin_inf();
+        }
+        return 0.0;
+    }
+    __device__ __forceinline__ double func_grad_white(double q, double &gradw) const       // NJ:71-90
+    {
+        const double x = tab_vec<GJT_BACKWARD>(nullptr, q);
+        double g;
+        const double ll = logl_grad(x, g);
+        const double lp = logp(x);
+        g = beta * g + 0.0;
+        gradw = tab_vec<GJT_GRADIENT>(nullptr, g);
+        return beta * ll + lp;
+    }
+    __device__ __forceinline__ double joint_of(double logl, double r) const { return logl - 0.5 * dot(r, r); }
+    __device__ __forceinline__ double leapfrog(double theta, double r, double grad, double eps, double &to, double &ro, double &go)   // NJ:149-169
+    {
+        nleap += 1;
+        const double he = 0.5 * eps;
+        const double rh = r + he * grad;
+        const double tn = theta + eps * rh;
+        double gn;
+        const double lpp = func_grad_white(tn, gn);
+        to = tn;
+        go = gn;
+        ro = rh + he * gn;
+        return lpp;
+    }
+    __device__ __forceinline__ bool keep_going(double tm, double tp, double rm, double rp) const                // NJ:465-493
+    {
+        const double dt = tp - tm;
+        const double cx = row_chain(dt, rm), cy = row_chain(dt, rp);      // two independent chains: they overlap
+        const double x = rows_sum(cx), y = rows_sum(cy);
+        return (x >= 0.0) & (y >= 0.0);
+    }
+    __device__ __forceinline__ bool any_inf(double v) const { return __ballot(act && __builtin_isinf(v)) != 0ull; }
+
+    // ------------------------------------------------------------------ HMC (NJ:238-291)
+    __device__ __forceinline__ double hmc(double *st, double x, double &qout)
+    {
+        st[GJ_HITER] += 1.0;
+        double q = tab_vec<GJT_FORWARD>(nullptr, x), grad;
+        const double logp0 = func_grad_white(q, grad);
+        double p = momenta();
+        const double joint0 = joint_of(logp0, p);
+        const int nsteps = randint(a.hmc_min, a.hmc_max);
+        double joint1 = joint0;
+        for (int k = 0; k < nsteps; ++k) {
+            const double logp1 = leapfrog(q, p, grad, a.hmc_eps, q, p, grad);
+            joint1 = joint_of(logp1, p);
+            if (joint1 - 1000.0 < joint0) break;                         // NJ:284-286
+        }
+        qout = tab_vec<GJT_BACKWARD>(nullptr, q);
+        return joint1 - joint0;
+    }
+
+    // ------------------------------------------------------------------ NUTS
+    __device__ __forceinline__ double find_reasonable_epsilon(double theta0, double grad0, double logp0)   // NJ:435-463, loops bounded
+    {
+        double tp, rp, gp;
+        double eps = 1.0;
+        const double r0 = momenta();
+        double logpp = leapfrog(theta0, r0, grad0, eps, tp, rp, gp);
+        const bool ginf = any_inf(gp);                                   // not refreshed in the loop (NJ:449-452)
+        double k = 1.0;
+        for (int n = 0; n < 100 && (__builtin_isinf(logpp) || ginf); ++n) {
+            k *= 0.5;
+            logpp = leapfrog(theta0, r0, grad0, eps * k, tp, rp, gp);
+        }
+        eps = 0.5 * k * eps;
+        double ap = det_exp(joint_of(logpp, rp) - joint_of(logp0, r0));
+        const bool up = ap > 0.5;
+        for (int n = 0; n < 100 && ((up ? ap : 1.0 / ap) > (up ? 0.5 : 2.0)); ++n) {
+            eps = eps * (up ? 2.0 : 0.5);
+            logpp = leapfrog(theta0, r0, grad0, eps, tp, rp, gp);
+            ap = det_exp(joint_of(logpp, rp) - joint_of(logp0, r0));
+        }
+        return eps;
+    }
+
+    struct Tree {
+        double far_t, far_r, cand_t, cand_g;
+        double logp, alpha;
+        long long n, nalpha;
+        int s;
+    };
+    // the tree stack (see GradJump::build_tree): the entry of height h in slot h of the block's LDS, pending heights in a mask
+    __device__ __forceinline__ int slot_of(int h) const { return a.gj_stack_off + h * gjw_level_doubles(); }
+    // NJ:495-652 as a loop, as GradJump::build_tree
+    __device__ __forceinline__ void build_tree(double &tg, double &rg, double &gg, double logu, int v, int j, double eps, double joint0, Tree &cur)
+    {
+        u32 pend = 0;
+        for (;;) {
+            const double logpp = leapfrog(tg, rg, gg, (double)v * eps, tg, rg, gg);
+            GJP_T0(tl0);
+            const double joint = joint_of(logpp, rg);
+            cur.n = logu < joint;
+            cur.s = (logu - 1000.0) < joint;
+            cur.far_t = tg; cur.far_r = rg; cur.cand_t = tg; cur.cand_g = gg;
+            cur.logp = logpp;
+            const double ex = det_exp(joint - joint0);
+            cur.alpha = ex < 1.0 ? ex : 1.0;                             // Python's min(1.0, e): 1.0 when e is NaN
+            cur.nalpha = 1;
+            GJP_ADD(GJP_LEAF, tl0);
+            int h = 0;
+            for (;;) {
+                const int top_h = pend ? (int)__builtin_ctz(pend) : -1;
+                if (top_h == h) {                                        // cur is the right sibling of the stack top
+                    GJP_T0(tm0);
+                    pend &= pend - 1u;
+                    const int b = slot_of(h);
+                    const double t_logp = gj_lds[b + GJL_VECS * 64 + GJS_LOGP], t_n = gj_lds[b + GJL_VECS * 64 + GJS_N];
+                    const double t_alpha = gj_lds[b + GJL_VECS * 64 + GJS_ALPHA], t_nalpha = gj_lds[b + GJL_VECS * 64 + GJS_NALPHA];
+                    const long long tot = (long long)t_n + cur.n;
+                    const double den = (double)tot > 1.0 ? (double)tot : 1.0;
+                    const bool take_u = uniform() < (double)cur.n / den;
+                    if (!take_u) {
+                        cur.cand_t = gj_lds[b + GJL_CAND_T * 64 + L];
+                        cur.cand_g = gj_lds[b + GJL_CAND_G * 64 + L];
+                        cur.logp = t_logp;
+                    }
+                    cur.far_t = gj_lds[b + GJL_FAR_T * 64 + L];
+                    cur.far_r = gj_lds[b + GJL_FAR_R * 64 + L];
+                    cur.n = tot;
+                    const bool go = v == 1 ? keep_going(cur.far_t, tg, cur.far_r, rg) : keep_going(tg, cur.far_t, rg, cur.far_r);
+                    cur.s = cur.s && go;                                 // the popped tree has s = 1
+                    cur.alpha = t_alpha + cur.alpha;
+                    cur.nalpha = (long long)t_nalpha + cur.nalpha;
+                    h += 1;
+                    GJP_ADD(GJP_MERGE, tm0);
+                    continue;
+                }
+                if (h == j) return;
+                if (cur.s == 0) {
+                    if (pend == 0) return;
+                    h = top_h;
+                    continue;
+                }
+                GJP_T0(tp0);
+                const int b = slot_of(h);                                // push: wait for the right sibling
+                gj_lds[b + GJL_FAR_T * 64 + L] = cur.far_t;
+                gj_lds[b + GJL_FAR_R * 64 + L] = cur.far_r;
+                gj_lds[b + GJL_CAND_T * 64 + L] = cur.cand_t;
+                gj_lds[b + GJL_CAND_G * 64 + L] = cur.cand_g;
+                if (L == 0) {
+                    gj_lds[b + GJL_VECS * 64 + GJS_LOGP] = cur.logp;
+                    gj_lds[b + GJL_VECS * 64 + GJS_N] = (double)cur.n;
+                    gj_lds[b + GJL_VECS * 64 + GJS_ALPHA] = cur.alpha;
+                    gj_lds[b + GJL_VECS * 64 + GJS_NALPHA] = (double)cur.nalpha;
+                }
+                __syncthreads();                                         // one wave per block: orders lane 0's writes before the others' reads
+                pend |= 1u << h;
+                GJP_ADD(GJP_PUSH, tp0);
+                break;
+            }
+        }
+    }
+
+    // NUTSJump.__call__ (NJ:654-840), as GradJump::nuts; the two ends of the trajectory and the sample stay in registers
+    __device__ __forceinline__ double nuts(double *st, double x, double &qout)
+    {
+        st[GJ_NITER] += 1.0;
+        const double q = tab_vec<GJT_FORWARD>(nullptr, x);
+        double grad;
+        const double logp0 = func_grad_white(q, grad);
+        if (st[GJ_HAVE_EPS] == 0.0) {
+            st[GJ_EPS] = find_reasonable_epsilon(q, grad, logp0);
+            st[GJ_MU] = det_log(10.0 * st[GJ_EPS]);
+            st[GJ_HAVE_EPS] = 1.0;
+        }
+        const double r0 = momenta();
+        const double joint = joint_of(logp0, r0);
+        const double logu = joint - exponential();
+        double lnprob = logp0;
+        double sample = q, tm = q, rm = r0, gm = grad, tp = q, rp = r0, gp = grad;
+        int j = 0, s = 1;
+        long long n = 1;
+        double alpha = 0.0;
+        long long nalpha = 1;
+        const double eps = st[GJ_EPS];
+        while (s == 1) {
+            const int dir = 2 * (int)(uniform() < 0.5) - 1;
+            double tg = dir == -1 ? tm : tp, rg = dir == -1 ? rm : rp, gg = dir == -1 ? gm : gp;
+            Tree t;
+            build_tree(tg, rg, gg, logu, dir, j, eps, joint, t);
+            if (dir == -1) { tm = tg; rm = rg; gm = gg; } else { tp = tg; rp = rg; gp = gg; }
+            if (t.s == 1) {
+                const double ratio = (double)t.n / (double)n;
+                if (uniform() < (1.0 < ratio ? 1.0 : ratio)) { sample = t.cand_t; lnprob = t.logp; }
+            }
+            n += t.n;
+            const bool go = keep_going(tm, tp, rm, rp);
+            s = t.s && go;
+            alpha = t.alpha;
+            nalpha = t.nalpha;
+            j += 1;
+            if (j > a.nuts_maxdepth) s = 0;                              // cap (not in the reference)
+        }
+        // dual averaging (NJ:805-816): gamma = 0.05, t0 = 10, kappa = 0.75
+        const double it_call = st[GJ_NITER];
+        double eta = 1.0 / (it_call + 10.0);
+        st[GJ_HBAR] = (1.0 - eta) * st[GJ_HBAR] + eta * (a.nuts_delta - alpha / (double)nalpha);
+        if (it <= (long long)a.gj_nburn) {
+            st[GJ_EPS] = det_exp(st[GJ_MU] - det_sqrt(it_call) / 0.05 * st[GJ_HBAR]);
+            eta = det_exp(-0.75 * det_log(it_call));
+            st[GJ_EPSBAR] = det_exp((1.0 - eta) * det_log(st[GJ_EPSBAR]) + eta * det_log(st[GJ_EPS]));
+        } else {
+            st[GJ_EPS] = st[GJ_EPSBAR];
+        }
+        qout = tab_vec<GJT_BACKWARD>(nullptr, sample);
+        return logp0 - lnprob;                                           // undoes the outer Hastings ratio (NJ:838)
+    }
+};
+
 // Fused MH steps with the gradient jumps in the cycle: the non-staged full kernel (ptmi_mh.inc.h) plus the NUTS / HMC
 // branch.  Every chain group runs its nsteps iterations on its own, so a long NUTS tree delays only its wave for that
 // iteration and the launch costs the longest SUM over iterations, not the sum of the per-iteration maxima.
@@ -414,14 +856,23 @@ template <int G, int EPL, int LOGL>
 __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
 {
     constexpr int CPB = GJ_BLOCK / G;
+    constexpr bool WIDE = G == 4;                // a gradient jump takes the whole wave (GradJumpWide)
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
-    if (G == 4) {
-        for (int i = (int)threadIdx.x; i < 3 * d * d; i += GJ_BLOCK) gj_lds[i] = a.gj_tab[i];
-        __syncthreads();
+    if (WIDE) {
+        constexpr int LD = 4 * EPL;
+        for (int i = (int)threadIdx.x; i < 3 * LD * LD; i += GJ_BLOCK) {
+            const int w = i / (LD * LD), r = (i / LD) % LD, c = i % LD;
+            gj_lds[i] = (r < d && c < d) ? a.gj_tab[((size_t)w * d + r) * d + c] : 0.0;
+        }
     }
-    const long long cslot = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
-    if (cslot >= nch) return;                    // no block-wide synchronisation below: whole chain groups may leave
+    box_table_fill<G, EPL>(a, gj_lds, GJ_BLOCK);
+    __syncthreads();
+    const long long cslot0 = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
+    // a chain group past the end repeats the last chain and writes nothing (the whole wave takes part in the gradient jumps)
+    const bool live = cslot0 < nch;
+    if (!WIDE && !live) return;                  // no block-wide synchronisation below for the wider layouts: whole chain groups may leave
+    const long long cslot = live ? cslot0 : nch - 1;
     // The chains of a wave run in lock step: every iteration costs the wave its longest tree, and the launch ends with its
     // slowest wave.  On the curved likelihood a per cent of the ranks keep a small NUTS step size (trees of ~100
     // leapfrogs) while the rest run away to huge ones (one leapfrog): the host deals the chains over the waves by step
@@ -452,9 +903,13 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
     }
     double lnL = a.lnL[ch], lp = a.lp[ch];
     u32 nacc = 0, jp[PTMI_J_NTYPES] = {0, 0, 0, 0, 0}, ja[PTMI_J_NTYPES] = {0, 0, 0, 0, 0};
-    const bool cold = tg == 0 && a.AM != nullptr;
+    const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
 
+#ifdef PTMI_GJ_PROFILE
+    unsigned long long prof_sum[GJP_N + 2] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long prof_k0 = __builtin_readcyclecounter();
+#endif
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
         double q[EPL], qxy = 0.0;
@@ -462,26 +917,83 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
         draws_for_step<false, true>(batch, dr, a, k, sid, sid0, gl);
         const double log_u = dr.log_u;
         const int jt = propose<G, EPL, true, false, false, true>(a, it, sid, gl, cc, dr, Ut, false, S, DE, q);
-        if (jt == PTMI_J_NUTS || jt == PTMI_J_HMC) {
-            GradJump<G, EPL, LOGL> gj(a, gl, ch, beta, it, sid);
-            double st[GJ_NSTATE];
+        const bool is_gj = jt == PTMI_J_NUTS || jt == PTMI_J_HMC;
+        if constexpr (WIDE) {
+            // one chain after the other, each on all 64 lanes: its row goes through LDS into the whole-wave layout and the
+            // proposal comes back the same way; everything in between is wave-uniform
+            u64 todo = __ballot(is_gj && live);
+            const int xch = a.gj_stack_off + (a.nuts_maxdepth + 1) * gjw_level_doubles();
+            const int L = (int)threadIdx.x;
+            while (todo) {
+                const int lane0 = (int)__builtin_ctzll(todo);                    // first lane of the chain
+                todo &= ~(0xFull << lane0);
+                const bool mine = (L & ~3) == lane0;
+                if (mine) {
 #pragma unroll
-            for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stg[j];
-            qxy = jt == PTMI_J_NUTS ? gj.nuts(st, x, q) : gj.hmc(st, x, q);
-            st[GJ_NLEAP] += (double)gj.nleap;
-            if (gl == 0) {
+                    for (int e = 0; e < EPL; ++e) gj_lds[xch + 16 * gl + e] = x[e];
+                }
+                __syncthreads();
+                const double xw = (L & 15) < EPL ? gj_lds[xch + L] : 0.0;
+                const long long ch_c = ((long long)__builtin_amdgcn_readlane((int)(ch >> 32), lane0) << 32) | (u32)__builtin_amdgcn_readlane((int)ch, lane0);
+                const double beta_c = lane_get(beta, lane0);
+                const u32 sid_c = (u32)__builtin_amdgcn_readlane((int)sid, lane0);
+                const int jt_c = __builtin_amdgcn_readlane(jt, lane0);
+                const int w_c = (int)(ch_c / nt), t_c = __builtin_amdgcn_readlane(t, lane0);
+                double *stc = a.gj + ((size_t)w_c * nt + t_c) * GJ_NSTATE;
+                GradJumpWide<EPL, LOGL> gj(a, ch_c, beta_c, it, sid_c, xch);
+                double st[GJ_NSTATE];
 #pragma unroll
-                for (int j = 0; j < GJ_NSTATE; ++j) stg[j] = st[j];
+                for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stc[j];
+                double qw;
+                GJP_T0(tc0);
+                const double qxy_c = jt_c == PTMI_J_NUTS ? gj.nuts(st, xw, qw) : gj.hmc(st, xw, qw);
+#ifdef PTMI_GJ_PROFILE
+                gj.prof[GJP_CALL] += __builtin_readcyclecounter() - tc0;
+                for (int j = 0; j < GJP_N; ++j) prof_sum[j] += gj.prof[j];
+                prof_sum[GJP_N] += gj.nleap;
+                prof_sum[GJP_N + 1] += 1;
+#endif
+                st[GJ_NLEAP] += (double)gj.nleap;
+                if (L == 0) {
+#pragma unroll
+                    for (int j = 0; j < GJ_NSTATE; ++j) stc[j] = st[j];
+                }
+                __threadfence_block();           // the wave reads the state again at the chain's next gradient jump
+                gj_lds[xch + L] = qw;
+                __syncthreads();
+                if (mine) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) q[e] = gj_lds[xch + 16 * gl + e];
+                    qxy = qxy_c;
+                }
+                __syncthreads();                 // the exchange area is free for the next chain
             }
-            __threadfence_block();               // the chain's other lanes read the state at its next gradient jump
-        } else {
+            if (!is_gj) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) q[e] = x[e] + q[e];            // propose() returned the increment
+                for (int e = 0; e < EPL; ++e) q[e] = x[e] + q[e];            // propose() returned the increment
+            }
+        } else {
+            if (is_gj) {
+                GradJump<G, EPL, LOGL> gj(a, gl, ch, beta, it, sid);
+                double st[GJ_NSTATE];
+#pragma unroll
+                for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stg[j];
+                qxy = jt == PTMI_J_NUTS ? gj.nuts(st, x, q) : gj.hmc(st, x, q);
+                st[GJ_NLEAP] += (double)gj.nleap;
+                if (gl == 0) {
+#pragma unroll
+                    for (int j = 0; j < GJ_NSTATE; ++j) stg[j] = st[j];
+                }
+                __threadfence_block();               // the chain's other lanes read the state at its next gradient jump
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) q[e] = x[e] + q[e];            // propose() returned the increment
+            }
         }
 #pragma unroll
         for (int j = 0; j < PTMI_J_NTYPES; ++j) jp[j] += (jt == j);
         // PT:605-612
-        const double nlp = eval_logp<G, EPL, false>(a, q, gl);
+        const double nlp = eval_logp<G, EPL, false>(a, q, gl, gj_lds);
         const double nlnL = eval_logl<G, EPL, LOGL, false>(a, q, gl, PtG);
         const double nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
         // PT:615-622
@@ -512,6 +1024,13 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
         }
         am_row = am_row + 1 == a.cov_update ? 0 : am_row + 1;
     }
+#ifdef PTMI_GJ_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("gjprof kernel %llu | calls %llu leaps %llu | call %llu tabvec %llu logl %llu dot %llu leaf %llu merge %llu push %llu draw %llu\n",
+               __builtin_readcyclecounter() - prof_k0, prof_sum[GJP_N + 1], prof_sum[GJP_N], prof_sum[GJP_CALL], prof_sum[GJP_TABVEC], prof_sum[GJP_LOGL],
+               prof_sum[GJP_DOT], prof_sum[GJP_LEAF], prof_sum[GJP_MERGE], prof_sum[GJP_PUSH], prof_sum[GJP_DRAW]);
+#endif
+    if (!live) return;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int i = gl + G * e;

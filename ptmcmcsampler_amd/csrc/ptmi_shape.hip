@@ -25,8 +25,35 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
         if constexpr (E <= 8) {                 // the tree build keeps seven chain vectors in registers
             const long long nch = (long long)h->cfg.nwalkers * h->cfg.ntemps;
             const int cpb = GJ_BLOCK / G;
+            // LDS of a block (one wave).  4-lane shapes (GradJumpWide): whitening tables with rows of 4 E | the tree stack,
+            // one level per height | the exchange area of the layout change (64 doubles) | box bounds of the 4-lane test.
+            // Wider shapes: lowest levels of the tree stack | box bounds.
+            size_t off = 0;
+            const size_t box = h->cfg.logp_kind == PTMI_LOGP_BOX ? (size_t)box_table_doubles(G, E) : 0;
+            if constexpr (G == 4) {
+                off = (size_t)gjw_table_doubles(E);
+                a.gj_stack_off = (int)off;
+                a.gj_lds_levels = h->cfg.nuts_maxdepth + 1;
+                off += (size_t)a.gj_lds_levels * gjw_level_doubles() + 64;
+            } else {
+                static const char *lv = getenv("PTMI_GJ_LDS_LEVELS");       // measurement switch: same results for any value
+                const size_t budget = 40 * 1024 / sizeof(double);           // one wave per SIMD (register count): a quarter of the CU's LDS each
+                int levels = box < budget ? (int)((budget - box) / gj_level_doubles(E)) : 0;
+                if (levels > h->cfg.nuts_maxdepth + 1) levels = h->cfg.nuts_maxdepth + 1;
+                if (lv) levels = atoi(lv) < levels ? atoi(lv) : levels;
+                a.gj_stack_off = 0;
+                a.gj_lds_levels = levels;
+                off = (size_t)levels * gj_level_doubles(E);
+            }
+            off = (off + 1) & ~(size_t)1;
+            a.box_off = box ? (int)off : -1;
+            off += box;
+            if (sizeof(double) * off > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void *)mh_steps_gj_kernel<G, E, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * off));
+                if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", sizeof(double) * off, hipGetErrorString(e));
+            }
             hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK),
-                               G == 4 ? sizeof(double) * 3 * (size_t)h->cfg.ndim * h->cfg.ndim : 0, h->stream, a);
+                               sizeof(double) * off, h->stream, a);
             return PTMI_OK;
         } else {
             return fail(PTMI_EUNSUPPORTED, "gradient jumps are built for kernel shapes with at most 8 register slots per lane");
