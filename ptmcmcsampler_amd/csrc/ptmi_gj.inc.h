@@ -462,7 +462,7 @@ struct GradJump {
 // order are those of the 4-lane code above (and of the oracle): a sum over a vector is the lane's chain of fmas over its
 // slots -- here a scan along the row -- followed by (p0 + p2) + (p1 + p3).
 constexpr int gjw_table_doubles(int EPL) { return 3 * (4 * EPL) * (4 * EPL); }          // rows padded to 4 EPL: constant offsets
-constexpr int gjw_level_doubles() { return GJL_VECS * 64 + 4; }
+constexpr int gjw_level_doubles(int EPL) { return GJL_VECS * 4 * EPL + 4; }         // a stack entry: four vectors in element order, four scalars
 __device__ __forceinline__ double lane_get(double v, int lane)
 {
     const long long b = __double_as_longlong(v);
@@ -521,13 +521,24 @@ struct GradJumpWide {
         }
         return r;
     }
+    // Scalar draws: slot n of the call is a Philox call of its own.  Lane j evaluates slot 64 b + j, so one pass of the
+    // generator (the same instructions a single draw would cost the wave) serves the next 64 draws of the call.
+    u64 sw_cache = 0;
+    u32 sw_base = 0xFFFFFFFFu;
     __device__ __forceinline__ u64 scalar_word()
     {
         GJP_T0(t0);
-        u64 w0, w1;
-        philox_words(a.seed, (u64)it, sid, SLOT_GJS + ns++, w0, w1);
+        const u32 slot = ns++;
+        if ((slot & ~63u) != sw_base) {
+            sw_base = slot & ~63u;
+            u64 w0, w1;
+            philox_words(a.seed, (u64)it, sid, SLOT_GJS + sw_base + (u32)L, w0, w1);
+            sw_cache = w0;
+        }
+        const int src = (int)(slot & 63u);
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)sw_cache, src), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(sw_cache >> 32), src);
         GJP_ADD(GJP_DRAW, t0);
-        return w0;
+        return ((u64)hi << 32) | lo;
     }
     __device__ __forceinline__ double uniform() { return w2uniform(scalar_word()); }
     __device__ __forceinline__ double exponential() { return -det_log(w2uniform_open(scalar_word())); }
@@ -719,7 +730,7 @@ struct GradJumpWide {
         int s;
     };
     // the tree stack (see GradJump::build_tree): the entry of height h in slot h of the block's LDS, pending heights in a mask
-    __device__ __forceinline__ int slot_of(int h) const { return a.gj_stack_off + h * gjw_level_doubles(); }
+    __device__ __forceinline__ int slot_of(int h) const { return a.gj_stack_off + h * gjw_level_doubles(EPL); }
     // NJ:495-652 as a loop, as GradJump::build_tree
     __device__ __forceinline__ void build_tree(double &tg, double &rg, double &gg, double logu, int v, int j, double eps, double joint0, Tree &cur)
     {
@@ -743,18 +754,18 @@ struct GradJumpWide {
                     GJP_T0(tm0);
                     pend &= pend - 1u;
                     const int b = slot_of(h);
-                    const double t_logp = gj_lds[b + GJL_VECS * 64 + GJS_LOGP], t_n = gj_lds[b + GJL_VECS * 64 + GJS_N];
-                    const double t_alpha = gj_lds[b + GJL_VECS * 64 + GJS_ALPHA], t_nalpha = gj_lds[b + GJL_VECS * 64 + GJS_NALPHA];
+                    const double t_logp = gj_lds[b + GJL_VECS * LD + GJS_LOGP], t_n = gj_lds[b + GJL_VECS * LD + GJS_N];
+                    const double t_alpha = gj_lds[b + GJL_VECS * LD + GJS_ALPHA], t_nalpha = gj_lds[b + GJL_VECS * LD + GJS_NALPHA];
                     const long long tot = (long long)t_n + cur.n;
                     const double den = (double)tot > 1.0 ? (double)tot : 1.0;
                     const bool take_u = uniform() < (double)cur.n / den;
                     if (!take_u) {
-                        cur.cand_t = gj_lds[b + GJL_CAND_T * 64 + L];
-                        cur.cand_g = gj_lds[b + GJL_CAND_G * 64 + L];
+                        cur.cand_t = act ? gj_lds[b + GJL_CAND_T * LD + col] : 0.0;
+                        cur.cand_g = act ? gj_lds[b + GJL_CAND_G * LD + col] : 0.0;
                         cur.logp = t_logp;
                     }
-                    cur.far_t = gj_lds[b + GJL_FAR_T * 64 + L];
-                    cur.far_r = gj_lds[b + GJL_FAR_R * 64 + L];
+                    cur.far_t = act ? gj_lds[b + GJL_FAR_T * LD + col] : 0.0;
+                    cur.far_r = act ? gj_lds[b + GJL_FAR_R * LD + col] : 0.0;
                     cur.n = tot;
                     const bool go = v == 1 ? keep_going(cur.far_t, tg, cur.far_r, rg) : keep_going(tg, cur.far_t, rg, cur.far_r);
                     cur.s = cur.s && go;                                 // the popped tree has s = 1
@@ -772,15 +783,17 @@ struct GradJumpWide {
                 }
                 GJP_T0(tp0);
                 const int b = slot_of(h);                                // push: wait for the right sibling
-                gj_lds[b + GJL_FAR_T * 64 + L] = cur.far_t;
-                gj_lds[b + GJL_FAR_R * 64 + L] = cur.far_r;
-                gj_lds[b + GJL_CAND_T * 64 + L] = cur.cand_t;
-                gj_lds[b + GJL_CAND_G * 64 + L] = cur.cand_g;
+                if (act) {                                               // in element order: 4 LD doubles per entry instead of 4 x 64
+                    gj_lds[b + GJL_FAR_T * LD + wi] = cur.far_t;
+                    gj_lds[b + GJL_FAR_R * LD + wi] = cur.far_r;
+                    gj_lds[b + GJL_CAND_T * LD + wi] = cur.cand_t;
+                    gj_lds[b + GJL_CAND_G * LD + wi] = cur.cand_g;
+                }
                 if (L == 0) {
-                    gj_lds[b + GJL_VECS * 64 + GJS_LOGP] = cur.logp;
-                    gj_lds[b + GJL_VECS * 64 + GJS_N] = (double)cur.n;
-                    gj_lds[b + GJL_VECS * 64 + GJS_ALPHA] = cur.alpha;
-                    gj_lds[b + GJL_VECS * 64 + GJS_NALPHA] = (double)cur.nalpha;
+                    gj_lds[b + GJL_VECS * LD + GJS_LOGP] = cur.logp;
+                    gj_lds[b + GJL_VECS * LD + GJS_N] = (double)cur.n;
+                    gj_lds[b + GJL_VECS * LD + GJS_ALPHA] = cur.alpha;
+                    gj_lds[b + GJL_VECS * LD + GJS_NALPHA] = (double)cur.nalpha;
                 }
                 __syncthreads();                                         // one wave per block: orders lane 0's writes before the others' reads
                 pend |= 1u << h;
@@ -853,7 +866,7 @@ struct GradJumpWide {
 // SIMDs as soon as a wave's chains are through their (very unequal) trees.
 constexpr int GJ_BLOCK = 64;
 template <int G, int EPL, int LOGL>
-__global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
+__global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? 2 : 1) void mh_steps_gj_kernel(const KArgs a)
 {
     constexpr int CPB = GJ_BLOCK / G;
     constexpr bool WIDE = G == 4;                // a gradient jump takes the whole wave (GradJumpWide)
@@ -922,7 +935,7 @@ __global__ __launch_bounds__(GJ_BLOCK) void mh_steps_gj_kernel(const KArgs a)
             // one chain after the other, each on all 64 lanes: its row goes through LDS into the whole-wave layout and the
             // proposal comes back the same way; everything in between is wave-uniform
             u64 todo = __ballot(is_gj && live);
-            const int xch = a.gj_stack_off + (a.nuts_maxdepth + 1) * gjw_level_doubles();
+            const int xch = a.gj_stack_off + (a.nuts_maxdepth + 1) * gjw_level_doubles(EPL);
             const int L = (int)threadIdx.x;
             while (todo) {
                 const int lane0 = (int)__builtin_ctzll(todo);                    // first lane of the chain

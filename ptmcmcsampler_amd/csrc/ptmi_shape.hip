@@ -34,7 +34,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
                 off = (size_t)gjw_table_doubles(E);
                 a.gj_stack_off = (int)off;
                 a.gj_lds_levels = h->cfg.nuts_maxdepth + 1;
-                off += (size_t)a.gj_lds_levels * gjw_level_doubles() + 64;
+                off += (size_t)a.gj_lds_levels * gjw_level_doubles(E) + 64;
             } else {
                 static const char *lv = getenv("PTMI_GJ_LDS_LEVELS");       // measurement switch: same results for any value
                 const size_t budget = 40 * 1024 / sizeof(double);           // one wave per SIMD (register count): a quarter of the CU's LDS each
