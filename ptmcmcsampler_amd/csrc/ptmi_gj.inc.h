@@ -480,6 +480,19 @@ __device__ __forceinline__ double lane_get(double v, int lane)
 #endif
 enum { GJP_TABVEC = 0, GJP_LOGL = 1, GJP_DOT = 2, GJP_LEAF = 3, GJP_MERGE = 4, GJP_PUSH = 5, GJP_CALL = 6, GJP_DRAW = 7, GJP_N = 8 };
 
+// the value of lane L ^ 16 (the neighbouring row of 16 lanes): v_permlane16_swap trades the odd rows of its first operand
+// for the even rows of its second, so swapping a register with a copy of itself leaves {row0, row0, row2, row2} in the
+// first result and {row1, row1, row3, row3} in the second (checked on the hardware); no LDS round trip as with a shuffle
+__device__ __forceinline__ double lane_xor16(double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((u32)b, (u32)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((u32)(b >> 32), (u32)(b >> 32), false, false);
+    const bool odd = (threadIdx.x >> 4) & 1;
+    const u32 l = odd ? lo[0] : lo[1], h = odd ? hi[0] : hi[1];
+    return __longlong_as_double((long long)(((u64)h << 32) | l));
+}
+
 template <int EPL, int LOGL>
 struct GradJumpWide {
     static constexpr int G = 4, LD = 4 * EPL;
@@ -618,7 +631,7 @@ struct GradJumpWide {
             GJP_ADD(GJP_LOGL, t0);
             return rr;
         } else {
-            const double other = __shfl_xor(x, 16, 64);                    // the pair's other member: lane group g ^ 1, same slot
+            const double other = lane_xor16(x);                            // the pair's other member: lane group g ^ 1, same slot
             const bool even = !(wg & 1);
             const bool pair = we < EPL && (even ? wi + 1 < d : wi < d);
             const double xx = even ? x : other, y = even ? other : x;
@@ -627,7 +640,9 @@ struct GradJumpWide {
             const double l0 = -x2 - gg * gg;
             const double ym = y - 2.0;
             const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
-            const double e0 = det_exp(l0), e1 = 0.5 * det_exp(l1);
+            // both lanes of a pair hold the same l0 and l1: the even one takes exp(l0), the odd one exp(l1), and they trade
+            const double ex = det_exp(even ? l0 : l1), ox = lane_xor16(ex);
+            const double e0 = even ? ex : ox, e1 = 0.5 * (even ? ox : ex);
             const double sum = e0 + e1;
             const double tl = det_log(sum);                                // wanted on the even lanes only; same cost for the wave
             const double d0 = even ? -2.0 * xx - 16.0 * gg * xx : -18.0 * gg;
