@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libptmi.so")
+# PTMI_LIB: another build of the same ABI (A/B measurements of a kernel change); the default is the in-tree library
+SO = os.environ.get("PTMI_LIB") or os.path.join(HERE, "libptmi.so")
 
 LOGL = {"iso": 0, "dense": 1, "curved": 2}
 LOGP = {"flat": 0, "box": 1}

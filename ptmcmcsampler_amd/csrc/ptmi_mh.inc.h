@@ -391,6 +391,63 @@ __device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, con
     b.take(dr, walker);
 }
 
+// The AM increment U (cd sqrt(S) z) (PT:879-933) of the 16 chains in the columns of the wave, on the matrix cores (strided
+// layout: lane (c16, g4) draws the weights of directions k = g4 + 4e of column c16's chain).  The weights of two k-steps come
+// out of one Box-Muller and go straight into the two accumulation steps -- no weight array is kept, and the matrix pipe
+// works on pair e while the vector pipe draws pair e + 2.  The accumulation order (k ascending) is that of mfma_tab_vec.
+// active / sid / it / cd are the column's: the chain's own (propose) or those of a queued AM event (mh_steps_kernel).
+template <int EPL>
+__device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32 sid, long long it, double cd, int ng,
+                                                const double *Ut, bool ut_padded, int uld, const double *S, bool s_sqrt, MfmaAcc<EPL> &acc)
+{
+    constexpr int G = 4, NT = MfmaAcc<EPL>::NT;
+    const int d = a.d;
+    const int c16 = (int)(threadIdx.x & 15), g4 = (int)((threadIdx.x & 63) >> 4);
+    auto root_s = [&](int k) { const double v = S[k]; return s_sqrt ? v : det_sqrt(v); };
+    // directions k = g4 + 4e and k + 4 (slots e even / odd) are the cos and sin branches of ONE Box-Muller
+    auto weights = [&](int e, double &wa, double &wb) {
+        wa = 0.0;
+        wb = 0.0;
+        const int k = g4 + G * e;
+        if (active && k < ng) {
+            u64 e0, e1;
+            philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
+            const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
+            double sn, cs;
+            det_sincos2pi(w2uniform(e1), sn, cs);
+            wa = (r * cs) * cd * root_s(k);                             // PT:930
+            if (e + 1 < EPL && k + G < ng) wb = (r * sn) * cd * root_s(k + G);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc.t[t] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
+    // a ROLLED loop over the pairs: unrolled, the thirteen Box-Muller bodies alone are half of the kernel's code and
+    // the kernel outgrows the instruction cache
+    const int esteps = (d + 3) / 4 < EPL ? (d + 3) / 4 : EPL;     // k-steps that hold a table row
+#pragma unroll 1
+    for (int e = 0; e < esteps; e += 2) {
+        double ta[NT], wa, wb;
+        const bool second = e + 1 < esteps;
+        auto rows = [&](int k) {                           // table row block of one k-step
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = 16 * t + c16;
+                if (ut_padded) ta[t] = Ut[(size_t)k * uld + col];
+                else ta[t] = (k < d && col < d) ? Ut[(size_t)k * uld + col] : 0.0;
+            }
+        };
+        rows(4 * e + g4);                                  // in flight during the draw
+        weights(e, wa, wb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wa, acc.t[t], 0, 0, 0);
+        if (second) {
+            rows(4 * e + 4 + g4);                          // behind the seven products above
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wb, acc.t[t], 0, 0, 0);
+        }
+    }
+}
+
 // One proposal for the caller's chain (PT:1048-1067, 820-985) from the iteration's draws: writes the increment dq
 // (q = x + dq) and returns the jump type.
 // STR: strided lane layout (see "lane groups"); then Ut is the zero-padded LDS copy when ut_padded, and the AM
@@ -401,7 +458,7 @@ __device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, con
 template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, const Draws &dr,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
-                                       double (&dq)[EPL], bool s_sqrt = false)
+                                       double (&dq)[EPL], bool s_sqrt = false, bool am_here = true)
 {
     // s_sqrt: S holds sqrt(eigenvalue) already (the block's LDS copy; sqrt is correctly rounded, so the bits are the same)
     auto root_s = [&](int k) { const double v = S[k]; return s_sqrt ? v : det_sqrt(v); };
@@ -502,42 +559,13 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
                 }
             };
             if (STR) {
-                // Matrix cores: the weights of two k-steps come out of one Box-Muller and go straight into the two
-                // accumulation steps -- no weight array is kept, and the matrix pipe works on pair e while the vector
-                // pipe draws pair e + 2.  The accumulation order (k ascending) is that of mfma_tab_vec.
-                constexpr int NT = MfmaAcc<EPL>::NT;
-                MfmaAcc<EPL> acc;
+                if constexpr (G == 4) {
+                    MfmaAcc<EPL> acc;
+                    am_mfma_product<EPL>(a, is_am, sid, it, cd, ng, Ut, ut_padded, uld, S, s_sqrt, acc);
+                    if (is_am) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc.t[t] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
-                const int c16 = (int)(threadIdx.x & 15), g4 = (int)((threadIdx.x & 63) >> 4);
-                // a ROLLED loop over the pairs: unrolled, the thirteen Box-Muller bodies alone are half of the kernel's code and
-                // the kernel outgrows the instruction cache
-                const int esteps = (d + 3) / 4 < EPL ? (d + 3) / 4 : EPL;     // k-steps that hold a table row
-#pragma unroll 1
-                for (int e = 0; e < esteps; e += 2) {
-                    double ta[NT], wa, wb;
-                    const bool second = e + 1 < esteps;
-                    auto rows = [&](int k) {                           // table row block of one k-step
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const int col = 16 * t + c16;
-                            if (ut_padded) ta[t] = Ut[(size_t)k * uld + col];
-                            else ta[t] = (k < d && col < d) ? Ut[(size_t)k * uld + col] : 0.0;
-                        }
-                    };
-                    rows(4 * e + g4);                                  // in flight during the draw
-                    weights(e, wa, wb);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wa, acc.t[t], 0, 0, 0);
-                    if (second) {
-                        rows(4 * e + 4 + g4);                          // behind the seven products above
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wb, acc.t[t], 0, 0, 0);
+                        for (int e = 0; e < EPL; ++e) dq[e] = acc.at(e);
                     }
-                }
-                if (is_am) {
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) dq[e] = acc.at(e);
                 }
             } else {
                 double wk[EPL];
@@ -572,7 +600,8 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
     };
     if (jt == PTMI_J_SCAM) scam_body();
     else if (FULL && jt == PTMI_J_DE) de_body();
-    if (FULL && (!STR ? is_am : __any(is_am))) am_body();
+    // !am_here (wave-uniform): the caller takes the AM increments from its queue (mh_steps_kernel, "AM queue")
+    if (FULL && am_here && (!STR ? is_am : __any(is_am))) am_body();
     return jt;
 }
 
@@ -669,6 +698,25 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     box_table_fill<G, EPL>(a, smem, BLK);
     if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
 
+    // ---- AM queue (staged full kernels).  An AM increment U (cd sqrt(S) z) does not depend on the chain's state, only on
+    // its stream, the iteration and the scale branch -- all known from the draws -- and the matrix instruction computes 16
+    // columns whether 16 chains of the wave picked AM or one.  With every chain picking its own proposal (the reference's
+    // _jump) a third of the columns were used.  So every four steps each lane looks ahead: lane (c16, g4) evaluates the
+    // pick of chain c16 for step g4 of the next four; the AM events of the wave, in step order, get consecutive ranks,
+    // and a matrix pass computes 16 of them at a time into a ring of 16 increments in LDS, just in time for the step that
+    // needs them (ranks [done, min(total, consumed + 16)): what a pass overwrites has been consumed).  The arithmetic of an
+    // increment is unchanged.  A pass through the queue costs 1.28 x a pass in place (LDS round trip of the increments,
+    // per-lane counters in the generator), so each block of four steps takes the cheaper way: in place when most of its
+    // steps would fill a pass anyway (one pick per walker, AM-heavy cycles), the queue when the picks are sparse.
+    constexpr bool AMQ = STAGE && FULL && G == 4;
+    constexpr int AMQ_LD = 4 * EPL + 2;              // doubles of one queued increment (lane-major like a DE row; + 2: the 16 slots start 20 banks apart)
+    bool amq_on = false;                             // this block of four steps goes through the queue
+#define PTMI_AMQ(slot) (smem + a.amq_off + ((size_t)wave * 16 + (size_t)(slot)) * AMQ_LD)
+#define PTMI_AMQ_IDX ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD) + wave * 64)
+    u64 ev_mask = 0;
+    int ev_rank = 0, q_done = 0;
+    double ev_cd = 0.0;
+
     double x[EPL], dq[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
@@ -679,15 +727,87 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
+        if constexpr (AMQ) {
+            const int s4 = k & 3, c16 = lane & 15;
+            if (s4 == 0) {                                               // look ahead: the picks of steps k .. k + 3
+                bool ev = false;
+                double cdv = 0.0;
+                if (k + gl < a.nsteps) {
+                    u64 p0, p1;
+                    philox_words(a.seed, (u64)(it + gl), sid, 0u, p0, p1);
+                    u32 pickw = (u32)(p0 >> 32);
+                    if (a.pick_walker) {
+                        u64 r0, r1;
+                        philox_words(a.seed, (u64)(it + gl), sid0, 0u, r0, r1);
+                        pickw = (u32)(r0 >> 32);
+                    }
+                    const int w_de = a.de_on ? a.w_de : 0;
+                    const int ind = (int)h2index(pickw, (u32)(a.w_host + a.w_scam + a.w_am + w_de)) - a.w_host;   // as propose()
+                    ev = live && ind >= a.w_scam && ind < a.w_scam + a.w_am;
+                    constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
+                    const u32 plo = (u32)p0;
+                    cdv = a.gcn[0] * cc.sc(plo > T97 ? 0 : (plo > T90 ? 1 : 2));                                  // PT:928
+                }
+                ev_mask = __ballot(ev);
+                ev_rank = (int)__popcll(ev_mask & ((1ull << lane) - 1ull));
+                ev_cd = cdv;
+                if (ev) PTMI_AMQ_IDX[ev_rank] = lane;
+                q_done = 0;
+                asm volatile("" ::: "memory");                           // LDS serves a wave in order; this orders the compiler
+                // passes either way (wave-uniform scalars): in place one per step with an event, through the queue as below
+                int here = 0, queued = 0, dn = 0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int cs = s ? (int)__popcll(ev_mask & ((1ull << (16 * s)) - 1ull)) : 0;
+                    const int nd = (int)__popcll(ev_mask & (s == 3 ? ~0ull : ((1ull << (16 * s + 16)) - 1ull)));
+                    here += nd > cs;
+                    if (dn < nd) {
+                        const int tot = (int)__popcll(ev_mask);
+                        dn = tot < cs + 16 ? tot : cs + 16;
+                        queued += 1;
+                    }
+                }
+                amq_on = 32 * queued < 25 * here;                        // 1.28 passes in place per pass through the queue
+            }
+            const int cons = (int)__popcll(ev_mask & ((1ull << (16 * s4)) - 1ull));                               // events of the steps before this one
+            const int need = (int)__popcll(ev_mask & (s4 == 3 ? ~0ull : ((1ull << (16 * s4 + 16)) - 1ull)));      // ... up to and including it
+            if (amq_on && q_done < need) {                               // wave-uniform: a matrix pass for ranks [q_done, hi)
+                const int total = (int)__popcll(ev_mask);
+                const int hi = total < cons + 16 ? total : cons + 16;
+                const int r = q_done + c16;
+                const bool valid = r < hi;
+                const int owner = PTMI_AMQ_IDX[valid ? r : q_done];
+                const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
+                const double cd_ev = __shfl(ev_cd, owner, 64);
+                const long long it_ev = a.iter0 + (k - s4) + (owner >> 4);
+                MfmaAcc<EPL> acc;
+                if (UT_ALWAYS_LDS || a.lds_u) am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_UL, true, mfma_ld(EPL), PTMI_SQ, true, acc);
+                else am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, UtBlock, false, d, PTMI_SQ, true, acc);
+                if (valid) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) PTMI_AMQ(r & 15)[gl * EPL + e] = acc.at(e);
+                }
+                q_done = hi;
+                asm volatile("" ::: "memory");
+            }
+        }
         Draws dr;
         draws_for_step<STR, FULL>(batch, dr, a, k, sid, sid0, gl);
         const double log_u = dr.log_u;
         int jt;
         if (ULDS && ulds_box) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, S, DE, dq, false);
         else if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
-        else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true);
-        else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true);
+        else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true, !amq_on);
+        else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true, !amq_on);
         else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
+        if constexpr (AMQ) {
+            // the rank of this chain's event of this step is held by its lane of row (k & 3)
+            const int rk = __shfl(ev_rank, 16 * (k & 3) + (lane & 15), 64);
+            if (amq_on && jt == PTMI_J_AM) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dq[e] = PTMI_AMQ(rk & 15)[gl * EPL + e];
+            }
+        }
         if (FULL) {
 #pragma unroll
             for (int j = 0; j < PTMI_J_FUSED; ++j) jp[j] += (jt == j);
@@ -1064,7 +1184,13 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
         size_t lds = LOGL == PTMI_LOGL_DENSE ? tab : 0;
         if (FULL && lds + tab + sizeof(double) * c.ndim <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
         if (FULL) lds += sizeof(double) * c.ndim;                               // sqrt(eigenvalues)
-        if (lds <= 160 * 1024 && one_table_per_block) {
+        // AM queue of the block's four waves: 16 increments of 4 EPL + 2 doubles and 64 lane numbers each
+        const size_t amq = FULL ? sizeof(double) * 4 * 16 * (4 * EPL + 2) + sizeof(int) * 4 * 64 : 0;
+        if (sizeof(double) * even(lds / sizeof(double)) + amq <= 160 * 1024 && one_table_per_block) {
+            if (FULL) {
+                a.amq_off = (int)even(lds / sizeof(double));
+                lds = sizeof(double) * (size_t)a.amq_off + amq;
+            }
             if (box_bytes && sizeof(double) * even(lds / sizeof(double)) + box_bytes <= 160 * 1024) {
                 a.box_off = (int)even(lds / sizeof(double));
                 lds = sizeof(double) * (size_t)a.box_off + box_bytes;
