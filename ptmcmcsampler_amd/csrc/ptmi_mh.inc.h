@@ -701,21 +701,30 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     // ---- AM queue (staged full kernels).  An AM increment U (cd sqrt(S) z) does not depend on the chain's state, only on
     // its stream, the iteration and the scale branch -- all known from the draws -- and the matrix instruction computes 16
     // columns whether 16 chains of the wave picked AM or one.  With every chain picking its own proposal (the reference's
-    // _jump) a third of the columns were used.  So every four steps each lane looks ahead: lane (c16, g4) evaluates the
-    // pick of chain c16 for step g4 of the next four; the AM events of the wave, in step order, get consecutive ranks,
-    // and a matrix pass computes 16 of them at a time into a ring of 16 increments in LDS, just in time for the step that
-    // needs them (ranks [done, min(total, consumed + 16)): what a pass overwrites has been consumed).  The arithmetic of an
-    // increment is unchanged.  A pass through the queue costs 1.28 x a pass in place (LDS round trip of the increments,
-    // per-lane counters in the generator), so each block of four steps takes the cheaper way: in place when most of its
-    // steps would fill a pass anyway (one pick per walker, AM-heavy cycles), the queue when the picks are sparse.
+    // _jump) a third of the columns were used.  So the wave looks ahead in blocks of four steps, one block in advance: lane
+    // (c16, g4) evaluates the pick of chain c16 for step g4 of the block.  The AM events of the wave, in step order, get
+    // consecutive ranks, and a matrix pass computes 16 of them at a time into a ring of 16 increments in LDS, just in time
+    // for the step that needs them: ranks [done, min(known, consumed + 16)) -- what a pass overwrites has been consumed,
+    // and with 4 to 7 steps known ahead a pass is almost always full.  The arithmetic of an increment is unchanged.
+    // A pass through the queue costs 1.28 x a pass in place (LDS round trip of the increments, per-lane counters in the
+    // generator): the launch uses the queue when 1.28 x the expected events per step / 16 is below the chance that a step
+    // has an event at all, i.e. for per-chain picks unless the cycle is nearly all AM; with one pick per walker every pass
+    // in place is full anyway.
     constexpr bool AMQ = STAGE && FULL && G == 4;
     constexpr int AMQ_LD = 4 * EPL + 2;              // doubles of one queued increment (lane-major like a DE row; + 2: the 16 slots start 20 banks apart)
-    bool amq_on = false;                             // this block of four steps goes through the queue
 #define PTMI_AMQ(slot) (smem + a.amq_off + ((size_t)wave * 16 + (size_t)(slot)) * AMQ_LD)
-#define PTMI_AMQ_IDX ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD) + wave * 64)
-    u64 ev_mask = 0;
-    int ev_rank = 0, q_done = 0;
-    double ev_cd = 0.0;
+#define PTMI_AMQ_IDX ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD) + wave * 128)
+    bool amq_on = false;
+    if constexpr (AMQ) {
+        const int Lw = a.w_host + a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
+        const double f = Lw > 0 ? (double)a.w_am / (double)Lw : 0.0;
+        double none = 1.0;
+        for (int j = 0; j < 16; ++j) none *= 1.0 - f;
+        amq_on = !a.pick_walker && a.w_am > 0 && 1.28 * f < 1.0 - none;
+    }
+    u64 mask_c = 0, mask_n = 0;                      // AM events of the current / the next block of four steps (bit 16 step + chain)
+    int rank_c = 0, rank_n = 0, base_c = 0, base_n = 0, q_done = 0;
+    double cd_c = 0.0, cd_n = 0.0;
 
     double x[EPL], dq[EPL];
 #pragma unroll
@@ -728,67 +737,57 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
         if constexpr (AMQ) {
-            const int s4 = k & 3, c16 = lane & 15;
-            if (s4 == 0) {                                               // look ahead: the picks of steps k .. k + 3
-                bool ev = false;
-                double cdv = 0.0;
-                if (k + gl < a.nsteps) {
-                    u64 p0, p1;
-                    philox_words(a.seed, (u64)(it + gl), sid, 0u, p0, p1);
-                    u32 pickw = (u32)(p0 >> 32);
-                    if (a.pick_walker) {
-                        u64 r0, r1;
-                        philox_words(a.seed, (u64)(it + gl), sid0, 0u, r0, r1);
-                        pickw = (u32)(r0 >> 32);
-                    }
-                    const int w_de = a.de_on ? a.w_de : 0;
-                    const int ind = (int)h2index(pickw, (u32)(a.w_host + a.w_scam + a.w_am + w_de)) - a.w_host;   // as propose()
-                    ev = live && ind >= a.w_scam && ind < a.w_scam + a.w_am;
-                    constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
-                    const u32 plo = (u32)p0;
-                    cdv = a.gcn[0] * cc.sc(plo > T97 ? 0 : (plo > T90 ? 1 : 2));                                  // PT:928
+            if (amq_on) {
+                const int s4 = k & 3, c16 = lane & 15;
+                if (s4 == 0) {
+                    // the picks of the block of four steps that starts at step kb; its events take ranks from `base` on
+                    auto look = [&](int kb, u64 &mask, int &rank, double &cdv, int base) {
+                        bool ev = false;
+                        cdv = 0.0;
+                        if (kb + gl < a.nsteps) {
+                            u64 p0, p1;
+                            philox_words(a.seed, (u64)(a.iter0 + kb + gl), sid, 0u, p0, p1);
+                            const int w_de = a.de_on ? a.w_de : 0;
+                            const int ind = (int)h2index((u32)(p0 >> 32), (u32)(a.w_host + a.w_scam + a.w_am + w_de)) - a.w_host;   // as propose()
+                            ev = live && ind >= a.w_scam && ind < a.w_scam + a.w_am;
+                            constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
+                            const u32 plo = (u32)p0;
+                            cdv = a.gcn[0] * cc.sc(plo > T97 ? 0 : (plo > T90 ? 1 : 2));                                    // PT:928
+                        }
+                        mask = __ballot(ev);
+                        rank = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+                        if (ev) PTMI_AMQ_IDX[rank & 127] = lane | (((kb >> 2) & 1) << 6);
+                    };
+                    if (k == 0) look(0, mask_n, rank_n, cd_n, 0);
+                    mask_c = mask_n; rank_c = rank_n; cd_c = cd_n; base_c = base_n;
+                    base_n = base_c + (int)__popcll(mask_c);
+                    look(k + 4, mask_n, rank_n, cd_n, base_n);
+                    asm volatile("" ::: "memory");                       // LDS serves a wave in order; this orders the compiler
                 }
-                ev_mask = __ballot(ev);
-                ev_rank = (int)__popcll(ev_mask & ((1ull << lane) - 1ull));
-                ev_cd = cdv;
-                if (ev) PTMI_AMQ_IDX[ev_rank] = lane;
-                q_done = 0;
-                asm volatile("" ::: "memory");                           // LDS serves a wave in order; this orders the compiler
-                // passes either way (wave-uniform scalars): in place one per step with an event, through the queue as below
-                int here = 0, queued = 0, dn = 0;
+                const int cons = base_c + (int)__popcll(mask_c & ((1ull << (16 * s4)) - 1ull));                             // events of the steps before this one
+                const int need = base_c + (int)__popcll(mask_c & (s4 == 3 ? ~0ull : ((1ull << (16 * s4 + 16)) - 1ull)));    // ... up to and including it
+                if (q_done < need) {                                     // wave-uniform: a matrix pass for ranks [q_done, hi)
+                    const int known = base_n + (int)__popcll(mask_n);
+                    const int hi = known < cons + 16 ? known : cons + 16;
+                    const int r = q_done + c16;
+                    const bool valid = r < hi;
+                    const int entry = PTMI_AMQ_IDX[(valid ? r : q_done) & 127];
+                    const int owner = entry & 63;
+                    const bool of_cur = (entry >> 6) == ((k >> 2) & 1);
+                    const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
+                    const double cdc = __shfl(cd_c, owner, 64), cdn = __shfl(cd_n, owner, 64);
+                    const double cd_ev = of_cur ? cdc : cdn;
+                    const long long it_ev = a.iter0 + (k - s4) + (of_cur ? 0 : 4) + (owner >> 4);
+                    MfmaAcc<EPL> acc;
+                    if (UT_ALWAYS_LDS || a.lds_u) am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_UL, true, mfma_ld(EPL), PTMI_SQ, true, acc);
+                    else am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, UtBlock, false, d, PTMI_SQ, true, acc);
+                    if (valid) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int cs = s ? (int)__popcll(ev_mask & ((1ull << (16 * s)) - 1ull)) : 0;
-                    const int nd = (int)__popcll(ev_mask & (s == 3 ? ~0ull : ((1ull << (16 * s + 16)) - 1ull)));
-                    here += nd > cs;
-                    if (dn < nd) {
-                        const int tot = (int)__popcll(ev_mask);
-                        dn = tot < cs + 16 ? tot : cs + 16;
-                        queued += 1;
+                        for (int e = 0; e < EPL; ++e) PTMI_AMQ(r & 15)[gl * EPL + e] = acc.at(e);
                     }
+                    q_done = hi;
+                    asm volatile("" ::: "memory");
                 }
-                amq_on = 32 * queued < 25 * here;                        // 1.28 passes in place per pass through the queue
-            }
-            const int cons = (int)__popcll(ev_mask & ((1ull << (16 * s4)) - 1ull));                               // events of the steps before this one
-            const int need = (int)__popcll(ev_mask & (s4 == 3 ? ~0ull : ((1ull << (16 * s4 + 16)) - 1ull)));      // ... up to and including it
-            if (amq_on && q_done < need) {                               // wave-uniform: a matrix pass for ranks [q_done, hi)
-                const int total = (int)__popcll(ev_mask);
-                const int hi = total < cons + 16 ? total : cons + 16;
-                const int r = q_done + c16;
-                const bool valid = r < hi;
-                const int owner = PTMI_AMQ_IDX[valid ? r : q_done];
-                const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
-                const double cd_ev = __shfl(ev_cd, owner, 64);
-                const long long it_ev = a.iter0 + (k - s4) + (owner >> 4);
-                MfmaAcc<EPL> acc;
-                if (UT_ALWAYS_LDS || a.lds_u) am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_UL, true, mfma_ld(EPL), PTMI_SQ, true, acc);
-                else am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, UtBlock, false, d, PTMI_SQ, true, acc);
-                if (valid) {
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) PTMI_AMQ(r & 15)[gl * EPL + e] = acc.at(e);
-                }
-                q_done = hi;
-                asm volatile("" ::: "memory");
             }
         }
         Draws dr;
@@ -802,7 +801,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
         if constexpr (AMQ) {
             // the rank of this chain's event of this step is held by its lane of row (k & 3)
-            const int rk = __shfl(ev_rank, 16 * (k & 3) + (lane & 15), 64);
+            const int rk = __shfl(rank_c, 16 * (k & 3) + (lane & 15), 64);
             if (amq_on && jt == PTMI_J_AM) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) dq[e] = PTMI_AMQ(rk & 15)[gl * EPL + e];
@@ -1184,8 +1183,8 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
         size_t lds = LOGL == PTMI_LOGL_DENSE ? tab : 0;
         if (FULL && lds + tab + sizeof(double) * c.ndim <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
         if (FULL) lds += sizeof(double) * c.ndim;                               // sqrt(eigenvalues)
-        // AM queue of the block's four waves: 16 increments of 4 EPL + 2 doubles and 64 lane numbers each
-        const size_t amq = FULL ? sizeof(double) * 4 * 16 * (4 * EPL + 2) + sizeof(int) * 4 * 64 : 0;
+        // AM queue of the block's four waves: 16 increments of 4 EPL + 2 doubles and 128 event entries each
+        const size_t amq = FULL ? sizeof(double) * 4 * 16 * (4 * EPL + 2) + sizeof(int) * 4 * 128 : 0;
         if (sizeof(double) * even(lds / sizeof(double)) + amq <= 160 * 1024 && one_table_per_block) {
             if (FULL) {
                 a.amq_off = (int)even(lds / sizeof(double));
