@@ -188,7 +188,9 @@ enum { PTMI_VAR_STAGED = 1,    /* strided lane layout, tables in LDS, products o
        PTMI_VAR_LDS_UT = 4,    /* staged: the eigenvector table is in LDS too */
        PTMI_VAR_GROUPS = 8,    /* parameter groups */
        PTMI_VAR_GRADJUMP = 16, /* the kernel with the NUTS / HMC branch */
-       PTMI_VAR_UNIFORM = 32   /* wave-uniform cycle pick (pick_mode = PTMI_PICK_WALKER) */ };
+       PTMI_VAR_UNIFORM = 32,  /* wave-uniform cycle pick (pick_mode = PTMI_PICK_WALKER) */
+       PTMI_VAR_AMQ = 64,      /* staged full kernel: AM increments queued 16 at a time for the matrix cores */
+       PTMI_VAR_LDS_BOX = 128  /* box prior: the bounds table is in LDS */ };
 int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant);
 
 /* PTswap (:631-697) for iteration `iter` when the whole ladder is on this GPU. */

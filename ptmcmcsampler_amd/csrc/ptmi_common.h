@@ -46,6 +46,7 @@ struct KArgs {
     int pick_walker;             // pick_mode WALKER: the cycle entry comes from the stream of the walker's rank 0
     int lds_u;                   // staged kernels: the block's Ut is copied to LDS (else read from global)
     int amq_off;                 // staged full kernels: offset (doubles, even) of the AM queue in the block's LDS (mh_steps_kernel)
+    int amq_on;                  // ... and whether this launch takes its AM increments from the queue (launch_mh_k)
     int box_off;                 // box prior: offset (doubles, even) of the bounds table in the block's LDS, or -1: bounds read from global
     // gradient jumps (ptmi_gj.inc.h)
     int w_nuts, w_hmc, gj_nburn, hmc_min, hmc_max, nuts_maxdepth;

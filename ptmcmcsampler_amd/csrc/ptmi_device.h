@@ -70,7 +70,8 @@ __device__ __forceinline__ void philox_words(u64 seed, u64 iter, u32 stream, u32
     for (int r = 0; r < 10; ++r) {
         const u64 p0 = (u64)0xD2511F53u * (u64)c0, p1 = (u64)0xCD9E8D57u * (u64)c2;   // v_mad_u64_u32
         const u32 h0 = (u32)(p0 >> 32), l0 = (u32)p0, h1 = (u32)(p1 >> 32), l1 = (u32)p1;
-        const u32 n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        // three-input xor in one instruction (v_bitop3_b32, truth table 0x96): hipcc emits two v_xor_b32 for a ^ b ^ c
+        const u32 n0 = __builtin_amdgcn_bitop3_b32(h1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(h0, c3, k1, 0x96);
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }

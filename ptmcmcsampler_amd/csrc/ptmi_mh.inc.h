@@ -714,14 +714,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     constexpr int AMQ_LD = 4 * EPL + 2;              // doubles of one queued increment (lane-major like a DE row; + 2: the 16 slots start 20 banks apart)
 #define PTMI_AMQ(slot) (smem + a.amq_off + ((size_t)wave * 16 + (size_t)(slot)) * AMQ_LD)
 #define PTMI_AMQ_IDX ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD) + wave * 128)
-    bool amq_on = false;
-    if constexpr (AMQ) {
-        const int Lw = a.w_host + a.w_scam + a.w_am + (a.de_on ? a.w_de : 0);
-        const double f = Lw > 0 ? (double)a.w_am / (double)Lw : 0.0;
-        double none = 1.0;
-        for (int j = 0; j < 16; ++j) none *= 1.0 - f;
-        amq_on = !a.pick_walker && a.w_am > 0 && 1.28 * f < 1.0 - none;
-    }
+    const bool amq_on = AMQ && a.amq_on;
     u64 mask_c = 0, mask_n = 0;                      // AM events of the current / the next block of four steps (bit 16 step + chain)
     int rank_c = 0, rank_n = 0, base_c = 0, base_n = 0, q_done = 0;
     double cd_c = 0.0, cd_n = 0.0;
@@ -1170,7 +1163,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 }
                 const int cpb = BLKv / G;
                 hipLaunchKernelGGL(kern, dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(BLKv), lds2, h->stream, a);
-                h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_LDS_UT;
+                h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_LDS_UT | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
                 return PTMI_OK;
             };
             return want == 256 ? launch(mh_dense_scam_kernel<EPL, 256>, 256) : launch(mh_dense_scam_kernel<EPL, 512>, 512);
@@ -1189,6 +1182,11 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             if (FULL) {
                 a.amq_off = (int)even(lds / sizeof(double));
                 lds = sizeof(double) * (size_t)a.amq_off + amq;
+                // through the queue when 1.28 x (expected AM events per step) / 16 is below the chance that a step of a wave
+                // has an AM event at all; with one pick per walker every pass in place is full anyway
+                const int Lw = c.w_host + c.w_scam + c.w_am + (h->de_on ? c.w_de : 0);
+                const double f = Lw > 0 ? (double)c.w_am / (double)Lw : 0.0;
+                a.amq_on = c.pick_mode != PTMI_PICK_WALKER && c.w_am > 0 && 1.28 * f < 1.0 - pow(1.0 - f, 16.0);
             }
             if (box_bytes && sizeof(double) * even(lds / sizeof(double)) + box_bytes <= 160 * 1024) {
                 a.box_off = (int)even(lds / sizeof(double));
@@ -1200,7 +1198,8 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, h->stream, a);
-            h->last_variant = PTMI_VAR_STAGED | (FULL ? PTMI_VAR_FULL : 0) | (a.lds_u ? PTMI_VAR_LDS_UT : 0);
+            h->last_variant = PTMI_VAR_STAGED | (FULL ? PTMI_VAR_FULL : 0) | (a.lds_u ? PTMI_VAR_LDS_UT : 0) | (a.amq_on ? PTMI_VAR_AMQ : 0) |
+                              (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
             return PTMI_OK;
         }
     }
@@ -1227,14 +1226,14 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", tab, hipGetErrorString(e));
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), tab, h->stream, a);
-            h->last_variant = PTMI_VAR_LDS_UT;
+            h->last_variant = PTMI_VAR_LDS_UT | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
             return PTMI_OK;
         }
     }
     a.box_off = box_bytes ? 0 : -1;               // no other table in LDS
     if (c.ngroups > 1) hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, true>), dim3(grid), dim3(256), box_bytes, h->stream, a);
     else hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, false>), dim3(grid), dim3(256), box_bytes, h->stream, a);
-    h->last_variant = (FULL ? PTMI_VAR_FULL : 0) | (c.ngroups > 1 ? PTMI_VAR_GROUPS : 0);
+    h->last_variant = (FULL ? PTMI_VAR_FULL : 0) | (c.ngroups > 1 ? PTMI_VAR_GROUPS : 0) | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
     return PTMI_OK;
 }
 template <int G, int EPL, int LOGL>

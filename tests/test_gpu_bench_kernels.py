@@ -63,8 +63,55 @@ def test_iso_default_mix_pooled_runs_staged(mods):
     o.run(170)
     flags, G, E = g.last_variant()
     assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and flags & _lib.VAR_LDS_UT
+    assert flags & _lib.VAR_AMQ                                # per-chain picks, a third of them AM: increments through the queue
     _compare(g, o, "mix ")
     assert o.jstat[..., 2, 0].sum() > 0
+
+
+@pytest.mark.parametrize("weights,nt,W,n,queued", [((20, 20, 0), 64, 2, 131, True), ((30, 5, 0), 5, 7, 97, True), ((5, 1, 20), 3, 5, 150, True),
+                                                   ((0, 20, 0), 4, 4, 60, False), ((1, 30, 0), 4, 4, 60, False)])
+def test_am_queue_matches_in_place_am(mods, weights, nt, W, n, queued):
+    """The AM queue of the staged full kernel (increments computed 16 events at a time, four to seven steps ahead, through a
+    ring in LDS) against the oracle's AM (PTMCMCSampler.py:879-933): launches of odd lengths, sparse and dense AM picks, a
+    wave with dead lanes, DE switching on in between; AM-heavy cycles stay in place."""
+    orc, _lib, _ = mods
+    d = 100
+    g, o = _pair(mods, d, nt, W, cov0=np.eye(d) * 0.01, weights=weights, cov_update=20, burn=40, tskip=7, seed=17, cov_mode="pooled")
+    for m in (n, 3, 1, 46):                                    # the queue restarts with every launch, whatever its length
+        g.run(m)
+        o.run(m)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and bool(flags & _lib.VAR_AMQ) == queued
+    _compare(g, o, "am queue %r " % (weights,))
+    assert o.jstat[..., 1, 0].sum() > 0
+
+
+@pytest.mark.parametrize("kind", ["scam", "mix", "dense"])
+def test_box_prior_from_lds_table(mods, kind):
+    """Box prior (-inf outside [pmin, pmax], the reference's usual lnpriorfn) in the kernels bench.py --prior box times: the
+    bounds table in LDS (SCAM-only table kernel, staged full kernel, dense 512-thread kernel), walls close enough to be hit."""
+    orc, _lib, _ = mods
+    d, nt, W = 100, 64, 2
+    rs = np.random.RandomState(4)
+    lo, hi = -0.25 - rs.rand(d) * 0.1, 0.2 + rs.rand(d) * 0.1      # per-parameter bounds
+    kw = dict(cov0=np.eye(d) * 0.01, cov_update=30, burn=60, tskip=10, seed=23, cov_mode="pooled", logp=("box", lo, hi),
+              p0=rs.uniform(-0.05, 0.05, (W, nt, d)))
+    if kind == "scam":
+        kw.update(weights=(20, 0, 0))
+    elif kind == "mix":
+        kw.update(weights=(20, 20, 20))
+    else:
+        kw.update(weights=(20, 0, 0), logl=_dense(d))
+    g, o = _pair(mods, d, nt, W, **kw)
+    g.run(140)
+    o.run(140)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_LDS_BOX and (G, E) == (4, 26)
+    if kind == "scam":
+        assert flags & _lib.VAR_LDS_UT and not flags & _lib.VAR_STAGED
+    _compare(g, o, "box %s " % kind)
+    rej = o.jstat[..., 0, 0].sum() - o.jstat[..., 0, 1].sum()
+    assert np.isinf(o.lp).sum() == 0 and rej > 0                # proposals did leave the box and were refused
 
 
 class _Subset(object):
