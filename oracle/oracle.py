@@ -70,6 +70,14 @@ def lib():
         L.orc_log.argtypes = L.orc_exp.argtypes = L.orc_cos2pi.argtypes = [C.c_double]
         L.orc_normal.restype = L.orc_normal_sin.restype = L.orc_sin2pi.restype = C.c_double
         L.orc_normal.argtypes = L.orc_normal_sin.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_unit_log.restype = C.c_double
+        L.orc_unit_log.argtypes = [C.c_uint64]
+        L.orc_unit_sincos64.restype = L.orc_unit_sincos32.restype = L.orc_unit_normals.restype = None
+        L.orc_unit_sincos64.argtypes = [C.c_uint64, _dp, _dp]
+        L.orc_unit_sincos32.argtypes = [C.c_uint32, _dp, _dp]
+        L.orc_unit_normals.argtypes = [C.c_uint64, C.c_uint64, _dp, _dp]
+        L.orc_unit_normal32.restype = C.c_double
+        L.orc_unit_normal32.argtypes = [C.c_uint64, C.c_uint32]
         L.orc_sin2pi.argtypes = [C.c_double]
         L.orc_uniform.restype = C.c_double
         L.orc_uniform.argtypes = [C.c_uint64]

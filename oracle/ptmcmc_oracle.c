@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "orc_tables.h"
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -200,6 +201,79 @@ ORC_API double orc_sin2pi(double u)
         double s = p * r;
         return qi == 0 ? s : -s;
     }
+}
+
+/* ------------------------------------------ the draws of the MH path (table driven; ptmi_device.h unit_log / unit_sincos)
+ * ln u of the (0,1] uniform u = ((w >> 11) + 1) 2^-53: x = (double)n = z 2^k, z in [0.6875, 1.375) cut into 64 slices by
+ * bit pattern, r = z invc - 1, ln = k ln2 + logc + log1p(r) with log1p by its Taylor polynomial to r^9. */
+ORC_API double orc_unit_log(uint64_t w)
+{
+    const uint64_t n = (w >> 11) + 1;
+    const double x = (double)n;                                        /* exact: n <= 2^53 */
+    const uint64_t xb = d2u(x);
+    const uint32_t hi = (uint32_t)(xb >> 32), tmp = hi - 0x3FE60000u;
+    const int k = (int)((int32_t)tmp >> 20) - 53;
+    const uint32_t i = (tmp >> 14) & 63u;
+    const double z = u2d(((uint64_t)(hi - (tmp & 0xFFF00000u)) << 32) | (uint32_t)xb);
+    const double invc = ORC_LOGT[2 * i], logc = ORC_LOGT[2 * i + 1];
+    const double r = fma(z, invc, -1.0);
+    double p = 0x1.c71c71c71c71cp-4;
+    p = fma(p, r, -0x1.0p-3);
+    p = fma(p, r, 0x1.2492492492492p-3);
+    p = fma(p, r, -0x1.5555555555555p-3);
+    p = fma(p, r, 0x1.999999999999ap-3);
+    p = fma(p, r, -0x1.0p-2);
+    p = fma(p, r, 0x1.5555555555555p-2);
+    p = fma(p, r, -0x1.0p-1);
+    const double l1 = fma(r * r, p, r);
+    return fma((double)k, 0x1.62e42fefa39efp-1, logc) + l1;
+}
+/* cos and sin of 2 pi (j + 1/2 + t) / 64: the base angle's pair from the table, rotated by beta = 2 pi t / 64 */
+static void unit_sincos(uint32_t j, double t, double *sn, double *cs)
+{
+    const double bc = ORC_SCT[2 * j], bs = ORC_SCT[2 * j + 1];
+    const double be = t * 0x1.921fb54442d18p-4, zz = be * be;
+    double ps = 0x1.71de3a556c734p-19;
+    ps = fma(ps, zz, -0x1.a01a01a01a01ap-13);
+    ps = fma(ps, zz, 0x1.1111111111111p-7);
+    ps = fma(ps, zz, -0x1.5555555555555p-3);
+    const double sb = fma(be * zz, ps, be);
+    double pc = 0x1.a01a01a01a01ap-16;
+    pc = fma(pc, zz, -0x1.6c16c16c16c17p-10);
+    pc = fma(pc, zz, 0x1.5555555555555p-5);
+    pc = fma(pc, zz, -0x1.0p-1);
+    const double cb = fma(zz, pc, 1.0);
+    *cs = fma(-bs, sb, bc * cb);
+    *sn = fma(bc, sb, bs * cb);
+}
+/* the angle of a 64-bit word (j = its top 6 bits, t in [-1/2, 1/2) from the 52 bits below) ... */
+ORC_API void orc_unit_sincos64(uint64_t w, double *sn, double *cs)
+{
+    const double t = u2d(((w >> 6) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull) - 1.5;
+    unit_sincos((uint32_t)(w >> 58), t, sn, cs);
+}
+/* ... and of a 32-bit half (j = top 6 bits, t from the 26 bits below) */
+ORC_API void orc_unit_sincos32(uint32_t h, double *sn, double *cs)
+{
+    const uint32_t f = h & 0x03FFFFFFu;
+    const double t = u2d(((uint64_t)(0x3FF00000u | (f >> 6)) << 32) | (uint64_t)(uint32_t)(f << 26)) - 1.5;
+    unit_sincos(h >> 26, t, sn, cs);
+}
+/* the Box-Muller pair of two words (AM): cos branch, sin branch */
+ORC_API void orc_unit_normals(uint64_t w0, uint64_t w1, double *zc, double *zs)
+{
+    const double r = sqrt(-2.0 * orc_unit_log(w0));
+    double sn, cs;
+    orc_unit_sincos64(w1, &sn, &cs);
+    *zc = r * cs;
+    *zs = r * sn;
+}
+/* the SCAM normal: radius from a word, 32-bit angle */
+ORC_API double orc_unit_normal32(uint64_t w0, uint32_t h)
+{
+    double sn, cs;
+    orc_unit_sincos32(h, &sn, &cs);
+    return sqrt(-2.0 * orc_unit_log(w0)) * cs;
 }
 
 /* Box-Muller (cos branch): one normal from two words */
@@ -738,7 +812,7 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
             if (r) { k = (int)rp_next(r, K_INT, ng); z = rp_next(r, K_NRM, 0); }
             else {
                 k = (int)h2index(hi32(Q[1]), (uint32_t)ng);
-                z = sqrt(-2.0 * orc_log(w2uniform_open(Q[0]))) * orc_cos2pi(h2uniform(lo32(Q[1])));   /* Box-Muller, 32-bit angle */
+                z = orc_unit_normal32(Q[0], lo32(Q[1]));                 /* Box-Muller, 32-bit angle */
             }
             const double cd = 2.4 / sqrt(2.0 * 1.0) * scale;            /* PT:870, neff = 1 */
             const double a = z * cd * sqrt(S[k]);                       /* PT:873 */
@@ -753,7 +827,9 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
                     const int which = (k / c->lanes) & 1, base = which ? k - c->lanes : k;
                     uint64_t E[2];
                     philox_words(c->seed, (uint64_t)it, sid, SLOT_AM + (uint32_t)base, E);
-                    z = which ? orc_normal_sin(E[0], E[1]) : orc_normal(E[0], E[1]);
+                    double zc, zs;
+                    orc_unit_normals(E[0], E[1], &zc, &zs);
+                    z = which ? zs : zc;
                 }
                 wk[k] = z * cd * sqrt(S[k]);                            /* PT:930 */
             }
@@ -797,9 +873,10 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
 
     /* Hastings test (PT:615-622); lnprob0 is always 1/T*lnL + logp(x) of the held state */
     const double lnprob0 = beta * st->lnL[ch] + st->lp[ch];
-    const double u = r ? rp_next(r, K_UNI, 0) : w2uniform(P[1]);
+    /* native schedule: the accept uniform is the (0,1] one of word P[1], its log by orc_unit_log */
+    const double log_u = r ? orc_log(rp_next(r, K_UNI, 0)) : orc_unit_log(P[1]);
     const double diff = newlnprob - lnprob0 + qxy;                  /* qxy = 0 for SCAM / AM / DE */
-    if (diff > orc_log(u)) {
+    if (diff > log_u) {
         memcpy(x, q, sizeof(double) * d);
         st->lnL[ch] = newlnL; st->lp[ch] = lp;
         st->nacc[(size_t)w * nt + t] += 1;

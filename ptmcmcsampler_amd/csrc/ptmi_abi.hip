@@ -659,6 +659,23 @@ __global__ void selftest_math_kernel(int op, const double *in, const double *in2
     case 3: r = det_sqrt(x); break;
     case 4: r = x / in2[i]; break;
     case 5: r = det_normal((u64)__double_as_longlong(x), (u64)__double_as_longlong(in2[i])); break;
+    case 10: r = unit_log((u64)__double_as_longlong(x)); break;
+    case 11: case 12: {
+        u32 j;
+        double t, sn, cs;
+        unit_angle64((u64)__double_as_longlong(x), j, t);
+        unit_sincos(j, t, sn, cs);
+        r = op == 11 ? cs : sn;
+        break;
+    }
+    case 13: {
+        u32 j;
+        double t, sn, cs;
+        unit_angle32((u32)(u64)__double_as_longlong(x), j, t);
+        unit_sincos(j, t, sn, cs);
+        r = det_sqrt(-2.0 * unit_log((u64)__double_as_longlong(in2[i]))) * cs;
+        break;
+    }
     default: r = group_sum<16>(x); break;
     }
     out[i] = r;

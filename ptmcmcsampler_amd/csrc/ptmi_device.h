@@ -6,11 +6,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ptmi_tables.h"
 
 namespace ptmi {
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef double ptmi_dev_d2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------- cross-lane
 // DPP moves: full-rate lane permutations inside a row of 16 lanes (no LDS traffic).
@@ -62,21 +64,34 @@ __device__ __forceinline__ bool group_all(bool ok)
 
 // --------------------------------------------------------------------- Philox
 // Philox4x32-10 (Salmon et al., SC'11).  ctr = (iter_lo, iter_hi, stream, slot), key = seed.
+// The generator in three pieces so that a caller can place other work between the rounds (am_mfma_product).
+struct PhiloxState { u32 c0, c1, c2, c3, k0, k1; };
+__device__ __forceinline__ void philox_begin(PhiloxState &p, u64 seed, u64 iter, u32 stream, u32 slot)
+{
+    p.c0 = (u32)iter; p.c1 = (u32)(iter >> 32); p.c2 = stream; p.c3 = slot;
+    p.k0 = (u32)seed; p.k1 = (u32)(seed >> 32);
+}
+__device__ __forceinline__ void philox_round(PhiloxState &p)
+{
+    const u64 p0 = (u64)0xD2511F53u * (u64)p.c0, p1 = (u64)0xCD9E8D57u * (u64)p.c2;   // v_mad_u64_u32
+    const u32 h0 = (u32)(p0 >> 32), l0 = (u32)p0, h1 = (u32)(p1 >> 32), l1 = (u32)p1;
+    // three-input xor in one instruction (v_bitop3_b32, truth table 0x96): hipcc emits two v_xor_b32 for a ^ b ^ c
+    const u32 n0 = __builtin_amdgcn_bitop3_b32(h1, p.c1, p.k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(h0, p.c3, p.k1, 0x96);
+    p.c0 = n0; p.c1 = l1; p.c2 = n2; p.c3 = l0;
+    p.k0 += 0x9E3779B9u; p.k1 += 0xBB67AE85u;
+}
+__device__ __forceinline__ void philox_end(const PhiloxState &p, u64 &w0, u64 &w1)
+{
+    w0 = ((u64)p.c1 << 32) | p.c0;
+    w1 = ((u64)p.c3 << 32) | p.c2;
+}
 __device__ __forceinline__ void philox_words(u64 seed, u64 iter, u32 stream, u32 slot, u64 &w0, u64 &w1)
 {
-    u32 c0 = (u32)iter, c1 = (u32)(iter >> 32), c2 = stream, c3 = slot;
-    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+    PhiloxState p;
+    philox_begin(p, seed, iter, stream, slot);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const u64 p0 = (u64)0xD2511F53u * (u64)c0, p1 = (u64)0xCD9E8D57u * (u64)c2;   // v_mad_u64_u32
-        const u32 h0 = (u32)(p0 >> 32), l0 = (u32)p0, h1 = (u32)(p1 >> 32), l1 = (u32)p1;
-        // three-input xor in one instruction (v_bitop3_b32, truth table 0x96): hipcc emits two v_xor_b32 for a ^ b ^ c
-        const u32 n0 = __builtin_amdgcn_bitop3_b32(h1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(h0, c3, k1, 0x96);
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    w0 = ((u64)c1 << 32) | c0;
-    w1 = ((u64)c3 << 32) | c2;
+    for (int r = 0; r < 10; ++r) philox_round(p);
+    philox_end(p, w0, w1);
 }
 enum : u32 { SLOT_A = 0, SLOT_B = 1, SLOT_C = 2, SLOT_D = 3, SLOT_SWAP = 0x10000u, SLOT_AM = 0x1000000u };
 
@@ -192,6 +207,66 @@ __device__ __forceinline__ double det_sin2pi(double u)
 }
 
 __device__ __forceinline__ double det_sqrt(double x) { return __dsqrt_rn(x); }
+
+// ------------------------------------------ the draws of the MH path (table driven)
+// ln u of the (0,1] uniform u = ((w >> 11) + 1) 2^-53 of a 64-bit word.  x = (double)n = z 2^k with z in [0.6875, 1.375)
+// cut into 64 slices by bit pattern; r = z invc - 1 (one rounding, |r| <= 1/64), ln = k ln2 + logc + log1p(r), log1p by
+// its Taylor polynomial to r^9 (next term < 6e-18 r).  The two slices that touch z = 1 have invc = 1, logc = 0: a u just
+// below 1 gives r < 0 exactly and a result that is never positive.  25 instructions, no division, no special case
+// (det_log: about 60 with the conversion).  Oracle: orc_unit_log.
+__device__ __forceinline__ double unit_log(u64 w)
+{
+    const u64 n = (w >> 11) + 1ull;
+    const double x = __builtin_fma((double)(u32)(n >> 32), 0x1.0p32, (double)(u32)n);      // exact: n <= 2^53
+    const u64 xb = (u64)__double_as_longlong(x);
+    const u32 hi = (u32)(xb >> 32), tmp = hi - 0x3FE60000u;
+    const int k = ((int)tmp >> 20) - 53;
+    const u32 i = (tmp >> 14) & 63u;
+    const double z = __longlong_as_double((long long)(((u64)(hi - (tmp & 0xFFF00000u)) << 32) | (u32)xb));
+    const ptmi_dev_d2 e = *reinterpret_cast<const ptmi_dev_d2 *>(PTMI_LOGT + 2 * i);
+    const double r = __builtin_fma(z, e.x, -1.0);
+    double p = 0x1.c71c71c71c71cp-4;                    // +1/9
+    p = __builtin_fma(p, r, -0x1.0p-3);                 // -1/8
+    p = __builtin_fma(p, r, 0x1.2492492492492p-3);      // +1/7
+    p = __builtin_fma(p, r, -0x1.5555555555555p-3);     // -1/6
+    p = __builtin_fma(p, r, 0x1.999999999999ap-3);      // +1/5
+    p = __builtin_fma(p, r, -0x1.0p-2);                 // -1/4
+    p = __builtin_fma(p, r, 0x1.5555555555555p-2);      // +1/3
+    p = __builtin_fma(p, r, -0x1.0p-1);                 // -1/2
+    const double l1 = __builtin_fma(r * r, p, r);
+    return __builtin_fma((double)k, 0x1.62e42fefa39efp-1, e.y) + l1;
+}
+// The Box-Muller angle: 2 pi (j + 1/2 + t) / 64, j the top 6 bits of the word, t in [-1/2, 1/2) from the bits below them
+__device__ __forceinline__ void unit_angle64(u64 w, u32 &j, double &t)
+{
+    j = (u32)(w >> 58);
+    t = __longlong_as_double((long long)(((w >> 6) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull)) - 1.5;
+}
+__device__ __forceinline__ void unit_angle32(u32 h, u32 &j, double &t)
+{
+    j = h >> 26;
+    const u32 f = h & 0x03FFFFFFu;
+    t = __longlong_as_double((long long)(((u64)(0x3FF00000u | (f >> 6)) << 32) | (u64)(f << 26))) - 1.5;
+}
+// cos and sin of that angle: the base angle's pair from the table (exactly mirrored over the octants), rotated by
+// beta = 2 pi t / 64 (|beta| <= pi/64: sin to beta^9, cos to beta^8, next terms < 1e-20).  Oracle: orc_unit_sincos.
+__device__ __forceinline__ void unit_sincos(u32 j, double t, double &sn, double &cs)
+{
+    const ptmi_dev_d2 b = *reinterpret_cast<const ptmi_dev_d2 *>(PTMI_SCT + 2 * j);
+    const double be = t * 0x1.921fb54442d18p-4, zz = be * be;
+    double ps = 0x1.71de3a556c734p-19;                  // 1/9!
+    ps = __builtin_fma(ps, zz, -0x1.a01a01a01a01ap-13); // -1/7!
+    ps = __builtin_fma(ps, zz, 0x1.1111111111111p-7);   // 1/5!
+    ps = __builtin_fma(ps, zz, -0x1.5555555555555p-3);  // -1/3!
+    const double sb = __builtin_fma(be * zz, ps, be);
+    double pc = 0x1.a01a01a01a01ap-16;                  // 1/8!
+    pc = __builtin_fma(pc, zz, -0x1.6c16c16c16c17p-10); // -1/6!
+    pc = __builtin_fma(pc, zz, 0x1.5555555555555p-5);   // 1/4!
+    pc = __builtin_fma(pc, zz, -0x1.0p-1);              // -1/2!
+    const double cb = __builtin_fma(zz, pc, 1.0);
+    cs = __builtin_fma(-b.y, sb, b.x * cb);
+    sn = __builtin_fma(b.x, sb, b.y * cb);
+}
 
 // Box-Muller, cos branch
 __device__ __forceinline__ double det_normal(u64 w0, u64 w1)

@@ -350,8 +350,12 @@ struct DrawBatch {
     {
         const int j = gl & 3;
         philox_words(a.seed, (u64)(it + (j >> 1)), sid, (u32)(j & 1), w0, w1);
-        lg = det_log((j & 1) ? w2uniform_open(w0) : w2uniform(w1));
-        z = det_sqrt(-2.0 * lg) * det_cos2pi(h2uniform((u32)w1));                // meaningful on the odd lanes
+        lg = unit_log((j & 1) ? w0 : w1);                   // both uniforms are (0,1] ones
+        u32 aj;
+        double at, sn, cs;
+        unit_angle32((u32)w1, aj, at);
+        unit_sincos(aj, at, sn, cs);
+        z = det_sqrt(-2.0 * lg) * cs;                       // meaningful on the odd lanes
     }
     __device__ __forceinline__ void advance()
     {
@@ -391,10 +395,46 @@ __device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, con
     b.take(dr, walker);
 }
 
+#ifndef PTMI_AMV
+#define PTMI_AMV 1
+#endif
+// One matrix instruction whose accumulator is pinned to the accumulation registers.  With __builtin_amdgcn_mfma_* in a
+// ROLLED loop hipcc keeps the loop-carried accumulators in VGPRs and moves all of them to AGPRs and back on every trip
+// (2 x 56 v_accvgpr moves per Box-Muller pair, and the reads back wait until the matrix pipe has drained, so nothing of
+// the next pair's draw overlaps the products); an asm operand of class "a" stays where it is.  hipcc pads no hazards
+// of an asm statement: the chain through C needs no wait state, the first vector read of the result does (mfma_acc_settle).
+// GUARD: an operand may have been written by the vector pipe just before (the weight ahead of the first product of a
+// k-step; a table value selected against its bounds): two wait states inside the statement.
+template <bool GUARD>
+__device__ __forceinline__ void mfma_f64_acc(ptmi_d4 &acc, double ta, double w)
+{
+    if (GUARD) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(ta), "v"(w));
+    else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(ta), "v"(w));
+}
+template <int NT>
+__device__ __forceinline__ void mfma_acc_begin(ptmi_d4 (&t)[NT])
+{
+#pragma unroll
+    for (int i = 0; i < NT; ++i) t[i] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
+    asm volatile("s_nop 7");                           // v_accvgpr_write -> C operand of a matrix instruction
+#pragma unroll
+    for (int i = 0; i < NT; ++i) asm volatile("" : "+a"(t[i]));
+}
+template <int NT>
+__device__ __forceinline__ void mfma_acc_settle(ptmi_d4 (&t)[NT])
+{
+    asm volatile("s_nop 15\n\ts_nop 15");              // 16-pass matrix instruction -> vector read of its result (18 states needed)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) asm volatile("" : "+a"(t[i]));   // every read of the result is behind the wait
+}
+
 // The AM increment U (cd sqrt(S) z) (PT:879-933) of the 16 chains in the columns of the wave, on the matrix cores (strided
 // layout: lane (c16, g4) draws the weights of directions k = g4 + 4e of column c16's chain).  The weights of two k-steps come
-// out of one Box-Muller and go straight into the two accumulation steps -- no weight array is kept, and the matrix pipe
-// works on pair e while the vector pipe draws pair e + 2.  The accumulation order (k ascending) is that of mfma_tab_vec.
+// out of one Box-Muller and go straight into the two accumulation steps -- no weight array is kept.  Software pipeline,
+// hand placed: the 2 NT matrix instructions of pair e are issued with one Philox round of pair e + 2 behind each (a matrix
+// instruction holds its pipe for 64 cycles, the integer work of the next draw hides there); the double-precision half of
+// the draw (log, sqrt, sincos: it shares the pipe with the matrix instructions, tools/dp_share.hip) follows.
+// The accumulation order (k ascending) is that of mfma_tab_vec.
 // active / sid / it / cd are the column's: the chain's own (propose) or those of a queued AM event (mh_steps_kernel).
 template <int EPL>
 __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32 sid, long long it, double cd, int ng,
@@ -404,48 +444,118 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
     const int d = a.d;
     const int c16 = (int)(threadIdx.x & 15), g4 = (int)((threadIdx.x & 63) >> 4);
     auto root_s = [&](int k) { const double v = S[k]; return s_sqrt ? v : det_sqrt(v); };
-    // directions k = g4 + 4e and k + 4 (slots e even / odd) are the cos and sin branches of ONE Box-Muller
-    auto weights = [&](int e, double &wa, double &wb) {
-        wa = 0.0;
-        wb = 0.0;
+    // directions k = g4 + 4e and k + 4 (slots e even / odd) are the cos and sin branches of ONE Box-Muller; straight-line:
+    // lanes without a weight draw all the same and select zero
+    auto draw_f64 = [&](int e, u64 e0, u64 e1, double &wa, double &wb) {
         const int k = g4 + G * e;
-        if (active && k < ng) {
-            u64 e0, e1;
-            philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
-            const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
-            double sn, cs;
-            det_sincos2pi(w2uniform(e1), sn, cs);
-            wa = (r * cs) * cd * root_s(k);                             // PT:930
-            if (e + 1 < EPL && k + G < ng) wb = (r * sn) * cd * root_s(k + G);
+        const bool on = active && k < ng, on2 = on && e + 1 < EPL && k + G < ng;
+        const double r = det_sqrt(-2.0 * unit_log(e0));
+        u32 aj;
+        double at, sn, cs;
+        unit_angle64(e1, aj, at);
+        unit_sincos(aj, at, sn, cs);
+        const double va = (r * cs) * cd * root_s(on ? k : 0);          // PT:930
+        const double vb = (r * sn) * cd * root_s(on2 ? k + G : 0);
+        wa = on ? va : 0.0;
+        wb = on2 ? vb : 0.0;
+    };
+    auto rows = [&](int k, double (&dst)[NT]) {            // table row block of one k-step
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = 16 * t + c16;
+            if (ut_padded) dst[t] = Ut[(size_t)k * uld + col];
+            else dst[t] = (k < d && col < d) ? Ut[(size_t)k * uld + col] : 0.0;
         }
     };
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc.t[t] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
-    // a ROLLED loop over the pairs: unrolled, the thirteen Box-Muller bodies alone are half of the kernel's code and
-    // the kernel outgrows the instruction cache
     const int esteps = (d + 3) / 4 < EPL ? (d + 3) / 4 : EPL;     // k-steps that hold a table row
+    // the NT products of one k-step; the LDS copy's values come straight from the read, the global table's through a select
+    auto kstep = [&](const double (&tt)[NT], double w) {
+        if (ut_padded) {
+            mfma_f64_acc<true>(acc.t[0], tt[0], w);
+#pragma unroll
+            for (int t = 1; t < NT; ++t) mfma_f64_acc<false>(acc.t[t], tt[t], w);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mfma_f64_acc<true>(acc.t[t], tt[t], w);
+        }
+    };
+#if PTMI_AMV == 1
+#ifdef PTMI_AM_PROFILE
+    unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0, t1;
+#define PTMI_STAMP(i) t1 = __builtin_readcyclecounter(); tp[i] += t1 - t0; t0 = t1;
+    t0 = __builtin_readcyclecounter();
+#else
+#define PTMI_STAMP(i)
+#endif
+    mfma_acc_begin<NT>(acc.t);
 #pragma unroll 1
     for (int e = 0; e < esteps; e += 2) {
         double ta[NT], wa, wb;
+        u64 e0, e1;
         const bool second = e + 1 < esteps;
-        auto rows = [&](int k) {                           // table row block of one k-step
+        rows(4 * e + g4, ta);                              // in flight during the draw
+        philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)(g4 + G * e), e0, e1);
+        PTMI_STAMP(0)
+        draw_f64(e, e0, e1, wa, wb);
+        PTMI_STAMP(1)
+        kstep(ta, wa);
+        PTMI_STAMP(2)
+        if (second) {
+            rows(4 * e + 4 + g4, ta);
+            kstep(ta, wb);
+        }
+        PTMI_STAMP(3)
+    }
+#ifdef PTMI_AM_PROFILE
+    mfma_acc_settle<NT>(acc.t);
+    PTMI_STAMP(4)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && it % 64 == 0)
+        printf("am profile it %lld: philox+rows %llu  f64 %llu  mfmaA %llu  mfmaB %llu  settle %llu cycles (13 pairs)\n", it, tp[0], tp[1], tp[2], tp[3], tp[4]);
+#endif
+#else
+    PhiloxState ps;
+    u64 e0, e1;
+    double wa, wb, ta[NT], tb[NT];
+    rows(g4, ta);
+    philox_begin(ps, a.seed, (u64)it, sid, SLOT_AM + (u32)g4);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(ps);
+    philox_end(ps, e0, e1);
+    draw_f64(0, e0, e1, wa, wb);
+    mfma_acc_begin<NT>(acc.t);
+    // a ROLLED loop over the pairs: unrolled, the thirteen Box-Muller bodies alone are half of the kernel's code and
+    // the kernel outgrows the instruction cache
+#pragma unroll 1
+    for (int e = 0; e < esteps; e += 2) {
+        const bool second = e + 1 < esteps, more = e + 2 < esteps;
+        rows(4 * (second ? e + 1 : e) + g4, tb);
+        philox_begin(ps, a.seed, (u64)it, sid, SLOT_AM + (u32)(g4 + G * (e + 2)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            mfma_f64_acc<true>(acc.t[t], ta[t], wa);
+            if (t < 10) philox_round(ps);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rows(4 * (more ? e + 2 : e) + g4, ta);             // the next pair's first row block, behind the products that read this one
+        __builtin_amdgcn_sched_barrier(0);
+        if (second) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int col = 16 * t + c16;
-                if (ut_padded) ta[t] = Ut[(size_t)k * uld + col];
-                else ta[t] = (k < d && col < d) ? Ut[(size_t)k * uld + col] : 0.0;
+                mfma_f64_acc<true>(acc.t[t], tb[t], wb);
+                if (NT + t < 10) philox_round(ps);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        rows(4 * e + g4);                                  // in flight during the draw
-        weights(e, wa, wb);
+        }
+        if (more) {                                        // more implies second
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wa, acc.t[t], 0, 0, 0);
-        if (second) {
-            rows(4 * e + 4 + g4);                          // behind the seven products above
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], wb, acc.t[t], 0, 0, 0);
+            for (int r = 2 * NT; r < 10; ++r) philox_round(ps);
+            philox_end(ps, e0, e1);
+            draw_f64(e + 2, e0, e1, wa, wb);
         }
     }
+#endif
+    mfma_acc_settle<NT>(acc.t);
 }
 
 // One proposal for the caller's chain (PT:1048-1067, 820-985) from the iteration's draws: writes the increment dq
@@ -551,9 +661,11 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
                 if (is_am && k < ng) {
                     u64 e0, e1;
                     philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
-                    const double r = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
-                    double sn, cs;
-                    det_sincos2pi(w2uniform(e1), sn, cs);
+                    const double r = det_sqrt(-2.0 * unit_log(e0));
+                    u32 aj;
+                    double at, sn, cs;
+                    unit_angle64(e1, aj, at);
+                    unit_sincos(aj, at, sn, cs);
                     wa = (r * cs) * cd * root_s(k);                             // PT:930
                     if (e + 1 < EPL && k + G < ng) wb = (r * sn) * cd * root_s(k + G);
                 }
@@ -1043,7 +1155,7 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     DrawBatch<false> batch;
     Draws dr;
     draws_for_step<false, true>(batch, dr, a, 0, sid, sid0, gl);
-    const double log_u = dr.log_u, u_acc = w2uniform(batch.P1());
+    const double log_u = dr.log_u, u_acc = w2uniform_open(batch.P1());
     const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, dr, Ut, false, S, DE, dq);
     if (live) {
 #pragma unroll

@@ -61,6 +61,22 @@ def test_device_math_is_bit_identical_to_oracle(mods):
     w = rs.randint(0, 2 ** 62, size=(5000, 2)).astype(np.uint64) * np.uint64(4) + np.uint64(3)
     got = dev(5, w[:, 0].view(np.float64), w[:, 1].view(np.float64))
     assert_same(got, [O.orc_normal(int(p), int(q)) for p, q in w], "normal")
+    # the table-driven draws of the MH path: ln of the (0,1] uniform of a word, cos / sin of the angle of a word, the SCAM normal
+    import ctypes as C
+    ww = np.concatenate([w.reshape(-1), np.array([0, 2 ** 64 - 1, 2 ** 11, (2 ** 53 - 1) << 11, (2 ** 53 - 2) << 11, 2 ** 58 - 1, 2 ** 58], dtype=np.uint64),
+                         (np.uint64(2 ** 53 - 1) - np.arange(1, 3000, dtype=np.uint64)) << np.uint64(11)])
+    assert_same(dev(10, ww.view(np.float64)), [O.orc_unit_log(int(v)) for v in ww], "unit_log")
+    sn, cs = C.c_double(), C.c_double()
+    want = []
+    for v in ww:
+        O.orc_unit_sincos64(int(v), C.byref(sn), C.byref(cs))
+        want.append((cs.value, sn.value))
+    want = np.array(want)
+    assert_same(dev(11, ww.view(np.float64)), want[:, 0], "unit cos")
+    assert_same(dev(12, ww.view(np.float64)), want[:, 1], "unit sin")
+    hh = (ww[:len(w)] & np.uint64(0xFFFFFFFF))
+    assert_same(dev(13, hh.view(np.float64), ww[::-1][:len(w)].copy().view(np.float64)),
+                [O.orc_unit_normal32(int(q), int(h)) for h, q in zip(hh, ww[::-1][:len(w)])], "SCAM normal")
     # the 16-lane butterfly: every lane of a row gets the oracle's tree sum
     v = rs.randn(64 * 8)
     got = dev(6, v)
