@@ -181,8 +181,8 @@ int ptmi_set_de_active(ptmi_handle h, int on);
 int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps);
 
 /* Which instantiation of the fused kernel the most recent ptmi_mh_steps launched (the parity tests assert that they
- * reached the one they mean to test): a combination of the flags below, plus lanes per chain in bits 8-15 and register
- * slots per lane in bits 16-23. */
+ * reached the one they mean to test): a combination of the flags below, plus lanes per chain in bits 12-19 and register
+ * slots per lane in bits 20-27. */
 enum { PTMI_VAR_STAGED = 1,    /* strided lane layout, tables in LDS, products on the f64 matrix cores */
        PTMI_VAR_FULL = 2,      /* the cycle holds AM and / or an active DE (else SCAM only) */
        PTMI_VAR_LDS_UT = 4,    /* staged: the eigenvector table is in LDS too */
@@ -190,7 +190,8 @@ enum { PTMI_VAR_STAGED = 1,    /* strided lane layout, tables in LDS, products o
        PTMI_VAR_GRADJUMP = 16, /* the kernel with the NUTS / HMC branch */
        PTMI_VAR_UNIFORM = 32,  /* wave-uniform cycle pick (pick_mode = PTMI_PICK_WALKER) */
        PTMI_VAR_AMQ = 64,      /* staged full kernel: AM increments queued 16 at a time for the matrix cores */
-       PTMI_VAR_LDS_BOX = 128  /* box prior: the bounds table is in LDS */ };
+       PTMI_VAR_LDS_BOX = 128, /* box prior: the bounds table is in LDS */
+       PTMI_VAR_LDS_DRAWT = 256 /* the tables of the draws (log slices, base angles) are in LDS */ };
 int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant);
 
 /* PTswap (:631-697) for iteration `iter` when the whole ladder is on this GPU. */

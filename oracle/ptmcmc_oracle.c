@@ -204,18 +204,18 @@ ORC_API double orc_sin2pi(double u)
 }
 
 /* ------------------------------------------ the draws of the MH path (table driven; ptmi_device.h unit_log / unit_sincos)
- * ln u of the (0,1] uniform u = ((w >> 11) + 1) 2^-53: x = (double)n = z 2^k, z in [0.6875, 1.375) cut into 64 slices by
+ * ln u of the (0,1] uniform u = ((w >> 11) + 1) 2^-53: x = (double)n = z 2^k, z in [0.6953125, 1.390625) cut into 32 slices by
  * bit pattern, r = z invc - 1, ln = k ln2 + logc + log1p(r) with log1p by its Taylor polynomial to r^9. */
 ORC_API double orc_unit_log(uint64_t w)
 {
     const uint64_t n = (w >> 11) + 1;
     const double x = (double)n;                                        /* exact: n <= 2^53 */
     const uint64_t xb = d2u(x);
-    const uint32_t hi = (uint32_t)(xb >> 32), tmp = hi - 0x3FE60000u;
+    const uint32_t hi = (uint32_t)(xb >> 32), tmp = hi - 0x3FE64000u;
     const int k = (int)((int32_t)tmp >> 20) - 53;
-    const uint32_t i = (tmp >> 14) & 63u;
+    const uint32_t i = (tmp >> 15) & 31u;
     const double z = u2d(((uint64_t)(hi - (tmp & 0xFFF00000u)) << 32) | (uint32_t)xb);
-    const double invc = ORC_LOGT[2 * i], logc = ORC_LOGT[2 * i + 1];
+    const double invc = ORC_DRAWT[2 * i], logc = ORC_DRAWT[2 * i + 1];
     const double r = fma(z, invc, -1.0);
     double p = 0x1.c71c71c71c71cp-4;
     p = fma(p, r, -0x1.0p-3);
@@ -228,11 +228,11 @@ ORC_API double orc_unit_log(uint64_t w)
     const double l1 = fma(r * r, p, r);
     return fma((double)k, 0x1.62e42fefa39efp-1, logc) + l1;
 }
-/* cos and sin of 2 pi (j + 1/2 + t) / 64: the base angle's pair from the table, rotated by beta = 2 pi t / 64 */
+/* cos and sin of 2 pi (j + 1/2 + t) / 32: the base angle's pair from the table, rotated by beta = 2 pi t / 32 */
 static void unit_sincos(uint32_t j, double t, double *sn, double *cs)
 {
-    const double bc = ORC_SCT[2 * j], bs = ORC_SCT[2 * j + 1];
-    const double be = t * 0x1.921fb54442d18p-4, zz = be * be;
+    const double bc = ORC_DRAWT[64 + 2 * j], bs = ORC_DRAWT[64 + 2 * j + 1];
+    const double be = t * 0x1.921fb54442d18p-3, zz = be * be;
     double ps = 0x1.71de3a556c734p-19;
     ps = fma(ps, zz, -0x1.a01a01a01a01ap-13);
     ps = fma(ps, zz, 0x1.1111111111111p-7);
@@ -246,18 +246,18 @@ static void unit_sincos(uint32_t j, double t, double *sn, double *cs)
     *cs = fma(-bs, sb, bc * cb);
     *sn = fma(bc, sb, bs * cb);
 }
-/* the angle of a 64-bit word (j = its top 6 bits, t in [-1/2, 1/2) from the 52 bits below) ... */
+/* the angle of a 64-bit word (j = its top 5 bits, t in [-1/2, 1/2) from the 52 bits below) ... */
 ORC_API void orc_unit_sincos64(uint64_t w, double *sn, double *cs)
 {
-    const double t = u2d(((w >> 6) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull) - 1.5;
-    unit_sincos((uint32_t)(w >> 58), t, sn, cs);
+    const double t = u2d(((w >> 7) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull) - 1.5;
+    unit_sincos((uint32_t)(w >> 59), t, sn, cs);
 }
-/* ... and of a 32-bit half (j = top 6 bits, t from the 26 bits below) */
+/* ... and of a 32-bit half (j = top 5 bits, t from the 27 bits below) */
 ORC_API void orc_unit_sincos32(uint32_t h, double *sn, double *cs)
 {
-    const uint32_t f = h & 0x03FFFFFFu;
-    const double t = u2d(((uint64_t)(0x3FF00000u | (f >> 6)) << 32) | (uint64_t)(uint32_t)(f << 26)) - 1.5;
-    unit_sincos(h >> 26, t, sn, cs);
+    const uint32_t f = h & 0x07FFFFFFu;
+    const double t = u2d(((uint64_t)(0x3FF00000u | (f >> 7)) << 32) | (uint64_t)(uint32_t)(f << 25)) - 1.5;
+    unit_sincos(h >> 27, t, sn, cs);
 }
 /* the Box-Muller pair of two words (AM): cos branch, sin branch */
 ORC_API void orc_unit_normals(uint64_t w0, uint64_t w1, double *zc, double *zs)

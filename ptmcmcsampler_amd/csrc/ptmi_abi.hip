@@ -709,6 +709,7 @@ static KArgs make_args(ptmi_engine *h)
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.box_off = -1;
+    a.tab_off = -1;
     const ptmi_config &c = h->cfg;
     const ptmi_buffers &b = h->buf;
     a.X = b.X; a.lnL = b.lnL; a.lp = b.lp; a.temp_of = b.temp_of; a.slot_of = b.slot_of;
@@ -1003,7 +1004,7 @@ int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant)
 {
     if (!h || !variant) return fail(PTMI_EINVAL, "NULL argument");
     *variant = h->last_variant | ((h->cfg.pick_mode == PTMI_PICK_WALKER && (h->last_variant & PTMI_VAR_FULL)) ? PTMI_VAR_UNIFORM : 0) |
-               (h->G << 8) | (h->EPL << 16);
+               (h->G << 12) | (h->EPL << 20);
     return PTMI_OK;
 }
 

@@ -48,6 +48,7 @@ struct KArgs {
     int amq_off;                 // staged full kernels: offset (doubles, even) of the AM queue in the block's LDS (mh_steps_kernel)
     int amq_on;                  // ... and whether this launch takes its AM increments from the queue (launch_mh_k)
     int box_off;                 // box prior: offset (doubles, even) of the bounds table in the block's LDS, or -1: bounds read from global
+    int tab_off;                 // step kernels: offset (doubles, even) of the block's LDS copy of the draw tables (ptmi_tables.h), or -1: read from global
     // gradient jumps (ptmi_gj.inc.h)
     int w_nuts, w_hmc, gj_nburn, hmc_min, hmc_max, nuts_maxdepth;
     double hmc_eps, nuts_delta;

@@ -209,21 +209,38 @@ __device__ __forceinline__ double det_sin2pi(double u)
 __device__ __forceinline__ double det_sqrt(double x) { return __dsqrt_rn(x); }
 
 // ------------------------------------------ the draws of the MH path (table driven)
-// ln u of the (0,1] uniform u = ((w >> 11) + 1) 2^-53 of a 64-bit word.  x = (double)n = z 2^k with z in [0.6875, 1.375)
-// cut into 64 slices by bit pattern; r = z invc - 1 (one rounding, |r| <= 1/64), ln = k ln2 + logc + log1p(r), log1p by
-// its Taylor polynomial to r^9 (next term < 6e-18 r).  The two slices that touch z = 1 have invc = 1, logc = 0: a u just
-// below 1 gives r < 0 exactly and a result that is never positive.  25 instructions, no division, no special case
-// (det_log: about 60 with the conversion).  Oracle: orc_unit_log.
-__device__ __forceinline__ double unit_log(u64 w)
+// The 1 KB of tables (ptmi_tables.h, tools/make_draw_tables.py) is read from the block's LDS copy at smem[off ...] when
+// the kernel has one (off >= 0: draw_table_fill), else from global memory; the values are the same.
+// TM (compile time): 0 = global tables, 1 = the LDS copy, 2 = the LDS copy when off >= 0 (wave-uniform branch)
+template <int TM>
+__device__ __forceinline__ ptmi_dev_d2 draw_table(const double *smem, int off, u32 entry)
+{
+    // loads in their own address spaces: hipcc otherwise selects between the POINTERS and issues one flat load
+    typedef __attribute__((address_space(3))) const ptmi_dev_d2 lds_d2;
+    typedef __attribute__((address_space(1))) const ptmi_dev_d2 glb_d2;
+    if (TM == 1 || (TM == 2 && off >= 0)) return *(lds_d2 *)(smem + off + 2 * entry);
+    return *(glb_d2 *)(PTMI_DRAWT + 2 * entry);
+}
+__device__ __forceinline__ void draw_table_fill(double *smem, int off, int nthreads)
+{
+    if (off < 0) return;
+    for (int i = (int)threadIdx.x; i < 128; i += nthreads) smem[off + i] = PTMI_DRAWT[i];
+}
+// ln u of the (0,1] uniform u = ((w >> 11) + 1) 2^-53 of a 64-bit word.  x = (double)n = z 2^k with z in
+// [0.6953125, 1.390625) cut into 32 slices by bit pattern; r = z invc - 1 (one rounding, |r| <= 1/64),
+// ln = k ln2 + logc + log1p(r), log1p by its Taylor polynomial to r^9 (next term < 6e-18 r).  The slice around z = 1 has
+// invc = 1, logc = 0: a u just below 1 gives r < 0 exactly and a result that is never positive.  About 25 instructions,
+// no division, no special case (det_log: about 60 with the conversion).  Oracle: orc_unit_log.
+template <int TM = 0>
+__device__ __forceinline__ double unit_log(u64 w, const double *smem = nullptr, int off = -1)
 {
     const u64 n = (w >> 11) + 1ull;
     const double x = __builtin_fma((double)(u32)(n >> 32), 0x1.0p32, (double)(u32)n);      // exact: n <= 2^53
     const u64 xb = (u64)__double_as_longlong(x);
-    const u32 hi = (u32)(xb >> 32), tmp = hi - 0x3FE60000u;
+    const u32 hi = (u32)(xb >> 32), tmp = hi - 0x3FE64000u;
     const int k = ((int)tmp >> 20) - 53;
-    const u32 i = (tmp >> 14) & 63u;
+    const ptmi_dev_d2 e = draw_table<TM>(smem, off, (tmp >> 15) & 31u);
     const double z = __longlong_as_double((long long)(((u64)(hi - (tmp & 0xFFF00000u)) << 32) | (u32)xb));
-    const ptmi_dev_d2 e = *reinterpret_cast<const ptmi_dev_d2 *>(PTMI_LOGT + 2 * i);
     const double r = __builtin_fma(z, e.x, -1.0);
     double p = 0x1.c71c71c71c71cp-4;                    // +1/9
     p = __builtin_fma(p, r, -0x1.0p-3);                 // -1/8
@@ -236,24 +253,25 @@ __device__ __forceinline__ double unit_log(u64 w)
     const double l1 = __builtin_fma(r * r, p, r);
     return __builtin_fma((double)k, 0x1.62e42fefa39efp-1, e.y) + l1;
 }
-// The Box-Muller angle: 2 pi (j + 1/2 + t) / 64, j the top 6 bits of the word, t in [-1/2, 1/2) from the bits below them
+// The Box-Muller angle: 2 pi (j + 1/2 + t) / 32, j the top 5 bits of the word, t in [-1/2, 1/2) from the bits below them
 __device__ __forceinline__ void unit_angle64(u64 w, u32 &j, double &t)
 {
-    j = (u32)(w >> 58);
-    t = __longlong_as_double((long long)(((w >> 6) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull)) - 1.5;
+    j = (u32)(w >> 59);
+    t = __longlong_as_double((long long)(((w >> 7) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull)) - 1.5;
 }
 __device__ __forceinline__ void unit_angle32(u32 h, u32 &j, double &t)
 {
-    j = h >> 26;
-    const u32 f = h & 0x03FFFFFFu;
-    t = __longlong_as_double((long long)(((u64)(0x3FF00000u | (f >> 6)) << 32) | (u64)(f << 26))) - 1.5;
+    j = h >> 27;
+    const u32 f = h & 0x07FFFFFFu;
+    t = __longlong_as_double((long long)(((u64)(0x3FF00000u | (f >> 7)) << 32) | (u64)(f << 25))) - 1.5;
 }
 // cos and sin of that angle: the base angle's pair from the table (exactly mirrored over the octants), rotated by
-// beta = 2 pi t / 64 (|beta| <= pi/64: sin to beta^9, cos to beta^8, next terms < 1e-20).  Oracle: orc_unit_sincos.
-__device__ __forceinline__ void unit_sincos(u32 j, double t, double &sn, double &cs)
+// beta = 2 pi t / 32 (|beta| <= pi/32: sin to beta^9, cos to beta^8, next terms < 3e-17).  Oracle: orc_unit_sincos*.
+template <int TM = 0>
+__device__ __forceinline__ void unit_sincos(u32 j, double t, double &sn, double &cs, const double *smem = nullptr, int off = -1)
 {
-    const ptmi_dev_d2 b = *reinterpret_cast<const ptmi_dev_d2 *>(PTMI_SCT + 2 * j);
-    const double be = t * 0x1.921fb54442d18p-4, zz = be * be;
+    const ptmi_dev_d2 b = draw_table<TM>(smem, off, 32u + j);
+    const double be = t * 0x1.921fb54442d18p-3, zz = be * be;
     double ps = 0x1.71de3a556c734p-19;                  // 1/9!
     ps = __builtin_fma(ps, zz, -0x1.a01a01a01a01ap-13); // -1/7!
     ps = __builtin_fma(ps, zz, 0x1.1111111111111p-7);   // 1/5!
@@ -268,7 +286,7 @@ __device__ __forceinline__ void unit_sincos(u32 j, double t, double &sn, double 
     sn = __builtin_fma(b.x, sb, b.y * cb);
 }
 
-// Box-Muller, cos branch
+// Box-Muller, cos branch, by the generic functions (the gradient jumps' momenta: ptmi_gj.inc.h draws its own pairs)
 __device__ __forceinline__ double det_normal(u64 w0, u64 w1)
 {
     return det_sqrt(-2.0 * det_log(w2uniform_open(w0))) * det_cos2pi(w2uniform(w1));

@@ -346,15 +346,17 @@ struct DrawBatch {
         else if constexpr (sizeof(T) == 8) return (T)(by == 2 ? dpp64<0x4E>((u64)v) : dpp64<0x39>((u64)v));   // quad_perm [2,3,0,1] / [1,2,3,0]
         else return (T)(by == 2 ? dpp32<0x4E>((u32)v) : dpp32<0x39>((u32)v));
     }
-    __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl)
+    // TM: where the draw tables are read (draw_table); tsm: the block's LDS, tables at a.tab_off
+    template <int TM>
+    __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl, const double *tsm)
     {
         const int j = gl & 3;
         philox_words(a.seed, (u64)(it + (j >> 1)), sid, (u32)(j & 1), w0, w1);
-        lg = unit_log((j & 1) ? w0 : w1);                   // both uniforms are (0,1] ones
+        lg = unit_log<TM>((j & 1) ? w0 : w1, tsm, a.tab_off);   // both uniforms are (0,1] ones
         u32 aj;
         double at, sn, cs;
         unit_angle32((u32)w1, aj, at);
-        unit_sincos(aj, at, sn, cs);
+        unit_sincos<TM>(aj, at, sn, cs, tsm, a.tab_off);
         z = det_sqrt(-2.0 * lg) * cs;                       // meaningful on the odd lanes
     }
     __device__ __forceinline__ void advance()
@@ -382,10 +384,11 @@ struct DrawBatch {
     }
 };
 // Steps k = 0, 1, ... of a launch that starts at iteration iter0: keep the batch current for step k.
-template <bool STR, bool FULL>
-__device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, const KArgs &a, int k, u32 sid, u32 sid0, int gl)
+template <bool STR, bool FULL, int TM = 0>
+__device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, const KArgs &a, int k, u32 sid, u32 sid0, int gl,
+                                               const double *tsm = nullptr)
 {
-    if ((k & 1) == 0) b.refill(a, a.iter0 + k, sid, gl);
+    if ((k & 1) == 0) b.template refill<TM>(a, a.iter0 + k, sid, gl, tsm);
     else b.advance();
     const bool walker = FULL && a.pick_walker;
     if (walker) {
@@ -395,13 +398,9 @@ __device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, con
     b.take(dr, walker);
 }
 
-#ifndef PTMI_AMV
-#define PTMI_AMV 1
-#endif
 // One matrix instruction whose accumulator is pinned to the accumulation registers.  With __builtin_amdgcn_mfma_* in a
 // ROLLED loop hipcc keeps the loop-carried accumulators in VGPRs and moves all of them to AGPRs and back on every trip
-// (2 x 56 v_accvgpr moves per Box-Muller pair, and the reads back wait until the matrix pipe has drained, so nothing of
-// the next pair's draw overlaps the products); an asm operand of class "a" stays where it is.  hipcc pads no hazards
+// (2 x 56 v_accvgpr moves per Box-Muller pair); an asm operand of class "a" stays where it is.  hipcc pads no hazards
 // of an asm statement: the chain through C needs no wait state, the first vector read of the result does (mfma_acc_settle).
 // GUARD: an operand may have been written by the vector pipe just before (the weight ahead of the first product of a
 // k-step; a table value selected against its bounds): two wait states inside the statement.
@@ -430,15 +429,16 @@ __device__ __forceinline__ void mfma_acc_settle(ptmi_d4 (&t)[NT])
 
 // The AM increment U (cd sqrt(S) z) (PT:879-933) of the 16 chains in the columns of the wave, on the matrix cores (strided
 // layout: lane (c16, g4) draws the weights of directions k = g4 + 4e of column c16's chain).  The weights of two k-steps come
-// out of one Box-Muller and go straight into the two accumulation steps -- no weight array is kept.  Software pipeline,
-// hand placed: the 2 NT matrix instructions of pair e are issued with one Philox round of pair e + 2 behind each (a matrix
-// instruction holds its pipe for 64 cycles, the integer work of the next draw hides there); the double-precision half of
-// the draw (log, sqrt, sincos: it shares the pipe with the matrix instructions, tools/dp_share.hip) follows.
-// The accumulation order (k ascending) is that of mfma_tab_vec.
+// out of one Box-Muller and go straight into the two accumulation steps -- no weight array is kept.  Nothing overlaps an
+// f64 matrix instruction on its SIMD (tools/inst_rates.hip: 64 cycles + the full issue cost of whatever sits between two
+// of them, integer or double, one wave or two), so the cost of a pair is the plain sum of generator, draw and 2 NT matrix
+// instructions and only fewer instructions help: table-driven draws (ptmi_device.h unit_log / unit_sincos) and no
+// accumulator traffic.  The accumulation order (k ascending) is that of mfma_tab_vec.
 // active / sid / it / cd are the column's: the chain's own (propose) or those of a queued AM event (mh_steps_kernel).
 template <int EPL>
 __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32 sid, long long it, double cd, int ng,
-                                                const double *Ut, bool ut_padded, int uld, const double *S, bool s_sqrt, MfmaAcc<EPL> &acc)
+                                                const double *Ut, bool ut_padded, int uld, const double *S, bool s_sqrt, MfmaAcc<EPL> &acc,
+                                                const double *tsm = nullptr)
 {
     constexpr int G = 4, NT = MfmaAcc<EPL>::NT;
     const int d = a.d;
@@ -449,11 +449,12 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
     auto draw_f64 = [&](int e, u64 e0, u64 e1, double &wa, double &wb) {
         const int k = g4 + G * e;
         const bool on = active && k < ng, on2 = on && e + 1 < EPL && k + G < ng;
-        const double r = det_sqrt(-2.0 * unit_log(e0));
+        const double r = det_sqrt(-2.0 * (tsm ? unit_log<2>(e0, tsm, a.tab_off) : unit_log<0>(e0)));
         u32 aj;
         double at, sn, cs;
         unit_angle64(e1, aj, at);
-        unit_sincos(aj, at, sn, cs);
+        if (tsm) unit_sincos<2>(aj, at, sn, cs, tsm, a.tab_off);
+        else unit_sincos<0>(aj, at, sn, cs);
         const double va = (r * cs) * cd * root_s(on ? k : 0);          // PT:930
         const double vb = (r * sn) * cd * root_s(on2 ? k + G : 0);
         wa = on ? va : 0.0;
@@ -479,7 +480,8 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
             for (int t = 0; t < NT; ++t) mfma_f64_acc<true>(acc.t[t], tt[t], w);
         }
     };
-#if PTMI_AMV == 1
+    // -DPTMI_AM_PROFILE: shader-clock counts of the pieces, printed by the first wave (13 pairs at d = 100; measured:
+    // generator 4.3 k cycles, double-precision half of the draws 13.0 k before the tables, matrix instructions 12.9 k)
 #ifdef PTMI_AM_PROFILE
     unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0, t1;
 #define PTMI_STAMP(i) t1 = __builtin_readcyclecounter(); tp[i] += t1 - t0; t0 = t1;
@@ -512,49 +514,6 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
     if (blockIdx.x == 0 && threadIdx.x == 0 && it % 64 == 0)
         printf("am profile it %lld: philox+rows %llu  f64 %llu  mfmaA %llu  mfmaB %llu  settle %llu cycles (13 pairs)\n", it, tp[0], tp[1], tp[2], tp[3], tp[4]);
 #endif
-#else
-    PhiloxState ps;
-    u64 e0, e1;
-    double wa, wb, ta[NT], tb[NT];
-    rows(g4, ta);
-    philox_begin(ps, a.seed, (u64)it, sid, SLOT_AM + (u32)g4);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) philox_round(ps);
-    philox_end(ps, e0, e1);
-    draw_f64(0, e0, e1, wa, wb);
-    mfma_acc_begin<NT>(acc.t);
-    // a ROLLED loop over the pairs: unrolled, the thirteen Box-Muller bodies alone are half of the kernel's code and
-    // the kernel outgrows the instruction cache
-#pragma unroll 1
-    for (int e = 0; e < esteps; e += 2) {
-        const bool second = e + 1 < esteps, more = e + 2 < esteps;
-        rows(4 * (second ? e + 1 : e) + g4, tb);
-        philox_begin(ps, a.seed, (u64)it, sid, SLOT_AM + (u32)(g4 + G * (e + 2)));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            mfma_f64_acc<true>(acc.t[t], ta[t], wa);
-            if (t < 10) philox_round(ps);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        rows(4 * (more ? e + 2 : e) + g4, ta);             // the next pair's first row block, behind the products that read this one
-        __builtin_amdgcn_sched_barrier(0);
-        if (second) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                mfma_f64_acc<true>(acc.t[t], tb[t], wb);
-                if (NT + t < 10) philox_round(ps);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (more) {                                        // more implies second
-#pragma unroll
-            for (int r = 2 * NT; r < 10; ++r) philox_round(ps);
-            philox_end(ps, e0, e1);
-            draw_f64(e + 2, e0, e1, wa, wb);
-        }
-    }
-#endif
     mfma_acc_settle<NT>(acc.t);
 }
 
@@ -568,7 +527,7 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
 template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, const Draws &dr,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
-                                       double (&dq)[EPL], bool s_sqrt = false, bool am_here = true)
+                                       double (&dq)[EPL], bool s_sqrt = false, bool am_here = true, const double *tsm = nullptr)
 {
     // s_sqrt: S holds sqrt(eigenvalue) already (the block's LDS copy; sqrt is correctly rounded, so the bits are the same)
     auto root_s = [&](int k) { const double v = S[k]; return s_sqrt ? v : det_sqrt(v); };
@@ -661,11 +620,11 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
                 if (is_am && k < ng) {
                     u64 e0, e1;
                     philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)k, e0, e1);
-                    const double r = det_sqrt(-2.0 * unit_log(e0));
+                    const double r = det_sqrt(-2.0 * unit_log<0>(e0));
                     u32 aj;
                     double at, sn, cs;
                     unit_angle64(e1, aj, at);
-                    unit_sincos(aj, at, sn, cs);
+                    unit_sincos<0>(aj, at, sn, cs);
                     wa = (r * cs) * cd * root_s(k);                             // PT:930
                     if (e + 1 < EPL && k + G < ng) wb = (r * sn) * cd * root_s(k + G);
                 }
@@ -673,7 +632,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
             if (STR) {
                 if constexpr (G == 4) {
                     MfmaAcc<EPL> acc;
-                    am_mfma_product<EPL>(a, is_am, sid, it, cd, ng, Ut, ut_padded, uld, S, s_sqrt, acc);
+                    am_mfma_product<EPL>(a, is_am, sid, it, cd, ng, Ut, ut_padded, uld, S, s_sqrt, acc, tsm);
                     if (is_am) {
 #pragma unroll
                         for (int e = 0; e < EPL; ++e) dq[e] = acc.at(e);
@@ -735,6 +694,10 @@ template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS =
 __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
 {
     static_assert(!ULDS || (!STAGE && !FULL && !GRP), "ULDS is the SCAM-only contiguous-layout kernel");
+    // the draw tables (ptmi_tables.h, 1 KB): the staged full kernels read them from an LDS copy when the host found room
+    // (a.tab_off >= 0: 13.0 instead of 14.1 ms per 100 steps of the default mix); the SCAM-only kernels from global memory --
+    // measured in the ULDS kernel: 1.14 ms per 100 steps from global, 1.20 from LDS, whose pipe serves the direction rows
+    constexpr int TM = (STAGE && FULL) ? 2 : 0;
     constexpr int BLK = 256;
     constexpr int CPB = BLK / G;
     constexpr bool STR = STAGE;
@@ -771,6 +734,8 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     // with the dense likelihood both tables may not fit: then Ut stays in global memory (host decides, a.lds_u)
     constexpr bool UT_ALWAYS_LDS = LOGL != PTMI_LOGL_DENSE;
     const double *UtBlock = Ut;
+    const double *const tsm = TM ? smem : nullptr;
+    if (TM) draw_table_fill(smem, a.tab_off, BLK);
     if (STAGE) {
         if (LOGL == PTMI_LOGL_DENSE) {
             for (int i = (int)threadIdx.x; i < tab_n; i += BLK) {
@@ -884,8 +849,8 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
                     const double cd_ev = of_cur ? cdc : cdn;
                     const long long it_ev = a.iter0 + (k - s4) + (of_cur ? 0 : 4) + (owner >> 4);
                     MfmaAcc<EPL> acc;
-                    if (UT_ALWAYS_LDS || a.lds_u) am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_UL, true, mfma_ld(EPL), PTMI_SQ, true, acc);
-                    else am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, UtBlock, false, d, PTMI_SQ, true, acc);
+                    if (UT_ALWAYS_LDS || a.lds_u) am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_UL, true, mfma_ld(EPL), PTMI_SQ, true, acc, tsm);
+                    else am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, UtBlock, false, d, PTMI_SQ, true, acc, tsm);
                     if (valid) {
 #pragma unroll
                         for (int e = 0; e < EPL; ++e) PTMI_AMQ(r & 15)[gl * EPL + e] = acc.at(e);
@@ -896,13 +861,13 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             }
         }
         Draws dr;
-        draws_for_step<STR, FULL>(batch, dr, a, k, sid, sid0, gl);
+        draws_for_step<STR, FULL, TM>(batch, dr, a, k, sid, sid0, gl, tsm);
         const double log_u = dr.log_u;
         int jt;
         if (ULDS && ulds_box) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, S, DE, dq, false);
         else if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
-        else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true, !amq_on);
-        else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true, !amq_on);
+        else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true, !amq_on, tsm);
+        else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true, !amq_on, tsm);
         else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
         if constexpr (AMQ) {
             // the rank of this chain's event of this step is held by its lane of row (k & 3)
@@ -1253,6 +1218,8 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     constexpr bool WANTS = G == 4 && (FULL || LOGL == PTMI_LOGL_DENSE);   // the tables fit only for the small-ndim shapes
     a.lds_u = 0;
     a.box_off = -1;
+    a.tab_off = -1;
+    constexpr size_t DRAWT = sizeof(double) * 128;           // the draw tables (ptmi_tables.h), copied behind the other tables where they fit
     // box prior: the bounds table goes behind the variant's other LDS tables when it still fits (else global reads)
     const size_t box_bytes = c.logp_kind == PTMI_LOGP_BOX ? sizeof(double) * box_table_doubles(G, EPL) : 0;
     auto even = [](size_t doubles) { return (doubles + 1) & ~(size_t)1; };
@@ -1304,6 +1271,10 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 a.box_off = (int)even(lds / sizeof(double));
                 lds = sizeof(double) * (size_t)a.box_off + box_bytes;
             }
+            if (FULL && sizeof(double) * even(lds / sizeof(double)) + DRAWT <= 160 * 1024) {
+                a.tab_off = (int)even(lds / sizeof(double));
+                lds = sizeof(double) * (size_t)a.tab_off + DRAWT;
+            }
             auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, true, false>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1311,7 +1282,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, h->stream, a);
             h->last_variant = PTMI_VAR_STAGED | (FULL ? PTMI_VAR_FULL : 0) | (a.lds_u ? PTMI_VAR_LDS_UT : 0) | (a.amq_on ? PTMI_VAR_AMQ : 0) |
-                              (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
+                              (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | (a.tab_off >= 0 ? PTMI_VAR_LDS_DRAWT : 0);
             return PTMI_OK;
         }
     }

@@ -415,7 +415,7 @@ class PTEngine(object):
         """Flags of the fused-kernel instantiation the last ``mh_steps`` launched (``_lib.VAR_*``), lanes, slots."""
         v = C.c_int32(0)
         _lib.check(self.lib.ptmi_last_mh_variant(self.h, C.byref(v)))
-        return v.value & 0xFF, (v.value >> 8) & 0xFF, (v.value >> 16) & 0xFF
+        return v.value & 0xFFF, (v.value >> 12) & 0xFF, (v.value >> 20) & 0xFF
 
     def swap(self, it):
         """PT swap of iteration ``it`` with the whole ladder on this GPU (:631-697)."""

@@ -64,6 +64,7 @@ def test_iso_default_mix_pooled_runs_staged(mods):
     flags, G, E = g.last_variant()
     assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and flags & _lib.VAR_LDS_UT
     assert flags & _lib.VAR_AMQ                                # per-chain picks, a third of them AM: increments through the queue
+    assert flags & _lib.VAR_LDS_DRAWT                          # the draws' tables sit behind the queue in LDS
     _compare(g, o, "mix ")
     assert o.jstat[..., 2, 0].sum() > 0
 

@@ -63,7 +63,7 @@ def test_device_math_is_bit_identical_to_oracle(mods):
     assert_same(got, [O.orc_normal(int(p), int(q)) for p, q in w], "normal")
     # the table-driven draws of the MH path: ln of the (0,1] uniform of a word, cos / sin of the angle of a word, the SCAM normal
     import ctypes as C
-    ww = np.concatenate([w.reshape(-1), np.array([0, 2 ** 64 - 1, 2 ** 11, (2 ** 53 - 1) << 11, (2 ** 53 - 2) << 11, 2 ** 58 - 1, 2 ** 58], dtype=np.uint64),
+    ww = np.concatenate([w.reshape(-1), np.array([0, 2 ** 64 - 1, 2 ** 11, (2 ** 53 - 1) << 11, (2 ** 53 - 2) << 11, 2 ** 59 - 1, 2 ** 59, 2 ** 58], dtype=np.uint64),
                          (np.uint64(2 ** 53 - 1) - np.arange(1, 3000, dtype=np.uint64)) << np.uint64(11)])
     assert_same(dev(10, ww.view(np.float64)), [O.orc_unit_log(int(v)) for v in ww], "unit_log")
     sn, cs = C.c_double(), C.c_double()
