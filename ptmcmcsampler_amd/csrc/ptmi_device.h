@@ -231,17 +231,24 @@ __device__ __forceinline__ void draw_table_fill(double *smem, int off, int nthre
 // ln = k ln2 + logc + log1p(r), log1p by its Taylor polynomial to r^9 (next term < 6e-18 r).  The slice around z = 1 has
 // invc = 1, logc = 0: a u just below 1 gives r < 0 exactly and a result that is never positive.  About 25 instructions,
 // no division, no special case (det_log: about 60 with the conversion).  Oracle: orc_unit_log.
-template <int TM = 0>
-__device__ __forceinline__ double unit_log(u64 w, const double *smem = nullptr, int off = -1)
+// In three pieces so that a caller can put the table reads first and the work that does not need them behind
+// (DrawBatch::refill: from global memory a read takes a few hundred cycles).
+struct UnitLogArg { double z; int k; u32 slice; };
+__device__ __forceinline__ UnitLogArg unit_log_arg(u64 w)
 {
     const u64 n = (w >> 11) + 1ull;
     const double x = __builtin_fma((double)(u32)(n >> 32), 0x1.0p32, (double)(u32)n);      // exact: n <= 2^53
     const u64 xb = (u64)__double_as_longlong(x);
     const u32 hi = (u32)(xb >> 32), tmp = hi - 0x3FE64000u;
-    const int k = ((int)tmp >> 20) - 53;
-    const ptmi_dev_d2 e = draw_table<TM>(smem, off, (tmp >> 15) & 31u);
-    const double z = __longlong_as_double((long long)(((u64)(hi - (tmp & 0xFFF00000u)) << 32) | (u32)xb));
-    const double r = __builtin_fma(z, e.x, -1.0);
+    UnitLogArg g;
+    g.k = ((int)tmp >> 20) - 53;
+    g.slice = (tmp >> 15) & 31u;
+    g.z = __longlong_as_double((long long)(((u64)(hi - (tmp & 0xFFF00000u)) << 32) | (u32)xb));
+    return g;
+}
+__device__ __forceinline__ double unit_log_finish(const UnitLogArg &g, ptmi_dev_d2 e)
+{
+    const double r = __builtin_fma(g.z, e.x, -1.0);
     double p = 0x1.c71c71c71c71cp-4;                    // +1/9
     p = __builtin_fma(p, r, -0x1.0p-3);                 // -1/8
     p = __builtin_fma(p, r, 0x1.2492492492492p-3);      // +1/7
@@ -251,7 +258,13 @@ __device__ __forceinline__ double unit_log(u64 w, const double *smem = nullptr, 
     p = __builtin_fma(p, r, 0x1.5555555555555p-2);      // +1/3
     p = __builtin_fma(p, r, -0x1.0p-1);                 // -1/2
     const double l1 = __builtin_fma(r * r, p, r);
-    return __builtin_fma((double)k, 0x1.62e42fefa39efp-1, e.y) + l1;
+    return __builtin_fma((double)g.k, 0x1.62e42fefa39efp-1, e.y) + l1;
+}
+template <int TM = 0>
+__device__ __forceinline__ double unit_log(u64 w, const double *smem = nullptr, int off = -1)
+{
+    const UnitLogArg g = unit_log_arg(w);
+    return unit_log_finish(g, draw_table<TM>(smem, off, g.slice));
 }
 // The Box-Muller angle: 2 pi (j + 1/2 + t) / 32, j the top 5 bits of the word, t in [-1/2, 1/2) from the bits below them
 __device__ __forceinline__ void unit_angle64(u64 w, u32 &j, double &t)
@@ -267,23 +280,30 @@ __device__ __forceinline__ void unit_angle32(u32 h, u32 &j, double &t)
 }
 // cos and sin of that angle: the base angle's pair from the table (exactly mirrored over the octants), rotated by
 // beta = 2 pi t / 32 (|beta| <= pi/32: sin to beta^9, cos to beta^8, next terms < 3e-17).  Oracle: orc_unit_sincos*.
-template <int TM = 0>
-__device__ __forceinline__ void unit_sincos(u32 j, double t, double &sn, double &cs, const double *smem = nullptr, int off = -1)
+__device__ __forceinline__ void unit_rotation(double t, double &sb, double &cb)      // sin and cos of beta: no table
 {
-    const ptmi_dev_d2 b = draw_table<TM>(smem, off, 32u + j);
     const double be = t * 0x1.921fb54442d18p-3, zz = be * be;
     double ps = 0x1.71de3a556c734p-19;                  // 1/9!
     ps = __builtin_fma(ps, zz, -0x1.a01a01a01a01ap-13); // -1/7!
     ps = __builtin_fma(ps, zz, 0x1.1111111111111p-7);   // 1/5!
     ps = __builtin_fma(ps, zz, -0x1.5555555555555p-3);  // -1/3!
-    const double sb = __builtin_fma(be * zz, ps, be);
+    sb = __builtin_fma(be * zz, ps, be);
     double pc = 0x1.a01a01a01a01ap-16;                  // 1/8!
     pc = __builtin_fma(pc, zz, -0x1.6c16c16c16c17p-10); // -1/6!
     pc = __builtin_fma(pc, zz, 0x1.5555555555555p-5);   // 1/4!
     pc = __builtin_fma(pc, zz, -0x1.0p-1);              // -1/2!
-    const double cb = __builtin_fma(zz, pc, 1.0);
-    cs = __builtin_fma(-b.y, sb, b.x * cb);
-    sn = __builtin_fma(b.x, sb, b.y * cb);
+    cb = __builtin_fma(zz, pc, 1.0);
+}
+__device__ __forceinline__ double unit_cos_finish(ptmi_dev_d2 b, double sb, double cb) { return __builtin_fma(-b.y, sb, b.x * cb); }
+__device__ __forceinline__ double unit_sin_finish(ptmi_dev_d2 b, double sb, double cb) { return __builtin_fma(b.x, sb, b.y * cb); }
+template <int TM = 0>
+__device__ __forceinline__ void unit_sincos(u32 j, double t, double &sn, double &cs, const double *smem = nullptr, int off = -1)
+{
+    const ptmi_dev_d2 b = draw_table<TM>(smem, off, 32u + j);
+    double sb, cb;
+    unit_rotation(t, sb, cb);
+    cs = unit_cos_finish(b, sb, cb);
+    sn = unit_sin_finish(b, sb, cb);
 }
 
 // Box-Muller, cos branch, by the generic functions (the gradient jumps' momenta: ptmi_gj.inc.h draws its own pairs)

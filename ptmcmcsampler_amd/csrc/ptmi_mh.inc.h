@@ -352,12 +352,24 @@ struct DrawBatch {
     {
         const int j = gl & 3;
         philox_words(a.seed, (u64)(it + (j >> 1)), sid, (u32)(j & 1), w0, w1);
-        lg = unit_log<TM>((j & 1) ? w0 : w1, tsm, a.tab_off);   // both uniforms are (0,1] ones
         u32 aj;
-        double at, sn, cs;
+        double at;
         unit_angle32((u32)w1, aj, at);
-        unit_sincos<TM>(aj, at, sn, cs, tsm, a.tab_off);
-        z = det_sqrt(-2.0 * lg) * cs;                       // meaningful on the odd lanes
+        if constexpr (TM == 0) {
+            // global tables: both reads first, what does not need them behind (a read takes a few hundred cycles;
+            // config-2 kernel 1.145 -> 1.105 ms per 100 steps)
+            const UnitLogArg g = unit_log_arg((j & 1) ? w0 : w1);   // both uniforms are (0,1] ones
+            double sb, cb;
+            const ptmi_dev_d2 te = draw_table<0>(nullptr, -1, g.slice), tb = draw_table<0>(nullptr, -1, 32u + aj);
+            unit_rotation(at, sb, cb);
+            lg = unit_log_finish(g, te);
+            z = det_sqrt(-2.0 * lg) * unit_cos_finish(tb, sb, cb);  // meaningful on the odd lanes
+        } else {
+            double sn, cs;
+            lg = unit_log<TM>((j & 1) ? w0 : w1, tsm, a.tab_off);
+            unit_sincos<TM>(aj, at, sn, cs, tsm, a.tab_off);
+            z = det_sqrt(-2.0 * lg) * cs;
+        }
     }
     __device__ __forceinline__ void advance()
     {
@@ -449,6 +461,8 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
     auto draw_f64 = [&](int e, u64 e0, u64 e1, double &wa, double &wb) {
         const int k = g4 + G * e;
         const bool on = active && k < ng, on2 = on && e + 1 < EPL && k + G < ng;
+        // one function after the other: hoisting both table reads (as DrawBatch::refill does for the global tables) costs
+        // this loop registers and time (19.7 -> 20.7 ms per 100 AM steps)
         const double r = det_sqrt(-2.0 * (tsm ? unit_log<2>(e0, tsm, a.tab_off) : unit_log<0>(e0)));
         u32 aj;
         double at, sn, cs;
