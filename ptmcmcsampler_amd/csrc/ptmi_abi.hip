@@ -64,16 +64,29 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
 
 // parity >= 0 (odd/even mode): only the pairs with k = parity (mod 2) are tried; an untried pair never accepts, so
 // the carried state is always position k+1's own and the recurrence degenerates into independent pair tests.
+// STG: the tables the sweep writes are [walker][position] -- a lane per walker scatters 4-byte stores 4 n bytes apart, 64
+// memory transactions per store instruction, five of them per pair: 35 of the kernel's 63 us at 64 ranks.  So the block
+// (one wave = 64 walkers) keeps its walkers' tables and acceptance flags in LDS (rows of n + 1 ints: a lane per bank) and
+// writes them out at the end with the lanes along the position.  3 x 64 x (n + 1) ints: up to 207 ranks; longer ladders
+// take the direct stores (STG = false).
+template <bool STG>
 __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *pre, const int32_t *prow,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
                                   int parity, int32_t *inv /* with map: inv[w][map[w][j]] = j */)
 {
+    extern __shared__ int32_t sw_lds[];
     const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (w >= W) return;
     const size_t nW = (size_t)n * W;
     const bool fused = slot_of != nullptr;
-    int32_t *so = fused ? slot_of + (size_t)w * n : nullptr;
-    int32_t *to = fused ? temp_of + (size_t)w * n : nullptr;
+    const int ld = n + 1, lane = (int)threadIdx.x;
+    int32_t *const l0 = sw_lds + (size_t)lane * ld;                    // slot_of / map of this lane's walker
+    int32_t *const l1 = sw_lds + (size_t)(64 + lane) * ld;             // temp_of / inv
+    int32_t *const lf = sw_lds + (size_t)(128 + lane) * ld;            // pair k accepted
+    if (w < W) {
+    int32_t *so = fused ? (STG ? l0 : slot_of + (size_t)w * n) : nullptr;
+    int32_t *to = fused ? (STG ? l1 : temp_of + (size_t)w * n) : nullptr;
+    int32_t *mp = map ? (STG ? l0 : map + (size_t)w * n) : nullptr;
+    int32_t *iv = map ? (STG ? l1 : inv + (size_t)w * n) : nullptr;
     int c = n - 1;                         // position whose state is carried at k+1
     int crow = fused ? prow[(size_t)(n - 1) * W + w] : 0;
     double Lc = pre[nW + (size_t)(n - 1) * W + w];
@@ -108,7 +121,8 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
             const bool acc = (parity < 0 || (k & 1) == parity) && u <= det_exp(la);
             // position k+1 is final: it keeps the carried state, or takes position k's
             const int fin = acc ? k : c;
-            if (map) { map[(size_t)w * n + k + 1] = fin; inv[(size_t)w * n + fin] = k + 1; }
+            if (mp) { mp[k + 1] = fin; iv[fin] = k + 1; }
+            if (STG) lf[k] = acc ? 1 : 0;
             if (fused) {
                 const int frow = acc ? krow : crow;
                 so[k + 1] = frow;
@@ -117,17 +131,35 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
             }
             if (acc) {
                 // a no-return atomic: the recurrence must not wait for a load of the counter
-                if (k >= local0 && k < local0 + nlocal) atomicAdd((unsigned long long *)&nswap[(size_t)w * n + k], 1ull);
+                if (!STG && k >= local0 && k < local0 + nlocal) atomicAdd((unsigned long long *)&nswap[(size_t)w * n + k], 1ull);
             } else {
                 c = k;
                 Lc = La;
             }
         }
     }
-    if (map) { map[(size_t)w * n] = c; inv[(size_t)w * n + c] = 0; }
+    if (mp) { mp[0] = c; iv[c] = 0; }
     if (fused) {
         so[0] = crow;
         to[crow] = 0;
+    }
+    }
+    if (STG) {
+        __syncthreads();
+        const int w0 = (int)(blockIdx.x * blockDim.x);
+        int32_t *g0 = fused ? slot_of : map, *g1 = fused ? temp_of : inv;
+        const int nw = W - w0 < 64 ? W - w0 : 64;
+#pragma unroll 8
+        for (int wl = 0; wl < nw; ++wl) {                              // eight walkers' rows in flight
+            const size_t row = (size_t)(w0 + wl) * n;
+            for (int k = lane; k < n; k += 64) {
+                g0[row + k] = sw_lds[(size_t)wl * ld + k];
+                g1[row + k] = sw_lds[(size_t)(64 + wl) * ld + k];
+                // a no-return atomic: nothing here waits for a load of the counter
+                if (k < n - 1 && k >= local0 && k < local0 + nlocal && sw_lds[(size_t)(128 + wl) * ld + k])
+                    atomicAdd((unsigned long long *)&nswap[row + k], 1ull);
+            }
+        }
     }
 }
 
@@ -1051,6 +1083,25 @@ static int swap_parity(const ptmi_config &c, int64_t iter)
     return (int)((c.tskip > 0 ? iter / c.tskip : iter) & 1);
 }
 
+static int launch_swap_sweep(ptmi_engine *h, int W, int n, const double *pre, const int32_t *prow, int32_t *slot_of, int32_t *temp_of,
+                             int32_t *map, u64 *nswap, int local0, int nlocal, int parity, int32_t *inv)
+{
+    const size_t lds = sizeof(int32_t) * 3 * 64 * (size_t)(n + 1);
+    const dim3 grid((unsigned)((W + 63) / 64)), block(64);
+    if (lds <= 160 * 1024) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)swap_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(swap_sweep_kernel<true>, grid, block, lds, h->stream, W, n, h->d_ladder, pre, prow, slot_of, temp_of, map, nswap,
+                           local0, nlocal, parity, inv);
+    } else {
+        hipLaunchKernelGGL(swap_sweep_kernel<false>, grid, block, 0, h->stream, W, n, h->d_ladder, pre, prow, slot_of, temp_of, map, nswap,
+                           local0, nlocal, parity, inv);
+    }
+    return PTMI_OK;
+}
+
 int ptmi_swap(ptmi_handle h, int64_t iter)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
@@ -1073,9 +1124,8 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps, h->d_ladder,
                        (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, h->d_pre, h->d_prow,
                        (long long)iter, c.seed, c.walker0, 0);
-    hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps, h->d_ladder,
-                       (const double *)h->d_pre, (const int32_t *)h->d_prow, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr,
-                       (u64 *)h->buf.nswap, 0, c.ntemps, -1, (int32_t *)nullptr);
+    if (int rc = launch_swap_sweep(h, W, c.ntemps, (const double *)h->d_pre, (const int32_t *)h->d_prow, h->buf.slot_of, h->buf.temp_of,
+                                   (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1, (int32_t *)nullptr)) return rc;
     HIPCHK(hipGetLastError());
     return ptmi_swap_write_am(h, iter);
 }
@@ -1117,10 +1167,9 @@ static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t 
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global,
                        h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, h->d_pre, h->d_prow,
                        (long long)iter, c.seed, c.walker0, block_nt);
-    hipLaunchKernelGGL(swap_sweep_kernel, dim3((W + 63) / 64), dim3(64), 0, h->stream, W, c.ntemps_global, h->d_ladder,
-                       (const double *)h->d_pre, (const int32_t *)h->d_prow, (int32_t *)nullptr, (int32_t *)nullptr, map,
-                       (u64 *)h->buf.nswap, c.temp0, c.ntemps, c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1,
-                       h->d_xint /* inv[W][ntemps_global] */);
+    if (int rc = launch_swap_sweep(h, W, c.ntemps_global, (const double *)h->d_pre, (const int32_t *)h->d_prow, (int32_t *)nullptr,
+                                   (int32_t *)nullptr, map, (u64 *)h->buf.nswap, c.temp0, c.ntemps,
+                                   c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1, h->d_xint /* inv[W][ntemps_global] */)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
