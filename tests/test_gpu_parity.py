@@ -77,6 +77,24 @@ def test_device_math_is_bit_identical_to_oracle(mods):
     hh = (ww[:len(w)] & np.uint64(0xFFFFFFFF))
     assert_same(dev(13, hh.view(np.float64), ww[::-1][:len(w)].copy().view(np.float64)),
                 [O.orc_unit_normal32(int(q), int(h)) for h, q in zip(hh, ww[::-1][:len(w)])], "SCAM normal")
+    # ... and their distribution at a size the CPU tests do not reach: 4 M device normals of either kind, moments within
+    # five standard errors and a chi-square over 256 equiprobable bins
+    from scipy import stats
+    nbig = 1 << 22
+    big = rs.randint(0, 2 ** 63, size=(nbig, 2), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rs.randint(0, 2, size=(nbig, 2)).astype(np.uint64)
+    z_scam = dev(13, (big[:, 1] & np.uint64(0xFFFFFFFF)).view(np.float64), big[:, 0].copy().view(np.float64))
+    rad = np.sqrt(-2.0 * dev(10, big[:, 0].copy().view(np.float64)))
+    z_cos, z_sin = rad * dev(11, big[:, 1].copy().view(np.float64)), rad * dev(12, big[:, 1].copy().view(np.float64))
+    edges = stats.norm.ppf(np.arange(1, 256) / 256.0)
+    for name, z in (("SCAM", z_scam), ("AM cos", z_cos), ("AM sin", z_sin)):
+        assert np.isfinite(z).all(), name
+        se = 1.0 / np.sqrt(nbig)
+        assert abs(z.mean()) < 5 * se and abs(z.var() - 1) < 5 * np.sqrt(2.0) * se, name
+        assert abs((z ** 3).mean()) < 5 * np.sqrt(15.0) * se and abs((z ** 4).mean() - 3) < 5 * np.sqrt(96.0) * se, name
+        counts = np.bincount(np.searchsorted(edges, z), minlength=256)
+        chi2 = ((counts - nbig / 256.0) ** 2 / (nbig / 256.0)).sum()
+        assert stats.chi2.sf(chi2, 255) > 1e-4, (name, chi2)
+    assert abs(np.corrcoef(z_cos, z_sin)[0, 1]) < 5.0 / np.sqrt(nbig)
     # the 16-lane butterfly: every lane of a row gets the oracle's tree sum
     v = rs.randn(64 * 8)
     got = dev(6, v)
