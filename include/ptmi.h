@@ -159,8 +159,9 @@ int ptmi_lanes_for_grad(int ndim);
 int ptmi_temperature_ladder(int nchain, int ndim, double Tmin, double Tmax, double tstep, double *out);
 
 /* Row format of the DE buffer for a given ndim (grad != 0: with gradient jumps in the cycle): *stride doubles per row;
- * *epl == 0: a row holds the parameters in order (stride == ndim); *epl > 0 (4 lanes per chain): the row is lane-major,
- * row[lane * epl + e] = parameter lane + 4 e (zero past ndim), stride == 4 * epl -- a lane's share of a row is contiguous. */
+ * *epl == 0: a row holds the parameters in order (stride == ndim); *epl > 0 (4 lanes per chain, *epl slots per lane): the
+ * row is dealt to the lanes in 16-byte pieces, row[8 * (e / 2) + 2 * lane + e % 2] = parameter lane + 4 e (zero past ndim
+ * and for e >= *epl), stride == 8 * ((*epl + 1) / 2) -- one read instruction of the kernel takes 64 contiguous bytes per chain. */
 int ptmi_de_row_stride(int ndim, int grad, int *stride, int *epl);
 
 int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out);

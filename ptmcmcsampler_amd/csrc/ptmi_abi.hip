@@ -492,10 +492,12 @@ __global__ void pool_combine_kernel(const double *mu, const double *M2, double *
 }
 
 // DE history ring: rows [head, head+mem) are the oldest; overwrite them with the AM buffer.
-// Row layout (ptmi_de_row_stride): with 4 lanes per chain a row is stored LANE-MAJOR -- de[lane * epl + e] = element
-// lane + 4 e, zero where that is past ndim -- so that a lane's 26 values of a row are 208 contiguous bytes (13 loads of
-// 16 B); in element order the four lanes of a chain pulled 8 B each out of 26 x 32-B pieces of every row, and the 16
-// chains of a wave made every one of the 52 load instructions of a DE proposal touch 16 cache lines four times over.
+// Row layout (ptmi_de_row_stride): with 4 lanes per chain a row is stored in 16-byte PIECES dealt to the lanes in turn --
+// position 8 (e / 2) + 2 lane + e % 2 holds element lane + 4 e, zero where that is past ndim -- so that one read
+// instruction of a DE proposal takes 64 contiguous bytes per chain (16 cache lines per wave instruction, each used
+// again by the next instruction).  Round-2 history: in element order the four lanes pulled 8 B each out of 26 x 32-B
+// pieces (140 us per step of 262 144 chains); lane-major rows (a lane's 26 values contiguous, 208 B) made every
+// instruction touch 64 different lines and a piece straddle 2-3 of them (85 us).
 __global__ void de_update_kernel(double *DE, const double *AM, int d, int de_size, int mem, int head, int W, int pooled, int ld, int epl)
 {
     const int r = (int)blockIdx.x;   // new row index 0..mem-1 (or the tail when mem > de_size)
@@ -507,7 +509,11 @@ __global__ void de_update_kernel(double *DE, const double *AM, int d, int de_siz
     const double *src = AM + ((size_t)src_w * mem + r) * d;
     double *dst = DE + ((size_t)wc * de_size + phys) * ld;
     for (int j = (int)threadIdx.x; j < ld; j += (int)blockDim.x) {
-        const int i = epl ? (j / epl) + 4 * (j % epl) : j;            // element stored at position j
+        int i = j;                                                    // element stored at position j
+        if (epl) {
+            const int e = 2 * (j / 8) + (j & 1);
+            i = e < epl ? ((j & 7) >> 1) + 4 * e : d;
+        }
         dst[j] = i < d ? src[i] : 0.0;
     }
 }
@@ -755,7 +761,7 @@ static KArgs make_args(ptmi_engine *h)
     a.w_host = c.w_host; a.w_scam = c.w_scam; a.w_am = c.w_am; a.w_de = c.w_de; a.de_on = h->de_on; a.de_size = c.de_size; a.de_head = h->de_head;
     a.cov_update = c.cov_update; a.tskip = c.tskip; a.per_walker = c.cov_per_walker; a.logp_kind = c.logp_kind;
     a.pick_walker = c.pick_mode == PTMI_PICK_WALKER;
-    a.de_ld = h->G == 4 ? 4 * h->EPL : c.ndim;
+    a.de_ld = h->G == 4 ? 8 * ((h->EPL + 1) / 2) : c.ndim;
     a.w_nuts = c.w_nuts; a.w_hmc = c.w_hmc; a.gj_nburn = c.gj_nburn; a.hmc_min = c.hmc_min; a.hmc_max = c.hmc_max;
     a.nuts_maxdepth = c.nuts_maxdepth; a.hmc_eps = c.hmc_eps; a.nuts_delta = c.nuts_delta;
     a.gj_tab = h->d_gj_tab; a.gj = b.gj; a.gj_scr = h->d_gj_scr; a.gj_scal = h->d_gj_scal;
@@ -820,13 +826,13 @@ int ptmi_temperature_ladder(int nchain, int ndim, double Tmin, double Tmax, doub
     return PTMI_OK;
 }
 
-// doubles per row of the DE buffer and the lane-major block length (0 = rows in element order), see de_update_kernel
+// doubles per row of the DE buffer and the slots per lane of its piece-cyclic format (0 = rows in element order), see de_update_kernel
 int ptmi_de_row_stride(int ndim, int grad, int *stride, int *epl)
 {
     Shape s;
     if (!stride || !epl) return fail(PTMI_EINVAL, "NULL argument");
     if (!pick_shape(ndim, grad != 0, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported", ndim);
-    *stride = s.G == 4 ? 4 * s.EPL : ndim;
+    *stride = s.G == 4 ? 8 * ((s.EPL + 1) / 2) : ndim;
     *epl = s.G == 4 ? s.EPL : 0;
     return PTMI_OK;
 }
@@ -1416,7 +1422,7 @@ int ptmi_update_de(ptmi_handle h)
     const int wc = c.cov_per_walker ? c.nwalkers : 1;
     hipLaunchKernelGGL(de_update_kernel, dim3(c.cov_update, wc), dim3(64), 0, h->stream, h->buf.DE, (const double *)h->buf.AM,
                        c.ndim, c.de_size, c.cov_update, h->de_head, c.nwalkers, c.cov_per_walker ? 0 : 1,
-                       h->G == 4 ? 4 * h->EPL : c.ndim, h->G == 4 ? h->EPL : 0);
+                       h->G == 4 ? 8 * ((h->EPL + 1) / 2) : c.ndim, h->G == 4 ? h->EPL : 0);
     HIPCHK(hipGetLastError());
     const int adv = c.cov_update < c.de_size ? c.cov_update : c.de_size;
     h->de_head = (h->de_head + adv) % c.de_size;

@@ -42,7 +42,7 @@ struct KArgs {
     int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
     int cov_update, tskip, per_walker, logp_kind, ngroups;
     int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
-    int de_ld;                   // doubles per row of the DE buffer (lane-major rows of 4 * EPL with 4 lanes per chain, else ndim)
+    int de_ld;                   // doubles per row of the DE buffer (ptmi_de_row_stride: 8 * ceil(EPL / 2) with 4 lanes per chain, else ndim)
     int pick_walker;             // pick_mode WALKER: the cycle entry comes from the stream of the walker's rank 0
     int lds_u;                   // staged kernels: the block's Ut is copied to LDS (else read from global)
     int amq_off;                 // staged full kernels: offset (doubles, even) of the AM queue in the block's LDS (mh_steps_kernel)

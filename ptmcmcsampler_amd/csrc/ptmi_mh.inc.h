@@ -604,12 +604,26 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         else scale = w2uniform(dr.Q1) * 2.4 / a.gdiv[g] * cc.de_mul;  // PT:976
         const double *rm = DE + (size_t)((mm + (u32)a.de_head) % Bn) * a.de_ld;
         const double *rn = DE + (size_t)((nn + (u32)a.de_head) % Bn) * a.de_ld;
+        // G == 4: rows are stored in 16-byte pieces dealt to the four lanes in turn (ptmi_de_row_stride: piece 4 e2 + lane
+        // holds the lane's slots 2 e2 and 2 e2 + 1, pads are stored zeros), so one read instruction takes 64 contiguous
+        // bytes per chain and the next one the other half of the cache line.  ALL reads of both rows first, then the
+        // arithmetic: left to itself hipcc issued them six at a time with a wait behind each batch.
+        constexpr int EP2 = (EPL + 1) / 2;
+        double vmr[G == 4 ? 2 * EP2 : 1], vnr[G == 4 ? 2 * EP2 : 1];
+        if constexpr (G == 4) {
+            const ptmi_d2 *pm = reinterpret_cast<const ptmi_d2 *>(rm) + gl, *pn = reinterpret_cast<const ptmi_d2 *>(rn) + gl;
+#pragma unroll
+            for (int e2 = 0; e2 < EP2; ++e2) { const ptmi_d2 v = pm[4 * e2]; vmr[2 * e2] = v.x; vmr[2 * e2 + 1] = v.y; }
+#pragma unroll
+            for (int e2 = 0; e2 < EP2; ++e2) { const ptmi_d2 v = pn[4 * e2]; vnr[2 * e2] = v.x; vnr[2 * e2 + 1] = v.y; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             double vm, vn;
-            if (G == 4) {                              // lane-major rows: this lane's EPL values are contiguous, pads are stored zeros
-                vm = rm[gl * EPL + e];
-                vn = rn[gl * EPL + e];
+            if constexpr (G == 4) {
+                vm = vmr[e];
+                vn = vnr[e];
             } else {
                 PTMI_ROW_LOAD_S(PSAFE, vm, rm, e);
                 PTMI_ROW_LOAD_S(PSAFE, vn, rn, e);

@@ -227,7 +227,8 @@ class PTEngine(object):
         """Device array -> numpy (counters as uint64; DE rows in parameter order whatever their device format)."""
         a = self.t[name].cpu().numpy()
         if name == "DE" and self.de_epl:
-            pos = (np.arange(self.d) % 4) * self.de_epl + np.arange(self.d) // 4       # where parameter i sits in a lane-major row
+            lane, slot = np.arange(self.d) % 4, np.arange(self.d) // 4
+            pos = 8 * (slot // 2) + 2 * lane + slot % 2                # where parameter i sits in a row (ptmi_de_row_stride)
             return np.ascontiguousarray(a[..., pos])
         return a.view(np.uint64) if name in ("nacc", "jstat", "nswap") else a
 
