@@ -509,15 +509,18 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
         double ta[NT], tb[NT], wa, wb;
         u64 e0, e1;
         const bool second = e + 1 < esteps;
-        rows(4 * e + g4, ta);                              // both row blocks in flight during the draw
-        rows(4 * (second ? e + 1 : e) + g4, tb);
+        rows(4 * e + g4, ta);                              // both row blocks in flight during the draw (LDS table; the dense
+        if (ut_padded) rows(4 * (second ? e + 1 : e) + g4, tb);   // kernel reads the global table and has no registers for a second block)
         philox_words(a.seed, (u64)it, sid, SLOT_AM + (u32)(g4 + G * e), e0, e1);
         PTMI_STAMP(0)
         draw_f64(e, e0, e1, wa, wb);
         PTMI_STAMP(1)
         kstep(ta, wa);
         PTMI_STAMP(2)
-        if (second) kstep(tb, wb);
+        if (second) {
+            if (!ut_padded) rows(4 * e + 4 + g4, tb);
+            kstep(tb, wb);
+        }
         PTMI_STAMP(3)
     }
 #ifdef PTMI_AM_PROFILE
