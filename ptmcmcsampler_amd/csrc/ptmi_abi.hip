@@ -67,22 +67,24 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
 // STG: the tables the sweep writes are [walker][position] -- a lane per walker scatters 4-byte stores 4 n bytes apart, 64
 // memory transactions per store instruction, five of them per pair: 35 of the kernel's 63 us at 64 ranks.  So the block
 // (one wave = 64 walkers) keeps its walkers' tables and acceptance flags in LDS (rows of n + 1 ints: a lane per bank) and
-// writes them out at the end with the lanes along the position.  3 x 64 x (n + 1) ints: up to 207 ranks; longer ladders
-// take the direct stores (STG = false).
+// writes them out at the end with the lanes along the position.  3 x wpb x (n + 1) ints: 64 walkers per block up to 207
+// ranks, 32 / 16 / 8 for longer ladders (512 ranks of an 8-GPU ladder: 16); beyond that the direct stores (STG = false).
 template <bool STG>
 __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *pre, const int32_t *prow,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
-                                  int parity, int32_t *inv /* with map: inv[w][map[w][j]] = j */)
+                                  int parity, int32_t *inv /* with map: inv[w][map[w][j]] = j */,
+                                  int wpb /* walkers per block: 64, fewer when a long ladder's tables would not fit the LDS */)
 {
     extern __shared__ int32_t sw_lds[];
-    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int lane = (int)threadIdx.x;
+    const int w = (int)blockIdx.x * wpb + lane;
     const size_t nW = (size_t)n * W;
     const bool fused = slot_of != nullptr;
-    const int ld = n + 1, lane = (int)threadIdx.x;
+    const int ld = n + 1;
     int32_t *const l0 = sw_lds + (size_t)lane * ld;                    // slot_of / map of this lane's walker
-    int32_t *const l1 = sw_lds + (size_t)(64 + lane) * ld;             // temp_of / inv
-    int32_t *const lf = sw_lds + (size_t)(128 + lane) * ld;            // pair k accepted
-    if (w < W) {
+    int32_t *const l1 = sw_lds + (size_t)(wpb + lane) * ld;            // temp_of / inv
+    int32_t *const lf = sw_lds + (size_t)(2 * wpb + lane) * ld;        // pair k accepted
+    if (lane < wpb && w < W) {
     int32_t *so = fused ? (STG ? l0 : slot_of + (size_t)w * n) : nullptr;
     int32_t *to = fused ? (STG ? l1 : temp_of + (size_t)w * n) : nullptr;
     int32_t *mp = map ? (STG ? l0 : map + (size_t)w * n) : nullptr;
@@ -146,17 +148,17 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
     }
     if (STG) {
         __syncthreads();
-        const int w0 = (int)(blockIdx.x * blockDim.x);
+        const int w0 = (int)blockIdx.x * wpb;
         int32_t *g0 = fused ? slot_of : map, *g1 = fused ? temp_of : inv;
-        const int nw = W - w0 < 64 ? W - w0 : 64;
+        const int nw = W - w0 < wpb ? W - w0 : wpb;
 #pragma unroll 8
         for (int wl = 0; wl < nw; ++wl) {                              // eight walkers' rows in flight
             const size_t row = (size_t)(w0 + wl) * n;
             for (int k = lane; k < n; k += 64) {
                 g0[row + k] = sw_lds[(size_t)wl * ld + k];
-                g1[row + k] = sw_lds[(size_t)(64 + wl) * ld + k];
+                g1[row + k] = sw_lds[(size_t)(wpb + wl) * ld + k];
                 // a no-return atomic: nothing here waits for a load of the counter
-                if (k < n - 1 && k >= local0 && k < local0 + nlocal && sw_lds[(size_t)(128 + wl) * ld + k])
+                if (k < n - 1 && k >= local0 && k < local0 + nlocal && sw_lds[(size_t)(2 * wpb + wl) * ld + k])
                     atomicAdd((unsigned long long *)&nswap[row + k], 1ull);
             }
         }
@@ -1092,18 +1094,20 @@ static int swap_parity(const ptmi_config &c, int64_t iter)
 static int launch_swap_sweep(ptmi_engine *h, int W, int n, const double *pre, const int32_t *prow, int32_t *slot_of, int32_t *temp_of,
                              int32_t *map, u64 *nswap, int local0, int nlocal, int parity, int32_t *inv)
 {
-    const size_t lds = sizeof(int32_t) * 3 * 64 * (size_t)(n + 1);
-    const dim3 grid((unsigned)((W + 63) / 64)), block(64);
+    int wpb = 64;                                                      // 3 tables of wpb x (n + 1) ints must fit the CU's LDS
+    while (wpb > 8 && sizeof(int32_t) * 3 * (size_t)wpb * (size_t)(n + 1) > 160 * 1024) wpb /= 2;
+    const size_t lds = sizeof(int32_t) * 3 * (size_t)wpb * (size_t)(n + 1);
+    const dim3 block(64);
     if (lds <= 160 * 1024) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)swap_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(swap_sweep_kernel<true>, grid, block, lds, h->stream, W, n, h->d_ladder, pre, prow, slot_of, temp_of, map, nswap,
-                           local0, nlocal, parity, inv);
+        hipLaunchKernelGGL(swap_sweep_kernel<true>, dim3((unsigned)((W + wpb - 1) / wpb)), block, lds, h->stream, W, n, h->d_ladder, pre, prow,
+                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, wpb);
     } else {
-        hipLaunchKernelGGL(swap_sweep_kernel<false>, grid, block, 0, h->stream, W, n, h->d_ladder, pre, prow, slot_of, temp_of, map, nswap,
-                           local0, nlocal, parity, inv);
+        hipLaunchKernelGGL(swap_sweep_kernel<false>, dim3((unsigned)((W + 63) / 64)), block, 0, h->stream, W, n, h->d_ladder, pre, prow,
+                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, 64);
     }
     return PTMI_OK;
 }

@@ -318,7 +318,8 @@ def test_full_size_properties_and_subset_parity(mods):
         assert_same(g.get("nswap")[w0], o.nswap[0], "walker %d nswap" % w0)
 
 
-@pytest.mark.parametrize("d,nt,W", [(1, 1, 1), (2, 1, 3), (3, 2, 1), (7, 5, 13), (33, 3, 11), (104, 2, 9), (105, 2, 5), (417, 2, 2), (641, 2, 2), (1025, 2, 2)])
+@pytest.mark.parametrize("d,nt,W", [(1, 1, 1), (2, 1, 3), (3, 2, 1), (7, 5, 13), (33, 3, 11), (104, 2, 9), (105, 2, 5), (417, 2, 2), (641, 2, 2), (1025, 2, 2),
+                                    (3, 300, 5), (2, 520, 37)])     # long ladders: the swap sweep stages fewer walkers per block
 def test_ragged_and_boundary_sizes(mods, d, nt, W):
     """Sizes that do not fill a block or a shape: one dimension, one temperature (no swaps), chain counts that
     are not multiples of the block, the last ndim of the 4-lane shapes (104) and the first of the next ones."""

@@ -54,7 +54,7 @@ def test_sharded_world1_equals_single_engine_and_oracle(world1, cov_mode):
     assert s.swap_proposed == g.swap_proposed == n // 10
 
 
-@pytest.mark.parametrize("nranks,cov_mode,ntb", [(2, "per_walker", 3), (4, "pooled", 3), (8, "per_walker", 3), (2, "pooled", 70)])
+@pytest.mark.parametrize("nranks,cov_mode,ntb", [(2, "per_walker", 3), (4, "pooled", 3), (8, "per_walker", 3), (2, "pooled", 70), (4, "pooled", 70)])
 def test_device_exchange_with_emulated_ranks(nranks, cov_mode, ntb):
     """Several temperature blocks on ONE GPU (one thread per rank, in-process communicator): the device-side
     exchange (ptmi_swap_sweep_blocks / ptmi_exchange_pack / ptmi_exchange_apply) must reproduce the single-engine
@@ -113,8 +113,10 @@ def test_device_exchange_with_emulated_ranks(nranks, cov_mode, ntb):
     # with three-rank blocks some sweep carried a row across a whole block (the all-to-all fallback)
     hops = {e.neighbour_swaps for e in engines}
     assert len(hops) == 1 and 0 <= engines[0].neighbour_swaps <= n // 10
-    if nranks == 2 or ntb >= 64:
-        assert engines[0].neighbour_swaps == n // 10          # two blocks have no one but each other; 70 ranks are never crossed whole
+    if nranks == 2:
+        assert engines[0].neighbour_swaps == n // 10          # two blocks have no one but each other
+    # (4 x 70 ranks at d = 4: the ladder's hot end is flat, every pair there accepts and the carried state crosses whole
+    # blocks -- all epochs take the all-to-all; the case is here for the 280-rank sweep, 32 walkers per block)
     if ntb == 3 and nranks >= 4:
         assert engines[0].neighbour_swaps < n // 10           # 33 walkers on three-rank blocks: some sweep always crosses one
 
