@@ -69,6 +69,9 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
 // (one wave = 64 walkers) keeps its walkers' tables and acceptance flags in LDS (rows of n + 1 ints: a lane per bank) and
 // writes them out at the end with the lanes along the position.  3 x wpb x (n + 1) ints: 64 walkers per block up to 207
 // ranks, 32 / 16 / 8 for longer ladders (512 ranks of an 8-GPU ladder: 16); beyond that the direct stores (STG = false).
+#ifndef PTMI_SWEEP_BATCH
+#define PTMI_SWEEP_BATCH 8
+#endif
 template <bool STG>
 __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *pre, const int32_t *prow,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
@@ -93,8 +96,10 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
     int crow = fused ? prow[(size_t)(n - 1) * W + w] : 0;
     double Lc = pre[nW + (size_t)(n - 1) * W + w];
     // Only Lc is carried from pair to pair: the scratch of SW pairs is fetched at once (independent loads, one HBM / L2
-    // latency per SW pairs instead of one per pair), then the SW dependent steps run from registers.
-    constexpr int SW = 8;
+    // latency per SW pairs instead of one per pair), then the SW dependent steps run from registers.  Batches of 2, 4
+    // and 8 pairs take the same time (the kernel is bound by the ~130 instructions of a pair on a lone wave, three
+    // divisions among them: 0.65 us per pair), 16 and 32 are slower (-DPTMI_SWEEP_BATCH).
+    constexpr int SW = PTMI_SWEEP_BATCH;
     for (int k0 = n - 2; k0 >= 0; k0 -= SW) {
         double pu[SW], pL[SW], pa[SW], pb[SW], pT[SW + 1];
         int pr[SW];
