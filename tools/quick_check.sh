@@ -1,3 +1,5 @@
+# GPU tests + the six kernel timings watched while tuning (developer tool): gpurun --timeout 1500 -- 'bash tools/quick_check.sh'
+# prints updates/s and the average MH launch (100 steps) in ms per workload
 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|error" | tail -3
 B="python bench.py --no-cpu-baseline"
 run() { name=$1; shift; $B "$@" 2>/dev/null | python -c "
