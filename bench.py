@@ -63,7 +63,10 @@ def parse():
                          "iteration) instead of inside the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100000, help="iterations per usable host core of the CPU baseline (10-30 s)")
-    ap.add_argument("--ess-walkers", type=int, default=64)
+    ap.add_argument("--ess-walkers", type=int, default=16, help="walkers whose T=1 chains the autocorrelation time is estimated from")
+    ap.add_argument("--ess-burn", type=int, default=40000, help="the ESS window starts at this iteration at the earliest (adaptation settled)")
+    ap.add_argument("--ess-window", type=int, default=80000, help="iterations of the ESS window, run AFTER the timed region (0 = no ESS)")
+    ap.add_argument("--ess-max-seconds", type=float, default=60.0, help="the ESS leg is shortened to fit this (flagged when < 50 tau)")
     return ap.parse_args()
 
 
@@ -229,29 +232,77 @@ def main():
         events.append((e0, e1, 1 if a.callback else rest[0]))
 
     setattr(eng, hot, timed_mh)
-    cold = ColdSamples(eng, min(a.ess_walkers, W) if eng.owns_cold else 0)
     orig_cov = eng.update_cov
     n_cov = [0]
 
-    def cov_and_keep(it_done):
-        cold.snap(it_done)                      # device-side copy of a few walkers' cold samples, before the ring wraps
+    def cov_and_count(it_done):
         n_cov[0] += 1
         orig_cov(it_done)
 
-    eng.update_cov = cov_and_keep
+    eng.update_cov = cov_and_count
     t0 = time.perf_counter()
     eng.run(it_timed)
     fence()
     wall = time.perf_counter() - t0
     setattr(eng, hot, orig)
     eng.update_cov = orig_cov
-    cold.snap(it_warm + it_timed)
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
     log("timed region %.3f s (%d iterations, %d covariance epochs)" % (wall, it_timed, n_cov[0]))
 
+    # ---- ESS leg, OUTSIDE the timed wall.  ESS/sec = (walkers x iterations/s of the timed region) / tau_int, with the
+    # integrated autocorrelation time of the T = 1 chains estimated where it can be: on a stationary window of >= 50 tau
+    # after the adaptation has settled (a window inside a 2000-iteration timed region that starts 500 iterations after
+    # p0 = 0 measures the transient, not the sampler).  Every rank runs the leg (the swaps are collective); rank 0 reports.
+    ess_out = {"ess_per_sec": None}
+    if a.ess_window > 0:
+        rate = it_timed / wall                                        # iterations/s of every chain
+        it_now = it_warm + it_timed
+        burn_more = max(0, a.ess_burn - it_now)
+        window = a.ess_window
+        budget = a.ess_max_seconds * rate
+        if burn_more + window > budget:                               # slow workloads: keep the leg bounded, say so
+            window = int(max(2000, min(window, budget * 2 / 3)))
+            burn_more = int(max(0, min(burn_more, budget - window)))
+        window = (window // 1000) * 1000 or 1000
+        eng.run(burn_more)
+        first = it_now + burn_more + 1
+        cold = ColdSamples(eng, min(a.ess_walkers, W) if eng.owns_cold else 0)
+
+        def cov_and_keep(it_done):
+            cold.snap(it_done)                  # device-side copy of a few walkers' cold samples, before the ring wraps
+            orig_cov(it_done)
+
+        eng.update_cov = cov_and_keep
+        eng.run(window)
+        fence()
+        eng.update_cov = orig_cov
+        cold.snap(first + window - 1)
+        log("ESS leg done (%d + %d iterations)" % (burn_more, window))
+        if rank == 0 and eng.owns_cold:
+            from ptmcmcsampler_amd.ess import MIN_TAUS, integrated_time
+            chain = cold.series(first, first + window - 1)            # [nw][N][d]
+            taus, ok, drift = [], True, []
+            for wv in chain:
+                r = integrated_time(wv, full=True)
+                taus.append(float(np.max(r["tau"])))
+                ok = ok and bool(np.all(r["reliable"]))
+                h = wv.shape[0] // 2
+                drift.append(float((wv[h:] ** 2).sum(1).mean() / (wv[:h] ** 2).sum(1).mean()))
+            tau_int = 1.0 / float(np.mean(1.0 / np.asarray(taus)))    # mean over walkers of ESS / N = 1 / tau
+            ess_out = {
+                "ess_per_sec": W * (world if a.partition == "walkers" else 1) * rate / tau_int,
+                "tau_int": tau_int, "tau_int_max_walker": float(np.max(taus)), "ess_window_iters": int(chain.shape[1]),
+                "ess_window_first_iter": int(first), "ess_window_ok": bool(ok and chain.shape[1] >= MIN_TAUS * np.max(taus)),
+                "ess_window_taus": float(chain.shape[1] / np.max(taus)),
+                "ess_stationarity_r2_second_over_first_half": float(np.mean(drift)),
+                "ess_note": ("ESS/sec = walkers x iterations/s of the timed region / tau_int; tau_int = Sokal-window integrated autocorrelation "
+                             "time (max over the %d parameters) of the T=1 chains of %d walkers over %d iterations from iteration %d on, run "
+                             "after the timed region; ess_window_ok = the window holds >= %d tau for every walker and parameter"
+                             % (d, chain.shape[0], chain.shape[1], first, MIN_TAUS)),
+            }
     nchains_total = nt * world * W
     value = nchains_total * it_timed / wall
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
@@ -311,16 +362,7 @@ def main():
         acc = eng.get("nacc").astype(np.float64)
         out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / (it_timed + it_warm))
         out["swap_accept_rate_pair0"] = float(eng.get("nswap")[:, 0].mean() / max(1, eng.swap_proposed))
-        chain = cold.series(it_warm + 1, it_warm + it_timed)
-        if chain is not None and chain.shape[1] >= 16:
-            from ptmcmcsampler_amd.ess import ess
-            per_walker = [ess(chain[w]) for w in range(chain.shape[0])]
-            covered = chain.shape[1]
-            out["ess_per_sec"] = float(np.mean(per_walker) / covered * it_timed * W / wall)
-            out["ess_note"] = ("Sokal-window ESS (min over dims) of the T=1 chains: mean over %d walkers x %d timed samples, scaled to "
-                               "the %d walkers of the batch" % (len(per_walker), covered, W))
-        else:
-            out["ess_per_sec"] = None
+        out.update(ess_out)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             # the C oracle on one core, for scale (a compiled scalar port; not what a reference user gets)

@@ -43,7 +43,13 @@ def stale():
 
 def _compile(job):
     src, obj, defs = job
-    subprocess.check_call([hipcc()] + FLAGS + defs + ["-c", src, "-o", obj])
+    r = subprocess.run([hipcc()] + FLAGS + defs + ["-c", src, "-o", obj], stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        hint = ""
+        if "-amdgpu-use-amdgpu-trackers" in defs and "amdgpu-use-amdgpu-trackers" in r.stderr:
+            hint = ("\nThis hipcc does not know -mllvm -amdgpu-use-amdgpu-trackers (LLVM's AMDGPU register-pressure trackers, ROCm >= 7): "
+                    "the iso / dense step kernels are tuned and parity-tested with it; build with ROCm 7.x.")
+        raise RuntimeError("hipcc failed on %s %s:\n%s%s" % (os.path.basename(src), " ".join(defs), r.stderr[-4000:], hint))
     return obj
 
 

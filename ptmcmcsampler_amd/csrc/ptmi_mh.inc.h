@@ -427,9 +427,11 @@ __device__ __forceinline__ void mfma_acc_begin(ptmi_d4 (&t)[NT])
 {
 #pragma unroll
     for (int i = 0; i < NT; ++i) t[i] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
-    asm volatile("s_nop 7");                           // v_accvgpr_write -> C operand of a matrix instruction
+    // the "+a" pins are where the zeros are materialised (v_accvgpr_write); the wait states between such a write and a
+    // matrix instruction that reads the register as C go BEHIND them (volatile statements keep their order)
 #pragma unroll
     for (int i = 0; i < NT; ++i) asm volatile("" : "+a"(t[i]));
+    asm volatile("s_nop 7");
 }
 template <int NT>
 __device__ __forceinline__ void mfma_acc_settle(ptmi_d4 (&t)[NT])
@@ -1271,7 +1273,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 }
                 const int cpb = BLKv / G;
                 hipLaunchKernelGGL(kern, dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(BLKv), lds2, h->stream, a);
-                h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_LDS_UT | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
+                h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_LDS_UT | PTMI_VAR_DENSE_SCAM | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
                 return PTMI_OK;
             };
             return want == 256 ? launch(mh_dense_scam_kernel<EPL, 256>, 256) : launch(mh_dense_scam_kernel<EPL, 512>, 512);

@@ -105,6 +105,9 @@ class _PerRankJump(object):
         return j(x, iter, beta)
 
 
+_CKPT_FORMAT = 2      # ptmi_checkpoint.npz: 2 = DE rows in the piece-cyclic device format + run fingerprint
+
+
 class PTSampler(object):
     def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
                  logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
@@ -119,7 +122,9 @@ class PTSampler(object):
         self.swap_mode = swap_mode                          # "sweep" = PTswap as the reference; "oddeven" see PTEngine
         self.pick_mode, self.eig_mode = pick_mode, eig_mode # engine options, see PTEngine
         # device checkpoints (ptmi_checkpoint.npz beside the chain file) are written at every save when the run may be
-        # resumed: checkpoint=True, or -- by default -- when it was itself started with resume=True
+        # resumed: checkpoint=True, or -- by default -- when it was itself started with resume=True.  A run of one chain
+        # (ntemps = nwalkers = 1) can also be resumed from its chain file alone, as in the reference (:290-319); a ladder or a
+        # batch needs checkpoint=True from its first run on (the device state of a large batch is GBs: opt-in)
         self.checkpoint = bool(resume) if checkpoint is None else bool(checkpoint)
         # batched=True: logl / logp take ALL proposals at once, f(X[n, ndim]) -> [n], as torch tensors on the GPU
         self.batched = bool(batched)
@@ -273,7 +278,8 @@ class PTSampler(object):
             # without checkpoints).  One chain only: a file holds one rank of one walker.
             if self.nchain != 1 or self.nwalkers != 1:
                 raise Exception("Couldn't resume: {0} exists but the device checkpoint {1} does not, and a chain file alone can "
-                                "only be replayed for one chain (ntemps = nwalkers = 1).  Refusing to overwrite it.".format(
+                                "only be replayed for one chain (ntemps = nwalkers = 1): runs with several chains are resumable "
+                                "when they were started with checkpoint=True (or resume=True).  Refusing to overwrite it.".format(
                                     self.fname, self._ckpt))
             try:
                 self.resumechain = np.loadtxt(self.fname, ndmin=2)
@@ -292,6 +298,11 @@ class PTSampler(object):
             open(self.fname, "w").close()
             for f in self._hot_names:
                 open(f, "w").close()
+            # a fresh start owns the directory: a checkpoint of an earlier run must not survive beside the new chain file
+            # (a later resume=True would continue THAT run and cut the newer chain file to its row count)
+            for stale in (self._ckpt, self._ckpt + ".tmp.npz"):
+                if os.path.isfile(stale):
+                    os.remove(stale)
         # ---- engine
         self.host_jumps = [f for f in self.propCycle if self._builtin(f) < 0]
         self.split = self.logl is not None or bool(self.host_jumps) or bool(self.aux)
@@ -375,13 +386,22 @@ class PTSampler(object):
             if end % self.isave == 0:
                 self.writeOutput(end)
             if self.neff and end % 1000 == 0 and end > 2 * self.burn:                               # :510-521
-                from .ess import integrated_time
-                lo = self.burn // self.thin
-                tau = max(1.0, np.nanmax([integrated_time(self._chain[lo:end // self.thin, ii]) for ii in range(self.ndim)]))
-                Neff = (end - self.burn) / self.thin / tau
-                if int(Neff) >= self.neff:
-                    message = "\nRun Complete with {0} effective samples".format(int(Neff))
-                    self.Niter = end
+                # acor.acor(chain[burn:iter-1, ii])[0] per dimension, Neff = iter / max(1, nanmax(tau)): with thin = 1 exactly the
+                # reference's expression (ess.acor restates the un-vendored package's published algorithm).  With thin > 1 the
+                # reference's slice runs past the rows written so far; here the rows [burn / thin, iter / thin) that exist are used.
+                from .ess import AcorError, acor
+                lo, hi = (self.burn, end - 1) if self.thin == 1 else (self.burn // self.thin, end // self.thin)
+                taus = []
+                for ii in range(self.ndim):
+                    try:
+                        taus.append(acor(self._chain[lo:hi, ii])[0])
+                    except AcorError:                                # too few samples for this autocorrelation time: no estimate yet
+                        taus.append(np.nan)
+                if np.isfinite(taus).any():
+                    Neff = (end // self.thin) / max(1.0, np.nanmax(taus))
+                    if int(Neff) >= self.neff:
+                        message = "\nRun Complete with {0} effective samples".format(int(Neff))
+                        self.Niter = end
             it = end + 1
         eng.iter = self.Niter
         self.writeOutput(self.Niter)
@@ -396,6 +416,8 @@ class PTSampler(object):
     def _save_checkpoint(self, iter):
         st = self.engine.checkpoint()
         st["iter"] = iter
+        st["f_format"] = _CKPT_FORMAT
+        st["f_fingerprint"] = self._fingerprint()
         n = self.ind_next_write                                # the stored part of the sample arrays only
         st.update(f_chains=self._chains[:, :n], f_lnlikes=self._lnlikes[:, :n], f_lnprobs=self._lnprobs[:, :n],
                   f_ind_next_write=self.ind_next_write,
@@ -406,8 +428,22 @@ class PTSampler(object):
         np.savez(tmp, **st)
         os.replace(tmp, self._ckpt)
 
+    def _fingerprint(self):
+        """What a checkpoint must agree on with the run that loads it."""
+        eng = self.engine
+        return np.asarray([self.seed & 0x7FFFFFFFFFFFFFFF, self.ndim, self.nchain, self.nwalkers, self.thin, self.covUpdate, self.burn,
+                           eng.de_ld, eng.de_epl, self.keep_walkers], dtype=np.int64)
+
     def _load_checkpoint(self):
         st = np.load(self._ckpt, allow_pickle=False)
+        if "f_format" not in st.files or int(st["f_format"]) != _CKPT_FORMAT:
+            raise Exception("{0} was written in checkpoint format {1}; this build reads format {2} (the DE history's row layout "
+                            "changed): it cannot be resumed from".format(self._ckpt, int(st["f_format"]) if "f_format" in st.files else 1, _CKPT_FORMAT))
+        fp = self._fingerprint()
+        if not np.array_equal(st["f_fingerprint"], fp):
+            names = ("seed", "ndim", "ntemps", "nwalkers", "thin", "covUpdate", "burn", "DE row stride", "DE row format", "keep_walkers")
+            bad = [n for n, a, b in zip(names, st["f_fingerprint"], fp) if a != b]
+            raise Exception("{0} belongs to a different run ({1} differ): refusing to resume from it".format(self._ckpt, ", ".join(bad)))
         self.engine.restore(st)
         n = min(self._chains.shape[1], st["f_chains"].shape[1])
         self._chains[:, :n], self._lnlikes[:, :n], self._lnprobs[:, :n] = st["f_chains"][:, :n], st["f_lnlikes"][:, :n], st["f_lnprobs"][:, :n]
@@ -420,14 +456,20 @@ class PTSampler(object):
         self.resumeLength = self.ind_next_write
         # the chain files must end where the checkpoint does: a run killed between the file write and the checkpoint
         # leaves rows the resumed run is about to write again
-        for k in range(self.keep_walkers):
-            fname = self.fname if k == 0 else self.fname[:-4] + "_w%d.txt" % k
-            if os.path.isfile(fname):
-                rows = open(fname).read().splitlines(True)
-                if len(rows) < self.ind_next_write:
-                    raise Exception("{0} has {1} rows but the checkpoint was written after {2}".format(fname, len(rows), self.ind_next_write))
-                if len(rows) > self.ind_next_write:
-                    open(fname, "w").writelines(rows[:self.ind_next_write])
+        names = [self.fname if k == 0 else self.fname[:-4] + "_w%d.txt" % k for k in range(self.keep_walkers)] + list(self._hot_names)
+        for fname in names:
+            if not os.path.isfile(fname):
+                continue
+            with open(fname, "rb+") as fh:                        # streamed: find the byte offset of row ind_next_write
+                nrows, cut = 0, None
+                for line in iter(fh.readline, b""):
+                    nrows += 1
+                    if nrows == self.ind_next_write:
+                        cut = fh.tell()
+                        break
+                if nrows < self.ind_next_write:
+                    raise Exception("{0} has {1} rows but the checkpoint was written after {2}".format(fname, nrows, self.ind_next_write))
+                fh.truncate(cut if self.ind_next_write > 0 else 0)
         i0 = int(st["iter"])
         print("Resuming with", self.resumeLength, "samples from file representing", i0 + 1, "original samples")
         return i0
@@ -442,9 +484,11 @@ class PTSampler(object):
         last = self.resumeLength * thin - 1                         # iterations 1 .. last are replayed
         X, lnl, lnp = rows[:, :d], rows[:, -3], rows[:, -4]
         beta0 = 1.0 / eng.temps_mh[0]
+        with np.errstate(invalid="ignore"):
+            lpr = np.where(np.isneginf(lnp), -np.inf, lnp - beta0 * lnl)      # log-prior of a row (a -inf row: lnlike may be -inf too)
         # iteration 0: the first row (:474-476, :491)
         eng.t["AM"][0, 0] = torch.from_numpy(X[0].copy())
-        eng.t["AMaux"][0, 0, 0], eng.t["AMaux"][0, 0, 1] = float(lnl[0]), float(lnp[0] - beta0 * lnl[0])
+        eng.t["AMaux"][0, 0, 0], eng.t["AMaux"][0, 0, 1] = float(lnl[0]), float(lpr[0])
         self._chains[0, 0], self._lnlikes[0, 0], self._lnprobs[0, 0] = X[0], lnl[0], lnp[0]
         it = 1
         while it <= last:
@@ -459,7 +503,7 @@ class PTSampler(object):
             its = np.arange(it, end + 1)
             src = its // thin
             eng.t["AM"][0, torch.from_numpy(its % cu).to(eng.device)] = torch.from_numpy(X[src]).to(eng.device)
-            aux = np.stack([lnl[src], lnp[src] - beta0 * lnl[src]], 1)
+            aux = np.stack([lnl[src], lpr[src]], 1)
             eng.t["AMaux"][0, torch.from_numpy(its % cu).to(eng.device)] = torch.from_numpy(aux).to(eng.device)
             keep = its[its % thin == 0]
             self._chains[0, keep // thin], self._lnlikes[0, keep // thin], self._lnprobs[0, keep // thin] = (
@@ -470,7 +514,7 @@ class PTSampler(object):
         state = np.broadcast_to(X[k], (eng.W, eng.nt, d)).copy()
         eng.t["X"].copy_(torch.from_numpy(state))
         eng.put("lnL", np.full((eng.W, eng.nt), lnl[k]))
-        eng.put("lp", np.full((eng.W, eng.nt), lnp[k] - beta0 * lnl[k]))
+        eng.put("lp", np.full((eng.W, eng.nt), lpr[k]))
         nacc = eng.get("nacc")
         nacc[0, 0] = int(round(last * rows[k, -2]))
         eng.put("nacc", nacc.astype(np.int64))

@@ -138,7 +138,8 @@ class ShardedPTEngine(object):
         self._parts = torch.empty((self.world * self.W, self.nt), dtype=torch.float64, device=self.device)
         self.rows_moved = 0
         self.neighbour_swaps = 0                                                 # swap epochs served by the two neighbour links alone
-        # device-side exchange (HIP engines): fixed [world][W][d+2] buffers, no host synchronisation per swap
+        # device-side exchange (HIP engines): fixed [world][W][d+2] buffers; the plan, the packing and the apply step need no host
+        # round trip -- the ONE host synchronisation per swap epoch is the 4-byte multi-hop flag that picks the transport (swap())
         self.device_exchange = hasattr(L, "exchange_pack")
         if self.device_exchange:
             self._send = torch.zeros((self.world, self.W, self.d + 2), dtype=torch.float64, device=self.device)

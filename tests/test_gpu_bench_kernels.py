@@ -16,11 +16,15 @@ def _dense(d, seed=0):
     return ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
 
 
-@pytest.mark.parametrize("cov_mode,nt,W", [("pooled", 4, 9), ("per_walker", 3, 5), ("per_walker", 64, 2)])
-def test_dense_scam_only_runs_staged_and_matches(mods, cov_mode, nt, W):
-    """Dense likelihood, SCAM-only cycle: the staged (matrix-core likelihood) kernel with the eigenvectors read per chain.
-    per_walker with nt = 3 puts several walkers in one block: each chain must use ITS walker's table after the first
-    covariance epoch (PTMCMCSampler.py:820-876 with the walker's own U, S)."""
+@pytest.mark.parametrize("cov_mode,nt,W,dense512", [("pooled", 4, 9, True), ("per_walker", 3, 5, False), ("per_walker", 64, 2, False),
+                                                     ("pooled", 64, 5, True), ("per_walker", 128, 3, True)])
+def test_dense_scam_only_runs_staged_and_matches(mods, cov_mode, nt, W, dense512):
+    """Dense likelihood, SCAM-only cycle (PTMCMCSampler.py:605-612, 820-876).  Two instantiations serve it and the variant
+    flag tells them apart: ``mh_dense_scam_kernel<26, 512>`` (PTMI_VAR_DENSE_SCAM: one table per 128-chain block -- pooled
+    covariance, or a walker's ranks filling whole blocks; the kernel bench.py --logl dense times), here on one block, on
+    2.5 blocks (64 x 5 chains) and on three walkers with a block each; and the older staged kernel with the eigenvectors
+    read per chain.  per_walker with nt = 3 puts several walkers in one block: each chain must use ITS walker's table
+    after the first covariance epoch."""
     orc, _lib, _ = mods
     d = 100
     g, o = _pair(mods, d, nt, W, logl=_dense(d), cov0=np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=25, burn=1000,
@@ -29,6 +33,7 @@ def test_dense_scam_only_runs_staged_and_matches(mods, cov_mode, nt, W):
     o.run(80)
     flags, G, E = g.last_variant()
     assert flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL and (G, E) == (4, 26)
+    assert bool(flags & _lib.VAR_DENSE_SCAM) == dense512
     _compare(g, o, "dense scam %s " % cov_mode)
     assert_same(g.get("Ut"), o.Ut, "Ut")
     if cov_mode == "per_walker":
@@ -204,6 +209,47 @@ def test_full_size_default_mix_with_covariance_and_de_epochs(mods):
     so = g.get("slot_of")
     assert (np.sort(so, axis=1) == np.arange(nt)).all()
     assert g.get("nswap").sum() > 0 and g.swap_proposed == 4
+
+
+def test_full_size_dense_scam_through_pooled_covariance_epochs(mods):
+    """BASELINE configs[2] at full size (100-d dense Gaussian, 64 temps x 4096 walkers = 2048 blocks of
+    mh_dense_scam_kernel<26, 512>), SCAM cycle, pooled covariance with covUpdate = 100: 300 iterations = two pooled
+    covariance epochs (matrix-core Welford over 4096 walkers, two-level pooling, factorization) and three swap epochs.
+    Pooled cov / Ut / S equal the oracle's on the same AM rows and three walkers' chains (first, middle, last block) match
+    the oracle bit for bit throughout (PTMCMCSampler.py:605-612, 820-876, 769-803; tests/test_simple.py:27-30 is the
+    reference's own dense Gaussian)."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    cov0 = np.eye(d) * 0.01
+    kw = dict(weights=(20, 0, 0), cov_update=100, burn=10000, tskip=100, seed=77, logl=_dense(d))
+    g = PTEngine(d, nt, W, cov0, cov_mode="pooled", **kw)
+    g.init_state(np.zeros(d))
+    sub = _Subset(orc, (0, 2049, 4095), d, nt, W, cov0, **kw)
+    for o in sub.subs:
+        o.init_state(np.zeros(d))
+    cu = kw["cov_update"]
+    for k in range(3):
+        if k > 0:
+            g.sync()
+            sub.epoch(g.get("AM"), k * cu)
+        g.run(cu)
+        for o in sub.subs:
+            o.run(cu)
+        flags, G, E = g.last_variant()
+        assert flags & _lib.VAR_DENSE_SCAM and flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL and (G, E) == (4, 26)
+        if k > 0:
+            assert_same(g.get("cov")[0], sub.subs[0].cov[0], "pooled cov after epoch %d" % k)
+            assert_same(g.get("Ut")[0], sub.subs[0].Ut[0], "Ut after epoch %d" % k)
+            assert_same(g.get("S")[0], sub.subs[0].S[0], "S after epoch %d" % k)
+        _check_subset(g, sub, "dense segment %d" % k)
+    # size-independent properties over the whole batch: lnL is the quadratic form of the held row, the tables are permutations
+    X, lnL = g.get("X"), g.get("lnL")
+    P = kw["logl"][2]
+    assert np.allclose(lnL, -0.5 * np.einsum("wti,ij,wtj->wt", X, P, X), rtol=1e-11, atol=1e-11)
+    so = g.get("slot_of")
+    assert (np.sort(so, axis=1) == np.arange(nt)).all()
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., 0, 0] == 300).all() and g.get("nswap").sum() > 0 and g.swap_proposed == 3
 
 
 def test_config4_slice_1000d_64_temps(mods):

@@ -216,6 +216,60 @@ def test_resume_without_checkpoint_refuses_to_truncate(tmp_path):
     assert open(tmp_path / "chain_1.0.txt").read() == before
 
 
+def test_a_fresh_start_removes_an_older_runs_checkpoint(tmp_path):
+    """Run 1 (checkpoint=True) leaves ptmi_checkpoint.npz.  Run 2 in the same outDir without resume truncates the chain file
+    and must also remove that checkpoint: a later resume=True then replays run 2's chain file (one chain) instead of
+    restoring run 1's device state over run 2's rows.  And a checkpoint of a different run is refused, not loaded."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 3
+    kw = dict(burn=100, thin=1, covUpdate=50, isave=100)
+
+    def make(seed, **extra):
+        return PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path), verbose=False, seed=seed, **extra)
+    make(1, checkpoint=True).sample(np.zeros(d), 300, **kw)
+    assert os.path.exists(tmp_path / "ptmi_checkpoint.npz")
+    old_ckpt = open(tmp_path / "ptmi_checkpoint.npz", "rb").read()
+    b = make(2)                                                                  # fresh start, no checkpoints
+    b.sample(np.zeros(d), 200, **kw)
+    assert not os.path.exists(tmp_path / "ptmi_checkpoint.npz")
+    run2 = open(tmp_path / "chain_1.txt").read().splitlines()
+    assert len(run2) == 201
+    c = make(2, resume=True)                                                     # replays run 2's file (201 rows), continues to 400
+    c.sample(np.zeros(d), 400, **kw)
+    rows = open(tmp_path / "chain_1.txt").read().splitlines()
+    assert len(rows) == 401 and rows[:201] == run2
+    # a checkpoint that belongs to another run (seed 1) beside this run's chain file: refused by its fingerprint
+    open(tmp_path / "ptmi_checkpoint.npz", "wb").write(old_ckpt)
+    e = make(2, resume=True)
+    with pytest.raises(Exception, match="different run .*seed"):
+        e.sample(np.zeros(d), 600, **kw)
+    assert open(tmp_path / "chain_1.txt").read().splitlines() == rows          # nothing was cut
+
+
+def test_resume_cuts_every_chain_file_back_to_the_checkpoint(tmp_path):
+    """A kill between the file write and the checkpoint leaves rows the resumed run writes again: cold, walker and hot
+    files are all cut back to the checkpoint's row count (the hot files are written in the same call)."""
+    from ptmcmcsampler_amd import PTSampler
+    d = 4
+    kw = dict(burn=100, thin=2, covUpdate=50, isave=100, Tskip=10, writeHotChains=True)
+
+    def make(resume=False):
+        return PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path), verbose=False, seed=5, ntemps=3, nwalkers=2,
+                         keep_walkers=2, resume=resume, checkpoint=True)
+    a = make()
+    a.sample(np.zeros(d), 400, **kw)
+    files = [f for f in sorted(os.listdir(tmp_path)) if f.startswith("chain_")]
+    assert len(files) == 4                                                       # cold, cold of walker 1, two hot ranks
+    good = {f: open(tmp_path / f).read() for f in files}
+    for f in files:                                                              # the torn write: 7 more rows everywhere
+        open(tmp_path / f, "a").write("".join(good[f].splitlines(True)[-7:]))
+    b = make(resume=True)
+    b.sample(np.zeros(d), 600, **kw)
+    for f in files:
+        rows = open(tmp_path / f).read().splitlines(True)
+        assert len(rows) == 301 and "".join(rows[:201]) == good[f], f
+
+
 def test_resume_from_a_chain_file_the_reference_wrote(tmp_path, golden, capsys):
     """PTMCMCSampler.py:290-319, 591-599: resume=True with nothing but the reference's chain_1.txt.  The rows are
     replayed as the chain's states; the covariance epochs and the DE history rebuilt from them equal the reference's own
@@ -270,9 +324,11 @@ def test_resume_from_a_chain_file_the_reference_wrote(tmp_path, golden, capsys):
 
 def test_neff_stops_the_run_early(tmp_path, capsys):
     """neff (PTMCMCSampler.py:510-521): every 1000 iterations past 2 * burn the effective sample size of the cold chain
-    is estimated, and the run ends once it reaches the request; the partial block is written."""
+    is estimated (the restated acor, ess.acor) and the run ends once it reaches the request; the partial block is written.
+    The stop is checked against an INDEPENDENT estimator on the same chain (Sokal window, ess.integrated_time; both are pinned
+    by AR(1) series of known tau in tests/test_ess.py) and against the analytic rate of this sampler on this target."""
     from ptmcmcsampler_amd import PTSampler
-    from ptmcmcsampler_amd.ess import integrated_time
+    from ptmcmcsampler_amd.ess import acor, integrated_time
     d = 3
     s = PTSampler(d, ("iso",), ("flat",), np.eye(d), outDir=str(tmp_path), verbose=True, seed=2)
     s.sample(np.zeros(d), 200000, burn=300, thin=1, covUpdate=300, isave=1000, neff=150)
@@ -280,9 +336,15 @@ def test_neff_stops_the_run_early(tmp_path, capsys):
     assert s.Niter < 200000 and s.Niter % 1000 == 0 and s.Niter > 600
     m = re.search(r"Run Complete with (\d+) effective samples", out)
     assert m and int(m.group(1)) >= 150
-    tau = max(integrated_time(s._chain[300:s.Niter, i]) for i in range(d))
-    assert (s.Niter - 300) / tau >= 150                                            # the criterion, recomputed
-    assert (s.Niter - 1000 - 300) / tau < 150 * 1.5                                # and it did stop about as early as it could
+    # the reference's expression, recomputed: iter / max(1, max_i acor(chain[burn:iter-1, i])[0])
+    tau_acor = max(acor(s._chain[300:s.Niter - 1, i])[0] for i in range(d))
+    assert int(s.Niter / max(1.0, tau_acor)) == int(m.group(1))
+    prev = s.Niter - 1000
+    if prev > 600:                                                                   # it did not pass the test one check earlier
+        assert int(prev / max(1.0, max(acor(s._chain[300:prev - 1, i])[0] for i in range(d)))) < 150
+    # an independent estimator on the same samples agrees on the autocorrelation time (both within their sampling error)
+    tau_sokal = max(integrated_time(s._chain[300:s.Niter - 1, i]) for i in range(d))
+    assert 0.6 < tau_acor / tau_sokal < 1.6, (tau_acor, tau_sokal)
     assert len(open(tmp_path / "chain_1.txt").read().splitlines()) == s.Niter + 1
     # without neff the same run goes on to the end
     s2 = PTSampler(d, ("iso",), ("flat",), np.eye(d), outDir=str(tmp_path / "b"), verbose=False, seed=2)

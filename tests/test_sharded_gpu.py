@@ -121,6 +121,111 @@ def test_device_exchange_with_emulated_ranks(nranks, cov_mode, ntb):
         assert engines[0].neighbour_swaps < n // 10           # 33 walkers on three-rank blocks: some sweep always crosses one
 
 
+def _run_emulated_ladder(nranks, ntb, d, W, n, cov0, p0, kw):
+    """One thread per temperature block on the one GPU (thread_comm.ThreadComm) + the whole ladder on the oracle."""
+    import sys
+    import threading
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from thread_comm import ThreadComm, ThreadWorld
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd.sharded import ShardedPTEngine
+    ntg = ntb * nranks
+    ref = orc.OracleEngine(d, ntg, W, cov0, **kw)
+    ref.init_state(p0)
+    ref.run(n)
+    world = ThreadWorld(nranks)
+    engines, errs = [None] * nranks, []
+
+    def rank_main(r):
+        try:
+            e = ShardedPTEngine(d, ntg, W, cov0, comm=ThreadComm(world, r), **kw)
+            assert e.device_exchange
+            engines[r] = e
+            e.init_state(p0)
+            e.run(n)
+            e.sync()
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            world.bar.abort()
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    return ref, engines
+
+
+def _check_blocks(ref, engines, ntb, n_swaps, gj=False):
+    for r, e in enumerate(engines):
+        L, sl = e.local, slice(r * ntb, (r + 1) * ntb)
+        assert L.exchange_violations() == 0
+        for name in ("X", "lnL", "lp"):
+            assert np.array_equal(L.by_temp(name), ref.by_temp(getattr(ref, name))[:, sl]), (r, name)
+        assert np.array_equal(L.get("nacc"), ref.nacc[:, sl]) and np.array_equal(L.get("jstat"), ref.jstat[:, sl]), r
+        assert np.array_equal(L.get("nswap")[:, sl], ref.nswap[:, sl]), r
+        assert np.array_equal(L.get("Ut"), ref.Ut) and np.array_equal(L.get("S"), ref.S), r
+        if gj:
+            assert np.array_equal(L.get("gj"), ref.gj[:, sl]), r                   # a rank's jump-object state
+        if r == 0:
+            assert np.array_equal(L.get("AM"), ref.AM) and np.array_equal(L.get("M2"), ref.M2)
+        assert e.swap_proposed == n_swaps
+    edges = ref.nswap[:, ntb - 1::ntb][:, :len(engines) - 1].sum(0)
+    assert (edges > 0).all(), "a block edge no swap ever crossed: %r" % (edges,)
+    assert len({e.neighbour_swaps for e in engines}) == 1                    # every rank chose the same transport at every epoch
+
+
+@pytest.mark.parametrize("start", ["equilibrium", "flat"])
+def test_config4_ladder_8_blocks_of_64_ranks_1000d(start):
+    """BASELINE configs[3] as it is sharded: 1000-d isotropic Gaussian, 512 temperature ranks = 8 blocks of 64 (one per
+    GPU; here eight emulated ranks on the one GPU), default SCAM/AM/DE cycle, pooled covariance, against the oracle's
+    single ladder, bit for bit: 8 KB rows packed / applied across all seven block edges (PTMCMCSampler.py:631-697),
+    the 8 MB factorization and the new DE rows broadcast from block 0 (:545-576), 64 lanes per chain.
+    ``equilibrium``: every rank starts from a draw of its own tempered target -- pairs accept at the ladder's design rate,
+    no state crosses a whole block, all epochs go over the two neighbour links.  ``flat``: all ranks start near the mode,
+    every pair accepts and the hottest state travels to rank 0 in one sweep -- the multi-hop epochs (all-to-all)."""
+    from ptmcmcsampler_amd import _lib
+    from ptmcmcsampler_amd.ladder import temperature_ladder
+    d, nranks, ntb, W, n = 1000, 8, 64, 8, 50
+    ntg = nranks * ntb
+    kw = dict(weights=(20, 4, 20), cov_update=20, burn=40, tskip=10, seed=5, cov_mode="pooled")
+    cov0 = np.eye(d) * 0.01
+    rs = np.random.RandomState(3)
+    if start == "equilibrium":
+        p0 = rs.randn(W, ntg, d) * np.sqrt(temperature_ladder(ntg, d))[None, :, None]
+    else:
+        p0 = rs.randn(W, ntg, d) * 0.1
+    ref, engines = _run_emulated_ladder(nranks, ntb, d, W, n, cov0, p0, kw)
+    _check_blocks(ref, engines, ntb, n // 10)
+    flags, G, E = engines[3].local.last_variant()
+    assert G == 64 and flags & _lib.VAR_FULL
+    assert ref.jstat[..., 2, 0].sum() > 0 and ref.jstat[..., 1, 1].sum() > 0        # DE became active; AM jumps were accepted
+    if start == "equilibrium":
+        assert engines[0].neighbour_swaps == n // 10
+    else:
+        assert engines[0].neighbour_swaps < n // 10
+
+
+def test_config5_ladder_8_blocks_of_16_ranks_curved_nuts():
+    """BASELINE configs[4] as it is sharded: 20-d curved likelihood, 128 ranks = 8 blocks of 16, SCAM + DE + NUTS cycle with
+    the box prior, against the oracle's single ladder, bit for bit, incl. every rank's NUTS step-size state (the jump
+    objects belong to ranks, nutsjump.py:379-433, and stay put while states cross the block edges)."""
+    from ptmcmcsampler_amd import _lib
+    d, nranks, ntb, W, n = 20, 8, 16, 9, 120
+    ntg = nranks * ntb
+    kw = dict(logl=("curved",), logp=("box", np.full(d, -10.0), np.full(d, 10.0)), weights=(10, 0, 10), grad_weights=(10, 0),
+              cov_update=30, burn=60, tskip=10, seed=7, cov_mode="pooled")
+    cov0 = np.eye(d)
+    rs = np.random.RandomState(5)
+    p0 = np.array([-0.1, -0.5] * (d // 2)) + rs.randn(W, ntg, d) * 0.3 * np.linspace(0.2, 3.0, ntg)[None, :, None]
+    p0 = np.clip(p0, -9.5, 9.5)
+    ref, engines = _run_emulated_ladder(nranks, ntb, d, W, n, cov0, p0, kw)
+    _check_blocks(ref, engines, ntb, n // 10, gj=True)
+    flags, G, E = engines[5].local.last_variant()
+    assert flags & _lib.VAR_GRADJUMP
+    assert ref.jstat[..., 3, 0].sum() > 0 and ref.jstat[..., 2, 0].sum() > 0        # NUTS and DE proposals were made
+
+
 def test_two_real_processes_share_the_gpu_over_gloo():
     """True multi-process run of ShardedPTEngine + DistComm (two ranks on cuda:0, gloo moving device tensors),
     both swap modes, against the oracle: tools/two_proc_one_gpu.py."""
@@ -133,8 +238,9 @@ def test_two_real_processes_share_the_gpu_over_gloo():
     assert r.returncode == 0 and "all ranks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` as the driver calls it: the script starts its two ranks itself.  A one-GPU box cannot give
+@pytest.mark.parametrize("extra,ntemps", [((), 16), (("--ndim", "1000", "--nwalkers", "64", "--mix", "default"), 64)])
+def test_bench_launches_its_own_ranks(extra, ntemps):
+    """`python bench.py --gpus 2` as the driver calls it (second case: BASELINE configs[3]'s shape, 1000-d, 64 ranks per GPU): the script starts its two ranks itself.  A one-GPU box cannot give
     RCCL two devices, so the rehearsal runs over gloo with both ranks on cuda:0 (PTMI_DIST_BACKEND=gloo); the sharded
     engine, the neighbour send/recv at the block edge and the JSON contract are the ones of the RCCL run."""
     import json
@@ -145,14 +251,20 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, PTMI_DIST_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--nwalkers", "128",
-                        "--ntemps", "16", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    args = ["--nwalkers", "128", "--ntemps", "16"] if not extra else list(extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
+                        "--ess-burn", "0", "--ess-window", "3000"] + args,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 12 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["rccl_ranks"] == 0                       # gloo rehearsal: no RCCL ranks
-    assert out["config"]["parallelism"] == "temperature blocks x2" and out["config"]["ntemps_per_gpu"] == 16
+    assert out["config"]["parallelism"] == "temperature blocks x2" and out["config"]["ntemps_per_gpu"] == ntemps
+    if extra:
+        assert out["config"]["ndim"] == 1000 and out["config"]["nwalkers"] == 64
     assert out["swap_epochs_timed"] == 12 and out["cov_epochs_timed"] == 1 and out["swap_accept_rate_pair0"] > 0
-    assert out["ess_per_sec"] is not None and out["roofline"]["frac"] <= 1.0
+    assert out["roofline"]["frac"] <= 1.0
+    # the ESS leg ran (after the timed region) and FLAGS its 3000-iteration window as too short to trust
+    assert out["ess_per_sec"] > 0 and out["tau_int"] >= 1 and out["ess_window_iters"] == 3000 and out["ess_window_ok"] is False
