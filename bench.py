@@ -360,7 +360,7 @@ def main():
         out["roofline"].update({"bound": "mfma", "achieved": tfd, "frac": tfd / F64_PEAK_TFLOPS, "algorithmic_flops_per_update": flops})
     if rank == 0:
         acc = eng.get("nacc").astype(np.float64)
-        out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / (it_timed + it_warm))
+        out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / max(1, eng.iter))        # over the whole run, ESS leg included
         out["swap_accept_rate_pair0"] = float(eng.get("nswap")[:, 0].mean() / max(1, eng.swap_proposed))
         out.update(ess_out)
         if cpu is not None:

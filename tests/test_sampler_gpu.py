@@ -328,7 +328,16 @@ def test_neff_stops_the_run_early(tmp_path, capsys):
     The stop is checked against an INDEPENDENT estimator on the same chain (Sokal window, ess.integrated_time; both are pinned
     by AR(1) series of known tau in tests/test_ess.py) and against the analytic rate of this sampler on this target."""
     from ptmcmcsampler_amd import PTSampler
-    from ptmcmcsampler_amd.ess import acor, integrated_time
+    from ptmcmcsampler_amd.ess import AcorError, acor, integrated_time
+
+    def taus(chain):                                                             # per dimension; NaN where acor itself gives up
+        out = []
+        for i in range(chain.shape[1]):
+            try:
+                out.append(acor(chain[:, i])[0])
+            except AcorError:
+                out.append(np.nan)
+        return out
     d = 3
     s = PTSampler(d, ("iso",), ("flat",), np.eye(d), outDir=str(tmp_path), verbose=True, seed=2)
     s.sample(np.zeros(d), 200000, burn=300, thin=1, covUpdate=300, isave=1000, neff=150)
@@ -337,11 +346,11 @@ def test_neff_stops_the_run_early(tmp_path, capsys):
     m = re.search(r"Run Complete with (\d+) effective samples", out)
     assert m and int(m.group(1)) >= 150
     # the reference's expression, recomputed: iter / max(1, max_i acor(chain[burn:iter-1, i])[0])
-    tau_acor = max(acor(s._chain[300:s.Niter - 1, i])[0] for i in range(d))
+    tau_acor = np.nanmax(taus(s._chain[300:s.Niter - 1]))                       # nanmax, as the reference
     assert int(s.Niter / max(1.0, tau_acor)) == int(m.group(1))
     prev = s.Niter - 1000
     if prev > 600:                                                                   # it did not pass the test one check earlier
-        assert int(prev / max(1.0, max(acor(s._chain[300:prev - 1, i])[0] for i in range(d)))) < 150
+        assert not np.isfinite(taus(s._chain[300:prev - 1])).any() or int(prev / max(1.0, np.nanmax(taus(s._chain[300:prev - 1])))) < 150
     # an independent estimator on the same samples agrees on the autocorrelation time (both within their sampling error)
     tau_sokal = max(integrated_time(s._chain[300:s.Niter - 1, i]) for i in range(d))
     assert 0.6 < tau_acor / tau_sokal < 1.6, (tau_acor, tau_sokal)
