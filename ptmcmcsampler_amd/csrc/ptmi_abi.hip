@@ -745,7 +745,7 @@ static bool pick_shape(int d, bool grad, Shape *s)
         PTMI_SHAPE_LIST(PTMI_TABLE_ENTRY)};
     const int G = grad ? ptmi_lanes_for_grad(d) : ptmi_lanes_for(d);
     for (const Shape &c : table)
-        if (c.G == G && c.G * c.EPL >= d && (!grad || c.EPL <= 8)) { *s = c; return true; }
+        if (c.G == G && c.G * c.EPL >= d && (!grad || c.EPL <= 8) && (!ptmi_shape_exact(c.G, c.EPL) || c.G * c.EPL == d)) { *s = c; return true; }
     return false;
 }
 

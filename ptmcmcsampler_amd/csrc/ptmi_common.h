@@ -105,8 +105,10 @@ struct ptmi_engine {
 enum { PTMI_OP_MH = 0, PTMI_OP_EVAL = 1, PTMI_OP_PROPOSE = 2, PTMI_OP_ACCEPT = 3, PTMI_OP_MH_GJ = 4 };
 // jump types the SCAM / AM / DE kernels count (the gradient jumps have their own fused kernel, ptmi_gj.inc.h)
 enum { PTMI_J_FUSED = 3 };
+// exact shapes serve ndim == G * EPL only: no slot of any lane needs a bounds check (and odd EPL: the paired LDS rows)
+constexpr bool ptmi_shape_exact(int G, int EPL) { return G == 4 && EPL == 25; }
 typedef int (*ptmi_shape_fn)(int op, ptmi_engine *h, KArgs &a, int grid, bool full);
-#define PTMI_SHAPE_LIST(X) X(4, 2) X(4, 5) X(4, 8) X(4, 14) X(4, 20) X(4, 26) X(16, 7) X(16, 13) X(16, 26) X(64, 8) X(64, 16) X(64, 32)
+#define PTMI_SHAPE_LIST(X) X(4, 2) X(4, 5) X(4, 8) X(4, 14) X(4, 20) X(4, 25) X(4, 26) X(16, 7) X(16, 13) X(16, 26) X(64, 8) X(64, 16) X(64, 32)
 // one unit per (shape, likelihood family); the split-path kernels live in the family-0 unit
 #define PTMI_DECLARE_SHAPE(G_, E_)                                                        \
     int ptmi_shape_##G_##_##E_##_0(int op, ptmi_engine *h, KArgs &a, int grid, bool full); \

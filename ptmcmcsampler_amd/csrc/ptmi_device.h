@@ -16,10 +16,12 @@ typedef double ptmi_dev_d2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------- cross-lane
 // DPP moves: full-rate lane permutations inside a row of 16 lanes (no LDS traffic).
+// (every control used here reads a valid lane for every lane, so no "old" value is needed: with update_dpp(0, ...) hipcc
+// emitted a v_mov_b32 0 in front of every DPP move)
 template <int CTRL>
 __device__ __forceinline__ u32 dpp32(u32 v)
 {
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ __forceinline__ u64 dpp64(u64 v)
@@ -73,7 +75,11 @@ __device__ __forceinline__ void philox_begin(PhiloxState &p, u64 seed, u64 iter,
 }
 __device__ __forceinline__ void philox_round(PhiloxState &p)
 {
-    const u64 p0 = (u64)0xD2511F53u * (u64)p.c0, p1 = (u64)0xCD9E8D57u * (u64)p.c2;   // v_mad_u64_u32
+    // one v_mad_u64_u32 per product (hi and lo at once).  Left to itself hipcc splits each into v_mul_hi_u32 + v_mul_lo_u32:
+    // four multiplies per round instead of two (tools/inst_rates.hip: 23 against 13.4 cycles per round and SIMD)
+    u64 p0, p1, cy0, cy1;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p0), "=s"(cy0) : "v"(p.c0), "s"(0xD2511F53u));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p1), "=s"(cy1) : "v"(p.c2), "s"(0xCD9E8D57u));
     const u32 h0 = (u32)(p0 >> 32), l0 = (u32)p0, h1 = (u32)(p1 >> 32), l1 = (u32)p1;
     // three-input xor in one instruction (v_bitop3_b32, truth table 0x96): hipcc emits two v_xor_b32 for a ^ b ^ c
     const u32 n0 = __builtin_amdgcn_bitop3_b32(h1, p.c1, p.k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(h0, p.c3, p.k1, 0x96);

@@ -169,9 +169,10 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
 // Kernel shapes: (lanes per chain G, register slots per lane EPL); a shape serves
 // G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
 // lane for every ndim the shape serves and need no bounds check.
+// Shape (4, 25) is EXACT: it serves ndim = 100 only (ptmi_abi.hip pick_shape), so every slot of every lane is valid.
 constexpr int safe_slots(int G, int EPL)
 {
-    return G == 4 ? (EPL == 26 ? 20 : EPL == 20 ? 14 : EPL == 14 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
+    return G == 4 ? (EPL == 26 ? 20 : EPL == 25 ? 25 : EPL == 20 ? 14 : EPL == 14 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
          : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
          : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
 }
@@ -408,6 +409,74 @@ __device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, con
         else b.advance_pick();
     }
     b.take(dr, walker);
+}
+
+// SCAM-only cycles with one parameter group (the config-2 / config-3 bench kernels): everything of the proposal that is a
+// scalar of the chain -- scale branch, eigen-direction k, amplitude z cd sqrt(S_k) (PT:843-873) -- is computed IN the draw
+// pass, where the four lanes of a chain work on different (iteration, slot) pairs, instead of four times over in the
+// step.  A step then takes three values from the batch (log u from the chain's lane 0; amplitude and direction from lane 1)
+// with five lane moves, and after the first of the two steps the batch rotates by two lanes.  Same operations in the same
+// order as propose(): bit-identical.
+struct ScamDraw { double log_u, amp; int k; };
+template <bool STR>
+struct ScamBatch {
+    double lg, amp;       // log of this lane's uniform (even lanes: the accept test's); odd lanes: the jump amplitude
+    int kdir;             // odd lanes: the eigen-direction
+    static __device__ __forceinline__ double rot2(double v)  // value of the chain's lane (gl + 2) & 3
+    {
+        if constexpr (STR) return __shfl(v, (int)((threadIdx.x + 32) & 63), 64);
+        else return dppf64<0x4E>(v);                         // quad_perm [2,3,0,1]
+    }
+    static __device__ __forceinline__ int rot2(int v)
+    {
+        if constexpr (STR) return __shfl(v, (int)((threadIdx.x + 32) & 63), 64);
+        else return (int)dpp32<0x4E>((u32)v);
+    }
+    // root_s(k): sqrt of the k-th eigenvalue of the chain's table; ng: directions to pick from
+    template <class RS>
+    __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, int ng, RS root_s)
+    {
+        const int j = gl & 3;
+        u64 w0, w1;
+        philox_words(a.seed, (u64)(it + (j >> 1)), sid, (u32)(j & 1), w0, w1);
+        u32 aj;
+        double at;
+        unit_angle32((u32)w1, aj, at);
+        const UnitLogArg g = unit_log_arg((j & 1) ? w0 : w1);       // both uniforms are (0,1] ones
+        double sb, cb;
+        const ptmi_dev_d2 te = draw_table<0>(nullptr, -1, g.slice), tb = draw_table<0>(nullptr, -1, 32u + aj);   // both reads first
+        kdir = (int)h2index((u32)(w1 >> 32), (u32)ng);              // PT:868 (odd lanes)
+        const double rs = root_s(kdir);
+        // the scale branch comes from the iteration's P word, which the chain's lane j - 1 holds (PT:843-858)
+        u32 plo;
+        if constexpr (STR) plo = (u32)__shfl((int)(u32)w0, (int)((threadIdx.x - 16) & 63), 64);
+        else plo = dpp32<0xA0>((u32)w0);                            // quad_perm [0,0,2,2]
+        constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
+        const int br = plo > T97 ? 0 : (plo > T90 ? 1 : 2);
+        unit_rotation(at, sb, cb);
+        lg = unit_log_finish(g, te);
+        const double z = det_sqrt(-2.0 * lg) * unit_cos_finish(tb, sb, cb);
+        amp = z * cc.cd_scam(br) * rs;                              // PT:873
+    }
+    __device__ __forceinline__ void advance()
+    {
+        lg = rot2(lg); amp = rot2(amp); kdir = rot2(kdir);
+    }
+    __device__ __forceinline__ void take(ScamDraw &d) const
+    {
+        d.log_u = grp_bcastf<STR, 0>(lg);
+        d.amp = grp_bcastf<STR, 1>(amp);
+        if constexpr (STR) d.k = __shfl(kdir, (int)(threadIdx.x & 15) + 16, 64);
+        else d.k = (int)dpp32<0x55>((u32)kdir);
+    }
+};
+template <bool STR, class RS>
+__device__ __forceinline__ void scam_draws_for_step(ScamBatch<STR> &b, ScamDraw &dr, const KArgs &a, int k, u32 sid, int gl,
+                                                    const ChainConst &cc, int ng, RS root_s)
+{
+    if ((k & 1) == 0) b.refill(a, a.iter0 + k, sid, gl, cc, ng, root_s);
+    else b.advance();
+    b.take(dr);
 }
 
 // One matrix instruction whose accumulator is pinned to the accumulation registers.  With __builtin_amdgcn_mfma_* in a
@@ -752,6 +821,14 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * a.de_ld : nullptr;
     double *xrow = a.X + (size_t)ch * d;
     DrawBatch<STR> batch;
+    // SCAM-only cycle, one parameter group: the chain-scalar half of the proposal moves into the draw pass (ScamBatch)
+    constexpr bool SCAMFAST = !FULL && !GRP;
+    ScamBatch<STR> sbatch;
+    // ULDS with the exact shape (4, 25) (ndim = 100): the table rows are stored in the lanes' order, 16-byte pieces dealt to
+    // the four lanes in turn (position 8 (e / 2) + 2 lane + e % 2 holds element lane + 4 e; the odd last slot at 96 + lane), so
+    // that a step reads its direction with 12 ds_read_b128 + 1 ds_read_b64 instead of 10 ds_read2_b64 + 6 ds_read_b64:
+    // 61 % of the LDS cycles of that kernel were bank conflicts of the 8-byte reads (profiles/r03_scam_lds.txt)
+    constexpr bool PAIRED = ULDS && G == 4 && EPL == 25;
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = mfma_ld(EPL);
@@ -799,7 +876,14 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         const long long ch0 = (long long)logical_block() * CPB;
         const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
         const double *src = a.Ut + w0 * d * d, *srcS = a.S + w0 * d;
-        for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = src[i];
+        if constexpr (PAIRED) {
+            for (int i = (int)threadIdx.x; i < d * d; i += BLK) {
+                const int r = i / d, c = i % d, ln = c & 3, e = c >> 2;
+                smem[r * d + (e < 2 * (EPL / 2) ? 8 * (e >> 1) + 2 * ln + (e & 1) : 8 * (EPL / 2) + ln)] = src[i];
+            }
+        } else {
+            for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = src[i];
+        }
         if (!ulds_box)
             for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
     }
@@ -891,15 +975,44 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
                 }
             }
         }
+        double log_u;
+        int jt = PTMI_J_SCAM;
+        if constexpr (SCAMFAST) {
+            ScamDraw sd;
+            // sqrt(S_k): from the block's LDS copy where it has one, else from the chain's table (sqrt is correctly rounded: same bits)
+            scam_draws_for_step<STR>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
+                if (ULDS && !ulds_box) return smem[d * d + kk];
+                return det_sqrt(S[kk]);
+            });
+            log_u = sd.log_u;
+            if constexpr (PAIRED) {
+                const double *row = smem + (size_t)sd.k * d;
+                const ptmi_d2 *rp = reinterpret_cast<const ptmi_d2 *>(row) + gl;
+#pragma unroll
+                for (int e2 = 0; e2 < EPL / 2; ++e2) { const ptmi_d2 v = rp[4 * e2]; dq[2 * e2] = v.x; dq[2 * e2 + 1] = v.y; }
+                if (EPL & 1) dq[EPL - 1] = row[8 * (EPL / 2) + gl];
+            } else {
+                if constexpr (ULDS) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], smem + (size_t)sd.k * d, e);
+                } else {
+                    const double *col = UtBlock + (size_t)sd.k * d;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], col, e);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dq[e] = sd.amp * dq[e];
+        } else {
         Draws dr;
         draws_for_step<STR, FULL, TM>(batch, dr, a, k, sid, sid0, gl, tsm);
-        const double log_u = dr.log_u;
-        int jt;
+        log_u = dr.log_u;
         if (ULDS && ulds_box) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, S, DE, dq, false);
         else if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
         else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true, !amq_on, tsm);
         else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true, !amq_on, tsm);
         else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
+        }
         if constexpr (AMQ) {
             // the rank of this chain's event of this step is held by its lane of row (k & 3)
             const int rk = __shfl(rank_c, 16 * (k & 3) + (lane & 15), 64);
@@ -1009,7 +1122,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
     const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
     const u32 sid = sid0 + (u32)tg;
     double *xrow = a.X + (size_t)ch * d;
-    DrawBatch<true> batch;
+    ScamBatch<true> sbatch;
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
 #define PTMI_D_P (smem)
@@ -1038,10 +1151,13 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
 
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
-        Draws dr;
-        draws_for_step<true, false>(batch, dr, a, k, sid, sid0, gl);
-        const double log_u = dr.log_u;
-        propose<G, EPL, false, true, false>(a, it, sid, gl, cc, dr, PTMI_D_U, false, PTMI_D_SQ, nullptr, dq, true);
+        ScamDraw sd;
+        scam_draws_for_step<true>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) { return PTMI_D_SQ[kk]; });
+        const double log_u = sd.log_u;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], PTMI_D_U + (size_t)sd.k * d, e);       // PT:868-873
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) dq[e] = sd.amp * dq[e];
         // PT:605-612: prior on q = x + dq, then -1/2 r^T P r with r = q - mu
         const double nlp = eval_logp_q<G, EPL, true>(a, smem, gl, [&](int e) { return x[e] + dq[e]; });
         MfmaAcc<EPL> acc;

@@ -395,9 +395,10 @@ class PTSampler(object):
                 for ii in range(self.ndim):
                     try:
                         taus.append(acor(self._chain[lo:hi, ii])[0])
-                    except AcorError:                                # too few samples for this autocorrelation time: no estimate yet
-                        taus.append(np.nan)
-                if np.isfinite(taus).any():
+                    except AcorError:                                # "autocorrelation time too long": the reference's run would die
+                        taus = []                                    # here with acor's RuntimeError; this one keeps sampling and asks again
+                        break                                        # in 1000 iterations
+                if len(taus) and np.isfinite(taus).any():
                     Neff = (end // self.thin) / max(1.0, np.nanmax(taus))
                     if int(Neff) >= self.neff:
                         message = "\nRun Complete with {0} effective samples".format(int(Neff))

@@ -32,7 +32,7 @@ def test_dense_scam_only_runs_staged_and_matches(mods, cov_mode, nt, W, dense512
     g.run(80)
     o.run(80)
     flags, G, E = g.last_variant()
-    assert flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL and (G, E) == (4, 26)
+    assert flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL and (G, E) == (4, 25)
     assert bool(flags & _lib.VAR_DENSE_SCAM) == dense512
     _compare(g, o, "dense scam %s " % cov_mode)
     assert_same(g.get("Ut"), o.Ut, "Ut")
@@ -52,7 +52,7 @@ def test_dense_with_am_runs_on_the_matrix_cores_and_matches(mods, cov_mode, nt, 
     g.run(130)
     o.run(130)
     flags, G, E = g.last_variant()
-    assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and (G, E) == (4, 26)
+    assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and (G, E) == (4, 25)
     _compare(g, o, "dense am %s " % cov_mode)
     assert_same(g.get("cov"), o.cov, "cov")
     assert_same(g.get("Ut"), o.Ut, "Ut")
@@ -112,7 +112,7 @@ def test_box_prior_from_lds_table(mods, kind):
     g.run(140)
     o.run(140)
     flags, G, E = g.last_variant()
-    assert flags & _lib.VAR_LDS_BOX and (G, E) == (4, 26)
+    assert flags & _lib.VAR_LDS_BOX and (G, E) == (4, 25)
     if kind == "scam":
         assert flags & _lib.VAR_LDS_UT and not flags & _lib.VAR_STAGED
     _compare(g, o, "box %s " % kind)
@@ -193,7 +193,7 @@ def test_full_size_default_mix_with_covariance_and_de_epochs(mods):
         for o in sub.subs:
             o.run(cu)
         flags, G, E = g.last_variant()
-        assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and flags & _lib.VAR_LDS_UT and (G, E) == (4, 26)
+        assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and flags & _lib.VAR_LDS_UT and (G, E) == (4, 25)
         if k > 0:
             assert_same(g.get("cov")[0], sub.subs[0].cov[0], "pooled cov after epoch %d" % k)
             assert_same(g.get("Ut")[0], sub.subs[0].Ut[0], "Ut after epoch %d" % k)
@@ -236,7 +236,7 @@ def test_full_size_dense_scam_through_pooled_covariance_epochs(mods):
         for o in sub.subs:
             o.run(cu)
         flags, G, E = g.last_variant()
-        assert flags & _lib.VAR_DENSE_SCAM and flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL and (G, E) == (4, 26)
+        assert flags & _lib.VAR_DENSE_SCAM and flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL and (G, E) == (4, 25)
         if k > 0:
             assert_same(g.get("cov")[0], sub.subs[0].cov[0], "pooled cov after epoch %d" % k)
             assert_same(g.get("Ut")[0], sub.subs[0].Ut[0], "Ut after epoch %d" % k)

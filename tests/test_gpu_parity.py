@@ -318,7 +318,7 @@ def test_full_size_properties_and_subset_parity(mods):
         assert_same(g.get("nswap")[w0], o.nswap[0], "walker %d nswap" % w0)
 
 
-@pytest.mark.parametrize("d,nt,W", [(1, 1, 1), (2, 1, 3), (3, 2, 1), (7, 5, 13), (33, 3, 11), (104, 2, 9), (105, 2, 5), (417, 2, 2), (641, 2, 2), (1025, 2, 2),
+@pytest.mark.parametrize("d,nt,W", [(1, 1, 1), (2, 1, 3), (3, 2, 1), (7, 5, 13), (33, 3, 11), (97, 3, 5), (99, 2, 7), (101, 3, 5), (104, 2, 9), (105, 2, 5), (417, 2, 2), (641, 2, 2), (1025, 2, 2),
                                     (3, 300, 5), (2, 520, 37)])     # long ladders: the swap sweep stages fewer walkers per block
 def test_ragged_and_boundary_sizes(mods, d, nt, W):
     """Sizes that do not fill a block or a shape: one dimension, one temperature (no swaps), chain counts that
@@ -330,6 +330,27 @@ def test_ragged_and_boundary_sizes(mods, d, nt, W):
     o.run(n)
     _compare(g, o, "ragged d=%d nt=%d W=%d " % (d, nt, W))
     assert_same(g.get("cov"), o.cov, "cov")
+
+
+@pytest.mark.parametrize("d,prior", [(99, "flat"), (100, "flat"), (100, "box"), (101, "flat"), (104, "box"), (81, "flat")])
+def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior):
+    """SCAM-only cycle with the eigenvector table in LDS (the config-2 bench kernel) on both sides of ndim = 100: 100 runs the
+    EXACT shape (4, 25) -- no bounds checks, table rows stored in lane order and read 16 bytes at a time, chain-scalar half of
+    the proposal computed in the draw pass -- its neighbours the general shape (4, 26).  Pooled covariance epochs in between
+    change the table; 70 walkers x 4 ranks fill more than one block (PTMCMCSampler.py:820-876, 605-622)."""
+    orc, _lib, _ = mods
+    kw = dict(weights=(20, 0, 0), cov_update=40, burn=1000, tskip=10, seed=d, cov_mode="pooled", cov0=np.eye(d) * 0.02)
+    if prior == "box":
+        kw.update(logp=("box", -0.4 * np.ones(d), 0.5 * np.ones(d)), p0=np.random.RandomState(d).uniform(-0.1, 0.1, (70, 4, d)))
+    g, o = _pair(mods, d, 4, 70, **kw)
+    for n in (97, 3, 50):                                      # odd launch lengths: the draw pass serves two steps
+        g.run(n)
+        o.run(n)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_LDS_UT and not flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL
+    assert (G, E) == ((4, 25) if d == 100 else (4, 26) if d > 80 else (4, 20))
+    _compare(g, o, "scam table d=%d %s " % (d, prior))
+    assert_same(g.get("Ut"), o.Ut, "Ut")
 
 
 def test_minus_inf_start_and_nan_safety(mods):
