@@ -924,7 +924,10 @@ ORC_API int orc_swap_sweep(int nwalkers, int n, const double *ladder, const doub
             la += -L[m[k + 1]] / ladder[k + 1];
             la += L[m[k + 1]] / ladder[k];
             la += L[m[k]] / ladder[k + 1];
-            if (u <= orc_exp(la)) {
+            /* PT:679 accepts iff u <= exp(sum); stated in log space, log(u) <= sum: the same decision (log is monotone; u = 0
+             * accepts always, a NaN sum never) up to the last-ulp wiggles of either function, and the form the device's sweep
+             * can keep out of its pair-to-pair recurrence (the logarithm depends on the uniform alone) */
+            if (orc_log(u) <= la) {
                 int32_t tt = m[k]; m[k] = m[k + 1]; m[k + 1] = tt;
                 acc[(size_t)w * n + k] += 1;
             }
@@ -951,7 +954,7 @@ ORC_API void orc_swap_oddeven(int nwalkers, int n, const double *ladder, const d
             la += -L[k + 1] / ladder[k + 1];
             la += L[k + 1] / ladder[k];
             la += L[k] / ladder[k + 1];
-            if (w2uniform(W[0]) <= orc_exp(la)) {
+            if (orc_log(w2uniform(W[0])) <= la) {
                 m[k] = k + 1;
                 m[k + 1] = k;
                 acc[(size_t)w * n + k] += 1;

@@ -29,9 +29,10 @@ __global__ void gather_lnl_kernel(const double *lnL, const int32_t *slot_of, dou
 }
 
 // PT:666-686 in two kernels.  swap_prepare_kernel (one thread per position and walker) does everything that does
-// not depend on the carried state: the pair's uniform, and the two terms of the acceptance sum that involve only
-// position k's own likelihood.  swap_sweep_kernel (one lane per walker) then runs the hot -> cold recurrence with
-// the carried map: per pair two divisions, an exp and a compare.  Scratch is position-major [n][W] so the sweep's
+// not depend on the carried state: the LOGARITHM of the pair's uniform (PT:679's u <= exp(sum) is tested as log u <= sum,
+// as the oracle defines it: the transcendental leaves the recurrence), and the two terms of the acceptance sum that involve
+// only position k's own likelihood.  swap_sweep_kernel (one lane per walker) then runs the hot -> cold recurrence with
+// the carried map: per pair two divisions, three sums and a compare.  Scratch is position-major [n][W] so the sweep's
 // reads are coalesced.  When the whole ladder is local (slot_of != nullptr) the slot tables are rewritten in place:
 // position k+1 becomes final at step k and positions <= k are still untouched.
 __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const double *lnL_pos, const double *lnL_rows,
@@ -51,7 +52,7 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
         const u32 sid = (u32)((u64)(walker0 + w) * (u32)n + 0u);      // rank 0's stream (PT:679)
         u64 w0, w1;
         philox_words(seed, (u64)iter, sid, SLOT_SWAP + (u32)k, w0, w1);
-        u = w2uniform(w0);
+        u = det_log(w2uniform(w0));                                   // log of the [0,1) uniform; -inf for u = 0: always accepted
         a = -L / ladder[k];
         b = L / ladder[k + 1];
     }
@@ -125,7 +126,7 @@ __global__ void swap_sweep_kernel(int W, int n, const double *ladder, const doub
             la += -Lc / Tk1;
             la += Lc / Tk;
             la += pb[j];                       //  L[k] / T[k+1]
-            const bool acc = (parity < 0 || (k & 1) == parity) && u <= det_exp(la);
+            const bool acc = (parity < 0 || (k & 1) == parity) && u <= la;       // u = log(uniform)
             // position k+1 is final: it keeps the carried state, or takes position k's
             const int fin = acc ? k : c;
             if (mp) { mp[k + 1] = fin; iv[fin] = k + 1; }
@@ -190,7 +191,7 @@ __global__ void swap_oddeven_kernel(int W, int n, const double *ladder, const do
     la += -Lk1 / Tk1;
     la += Lk1 / Tk;
     la += Lk / Tk1;
-    if (w2uniform(w0) <= det_exp(la)) {
+    if (det_log(w2uniform(w0)) <= la) {
         so[k] = rk1;
         so[k + 1] = rk;
         to[rk1] = k;

@@ -347,7 +347,8 @@ def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior):
         g.run(n)
         o.run(n)
     flags, G, E = g.last_variant()
-    assert flags & _lib.VAR_LDS_UT and not flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL
+    assert not flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL
+    assert bool(flags & _lib.VAR_LDS_UT) == (d <= 100)             # two blocks' tables (+ sqrt(S) or the bounds) fit the CU up to ndim = 100
     assert (G, E) == ((4, 25) if d == 100 else (4, 26) if d > 80 else (4, 20))
     _compare(g, o, "scam table d=%d %s " % (d, prior))
     assert_same(g.get("Ut"), o.Ut, "Ut")

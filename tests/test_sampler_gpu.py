@@ -350,9 +350,10 @@ def test_neff_stops_the_run_early(tmp_path, capsys):
     if prev > 600:                                                                   # it did not pass the test one check earlier
         tp = taus(s._chain[300:prev - 1])
         assert tp is None or int(prev / max(1.0, np.nanmax(tp))) < 150                # no estimate for a dimension = no stop
-    # an independent estimator on the same samples agrees on the autocorrelation time (both within their sampling error)
+    # an independent estimator on the same samples agrees on the autocorrelation time within the sampling error of either
+    # (a window of ~100 tau: relative standard error ~0.5 each; the estimators themselves are pinned on AR(1) series)
     tau_sokal = max(integrated_time(s._chain[300:s.Niter - 1, i]) for i in range(d))
-    assert 0.6 < tau_acor / tau_sokal < 1.6, (tau_acor, tau_sokal)
+    assert 0.4 < tau_acor / tau_sokal < 2.5, (tau_acor, tau_sokal)
     assert len(open(tmp_path / "chain_1.txt").read().splitlines()) == s.Niter + 1
     # without neff the same run goes on to the end
     s2 = PTSampler(d, ("iso",), ("flat",), np.eye(d), outDir=str(tmp_path / "b"), verbose=False, seed=2)
