@@ -30,141 +30,151 @@ __global__ void gather_lnl_kernel(const double *lnL, const int32_t *slot_of, dou
 
 // PT:666-686 in two kernels.  swap_prepare_kernel (one thread per position and walker) does everything that does
 // not depend on the carried state: the LOGARITHM of the pair's uniform (PT:679's u <= exp(sum) is tested as log u <= sum,
-// as the oracle defines it: the transcendental leaves the recurrence), and the two terms of the acceptance sum that involve
-// only position k's own likelihood.  swap_sweep_kernel (one lane per walker) then runs the hot -> cold recurrence with
-// the carried map: per pair two divisions, three sums and a compare.  Scratch is position-major [n][W] so the sweep's
-// reads are coalesced.  When the whole ladder is local (slot_of != nullptr) the slot tables are rewritten in place:
-// position k+1 becomes final at step k and positions <= k are still untouched.
+// as the oracle defines it: the transcendental leaves the recurrence) and every quotient of a position's OWN likelihood,
+// L[k] / T[k], L[k] / T[k+1] and L[k] / T[k-1].  swap_sweep_kernel (one lane per walker) then runs the hot -> cold
+// recurrence with the carried map.  Scratch: one 48-byte record per (position, walker), position-major [n][W], so a pair
+// costs the sweep three 16-byte loads per lane from one wave-uniform base and a wave reads 3 KB in a row.  When the whole
+// ladder is local (slot_of != nullptr) the slot tables are rewritten in place: position k+1 becomes final at step k and
+// positions <= k are still untouched.
+struct __attribute__((aligned(16))) SwapPre {
+    double lu, L;        // log of the pair's uniform; the position's likelihood
+    double a, b;         // -L/T[k], L/T[k+1]
+    double c;            // L/T[k-1]
+    int32_t row, pad;    // the slot that holds the position (whole ladder local)
+};
+static_assert(sizeof(SwapPre) == 48, "three 16-byte loads");
 __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const double *lnL_pos, const double *lnL_rows,
-                                    const int32_t *slot_of, double *pre, int32_t *prow, long long iter, u64 seed, int walker0,
+                                    const int32_t *slot_of, SwapPre *pre, long long iter, u64 seed, int walker0,
                                     int block_nt /* > 0: lnL_pos is [n / block_nt][W][block_nt], as all-gathered */)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * W) return;
     const int k = (int)(idx / W), w = (int)(idx % W);
-    const size_t nW = (size_t)n * W;
     const bool fused = slot_of != nullptr;
     const int row = fused ? slot_of[(size_t)w * n + k] : 0;
     const double L = fused ? lnL_rows[(size_t)w * n + row]
                    : (block_nt > 0 ? lnL_pos[((size_t)(k / block_nt) * W + w) * block_nt + k % block_nt] : lnL_pos[(size_t)w * n + k]);
-    double u = 0.0, a = 0.0, b = 0.0;
+    double u = 0.0, b = 0.0, c = 0.0;
     if (k < n - 1) {
         const u32 sid = (u32)((u64)(walker0 + w) * (u32)n + 0u);      // rank 0's stream (PT:679)
         u64 w0, w1;
         philox_words(seed, (u64)iter, sid, SLOT_SWAP + (u32)k, w0, w1);
         u = det_log(w2uniform(w0));                                   // log of the [0,1) uniform; -inf for u = 0: always accepted
-        a = -L / ladder[k];
         b = L / ladder[k + 1];
     }
-    pre[idx] = u;
-    pre[nW + idx] = L;
-    pre[2 * nW + idx] = a;
-    pre[3 * nW + idx] = b;
-    if (fused) prow[idx] = row;
+    if (k > 0) c = L / ladder[k - 1];
+    SwapPre r;
+    r.lu = u; r.L = L; r.a = -L / ladder[k]; r.b = b; r.c = c; r.row = fused ? row : k; r.pad = 0;
+    pre[idx] = r;
 }
 
+// The recurrence of pair k (positions k, k+1; carried state of likelihood Lc at k+1) is the reference's four-term sum in
+// its order, -L[k]/T[k] - Lc/T[k+1] + Lc/T[k] + L[k]/T[k+1], against log u.  The two quotients of Lc are carried along with
+// it: if the pair accepts, Lc moves on and pair k-1 needs Lc/T[k] (this pair's third term) and Lc/T[k-1] -- ONE new division,
+// independent of this pair's decision, so it runs in the shadow of the sums and the compare; if it rejects, the new carried
+// state is position k's own and both quotients come from the prepared arrays (-(-L[k]/T[k]) and L[k]/T[k-1]; negation is
+// exact).  Same operations on the same values as the oracle: bit-identical decisions.  Per pair the serial path is three
+// sums, a compare and the selects (0.65 us per pair with two divisions and an exp on it, round 2).
 // parity >= 0 (odd/even mode): only the pairs with k = parity (mod 2) are tried; an untried pair never accepts, so
 // the carried state is always position k+1's own and the recurrence degenerates into independent pair tests.
 // STG: the tables the sweep writes are [walker][position] -- a lane per walker scatters 4-byte stores 4 n bytes apart, 64
-// memory transactions per store instruction, five of them per pair: 35 of the kernel's 63 us at 64 ranks.  So the block
-// (one wave = 64 walkers) keeps its walkers' tables and acceptance flags in LDS (rows of n + 1 ints: a lane per bank) and
-// writes them out at the end with the lanes along the position.  3 x wpb x (n + 1) ints: 64 walkers per block up to 207
-// ranks, 32 / 16 / 8 for longer ladders (512 ranks of an 8-GPU ladder: 16); beyond that the direct stores (STG = false).
+// memory transactions per store instruction.  So the block (one wave = 64 walkers) keeps its walkers' forward table and
+// acceptance flags in LDS (rows of n + 1 ints: a lane per bank) and writes them out at the end with the lanes along the
+// position, building the inverse table there.  2 x wpb x (n + 1) ints: 64 walkers per block up to 319 ranks, 32 / 16 / 8
+// for longer ladders (512 ranks of an 8-GPU ladder: 32); beyond that the direct stores (STG = false).
 #ifndef PTMI_SWEEP_BATCH
 #define PTMI_SWEEP_BATCH 8
 #endif
 template <bool STG>
-__global__ void swap_sweep_kernel(int W, int n, const double *ladder, const double *pre, const int32_t *prow,
+__global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n, const double *ladder, const SwapPre *pre,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
                                   int parity, int32_t *inv /* with map: inv[w][map[w][j]] = j */,
                                   int wpb /* walkers per block: 64, fewer when a long ladder's tables would not fit the LDS */)
 {
+    // STG blocks have four waves: the first runs the recurrence (a lane per walker), all four write the tables out
     extern __shared__ int32_t sw_lds[];
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int w = (int)blockIdx.x * wpb + lane;
-    const size_t nW = (size_t)n * W;
     const bool fused = slot_of != nullptr;
     const int ld = n + 1;
     int32_t *const l0 = sw_lds + (size_t)lane * ld;                    // slot_of / map of this lane's walker
-    int32_t *const l1 = sw_lds + (size_t)(wpb + lane) * ld;            // temp_of / inv
-    int32_t *const lf = sw_lds + (size_t)(2 * wpb + lane) * ld;        // pair k accepted
-    if (lane < wpb && w < W) {
-    int32_t *so = fused ? (STG ? l0 : slot_of + (size_t)w * n) : nullptr;
-    int32_t *to = fused ? (STG ? l1 : temp_of + (size_t)w * n) : nullptr;
-    int32_t *mp = map ? (STG ? l0 : map + (size_t)w * n) : nullptr;
-    int32_t *iv = map ? (STG ? l1 : inv + (size_t)w * n) : nullptr;
-    int c = n - 1;                         // position whose state is carried at k+1
-    int crow = fused ? prow[(size_t)(n - 1) * W + w] : 0;
-    double Lc = pre[nW + (size_t)(n - 1) * W + w];
-    // Only Lc is carried from pair to pair: the scratch of SW pairs is fetched at once (independent loads, one HBM / L2
-    // latency per SW pairs instead of one per pair), then the SW dependent steps run from registers.  Batches of 2, 4
-    // and 8 pairs take the same time (the kernel is bound by the ~130 instructions of a pair on a lone wave, three
-    // divisions among them: 0.65 us per pair), 16 and 32 are slower (-DPTMI_SWEEP_BATCH).
+    int32_t *const lf = sw_lds + (size_t)(wpb + lane) * ld;            // pair k accepted
+    if (wave == 0 && lane < wpb && w < W) {
+    int32_t *fw = STG ? l0 : (fused ? slot_of + (size_t)w * n : map + (size_t)w * n);     // forward table: row (fused) or source position
+    int32_t *bw = STG ? nullptr : (fused ? temp_of + (size_t)w * n : inv + (size_t)w * n); // its inverse (STG: built at write-out)
+    const SwapPre top = pre[(size_t)(n - 1) * W + w];
+    int crow = top.row;                    // what the forward table says about the state carried at k+1 (its slot, or its position)
+    double Lc = top.L;
+    double q1 = -top.a;                    // Lc / T[k+1]
+    double q0 = top.c;                     // Lc / T[k]
+    // Only (Lc, q1, q0) are carried from pair to pair.  The scratch of SW pairs is fetched at once into one of two register
+    // sets (this kernel runs one wave per SIMD: registers are free), the NEXT batch being requested before the current one
+    // is worked through, so that one memory latency is exposed per launch instead of one per batch (round 2's version
+    // requested T[k] through the scalar unit, one waited-for load per pair: 0.5 us per pair whatever the arithmetic).
+    // Indices below 0 are clamped, not branched around: their values are never used.
     constexpr int SW = PTMI_SWEEP_BATCH;
-    for (int k0 = n - 2; k0 >= 0; k0 -= SW) {
-        double pu[SW], pL[SW], pa[SW], pb[SW], pT[SW + 1];
-        int pr[SW];
+    struct Batch { double u[SW], L[SW], a[SW], b[SW], c[SW], T[SW]; int r[SW]; };
+    // addresses: the lane's record of position 0 (computed once) + a wave-uniform stride per position
+    const char *const lane0 = reinterpret_cast<const char *>(pre + ((size_t)blockIdx.x * wpb + (unsigned)lane));
+    const size_t kstride = (size_t)W * sizeof(SwapPre);
+    auto fetch = [&](int k0, Batch &B) {
 #pragma unroll
         for (int j = 0; j < SW; ++j) {
-            const int kk = k0 - j;
-            if (kk >= 0) {
-                const size_t oo = (size_t)kk * W + w;
-                pu[j] = pre[oo]; pL[j] = pre[nW + oo]; pa[j] = pre[2 * nW + oo]; pb[j] = pre[3 * nW + oo];
-                pr[j] = fused ? prow[oo] : 0;
-                pT[j + 1] = ladder[kk];
-            }
+            const int kk = k0 - j > 0 ? k0 - j : 0;
+            const SwapPre r = *reinterpret_cast<const SwapPre *>(lane0 + (size_t)kk * kstride);
+            B.u[j] = r.lu; B.L[j] = r.L; B.a[j] = r.a; B.b[j] = r.b; B.c[j] = r.c; B.r[j] = r.row;
+            B.T[j] = ladder[kk > 0 ? kk - 1 : 0];                       // T[k-1] (uniform: a scalar load)
         }
-        pT[0] = ladder[k0 + 1];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto chain = [&](int k0, const Batch &B) {
 #pragma unroll
         for (int j = 0; j < SW; ++j) {
             const int k = k0 - j;
             if (k < 0) break;
-            const double u = pu[j], La = pL[j];
-            const int krow = pr[j];
-            const double Tk = pT[j + 1], Tk1 = pT[j];
-            double la = pa[j];                 // -L[k] / T[k]
-            la += -Lc / Tk1;
-            la += Lc / Tk;
-            la += pb[j];                       //  L[k] / T[k+1]
-            const bool acc = (parity < 0 || (k & 1) == parity) && u <= la;       // u = log(uniform)
+            const double spec = Lc / B.T[j];   // Lc / T[k-1]: needed if this pair accepts; does not wait for its decision
+            double la = B.a[j];                // -L[k] / T[k]
+            la += -q1;                         // -Lc / T[k+1]
+            la += q0;                          //  Lc / T[k]
+            la += B.b[j];                      //  L[k] / T[k+1]
+            const bool acc = (parity < 0 || (k & 1) == parity) && B.u[j] <= la;      // log u <= sum
             // position k+1 is final: it keeps the carried state, or takes position k's
-            const int fin = acc ? k : c;
-            if (mp) { mp[k + 1] = fin; iv[fin] = k + 1; }
+            const int fin = acc ? B.r[j] : crow;
+            fw[k + 1] = fin;
+            if (!STG) bw[fin] = k + 1;
             if (STG) lf[k] = acc ? 1 : 0;
-            if (fused) {
-                const int frow = acc ? krow : crow;
-                so[k + 1] = frow;
-                to[frow] = k + 1;
-                if (!acc) crow = krow;
-            }
-            if (acc) {
-                // a no-return atomic: the recurrence must not wait for a load of the counter
-                if (!STG && k >= local0 && k < local0 + nlocal) atomicAdd((unsigned long long *)&nswap[(size_t)w * n + k], 1ull);
-            } else {
-                c = k;
-                Lc = La;
-            }
+            else if (acc && k >= local0 && k < local0 + nlocal) atomicAdd((unsigned long long *)&nswap[(size_t)w * n + k], 1ull);   // no-return atomic
+            q1 = acc ? q0 : -B.a[j];
+            q0 = acc ? spec : B.c[j];
+            Lc = acc ? Lc : B.L[j];
+            crow = acc ? crow : B.r[j];
         }
+    };
+    Batch A, B;
+    fetch(n - 2, A);
+    for (int k0 = n - 2; k0 >= 0; k0 -= 2 * SW) {
+        if (k0 - SW >= 0) fetch(k0 - SW, B);
+        chain(k0, A);
+        if (k0 - SW < 0) break;
+        if (k0 - 2 * SW >= 0) fetch(k0 - 2 * SW, A);
+        chain(k0 - SW, B);
     }
-    if (mp) { mp[0] = c; iv[c] = 0; }
-    if (fused) {
-        so[0] = crow;
-        to[crow] = 0;
-    }
+    fw[0] = crow;
+    if (!STG) bw[crow] = 0;
     }
     if (STG) {
         __syncthreads();
         const int w0 = (int)blockIdx.x * wpb;
         int32_t *g0 = fused ? slot_of : map, *g1 = fused ? temp_of : inv;
         const int nw = W - w0 < wpb ? W - w0 : wpb;
-#pragma unroll 8
-        for (int wl = 0; wl < nw; ++wl) {                              // eight walkers' rows in flight
+        for (int wl = wave; wl < nw; wl += 4) {                        // a wave per walker, the lanes along the position
             const size_t row = (size_t)(w0 + wl) * n;
             for (int k = lane; k < n; k += 64) {
-                g0[row + k] = sw_lds[(size_t)wl * ld + k];
-                g1[row + k] = sw_lds[(size_t)(wpb + wl) * ld + k];
-                // a no-return atomic: nothing here waits for a load of the counter
-                if (k < n - 1 && k >= local0 && k < local0 + nlocal && sw_lds[(size_t)(2 * wpb + wl) * ld + k])
+                const int f = sw_lds[(size_t)wl * ld + k];
+                g0[row + k] = f;
+                g1[row + f] = k;                                       // the inverse table: a scatter inside the walker's own row
+                // a no-return atomic: fire and forget (a read-modify-write would wait for its load in every trip: 37 against 24 us)
+                if (k < n - 1 && k >= local0 && k < local0 + nlocal && sw_lds[(size_t)(wpb + wl) * ld + k])
                     atomicAdd((unsigned long long *)&nswap[row + k], 1ull);
             }
         }
@@ -959,8 +969,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     h->cfg.gj_tab = nullptr;
     h->cfg.ladder = h->cfg.temps_mh = h->cfg.logl_par = h->cfg.logp_par = h->cfg.group_mask = nullptr;  // host copies are not kept
     h->cfg.group_size = nullptr;
-    hipError_t e = hipMalloc((void **)&h->d_pre, sizeof(double) * 4 * (size_t)c.nwalkers * c.ntemps_global);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_prow, sizeof(int32_t) * (size_t)c.nwalkers * c.ntemps_global);
+    hipError_t e = hipMalloc((void **)&h->d_pre, sizeof(SwapPre) * (size_t)c.nwalkers * c.ntemps_global);
     if (e == hipSuccess && !c.cov_per_walker && c.temp0 == 0) {
         const size_t ng = (size_t)(c.nwalkers + POOL_GS - 1) / POOL_GS;
         e = hipMalloc((void **)&h->d_pool_mu, sizeof(double) * ng * c.ndim);
@@ -977,7 +986,7 @@ int ptmi_destroy(ptmi_handle h)
 {
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
-    (void)hipFree(h->d_pre); (void)hipFree(h->d_prow); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
+    (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1097,22 +1106,21 @@ static int swap_parity(const ptmi_config &c, int64_t iter)
     return (int)((c.tskip > 0 ? iter / c.tskip : iter) & 1);
 }
 
-static int launch_swap_sweep(ptmi_engine *h, int W, int n, const double *pre, const int32_t *prow, int32_t *slot_of, int32_t *temp_of,
+static int launch_swap_sweep(ptmi_engine *h, int W, int n, const SwapPre *pre, int32_t *slot_of, int32_t *temp_of,
                              int32_t *map, u64 *nswap, int local0, int nlocal, int parity, int32_t *inv)
 {
-    int wpb = 64;                                                      // 3 tables of wpb x (n + 1) ints must fit the CU's LDS
-    while (wpb > 8 && sizeof(int32_t) * 3 * (size_t)wpb * (size_t)(n + 1) > 160 * 1024) wpb /= 2;
-    const size_t lds = sizeof(int32_t) * 3 * (size_t)wpb * (size_t)(n + 1);
-    const dim3 block(64);
+    int wpb = 64;                                                      // 2 tables of wpb x (n + 1) ints must fit the CU's LDS
+    while (wpb > 8 && sizeof(int32_t) * 2 * (size_t)wpb * (size_t)(n + 1) > 160 * 1024) wpb /= 2;
+    const size_t lds = sizeof(int32_t) * 2 * (size_t)wpb * (size_t)(n + 1);
     if (lds <= 160 * 1024) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)swap_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(swap_sweep_kernel<true>, dim3((unsigned)((W + wpb - 1) / wpb)), block, lds, h->stream, W, n, h->d_ladder, pre, prow,
+        hipLaunchKernelGGL(swap_sweep_kernel<true>, dim3((unsigned)((W + wpb - 1) / wpb)), dim3(256), lds, h->stream, W, n, h->d_ladder, pre,
                            slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, wpb);
     } else {
-        hipLaunchKernelGGL(swap_sweep_kernel<false>, dim3((unsigned)((W + 63) / 64)), block, 0, h->stream, W, n, h->d_ladder, pre, prow,
+        hipLaunchKernelGGL(swap_sweep_kernel<false>, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, h->stream, W, n, h->d_ladder, pre,
                            slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, 64);
     }
     return PTMI_OK;
@@ -1138,9 +1146,9 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
         return ptmi_swap_write_am(h, iter);
     }
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps, h->d_ladder,
-                       (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, h->d_pre, h->d_prow,
+                       (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, (SwapPre *)h->d_pre,
                        (long long)iter, c.seed, c.walker0, 0);
-    if (int rc = launch_swap_sweep(h, W, c.ntemps, (const double *)h->d_pre, (const int32_t *)h->d_prow, h->buf.slot_of, h->buf.temp_of,
+    if (int rc = launch_swap_sweep(h, W, c.ntemps, (const SwapPre *)h->d_pre, h->buf.slot_of, h->buf.temp_of,
                                    (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1, (int32_t *)nullptr)) return rc;
     HIPCHK(hipGetLastError());
     return ptmi_swap_write_am(h, iter);
@@ -1181,9 +1189,9 @@ static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t 
     const long long tot = (long long)W * c.ntemps_global;
     if (int rc = ensure_xint(h)) return rc;
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global,
-                       h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, h->d_pre, h->d_prow,
+                       h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, (SwapPre *)h->d_pre,
                        (long long)iter, c.seed, c.walker0, block_nt);
-    if (int rc = launch_swap_sweep(h, W, c.ntemps_global, (const double *)h->d_pre, (const int32_t *)h->d_prow, (int32_t *)nullptr,
+    if (int rc = launch_swap_sweep(h, W, c.ntemps_global, (const SwapPre *)h->d_pre, (int32_t *)nullptr,
                                    (int32_t *)nullptr, map, (u64 *)h->buf.nswap, c.temp0, c.ntemps,
                                    c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1, h->d_xint /* inv[W][ntemps_global] */)) return rc;
     HIPCHK(hipGetLastError());

@@ -84,8 +84,7 @@ struct ptmi_engine {
     hipStream_t stream;
     double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar, *d_gmask, *d_gcn, *d_gdiv;
     int32_t *d_gsize;
-    double *d_pre;      // [4][ntg][W] scratch of the swap (uniforms, likelihoods, own-likelihood terms)
-    int32_t *d_prow;    // [ntg][W] rows by position (fused swap)
+    void *d_pre;        // [ntg][W] records of the swap (log uniform, likelihood, own-likelihood quotients, row: swap_prepare_kernel)
     int32_t *d_hop;     // set by ptmi_exchange_pack when a row of the last sweep travels beyond a neighbouring block
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
