@@ -130,8 +130,8 @@ typedef struct ptmi_buffers {
     uint64_t *nacc;     /* [W][T]      accepted MH updates per rank (:621) */
     uint64_t *jstat;    /* [W][T][PTMI_J_NTYPES][2]  proposed, accepted per jump type (:602,622) */
     uint64_t *nswap;    /* [W][ntemps_global]  accepted swaps credited to the lower rank (:681) */
-    double *mu;         /* [W][d]      running mean of the rank-0 chain (:148) */
-    double *M2;         /* [W][d][d]   running sum of outer products (:147) */
+    double *mu;         /* [Wc][d]     running mean of the rank-0 chain (:148); pooled: of all walkers' rank-0 samples */
+    double *M2;         /* [Wc][d][d]  running sum of outer products about the mean (:147) */
     double *cov;        /* [Wc][d][d]  published covariance (:794) */
     double *Q;          /* [W][T][d]   proposals, split path only (optional) */
     double *qaux;       /* [W][T][4]   split path: qxy, jump type (>= PTMI_J_NTYPES: host entry index + PTMI_J_NTYPES),
@@ -233,8 +233,10 @@ int ptmi_exchange_status(ptmi_handle h, int32_t *violations);
 int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag);
 
 /* _updateRecursive (:769-794) for every walker at iteration `iter` (= the multiple of
- * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 the
- * walkers' statistics are pooled into cov[0].  The eigendecomposition (:797-803) is a
+ * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 ONE set
+ * (mu[0], M2[0], cov[0]) is adapted from all walkers' buffered rows: shifted sums of outer products on the matrix
+ * cores, slab by slab, combined with the running statistics by Chan's formula (the sample covariance of every
+ * rank-0 sample so far; oracle: orc_pool_update).  The eigendecomposition (:797-803) is a
  * separate step: on the host (LAPACK, as the reference) or ptmi_eig_jacobi. */
 int ptmi_update_cov(ptmi_handle h, int64_t iter);
 

@@ -91,7 +91,8 @@ def lib():
         L.orc_swap_apply.argtypes = [C.POINTER(Cfg), C.POINTER(State), _ip, C.c_int64]
         L.orc_welford.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]
         L.orc_welford2.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_int]
-        L.orc_pool_cov.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]
+        L.orc_pool_update.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _dp, _dp, _dp]
+        L.orc_pool_update.restype = None
         L.orc_de_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.orc_de_update_pooled.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.orc_eval_state.argtypes = [C.POINTER(Cfg), C.POINTER(State)]
@@ -157,6 +158,22 @@ def welford(AM, mu, M2, it, fused=False):
     cov = np.empty((d, d))
     AMc = np.ascontiguousarray(AM)
     lib().orc_welford2(d, mem, it, _p(AMc), _p(mu), _p(M2), _p(cov), int(fused))
+    return cov
+
+
+def pool_slab(nwalkers, ndim):
+    """Walkers per slab of the pooled statistics (the engine's rule, ptmi_abi.hip pool_slab): up to 512 slabs for the
+    one-macro-tile shapes (ndim <= 111), up to 32 beyond (a slab's partial matrix is ndim x (ndim + 1) doubles)."""
+    target = 512 if ndim + 1 <= 112 else 32
+    return max(1, -(-nwalkers // target))
+
+
+def pool_update(AM, mu, M2, it, slab=None):
+    """Pooled-covariance epoch (orc_pool_update): AM [W][mem][d]; mu [d], M2 [d][d] updated in place; returns cov."""
+    W, mem, d = AM.shape
+    cov = np.empty((d, d))
+    AMc = np.ascontiguousarray(AM)
+    lib().orc_pool_update(d, W, mem, it, pool_slab(W, d) if slab is None else slab, _p(AMc), _p(mu), _p(M2), _p(cov))
     return cov
 
 
@@ -296,8 +313,9 @@ class OracleEngine(object):
         for w in range(self.Wc):
             self._svd(w)
         self._initial_done = True                          # the initial factorization is the host's in every mode (PT:139-145)
-        self.mu = np.zeros((W, d))
-        self.M2 = np.zeros((W, d, d))
+        # adaptation state: per walker, or ONE pooled (mu, M2) in pooled mode
+        self.mu = np.zeros((self.Wc, d))
+        self.M2 = np.zeros((self.Wc, d, d))
         self.DE = np.zeros((self.Wc, burn, d))
         self.AM = np.zeros((W, cov_update, d))
         self.nacc = np.zeros((W, nt), dtype=np.uint64)
@@ -385,14 +403,11 @@ class OracleEngine(object):
         cu, burn = self.cov_update, self.burn
         if self.temp0 == 0:
             if (it - 1) % cu == 0 and it - 1 != 0:
-                for w in range(self.W):
-                    c = welford(self.AM[w], self.mu[w], self.M2[w], it - 1, fused=not self.per_walker)
-                    if self.per_walker:
-                        self.cov[w] = c
-                if not self.per_walker:
-                    mu_o, cov_o = np.zeros(self.d), np.zeros((self.d, self.d))
-                    lib().orc_pool_cov(self.d, self.W, it - 1, _p(self.mu), _p(self.M2), _p(mu_o), _p(cov_o))
-                    self.cov[0] = cov_o
+                if self.per_walker:
+                    for w in range(self.W):
+                        self.cov[w] = welford(self.AM[w], self.mu[w], self.M2[w], it - 1)
+                else:
+                    self.cov[0] = pool_update(self.AM, self.mu[0], self.M2[0], it - 1)
                 for w in range(self.Wc):
                     self._svd(w)
             if (it - 1) % burn == 0 and it - 1 != 0:

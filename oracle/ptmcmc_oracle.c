@@ -1016,48 +1016,54 @@ ORC_API void orc_welford(int d, int mem, int64_t iter, const double *AM, double 
     orc_welford2(d, mem, iter, AM, mu, M2, cov, 0);
 }
 
-/* Chan et al. combination of `nin` partial statistics, inputs ascending; input k holds nb
- * samples (the last one nb_last). */
-static void chan_combine(int d, int nin, double nb, double nb_last, const double *mu, const double *M2,
-                         double *mu_out, double *M2_out)
-{
-    double *m = (double *)calloc((size_t)d, sizeof(double));
-    double *M = (double *)calloc((size_t)d * d, sizeof(double));
-    double na = 0.0;
-    for (int k = 0; k < nin; ++k) {
-        const double *mw = mu + (size_t)k * d, *Mw = M2 + (size_t)k * d * d;
-        const double nk = k == nin - 1 ? nb_last : nb, nn = na + nk;
-        const double f = na * nk / nn, g = nk / nn;
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) {
-                const double di = mw[i] - m[i], dj = mw[j] - m[j];
-                M[(size_t)i * d + j] = (M[(size_t)i * d + j] + Mw[(size_t)i * d + j]) + (di * dj) * f;
-            }
-        for (int i = 0; i < d; ++i) m[i] = m[i] + (mw[i] - m[i]) * g;
-        na = nn;
-    }
-    memcpy(mu_out, m, sizeof(double) * d);
-    memcpy(M2_out, M, sizeof(double) * d * d);
-    free(m); free(M);
-}
 
-/* pooled covariance over walkers: groups of 64 walkers combined in walker order, then the
- * groups combined in order (the two-level order of the engine's pool kernels) */
-ORC_API void orc_pool_cov(int d, int nwalkers, int64_t n_per, const double *mu, const double *M2,
-                          double *mu_out, double *cov_out)
+/* Pooled covariance (cov_mode "pooled": one covariance for all walkers, adapted from ALL their rank-0 samples; an engine
+ * mode, not a replica of a reference run -- the reference has one chain per covariance, PT:769-794).  The definition the
+ * HIP kernels are held to bit for bit:
+ *   - the epoch's chunk = the W * mem buffered rows, AM[w][r][:] in memory order, cut into slabs of `slab` walkers;
+ *   - shift c = the running pooled mean (the first epoch: walker 0's row 0), dx = x - c;
+ *   - per slab, rows ascending: T_s[i][j] = fma(dx_i, dx_j, T_s[i][j]) and t_s[i] = fma(dx_i, 1, t_s[i]) -- the order in which
+ *     v_mfma_f64_16x16x4 accumulates; the slabs are then summed in order (plain sums);
+ *   - chunk statistics about its own mean: M2_b = T - t t^T / n_b; combined with the running (n, mu, M2) by Chan's
+ *     formula with delta = t / n_b (the shift IS the running mean); cov = M2 / (n - 1).
+ * mu[d], M2[d][d] are the pooled state (updated in place); iter = the multiple of mem just completed. */
+ORC_API void orc_pool_update(int d, int nwalkers, int mem, int64_t iter, int slab, const double *AM, double *mu, double *M2, double *cov)
 {
-    const int GS = 64, ng = (nwalkers + GS - 1) / GS;
-    double *gm = (double *)malloc(sizeof(double) * (size_t)ng * d), *gM = (double *)malloc(sizeof(double) * (size_t)ng * d * d);
-    for (int g = 0; g < ng; ++g) {
-        const int w0 = g * GS, cnt = (w0 + GS <= nwalkers) ? GS : nwalkers - w0;
-        chan_combine(d, cnt, (double)n_per, (double)n_per, mu + (size_t)w0 * d, M2 + (size_t)w0 * d * d, gm + (size_t)g * d, gM + (size_t)g * d * d);
+    const int first = iter == mem;
+    const double nb = (double)nwalkers * (double)mem, nprev = (double)nwalkers * (double)(iter - mem);
+    double *c = (double *)malloc(sizeof(double) * (size_t)d), *dx = (double *)malloc(sizeof(double) * (size_t)d);
+    double *T = (double *)calloc((size_t)d * d, sizeof(double)), *Ts = (double *)malloc(sizeof(double) * (size_t)d * d);
+    double *t = (double *)calloc((size_t)d, sizeof(double)), *ts = (double *)malloc(sizeof(double) * (size_t)d);
+    for (int i = 0; i < d; ++i) c[i] = first ? AM[i] : mu[i];
+    for (int w0 = 0; w0 < nwalkers; w0 += slab) {
+        const int w1 = w0 + slab < nwalkers ? w0 + slab : nwalkers;
+        memset(Ts, 0, sizeof(double) * (size_t)d * d);
+        memset(ts, 0, sizeof(double) * (size_t)d);
+        for (size_t r = (size_t)w0 * mem; r < (size_t)w1 * mem; ++r) {
+            const double *x = AM + r * d;
+            for (int i = 0; i < d; ++i) dx[i] = x[i] - c[i];
+            for (int i = 0; i < d; ++i) {
+                ts[i] = fma(dx[i], 1.0, ts[i]);
+                for (int j = i; j < d; ++j) Ts[(size_t)i * d + j] = fma(dx[i], dx[j], Ts[(size_t)i * d + j]);
+            }
+        }
+        for (int i = 0; i < d; ++i) {
+            t[i] += ts[i];
+            for (int j = i; j < d; ++j) T[(size_t)i * d + j] += Ts[(size_t)i * d + j];
+        }
     }
-    const int last = nwalkers - (ng - 1) * GS;
-    double *M = (double *)malloc(sizeof(double) * (size_t)d * d);
-    chan_combine(d, ng, (double)GS * (double)n_per, (double)last * (double)n_per, gm, gM, mu_out, M);
-    const double den = (double)nwalkers * (double)n_per - 1.0;
-    for (int i = 0; i < d * d; ++i) cov_out[i] = M[i] / den;
-    free(gm); free(gM); free(M);
+    const double f = nprev * nb / (nprev + nb), g = nb / (nprev + nb), den = nprev + nb - 1.0;
+    for (int i = 0; i < d; ++i)
+        for (int j = i; j < d; ++j) {
+            const double M2b = T[(size_t)i * d + j] - (t[i] * t[j]) / nb;
+            double m;
+            if (first) m = M2b;
+            else m = (M2[(size_t)i * d + j] + M2b) + ((t[i] / nb) * (t[j] / nb)) * f;
+            M2[(size_t)i * d + j] = M2[(size_t)j * d + i] = m;
+            cov[(size_t)i * d + j] = cov[(size_t)j * d + i] = m / den;
+        }
+    for (int i = 0; i < d; ++i) mu[i] = first ? c[i] + t[i] / nb : mu[i] + (t[i] / nb) * g;
+    free(c); free(dx); free(T); free(Ts); free(t); free(ts);
 }
 
 /* ----------------------------------------------------------- DE buffer */

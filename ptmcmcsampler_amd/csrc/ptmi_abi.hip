@@ -328,140 +328,157 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
     if (gridDim.x == 1 && role == 0 && carrier) muw[rel] = m;
 }
 
-// Pooled-mode Welford on the matrix cores (d <= 112: one block per walker).  The rank-1 updates of RC buffered rows
-// are one [d x RC] . [RC x d] product: v_mfma_f64_16x16x4_f64 accumulates it as a row-ascending fma chain, which is
-// exactly the fused scalar definition (orc_welford2 with fused = 1), so the result is bit-identical.
-// The pooled definition keeps the upper triangle and mirrors it, so only the 28 tiles with ti <= tj are computed,
-// dealt round-robin over the four waves (7 each: the f64 matrix pipe retires one instruction per 64 cycles per SIMD,
-// so the balance across SIMDs is what matters).  The first 112 threads are the carriers: they run the mean
-// recurrence of their column one chunk ahead and hand the diff / e rows over through a double-buffered LDS chunk.
-// The reciprocals 1/(it+1+r) are the same for every column and walker: computed once per block into LDS.
-typedef double wf_d4 __attribute__((ext_vector_type(4)));
-constexpr int WRC = 8;                                      // rows per chunk (2 matrix instructions deep): 37 KB of LDS, four blocks per CU
-constexpr int WF_TILES = WT * (WT + 1) / 2;                 // upper-triangle tiles (28)
-// Tiles per wave: an equal deal.  (Giving the two carrier waves fewer tiles, 5/5/9/9, gained 7 %; what did pay was
-// occupancy: 8-row chunks need 37 KB of LDS and 115 VGPRs, so four blocks share a CU instead of two: 1.98 -> 1.48 ms per
-// epoch of 4096 walkers x 1000 rows.)  Which wave computes a tile does not enter its arithmetic.
-constexpr int WF_NT = 7;                                    // most tiles any wave holds
-__device__ __forceinline__ int wf_first(int wave) { return 7 * wave; }
-__device__ __forceinline__ int wf_count(int wave) { return 7; }
-static_assert(4 * 7 == WF_TILES, "the tile deal covers the upper triangle");
-constexpr int WF_THREADS = 256;
-constexpr int WF_MAXMEM = 1024;                             // reciprocal table (cov_update rows)
-// t-th upper-triangle tile in row-major order -> (ti, tj)
-__device__ __forceinline__ void wf_tile(int t, int &ti, int &tj)
+// ---------------------------------------------------------------- pooled covariance
+// cov_mode "pooled" (one covariance adapted from all walkers' rank-0 samples; oracle: orc_pool_update).  The epoch's chunk
+// -- the W x cov_update buffered rows as one [rows][d] matrix -- enters as shifted sums T = sum dx dx^T, t = sum dx with
+// dx = x - (the running pooled mean): a symmetric rank-k update with no recurrence in it, so the rows go straight from
+// memory through LDS into v_mfma_f64_16x16x4_f64, whose k-ascending fma chain is the oracle's row-ascending definition.
+// The column sums come out of the same instructions: column d of dx is the constant 1.
+// Grid: (slab, macro tile).  A slab is a contiguous run of rows (pool_slab walkers); a macro tile is 112 x 112 outputs
+// (7 x 7 matrix tiles) of the columns [112 I, 112 I + 112) x [112 J, 112 J + 112), I <= J.  DIAG (I == J): the 28 tiles with
+// ti <= tj, seven per wave; else all 49, 13 / 12 / 12 / 12.  Rows are staged 16 at a time (four k-steps) in a double-buffered LDS
+// chunk, the next chunk's global loads in flight during the matrix work; one barrier per chunk.  Each block writes its
+// slab's partial sums; pool_reduce_kernel adds the slabs in order, pool_finish_kernel applies Chan's formula.
+// Round 2 ran a per-walker Welford recurrence on the matrix cores (1.45 ms per epoch at 4096 x 1000 x 100, two carrier waves
+// feeding the recurrence) + a 328 MB two-level combination (0.12 ms); d > 112 had no matrix-core path at all (26 ms at d = 1000).
+constexpr int PS_W = 112;       // columns of a macro tile
+constexpr int PS_RC = 16;       // rows per staged chunk
+typedef double ps_d4 __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int pool_groups(int d) { return (d + 1 + PS_W - 1) / PS_W; }          // macro tiles per side (columns 0 .. d)
+// walkers per slab: up to 512 slabs when one macro tile covers the matrix, up to 32 beyond (a partial is d (d + 1) doubles);
+// part of the definition (summation order): oracle/oracle.py pool_slab is the same rule
+static inline int pool_slab(int nwalkers, int d) { const int target = d + 1 <= PS_W ? 512 : 32; const int s = (nwalkers + target - 1) / target; return s < 1 ? 1 : s; }
+template <bool DIAG>
+__global__ __launch_bounds__(256, DIAG ? 4 : 2) void pool_syrk_kernel(const double *rows, long long nrows, int d, const double *shift,
+                                                                     long long rows_per_slab, double *part)
 {
-    ti = 0;
-    int row = WT;
-    while (t >= row) { t -= row; ++ti; --row; }
-    tj = ti + t;
-}
-__global__ __launch_bounds__(WF_THREADS, 4) void welford_mfma_kernel(const double *AM, double *mu, double *M2, int d, int mem, long long iter)
-{
-    __shared__ double Dl[2][WRC][WTILE], El[2][WRC][WTILE];
-    __shared__ double rcp[WF_MAXMEM];
-    const int w = (int)blockIdx.x;
+    constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2;
+    __shared__ double Dl[NA][2][PS_RC][PS_W];
     const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, g = lane >> 4;
-    const double *am = AM + (size_t)w * mem * d;
-    double *muw = mu + (size_t)w * d, *M2w = M2 + (size_t)w * d * d;
-    const long long it0 = iter - mem;
-    const bool reset = it0 == 0;
-    const int col = (int)threadIdx.x;                       // carrier threads own one column each
-    const bool carrier = col < WTILE;
-    const bool incol = col < d;
-    double m = incol && !reset ? muw[col] : 0.0;
-    for (int r = (int)threadIdx.x; r < mem; r += WF_THREADS) rcp[r] = 1.0 / (double)(it0 + 1 + r);
-
-    wf_d4 acc[WF_NT];
-    int offa[WF_NT], offb[WF_NT];                           // column offsets of the tile's D and E fragments
-    const int t0 = wf_first(wave), tn = wf_count(wave);      // wave-uniform
+    const int ng = pool_groups(d);
+    int I = (int)blockIdx.y, J = (int)blockIdx.y;
+    if (!DIAG) {                                            // blockIdx.y enumerates the pairs I < J row by row
+        int p = (int)blockIdx.y;
+        I = 0;
+        while (p >= ng - 1 - I) { p -= ng - 1 - I; ++I; }
+        J = I + 1 + p;
+    }
+    const long long beg = (long long)blockIdx.x * rows_per_slab;
+    const long long end = beg + rows_per_slab < nrows ? beg + rows_per_slab : nrows;
+    // tiles of this wave: offsets of their A (rows of the output) and B (columns) fragments inside the macro tile
+    int offa[NTW], offb[NTW];
+    bool on[NTW];
+    ps_d4 acc[NTW];
 #pragma unroll
-    for (int n = 0; n < WF_NT; ++n) {
+    for (int n = 0; n < NTW; ++n) {
         int ti, tj;
-        wf_tile(t0 + (n < tn ? n : 0), ti, tj);
-        offa[n] = __builtin_amdgcn_readfirstlane(ti * 16);   // wave-uniform: scalar registers
+        if (DIAG) {
+            int t = 7 * wave + n, row = 7;
+            ti = 0;
+            while (t >= row) { t -= row; ++ti; --row; }
+            tj = ti + t;
+            on[n] = true;
+        } else {
+            const int t = wave + 4 * n;
+            on[n] = t < 49;
+            ti = on[n] ? t / 7 : 0;
+            tj = on[n] ? t % 7 : 0;
+        }
+        offa[n] = __builtin_amdgcn_readfirstlane(ti * 16);
         offb[n] = __builtin_amdgcn_readfirstlane(tj * 16);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
-            acc[n][r] = (n < tn && !reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
-        }
+        acc[n] = ps_d4{0.0, 0.0, 0.0, 0.0};
     }
-    // AM rows are requested TWO chunks before the carriers turn them into diff / e rows (one chunk of matrix work does not
-    // cover an HBM round trip), in two register buffers used alternately; and inside a chunk the carriers' recurrence is
-    // cut into four pieces slipped between the four groups of matrix instructions, so that the matrix pipe of their SIMD
-    // works while they compute.
-    double va[WRC], vb[WRC];
-    auto fetch = [&](int r0, double (&v)[WRC]) {
+    // staging: threads 0..223 own one column of the macro tile(s) and every other row of a chunk
+    const int scol = (int)threadIdx.x % PS_W, srow = (int)threadIdx.x / PS_W;     // srow 0 / 1 (2: idle)
+    const bool stager = srow < 2;
+    int gc[NA];
+    double sh[NA];
 #pragma unroll
-        for (int u = 0; u < WRC; ++u) v[u] = (incol && r0 + u < mem) ? am[(size_t)(r0 + u) * d + col] : 0.0;
-    };
-    auto produce4 = [&](int r0, int u0, int buf, const double (&v)[WRC]) {       // rows r0 + u0 .. r0 + u0 + 3 of a chunk
+    for (int a2 = 0; a2 < NA; ++a2) {
+        gc[a2] = (a2 == 0 ? I : J) * PS_W + scol;
+        sh[a2] = (stager && gc[a2] < d) ? shift[gc[a2]] : 0.0;
+    }
+    double v[NA][PS_RC / 2];
+    auto fetch = [&](long long r0) {
 #pragma unroll
-        for (int u = u0; u < u0 + 4; ++u) {
-            double df = 0.0, ev = 0.0;
-            if (incol && r0 + u < mem) {
-                df = v[u] - m;
-                m = m + df * rcp[r0 + u];
-                ev = v[u] - m;
+        for (int a2 = 0; a2 < NA; ++a2)
+#pragma unroll
+            for (int u = 0; u < PS_RC / 2; ++u) {
+                const long long r = r0 + 2 * u + srow;
+                double x = 0.0;
+                if (stager && r < end) x = gc[a2] < d ? rows[r * d + gc[a2]] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
+                v[a2][u] = x;
             }
-            Dl[buf][u][col] = df;                           // rows past the end and padded columns carry zeros
-            El[buf][u][col] = ev;
+    };
+    auto stage = [&](int buf) {
+        if (stager) {
+#pragma unroll
+            for (int a2 = 0; a2 < NA; ++a2)
+#pragma unroll
+                for (int u = 0; u < PS_RC / 2; ++u) Dl[a2][buf][2 * u + srow][scol] = v[a2][u];
         }
     };
-    // matrix work of chunk r0 (LDS buffer buf) with the production of chunk r0 + WRC (from v) in its gaps; then v is
-    // refilled with the rows two chunks further on
-    auto body = [&](int r0, int buf, double (&v)[WRC]) {
-        const double *Db = &Dl[buf][0][0] + g * WTILE + c, *Eb = &El[buf][0][0] + g * WTILE + c;
-        const bool more = carrier && r0 + WRC < mem;
-#pragma unroll
-        for (int k0 = 0; k0 < WRC; k0 += 4) {
-#pragma unroll
-            for (int n = 0; n < WF_NT; ++n)
-                if (n < tn) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Db[k0 * WTILE + offa[n]], Eb[k0 * WTILE + offb[n]], acc[n], 0, 0, 0);
-            if (more) produce4(r0 + WRC, k0, buf ^ 1, v);
-        }
-        if (more) fetch(r0 + 3 * WRC, v);
-        __syncthreads();
-    };
-    if (carrier) fetch(0, va);
-    __syncthreads();                                        // reciprocal table
-    if (carrier) {
-#pragma unroll
-        for (int u0 = 0; u0 < WRC; u0 += 4) produce4(0, u0, 0, va);
-        fetch(WRC, va);
-        fetch(2 * WRC, vb);
-    }
+    fetch(beg);
+    stage(0);
     __syncthreads();
-    for (int r0 = 0; r0 < mem; r0 += 2 * WRC) {
-        body(r0, 0, va);
-        if (r0 + WRC < mem) body(r0 + WRC, 1, vb);
-    }
+    int buf = 0;
+    for (long long r0 = beg; r0 < end; r0 += PS_RC) {
+        const bool more = r0 + PS_RC < end;
+        if (more) fetch(r0 + PS_RC);
+        const double *Ab = &Dl[0][buf][0][0] + g * PS_W + c, *Bb = &Dl[NA - 1][buf][0][0] + g * PS_W + c;
 #pragma unroll
-    for (int n = 0; n < WF_NT; ++n) {
-        int ti, tj;
-        wf_tile(t0 + (n < tn ? n : 0), ti, tj);
+        for (int k0 = 0; k0 < PS_RC; k0 += 4) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+                if (on[n]) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + offa[n]], Bb[k0 * PS_W + offb[n]], acc[n], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    double *out = part + (size_t)blockIdx.x * d * (d + 1);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        if (!on[n]) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = ti * 16 + g + 4 * r, j = tj * 16 + c;
-            if (n < tn && i < d && j < d && i <= j) {       // a diagonal tile also computed its lower half: dropped
-                M2w[(size_t)i * d + j] = acc[n][r];
-                M2w[(size_t)j * d + i] = acc[n][r];
-            }
+            const int i = I * PS_W + offa[n] + g + 4 * r, j = J * PS_W + offb[n] + c;
+            if (i < d && j <= d && i <= j) out[(size_t)i * (d + 1) + j] = acc[n][r];
         }
     }
-    if (incol) muw[col] = m;
 }
-
-// pooled definition for the tiled kernel (d > 112): the lower triangle is the mirror image of the upper one
-__global__ void symmetrize_kernel(double *M2, int d)
+// sum of the slabs' partials, slabs ascending (plain sums): Tsum[i][j], j in [i, d]; column d holds t
+__global__ void pool_reduce_kernel(const double *part, int nslab, int d, double *Tsum)
 {
-    double *M = M2 + (size_t)blockIdx.y * d * d;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ld = d + 1;
+    if (idx >= (long long)d * ld) return;
+    const int i = (int)(idx / ld), j = (int)(idx % ld);
+    if (j < i) return;
+    double sum = 0.0;
+    for (int s = 0; s < nslab; ++s) sum += part[(size_t)s * d * ld + idx];
+    Tsum[idx] = sum;
+}
+// Chan's combination of the chunk (nb samples, sums about the shift) with the running pooled statistics (nprev samples)
+__global__ void pool_finish_kernel(const double *Tsum, const double *shift, double *mu, double *M2, double *cov, int d, int first,
+                                   double nb, double f /* nprev nb / (nprev + nb) */, double gw /* nb / (nprev + nb) */, double den)
+{
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)d * d) return;
-    const int i = (int)(idx / d), j = (int)(idx % d);
-    if (j < i) M[idx] = M[(size_t)j * d + i];
+    const int i = (int)(idx / d), j = (int)(idx % d), ld = d + 1;
+    if (j < i) return;
+    const double ti = Tsum[(size_t)i * ld + d], tj = Tsum[(size_t)j * ld + d];
+    const double M2b = Tsum[(size_t)i * ld + j] - (ti * tj) / nb;
+    double m;
+    if (first) m = M2b;
+    else m = (M2[idx] + M2b) + ((ti / nb) * (tj / nb)) * f;
+    M2[idx] = m;
+    M2[(size_t)j * d + i] = m;
+    const double cv = m / den;
+    cov[idx] = cv;
+    cov[(size_t)j * d + i] = cv;
+    if (i == j) mu[i] = first ? shift[i] + ti / nb : mu[i] + (ti / nb) * gw;
 }
 
 __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem, long long iter, int fused)
@@ -479,34 +496,6 @@ __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem
         else m += df / (double)it;
     }
     mu[(size_t)w * d + j] = m;
-}
-
-// Pooled covariance: Chan et al. combination of partial statistics (n_k, mu_k, M2_k), inputs ascending, one thread
-// per (i,j).  Level 1 (blockIdx.y = group of 64 walkers) writes group partials, level 2 combines the groups; the
-// final pass divides by N-1.
-constexpr int POOL_GS = 64;
-__global__ void pool_combine_kernel(const double *mu, const double *M2, double *mu_out, double *M2_out, int d, int nin_total,
-                                    int gs, double nb, double nb_last_input, double den)
-{
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)d * d) return;
-    const int g = (int)blockIdx.y;
-    const int k0 = g * gs, cnt = k0 + gs <= nin_total ? gs : nin_total - k0;
-    const int i = (int)(idx / d), j = (int)(idx % d);
-    const double *mw = mu + (size_t)k0 * d, *Mw = M2 + (size_t)k0 * d * d;
-    double mi = 0.0, mj = 0.0, M = 0.0, na = 0.0;
-    for (int k = 0; k < cnt; ++k) {
-        const double nk = (k0 + k == nin_total - 1) ? nb_last_input : nb, nn = na + nk;
-        const double f = na * nk / nn, gg = nk / nn;
-        const double wi = mw[(size_t)k * d + i], wj = mw[(size_t)k * d + j];
-        const double di = wi - mi, dj = wj - mj;
-        M = (M + Mw[(size_t)k * d * d + idx]) + (di * dj) * f;
-        mi = mi + di * gg;
-        mj = mj + dj * gg;
-        na = nn;
-    }
-    M2_out[(size_t)g * d * d + idx] = den > 0.0 ? M / den : M;
-    if (mu_out && j == 0) mu_out[(size_t)g * d + i] = mi;
 }
 
 // DE history ring: rows [head, head+mem) are the oldest; overwrite them with the AM buffer.
@@ -971,9 +960,9 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     h->cfg.group_size = nullptr;
     hipError_t e = hipMalloc((void **)&h->d_pre, sizeof(SwapPre) * (size_t)c.nwalkers * c.ntemps_global);
     if (e == hipSuccess && !c.cov_per_walker && c.temp0 == 0) {
-        const size_t ng = (size_t)(c.nwalkers + POOL_GS - 1) / POOL_GS;
-        e = hipMalloc((void **)&h->d_pool_mu, sizeof(double) * ng * c.ndim);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_pool_M2, sizeof(double) * ng * c.ndim * c.ndim);
+        const int SL = pool_slab(c.nwalkers, c.ndim), nslab = (c.nwalkers + SL - 1) / SL;
+        e = hipMalloc((void **)&h->d_pool_part, sizeof(double) * (size_t)nslab * c.ndim * (c.ndim + 1));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_pool_T, sizeof(double) * (size_t)c.ndim * (c.ndim + 1));
     }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
@@ -987,7 +976,7 @@ int ptmi_destroy(ptmi_handle h)
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
-    (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_mu); (void)hipFree(h->d_pool_M2);
+    (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1383,32 +1372,30 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
     if (!h->buf.AM || !h->buf.mu || !h->buf.M2 || !h->buf.cov) return fail(PTMI_EINVAL, "AM/mu/M2/cov buffers missing");
     if (iter < c.cov_update || iter % c.cov_update) return fail(PTMI_EINVAL, "iter must be a positive multiple of cov_update");
     const int d = c.ndim, nt = (d + WTILE - 1) / WTILE;
-    const int per = c.cov_per_walker;
-    if (per)
+    if (c.cov_per_walker) {
         hipLaunchKernelGGL(welford_kernel<false>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
                            h->buf.mu, h->buf.M2, h->buf.cov, d, c.cov_update, (long long)iter, d * d);
-    else if (d <= WTILE && c.cov_update <= WF_MAXMEM)
-        hipLaunchKernelGGL(welford_mfma_kernel, dim3(c.nwalkers), dim3(WF_THREADS), 0, h->stream, (const double *)h->buf.AM, h->buf.mu,
-                           h->buf.M2, d, c.cov_update, (long long)iter);
-    else
-    {
-        hipLaunchKernelGGL(welford_kernel<true>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
-                           h->buf.mu, h->buf.M2, (double *)nullptr, d, c.cov_update, (long long)iter, 0);
-        hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)(((long long)d * d + 255) / 256), c.nwalkers), dim3(256), 0, h->stream,
-                           h->buf.M2, d);
-    }
-    if (nt > 1)
-        hipLaunchKernelGGL(welford_mean_kernel, dim3((d + 63) / 64, c.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.AM,
-                           h->buf.mu, d, c.cov_update, (long long)iter, per ? 0 : 1);
-    if (!per) {
-        const int W = c.nwalkers, ng = (W + POOL_GS - 1) / POOL_GS;
-        const unsigned gx = (unsigned)(((long long)d * d + 255) / 256);
-        const double n_per = (double)iter;
-        hipLaunchKernelGGL(pool_combine_kernel, dim3(gx, ng), dim3(256), 0, h->stream, (const double *)h->buf.mu,
-                           (const double *)h->buf.M2, h->d_pool_mu, h->d_pool_M2, d, W, POOL_GS, n_per, n_per, 0.0);
-        hipLaunchKernelGGL(pool_combine_kernel, dim3(gx, 1), dim3(256), 0, h->stream, (const double *)h->d_pool_mu,
-                           (const double *)h->d_pool_M2, (double *)nullptr, h->buf.cov, d, ng, ng, (double)POOL_GS * n_per,
-                           (double)(W - (ng - 1) * POOL_GS) * n_per, (double)W * n_per - 1.0);
+        if (nt > 1)
+            hipLaunchKernelGGL(welford_mean_kernel, dim3((d + 63) / 64, c.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.AM,
+                               h->buf.mu, d, c.cov_update, (long long)iter, 0);
+    } else {
+        // pooled statistics (orc_pool_update): mu[0 .. d), M2[0 .. d*d) of the buffers are the pooled state
+        const int W = c.nwalkers, SL = pool_slab(W, d), nslab = (W + SL - 1) / SL, ng = pool_groups(d);
+        const long long nrows = (long long)W * c.cov_update;
+        const bool first = iter == c.cov_update;
+        const double *shift = first ? (const double *)h->buf.AM : (const double *)h->buf.mu;     // the first epoch: walker 0's row 0
+        hipLaunchKernelGGL(pool_syrk_kernel<true>, dim3(nslab, ng), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d, shift,
+                           (long long)SL * c.cov_update, h->d_pool_part);
+        if (ng > 1)
+            hipLaunchKernelGGL(pool_syrk_kernel<false>, dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
+                               shift, (long long)SL * c.cov_update, h->d_pool_part);
+        const long long nel = (long long)d * (d + 1);
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->d_pool_part, nslab, d,
+                           h->d_pool_T);
+        const double nb = (double)W * (double)c.cov_update, nprev = (double)W * (double)(iter - c.cov_update);
+        hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)(((long long)d * d + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->d_pool_T,
+                           shift, h->buf.mu, h->buf.M2, h->buf.cov, d, first ? 1 : 0, nb, nprev * nb / (nprev + nb), nb / (nprev + nb),
+                           nprev + nb - 1.0);
     }
     HIPCHK(hipGetLastError());
     return PTMI_OK;

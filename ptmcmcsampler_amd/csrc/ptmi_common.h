@@ -89,7 +89,7 @@ struct ptmi_engine {
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
     int32_t *d_gj_order, *d_gj_bucket;         // launch order of the chains ([nch]) and its counting-sort scratch ([3][GJ_BUCKETS])
-    double *d_pool_mu, *d_pool_M2;   // [ngroups][d], [ngroups][d*d] partial statistics of the pooled covariance
+    double *d_pool_part, *d_pool_T;  // pooled covariance: the slabs' partial sums [nslab][d][d+1] and their total [d][d+1] (column d: the column sums)
     int G, EPL;
     int de_on, de_head;
     int last_variant;   // PTMI_VAR_* flags of the most recent fused-MH launch (ptmi_last_mh_variant)

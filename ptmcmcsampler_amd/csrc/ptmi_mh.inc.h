@@ -1102,6 +1102,8 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 // into the register file nothing of row size is kept besides x, dq and the accumulators: r = (x + dq) - mu is formed where
 // it is used (bit-identical both times).  An unpadded table makes the matrix instruction read past a row's end into the
 // next row; those columns only feed the padding outputs i >= d, which are masked.  Strided lane layout as STAGE.
+// doubles from the first even row to the first odd row of the dense kernel's LDS copy of P: past the even rows, = 16 (mod 32)
+__host__ __device__ constexpr int dense_podd(int d) { return ((d + 1) / 2) * d + ((16 - (((d + 1) / 2) * d) % 32) + 32) % 32; }
 template <int EPL, int BLK>
 __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KArgs a)
 {
@@ -1125,15 +1127,25 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
     ScamBatch<true> sbatch;
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // P is split by row parity: even rows first, odd rows dense_podd(d) doubles further on -- an offset of 16 (mod 32) doubles,
+    // so that the two rows a 32-lane group of a ds_read_b64 takes (k-step rows 4e + {0,1} and 4e + {2,3}) fall into
+    // disjoint bank halves.  Unsplit (consecutive rows 100 doubles = 8 banks apart) every read of the matrix operand was a
+    // two- to three-way bank conflict: 2.6 conflict cycles per LDS instruction (profiles/r02_dense_sq.txt).
+    const int podd = dense_podd(d), pall = podd + (d / 2) * d;
 #define PTMI_D_P (smem)
-#define PTMI_D_U (smem + (size_t)d * d)
-#define PTMI_D_MU (smem + 2 * (size_t)d * d)
-#define PTMI_D_SQ (smem + 2 * (size_t)d * d + 4 * EPL)
+#define PTMI_D_U (smem + (size_t)pall)
+#define PTMI_D_MU (smem + (size_t)pall + (size_t)d * d)
+#define PTMI_D_SQ (smem + (size_t)pall + (size_t)d * d + 4 * EPL)
     {
         const long long ch0 = (long long)logical_block() * CPB;
         const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
         const double *Pg = a.logl_par + d, *Ug = a.Ut + w0 * d * d, *Sg = a.S + w0 * d, *mug = a.logl_par;
-        for (int i = (int)threadIdx.x; i < d * d; i += BLK) { PTMI_D_P[i] = Pg[i]; PTMI_D_U[i] = Ug[i]; }
+        for (int i = (int)threadIdx.x; i < d * d; i += BLK) {
+            const int r = i / d, c = i % d;
+            PTMI_D_P[((r & 1) ? podd : 0) + (r >> 1) * d + c] = Pg[i];
+            PTMI_D_U[i] = Ug[i];
+        }
+        for (int i = ((d + 1) / 2) * d + (int)threadIdx.x; i < podd; i += BLK) PTMI_D_P[i] = 0.0;      // the gap is read past the last even row
         for (int i = (int)threadIdx.x; i < 4 * EPL; i += BLK) PTMI_D_MU[i] = i < d ? mug[i] : 0.0;
         for (int i = (int)threadIdx.x; i < d; i += BLK) PTMI_D_SQ[i] = det_sqrt(Sg[i]);
         box_table_fill<G, EPL>(a, smem, BLK);
@@ -1167,7 +1179,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         // barrier keeps the compiler from hoisting all 7 * 26 table reads to the top
         double cur[NT], nxt[NT];
         auto fetch = [&](int e, double (&dst)[NT]) {
-            const double *row = PTMI_D_P + (size_t)(4 * e + g4) * d + c16;
+            const double *row = PTMI_D_P + ((g4 & 1) ? podd : 0) + (2 * e + (g4 >> 1)) * d + c16;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) dst[tt] = row[16 * tt];
         };
@@ -1372,7 +1384,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     auto even = [](size_t doubles) { return (doubles + 1) & ~(size_t)1; };
     if constexpr (G == 4 && !FULL && LOGL == PTMI_LOGL_DENSE) {
         // dense likelihood + SCAM-only + one table for the block: all tables unpadded in LDS, 512-thread blocks
-        size_t lds2 = sizeof(double) * (2 * (size_t)c.ndim * c.ndim + 4 * EPL + c.ndim);
+        size_t lds2 = sizeof(double) * ((size_t)dense_podd(c.ndim) + (size_t)(c.ndim / 2) * c.ndim + (size_t)c.ndim * c.ndim + 4 * EPL + c.ndim);
         if (box_bytes && sizeof(double) * even(lds2 / sizeof(double)) + box_bytes <= 160 * 1024) {
             a.box_off = (int)even(lds2 / sizeof(double));
             lds2 = sizeof(double) * (size_t)a.box_off + box_bytes;

@@ -165,7 +165,7 @@ class PTEngine(object):
             DE=z((Wc, self.burn, self.de_ld)) if has_de else None,
             AM=z((W, self.cov_update, d)) if self.owns_cold else None,
             nacc=z((W, nt), i64), jstat=z((W, nt, _lib.J_NTYPES, 2), i64), nswap=z((W, self.ntg), i64),
-            mu=z((W, d)) if self.owns_cold else None, M2=z((W, d, d)) if self.owns_cold else None,
+            mu=z((Wc, d)) if self.owns_cold else None, M2=z((Wc, d, d)) if self.owns_cold else None,   # pooled: ONE running (mu, M2)
             cov=z((Wc, d, d)),
             Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
             AMaux=z((W, self.cov_update, 2)) if (keep_lnl and self.owns_cold) else None,

@@ -105,7 +105,7 @@ class _PerRankJump(object):
         return j(x, iter, beta)
 
 
-_CKPT_FORMAT = 2      # ptmi_checkpoint.npz: 2 = DE rows in the piece-cyclic device format + run fingerprint
+_CKPT_FORMAT = 3      # ptmi_checkpoint.npz: 2 = DE rows in the piece-cyclic device format + run fingerprint; 3 = pooled mode keeps ONE (mu, M2)
 
 
 class PTSampler(object):

@@ -70,14 +70,11 @@ class OracleLocal(object):
 
     def update_cov(self, it_done):
         o = self.o
-        for w in range(o.W):
-            c = orc.welford(o.AM[w], o.mu[w], o.M2[w], it_done, fused=not o.per_walker)
-            if o.per_walker:
-                o.cov[w] = c
-        if not o.per_walker:
-            mu_o, cov_o = np.zeros(o.d), np.zeros((o.d, o.d))
-            orc.lib().orc_pool_cov(o.d, o.W, it_done, orc._p(o.mu), orc._p(o.M2), orc._p(mu_o), orc._p(cov_o))
-            o.cov[0] = cov_o
+        if o.per_walker:
+            for w in range(o.W):
+                o.cov[w] = orc.welford(o.AM[w], o.mu[w], o.M2[w], it_done)
+        else:
+            o.cov[0] = orc.pool_update(o.AM, o.mu[0], o.M2[0], it_done)
         for w in range(o.Wc):
             o._svd(w)
 

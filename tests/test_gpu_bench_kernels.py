@@ -122,7 +122,7 @@ def test_box_prior_from_lds_table(mods, kind):
 
 class _Subset(object):
     """A few walkers of a big pooled run on the oracle.  Pooled tables depend on every walker, so the epochs are driven
-    from outside: the covariance / DE inputs are the device's AM buffers, run through the ORACLE's Welford, pooling,
+    from outside: the covariance / DE inputs are the device's AM buffers, run through the ORACLE's pooled statistics,
     factorization and DE update; the chains then continue on the oracle with those tables."""
 
     def __init__(self, orc, walkers, d, nt, W, cov0, **kw):
@@ -133,17 +133,14 @@ class _Subset(object):
             o._epochs = lambda it: None
             self.subs.append(o)
         self.cu, self.burn = kw["cov_update"], kw["burn"]
-        self.mu, self.M2 = np.zeros((W, d)), np.zeros((W, d, d))
+        self.mu, self.M2 = np.zeros(d), np.zeros((d, d))
         self.DE = np.zeros((self.burn, d))
 
     def epoch(self, AM, it_done):
         """PTMCMCSampler.py:545-585 for iteration it_done + 1, from all walkers' AM rows."""
         orc, d, W = self.orc, self.d, self.W
         if it_done % self.cu == 0:
-            for w in range(W):
-                orc.welford(AM[w], self.mu[w], self.M2[w], it_done, fused=True)
-            mu_o, cov_o = np.zeros(d), np.zeros((d, d))
-            orc.lib().orc_pool_cov(d, W, it_done, orc._p(self.mu), orc._p(self.M2), orc._p(mu_o), orc._p(cov_o))
+            cov_o = orc.pool_update(AM, self.mu, self.M2, it_done)
             for o in self.subs:
                 o.cov[0] = cov_o
                 o._svd(0)
