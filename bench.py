@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
     ap.add_argument("--prior", default="flat", choices=["flat", "box"],
                     help="flat: the headline workload; box: uniform on [-10, 10]^d, the usual lnpriorfn of a reference run")
-    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "per_walker", "per_walker_device"],
+    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "pooled_hipsolver", "per_walker", "per_walker_device"],
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
-                         "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK")
+                         "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK; "
+                         "_hipsolver: by the ROCm library's eigensolver on the stream (large ndim)")
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
@@ -176,13 +177,15 @@ def main():
             dist.init_process_group(backend)
 
     d, nt, W = a.ndim, a.ntemps, a.nwalkers
+    if a.cov_mode == "pooled" and d >= 512:
+        a.cov_mode = "pooled_hipsolver"     # one ndim x ndim factorization per epoch: the ROCm library on the stream beats the host's LAPACK from here on
     logl = ("iso",)
     if a.logl == "dense":
         A = np.random.default_rng(0).standard_normal((d, d))
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
               pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled",
-              eig_mode="jacobi" if a.cov_mode.endswith("_device") else "lapack")
+              eig_mode="jacobi" if a.cov_mode.endswith("_device") else ("hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack"))
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.prior == "box":
         kw.update(logp=("box", np.full(d, -10.0), np.full(d, 10.0)))

@@ -336,23 +336,25 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
 // The column sums come out of the same instructions: column d of dx is the constant 1.
 // Grid: (slab, macro tile).  A slab is a contiguous run of rows (pool_slab walkers); a macro tile is 112 x 112 outputs
 // (7 x 7 matrix tiles) of the columns [112 I, 112 I + 112) x [112 J, 112 J + 112), I <= J.  DIAG (I == J): the 28 tiles with
-// ti <= tj, seven per wave; else all 49, 13 / 12 / 12 / 12.  Rows are staged 16 at a time (four k-steps) in a double-buffered LDS
+// ti <= tj, seven per wave; else all 49, 13 / 12 / 12 / 12.  Rows are staged 32 at a time (eight k-steps) in a double-buffered LDS
 // chunk, the next chunk's global loads in flight during the matrix work; one barrier per chunk.  Each block writes its
 // slab's partial sums; pool_reduce_kernel adds the slabs in order, pool_finish_kernel applies Chan's formula.
 // Round 2 ran a per-walker Welford recurrence on the matrix cores (1.45 ms per epoch at 4096 x 1000 x 100, two carrier waves
 // feeding the recurrence) + a 328 MB two-level combination (0.12 ms); d > 112 had no matrix-core path at all (26 ms at d = 1000).
 constexpr int PS_W = 112;       // columns of a macro tile
-constexpr int PS_RC = 16;       // rows per staged chunk
+// rows per staged chunk: 32 (8 k-steps x 7 tiles) on the diagonal, 16 (4 k-steps x 13 tiles) off it: some 55 matrix instructions
+// per wave cover a memory round trip, and two blocks share a CU (57 KB of LDS each)
+constexpr int ps_rc(bool diag) { return diag ? 32 : 16; }
 typedef double ps_d4 __attribute__((ext_vector_type(4)));
 __host__ __device__ inline int pool_groups(int d) { return (d + 1 + PS_W - 1) / PS_W; }          // macro tiles per side (columns 0 .. d)
 // walkers per slab: up to 512 slabs when one macro tile covers the matrix, up to 32 beyond (a partial is d (d + 1) doubles);
 // part of the definition (summation order): oracle/oracle.py pool_slab is the same rule
 static inline int pool_slab(int nwalkers, int d) { const int target = d + 1 <= PS_W ? 512 : 32; const int s = (nwalkers + target - 1) / target; return s < 1 ? 1 : s; }
 template <bool DIAG>
-__global__ __launch_bounds__(256, DIAG ? 4 : 2) void pool_syrk_kernel(const double *rows, long long nrows, int d, const double *shift,
+__global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, long long nrows, int d, const double *shift,
                                                                      long long rows_per_slab, double *part)
 {
-    constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2;
+    constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG);
     __shared__ double Dl[NA][2][PS_RC][PS_W];
     const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, g = lane >> 4;
@@ -399,16 +401,21 @@ __global__ __launch_bounds__(256, DIAG ? 4 : 2) void pool_syrk_kernel(const doub
         gc[a2] = (a2 == 0 ? I : J) * PS_W + scol;
         sh[a2] = (stager && gc[a2] < d) ? shift[gc[a2]] : 0.0;
     }
+    // Loads are unconditional (row and column clamped into the slab: a branch per load made every one of them wait for its
+    // own round trip, 2.6 ms per epoch); what a slot really holds is decided when it is staged.
     double v[NA][PS_RC / 2];
+    int gcl[NA];
+#pragma unroll
+    for (int a2 = 0; a2 < NA; ++a2) gcl[a2] = gc[a2] < d ? gc[a2] : d - 1;
+    long long vr0 = beg;
     auto fetch = [&](long long r0) {
+        vr0 = r0;
 #pragma unroll
         for (int a2 = 0; a2 < NA; ++a2)
 #pragma unroll
             for (int u = 0; u < PS_RC / 2; ++u) {
-                const long long r = r0 + 2 * u + srow;
-                double x = 0.0;
-                if (stager && r < end) x = gc[a2] < d ? rows[r * d + gc[a2]] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
-                v[a2][u] = x;
+                const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
+                v[a2][u] = rows[rc * d + gcl[a2]];
             }
     };
     auto stage = [&](int buf) {
@@ -416,7 +423,11 @@ __global__ __launch_bounds__(256, DIAG ? 4 : 2) void pool_syrk_kernel(const doub
 #pragma unroll
             for (int a2 = 0; a2 < NA; ++a2)
 #pragma unroll
-                for (int u = 0; u < PS_RC / 2; ++u) Dl[a2][buf][2 * u + srow][scol] = v[a2][u];
+                for (int u = 0; u < PS_RC / 2; ++u) {
+                    const bool live = vr0 + 2 * u + srow < end;
+                    const double x = gc[a2] < d ? v[a2][u] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
+                    Dl[a2][buf][2 * u + srow][scol] = live ? x : 0.0;
+                }
         }
     };
     fetch(beg);
@@ -456,8 +467,18 @@ __global__ void pool_reduce_kernel(const double *part, int nslab, int d, double 
     if (idx >= (long long)d * ld) return;
     const int i = (int)(idx / ld), j = (int)(idx % ld);
     if (j < i) return;
+    // eight slabs' values requested at once (the sums stay in slab order)
+    const size_t st = (size_t)d * ld;
     double sum = 0.0;
-    for (int s = 0; s < nslab; ++s) sum += part[(size_t)s * d * ld + idx];
+    int s = 0;
+    for (; s + 8 <= nslab; s += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(s + u) * st + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; s < nslab; ++s) sum += part[(size_t)s * st + idx];
     Tsum[idx] = sum;
 }
 // Chan's combination of the chunk (nb samples, sums about the shift) with the running pooled statistics (nprev samples)

@@ -85,3 +85,29 @@ def test_sampling_with_device_eigensolver_matches_oracle(cov_mode, d, nt, W):
         a, b = g.get(name), getattr(o, name)
         assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), name
     assert g.eig_epochs == 4 and o.jstat[..., 1, 1].sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cov_mode,d,nt,W", [("pooled", 300, 4, 12), ("per_walker", 40, 3, 5)])
+def test_library_eigensolver_on_the_stream(cov_mode, d, nt, W):
+    """eig_mode="hipsolver": the ROCm library's symmetric eigensolver factorizes the adapted covariance on the engine's
+    stream (the large-ndim choice; PTMCMCSampler.py:797-803 calls LAPACK).  Its last bits are the library's, so what is
+    checked is the decomposition the proposals use -- U diag(S) U^T = cov, orthonormal rows, eigenvalues descending -- and
+    that the chains stay exact samples of their own arithmetic (lnL of the held row, proposal counters)."""
+    from ptmcmcsampler_amd.engine import PTEngine
+    rs = np.random.RandomState(8)
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 20, 0), cov_update=50, burn=1000, tskip=10, seed=3, cov_mode=cov_mode,
+                 eig_mode="hipsolver")
+    g.init_state(rs.randn(W, nt, d) * 0.2)
+    g.run(130)
+    g.sync()
+    assert g.eig_epochs == 2
+    cov, Ut, S = g.get("cov"), g.get("Ut")[:, 0], g.get("S")[:, 0]
+    for w in range(g.Wc):
+        assert np.allclose(Ut[w].T @ np.diag(S[w]) @ Ut[w], cov[w], rtol=0, atol=1e-12 * np.abs(cov[w]).max())
+        assert np.allclose(Ut[w] @ Ut[w].T, np.eye(d), atol=1e-12)
+        assert (np.diff(S[w]) <= 1e-15 * S[w].max()).all() and (S[w] >= 0).all()
+    X, lnL = g.get("X"), g.get("lnL")
+    assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12)
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., :2, 0].sum(-1) == 130).all() and js[..., 1, 1].sum() > 0
