@@ -94,7 +94,8 @@ typedef struct ptmi_config {
     int32_t w_nuts, w_hmc;
     int32_t gj_nburn;        /* nburn of the jump objects (= burn, :227,238,251) */
     int32_t hmc_min, hmc_max;/* HMC takes randint(hmc_min, hmc_max) leapfrogs (:240-241: 2, HMCsteps) */
-    int32_t nuts_maxdepth;   /* tree heights 0..nuts_maxdepth per call (the reference has no cap); <= 24 */
+    int32_t nuts_maxdepth;   /* tree heights 0..nuts_maxdepth per call, <= 24.  The reference doubles without a cap
+                              * (nutsjump.py:716-802): 24 (2^24 leapfrogs in one call) is never reached, i.e. its behaviour */
     int32_t pick_mode;       /* PTMI_PICK_CHAIN or PTMI_PICK_WALKER (below) */
     double hmc_eps;          /* HMCstepsize (:239) */
     double nuts_delta;       /* target acceptance of NUTS' dual averaging (0.6, :256) */

@@ -276,7 +276,7 @@ class OracleEngine(object):
                  weights=(20, 20, 20), cov_update=1000, burn=10000, tskip=100, seed=0,
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep",
-                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain",
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
                  eig_mode="lapack"):
         assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi")
         self.eig_mode = eig_mode

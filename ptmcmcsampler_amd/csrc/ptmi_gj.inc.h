@@ -744,8 +744,15 @@ struct GradJumpWide {
         long long n, nalpha;
         int s;
     };
-    // the tree stack (see GradJump::build_tree): the entry of height h in slot h of the block's LDS, pending heights in a mask
+    // the tree stack (see GradJump::build_tree): the entry of height h in slot h, pending heights in a mask.  Heights below
+    // gj_lds_levels (11: trees of up to 2^11 leapfrogs) are in the block's LDS; the higher ones -- the reference doubles without a
+    // cap (NJ:716-802), the ABI allows 24 -- in the wave's slice of the global scratch: reached once in 2^h leapfrogs, if ever,
+    // so only their correctness matters (keeping all 25 in LDS cost the config-5 kernel 25 %: five waves per CU instead of eight)
     __device__ __forceinline__ int slot_of(int h) const { return a.gj_stack_off + h * gjw_level_doubles(EPL); }
+    __device__ __forceinline__ double *glevel(int h) const
+    {
+        return a.gj_scr + ((size_t)blockIdx.x * (size_t)(a.nuts_maxdepth + 1) + (size_t)h) * gjw_level_doubles(EPL);
+    }
     // NJ:495-652 as a loop, as GradJump::build_tree
     __device__ __forceinline__ void build_tree(double &tg, double &rg, double &gg, double logu, int v, int j, double eps, double joint0, Tree &cur)
     {
@@ -768,19 +775,30 @@ struct GradJumpWide {
                 if (top_h == h) {                                        // cur is the right sibling of the stack top
                     GJP_T0(tm0);
                     pend &= pend - 1u;
-                    const int b = slot_of(h);
-                    const double t_logp = gj_lds[b + GJL_VECS * LD + GJS_LOGP], t_n = gj_lds[b + GJL_VECS * LD + GJS_N];
-                    const double t_alpha = gj_lds[b + GJL_VECS * LD + GJS_ALPHA], t_nalpha = gj_lds[b + GJL_VECS * LD + GJS_NALPHA];
+                    double t_logp, t_n, t_alpha, t_nalpha, e_ct, e_cg, e_ft, e_fr;
+                    if (h < a.gj_lds_levels) {                                     // wave-uniform
+                        const int b = slot_of(h);
+                        t_logp = gj_lds[b + GJL_VECS * LD + GJS_LOGP]; t_n = gj_lds[b + GJL_VECS * LD + GJS_N];
+                        t_alpha = gj_lds[b + GJL_VECS * LD + GJS_ALPHA]; t_nalpha = gj_lds[b + GJL_VECS * LD + GJS_NALPHA];
+                        e_ct = act ? gj_lds[b + GJL_CAND_T * LD + col] : 0.0; e_cg = act ? gj_lds[b + GJL_CAND_G * LD + col] : 0.0;
+                        e_ft = act ? gj_lds[b + GJL_FAR_T * LD + col] : 0.0; e_fr = act ? gj_lds[b + GJL_FAR_R * LD + col] : 0.0;
+                    } else {
+                        const double *gp = glevel(h);
+                        t_logp = gp[GJL_VECS * LD + GJS_LOGP]; t_n = gp[GJL_VECS * LD + GJS_N];
+                        t_alpha = gp[GJL_VECS * LD + GJS_ALPHA]; t_nalpha = gp[GJL_VECS * LD + GJS_NALPHA];
+                        e_ct = act ? gp[GJL_CAND_T * LD + col] : 0.0; e_cg = act ? gp[GJL_CAND_G * LD + col] : 0.0;
+                        e_ft = act ? gp[GJL_FAR_T * LD + col] : 0.0; e_fr = act ? gp[GJL_FAR_R * LD + col] : 0.0;
+                    }
                     const long long tot = (long long)t_n + cur.n;
                     const double den = (double)tot > 1.0 ? (double)tot : 1.0;
                     const bool take_u = uniform() < (double)cur.n / den;
                     if (!take_u) {
-                        cur.cand_t = act ? gj_lds[b + GJL_CAND_T * LD + col] : 0.0;
-                        cur.cand_g = act ? gj_lds[b + GJL_CAND_G * LD + col] : 0.0;
+                        cur.cand_t = e_ct;
+                        cur.cand_g = e_cg;
                         cur.logp = t_logp;
                     }
-                    cur.far_t = act ? gj_lds[b + GJL_FAR_T * LD + col] : 0.0;
-                    cur.far_r = act ? gj_lds[b + GJL_FAR_R * LD + col] : 0.0;
+                    cur.far_t = e_ft;
+                    cur.far_r = e_fr;
                     cur.n = tot;
                     const bool go = v == 1 ? keep_going(cur.far_t, tg, cur.far_r, rg) : keep_going(tg, cur.far_t, rg, cur.far_r);
                     cur.s = cur.s && go;                                 // the popped tree has s = 1
@@ -797,18 +815,35 @@ struct GradJumpWide {
                     continue;
                 }
                 GJP_T0(tp0);
-                const int b = slot_of(h);                                // push: wait for the right sibling
-                if (act) {                                               // in element order: 4 LD doubles per entry instead of 4 x 64
-                    gj_lds[b + GJL_FAR_T * LD + wi] = cur.far_t;
-                    gj_lds[b + GJL_FAR_R * LD + wi] = cur.far_r;
-                    gj_lds[b + GJL_CAND_T * LD + wi] = cur.cand_t;
-                    gj_lds[b + GJL_CAND_G * LD + wi] = cur.cand_g;
-                }
-                if (L == 0) {
-                    gj_lds[b + GJL_VECS * LD + GJS_LOGP] = cur.logp;
-                    gj_lds[b + GJL_VECS * LD + GJS_N] = (double)cur.n;
-                    gj_lds[b + GJL_VECS * LD + GJS_ALPHA] = cur.alpha;
-                    gj_lds[b + GJL_VECS * LD + GJS_NALPHA] = (double)cur.nalpha;
+                if (h < a.gj_lds_levels) {                               // push: wait for the right sibling
+                    const int b = slot_of(h);
+                    if (act) {                                           // in element order: 4 LD doubles per entry instead of 4 x 64
+                        gj_lds[b + GJL_FAR_T * LD + wi] = cur.far_t;
+                        gj_lds[b + GJL_FAR_R * LD + wi] = cur.far_r;
+                        gj_lds[b + GJL_CAND_T * LD + wi] = cur.cand_t;
+                        gj_lds[b + GJL_CAND_G * LD + wi] = cur.cand_g;
+                    }
+                    if (L == 0) {
+                        gj_lds[b + GJL_VECS * LD + GJS_LOGP] = cur.logp;
+                        gj_lds[b + GJL_VECS * LD + GJS_N] = (double)cur.n;
+                        gj_lds[b + GJL_VECS * LD + GJS_ALPHA] = cur.alpha;
+                        gj_lds[b + GJL_VECS * LD + GJS_NALPHA] = (double)cur.nalpha;
+                    }
+                } else {
+                    double *gp = glevel(h);
+                    if (act) {
+                        gp[GJL_FAR_T * LD + wi] = cur.far_t;
+                        gp[GJL_FAR_R * LD + wi] = cur.far_r;
+                        gp[GJL_CAND_T * LD + wi] = cur.cand_t;
+                        gp[GJL_CAND_G * LD + wi] = cur.cand_g;
+                    }
+                    if (L == 0) {
+                        gp[GJL_VECS * LD + GJS_LOGP] = cur.logp;
+                        gp[GJL_VECS * LD + GJS_N] = (double)cur.n;
+                        gp[GJL_VECS * LD + GJS_ALPHA] = cur.alpha;
+                        gp[GJL_VECS * LD + GJS_NALPHA] = (double)cur.nalpha;
+                    }
+                    __threadfence_block();                               // the wave's own global stores, visible to its other lanes
                 }
                 __syncthreads();                                         // one wave per block: orders lane 0's writes before the others' reads
                 pend |= 1u << h;
@@ -950,7 +985,7 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? 2 : 1) void mh_ste
             // one chain after the other, each on all 64 lanes: its row goes through LDS into the whole-wave layout and the
             // proposal comes back the same way; everything in between is wave-uniform
             u64 todo = __ballot(is_gj && live);
-            const int xch = a.gj_stack_off + (a.nuts_maxdepth + 1) * gjw_level_doubles(EPL);
+            const int xch = a.gj_stack_off + a.gj_lds_levels * gjw_level_doubles(EPL);
             const int L = (int)threadIdx.x;
             while (todo) {
                 const int lane0 = (int)__builtin_ctzll(todo);                    // first lane of the chain

@@ -30,13 +30,15 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
             // Wider shapes: lowest levels of the tree stack | box bounds.
             size_t off = 0;
             const size_t box = h->cfg.logp_kind == PTMI_LOGP_BOX ? (size_t)box_table_doubles(G, E) : 0;
+            static const char *lv = getenv("PTMI_GJ_LDS_LEVELS");       // measurement / test switch: same results for any value
             if constexpr (G == 4) {
                 off = (size_t)gjw_table_doubles(E);
                 a.gj_stack_off = (int)off;
-                a.gj_lds_levels = h->cfg.nuts_maxdepth + 1;
+                int levels = h->cfg.nuts_maxdepth + 1 < 11 ? h->cfg.nuts_maxdepth + 1 : 11;    // heights 0..10 in LDS, the rest in global scratch
+                if (lv) levels = atoi(lv) < levels ? atoi(lv) : levels;
+                a.gj_lds_levels = levels;
                 off += (size_t)a.gj_lds_levels * gjw_level_doubles(E) + 64;
             } else {
-                static const char *lv = getenv("PTMI_GJ_LDS_LEVELS");       // measurement switch: same results for any value
                 const size_t budget = 40 * 1024 / sizeof(double);           // one wave per SIMD (register count): a quarter of the CU's LDS each
                 int levels = box < budget ? (int)((budget - box) / gj_level_doubles(E)) : 0;
                 if (levels > h->cfg.nuts_maxdepth + 1) levels = h->cfg.nuts_maxdepth + 1;

@@ -90,6 +90,9 @@ class PTEngine(object):
     the disjoint pairs (k, k+1), k = swap epoch (mod 2), all at once (see include/ptmi.h).  ``pick_mode``: ``"chain"`` =
     every chain draws its own entry of the proposal cycle (the reference's ``_jump``); ``"walker"`` = one draw per walker
     and iteration fixes the proposal type of all its temperature ranks (wave-uniform on the device, include/ptmi.h).
+    ``nuts_maxdepth``: NUTS stops doubling at this tree height.  The reference doubles ``while s == 1`` with no cap
+    (nutsjump.py:716-802); the default 24 (2^24 leapfrogs in one call, the ABI's limit) is out of reach of any run, i.e. the
+    reference's behaviour.  A lower value is an engine option (bounded cost per call).
     ``eig_mode``: who factorizes the adapted covariance at a covariance epoch (PTMCMCSampler.py:797-803): ``"lapack"`` = the
     host, exactly as the reference (``np.linalg.svd`` per walker); ``"jacobi"`` = ``ptmi_eig_jacobi`` on the device, one
     block per walker, no host round trip (ndim <= 101, one parameter group; same subspaces, its own sign rule);
@@ -104,7 +107,7 @@ class PTEngine(object):
                  cov_mode="per_walker", hot_chain=False, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
                  w_host=0, keep_lnl=False, groups=None, swap_mode="sweep",
-                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=10, pick_mode="chain",
+                 grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
                  eig_mode="lapack"):
         torch = _torch()
         self.lib = _lib.load()

@@ -112,7 +112,7 @@ class PTSampler(object):
     def __init__(self, ndim, logl, logp, cov, groups=None, loglargs=[], loglkwargs={}, logpargs=[], logpkwargs={},
                  logl_grad=None, logp_grad=None, comm=None, outDir="./chains", verbose=True, resume=False, seed=None,
                  nwalkers=1, ntemps=None, device=0, cov_mode="per_walker", keep_walkers=1, swap_mode="sweep",
-                 pick_mode="chain", eig_mode="lapack", checkpoint=None, batched=False):
+                 pick_mode="chain", eig_mode="lapack", checkpoint=None, batched=False, nuts_maxdepth=24):
         self.comm = comm if comm is not None else _DummyComm()
         if self.comm.Get_size() != 1:
             raise NotImplementedError(
@@ -121,6 +121,7 @@ class PTSampler(object):
         self.nwalkers, self.device_index, self.cov_mode = int(nwalkers), device, cov_mode
         self.swap_mode = swap_mode                          # "sweep" = PTswap as the reference; "oddeven" see PTEngine
         self.pick_mode, self.eig_mode = pick_mode, eig_mode # engine options, see PTEngine
+        self.nuts_maxdepth = int(nuts_maxdepth)             # device NUTS: tree-height cap (24 = none in practice, as the reference)
         # device checkpoints (ptmi_checkpoint.npz beside the chain file) are written at every save when the run may be
         # resumed: checkpoint=True, or -- by default -- when it was itself started with resume=True.  A run of one chain
         # (ntemps = nwalkers = 1) can also be resumed from its chain file alone, as in the reference (:290-319); a ladder or a
@@ -316,7 +317,7 @@ class PTSampler(object):
             logl=self.logl_spec or ("iso",), logp=self.logp_spec or ("flat",),
             weights=(self.SCAMweight, self.AMweight, self.DEweight), cov_update=covUpdate, burn=burn, tskip=Tskip,
             seed=self.seed, cov_mode=self.cov_mode, hot_chain=hotChain, device=self.device_index, split=self.split,
-            swap_mode=self.swap_mode, pick_mode=self.pick_mode, eig_mode=self.eig_mode, grad_weights=self._grad_weights, hmc=(HMCstepsize, 2, HMCsteps),
+            swap_mode=self.swap_mode, pick_mode=self.pick_mode, eig_mode=self.eig_mode, grad_weights=self._grad_weights, hmc=(HMCstepsize, 2, HMCsteps), nuts_maxdepth=self.nuts_maxdepth,
             w_host=len(self.host_jumps), keep_lnl=True, groups=None if len(self.groups) == 1 and len(self.groups[0]) == self.ndim and np.array_equal(np.asarray(self.groups[0]), np.arange(self.ndim)) else self.groups)
 
     # ------------------------------------------------------------------ sample (:374-528)

@@ -35,10 +35,16 @@ CASES = [
     dict(d=100, nt=2, W=2, logl=("iso",), logp=("box", -4.0, 4.0), grad_weights=(10, 5), weights=(10, 0, 10)),
     dict(d=150, nt=2, W=2, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0)),
     dict(d=34, nt=2, W=3, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 0, 10), hmc=(0.08, 2, 50)),
+    # tree-height caps that ARE reached (the reference has none, nutsjump.py:716-802; the default 24 never binds): the capped
+    # call must end exactly as the oracle's, in the whole-wave layout (d <= 32) and in the per-chain one
+    dict(d=6, nt=2, W=5, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=2),
+    dict(d=20, nt=3, W=4, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(20, 0), weights=(5, 0, 5), nuts_maxdepth=3),
+    dict(d=40, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=1),
+    dict(d=5, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=0),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s" % (c["d"], c["logl"][0]))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else ""))
 def test_device_gradient_jumps_bit_exact(case):
     c = dict(case)
     d, nt, W = c.pop("d"), c.pop("nt"), c.pop("W")
@@ -71,6 +77,12 @@ def test_device_gradient_jumps_bit_exact(case):
     if c["grad_weights"][1]:
         assert js[4, 0] > 0
     assert js[:, 0].sum() == W * nt * n
+    if "nuts_maxdepth" in c:                                   # the cap did bind: without it the same run takes more leapfrogs
+        from oracle import oracle as orc
+        free = orc.OracleEngine(d, nt, W, cov0, **dict(kw, nuts_maxdepth=24))
+        free.init_state(p0)
+        free.run(n)
+        assert free.gj[..., 7].sum() > o.gj[..., 7].sum() > 0
 
 
 def test_sharded_ladder_with_gradient_jumps():
@@ -137,3 +149,17 @@ def test_facade_runs_device_gradient_jumps(tmp_path):
         assert (tmp_path / name).exists(), name
     chain = np.loadtxt(tmp_path / "chain_1.0.txt")
     assert chain.shape[1] == d + 4 and len(chain) in (400, 401) and np.isfinite(chain).all()
+
+
+def test_tree_levels_beyond_the_lds_budget_live_in_global_scratch():
+    """The tree stack keeps the low heights in LDS and the rest -- heights 11 .. 24 by default, never reached by a sane run --
+    in global scratch.  With PTMI_GJ_LDS_LEVELS=1 (read once per process, hence the child) every height above 0 takes the
+    global path: the same parity cases must still hold bit for bit, in the whole-wave layout and in the per-chain one."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gradjump_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "test_device_gradient_jumps_bit_exact and (d20-curved or d5-iso or d40-dense or d2-curved)"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, PTMI_GJ_LDS_LEVELS="1"), cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
