@@ -519,6 +519,185 @@ __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem
     mu[(size_t)w * d + j] = m;
 }
 
+// ------------------------------------------------- AM increments ahead of the launch (large ndim)
+// The AM proposal q = x + U (cd sqrt(S) z) (PT:879-933) costs 2 ndim^2 flops per pick, and its increment depends on the chain's
+// stream, the iteration and the scale branch only -- not on its state.  For the 16- and 64-lane shapes (ndim > 104), where a
+// chain is a quarter of a wave or a whole one and the kernel's own product ran on the vector pipe (1.2 s per 100 steps of the
+// default mix at ndim = 1000), the increments of a piece of the launch are computed AHEAD of it as one matrix product on the
+// matrix cores: the piece's AM picks are listed (am_count / am_scan / am_fill: one thread per chain repeats the kernel's cycle
+// draw), am_gemm_kernel computes INC[event][:] = sum_k Ut[k][:] w_event[k] -- 64 events per block, every weight generated in the
+// block from the event's stream, v_mfma_f64_16x16x4 accumulating k ascending: the oracle's fma chain -- and the step kernel
+// reads its increment instead of computing it.
+struct AmEvent { long long it; double cd; u32 sid, pad; };
+struct AmArgs {
+    u64 seed;
+    long long iter0, nch;
+    int nsteps, nt, ntg, temp0, walker0, w_host, w_scam, w_am, w_de, pick_walker;
+    double gcn;
+    const int32_t *temp_of;
+    const double *temps_mh;
+};
+// the cycle draw of propose() (ptmi_mh.inc.h) for one (chain, iteration); cd = 2.4 / sqrt(2 ndim) * scale (PT:846-862, 928)
+__device__ __forceinline__ bool am_pick(const AmArgs &p, long long ch, long long it, AmEvent &e)
+{
+    const int w = (int)(ch / p.nt), t = p.temp_of[ch];
+    const u32 sid0 = (u32)((u64)(p.walker0 + w) * (u32)p.ntg), sid = sid0 + (u32)(p.temp0 + t);
+    u64 p0, p1;
+    philox_words(p.seed, (u64)it, sid, 0u, p0, p1);
+    u32 pickw = (u32)(p0 >> 32);
+    if (p.pick_walker) {
+        u64 q0, q1;
+        philox_words(p.seed, (u64)it, sid0, 0u, q0, q1);
+        pickw = (u32)(q0 >> 32);
+    }
+    const int L = p.w_host + p.w_scam + p.w_am + p.w_de;
+    const int ind = (int)__umulhi(pickw, (u32)L) - p.w_host;
+    if (ind < p.w_scam || ind >= p.w_scam + p.w_am) return false;
+    constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
+    const u32 plo = (u32)p0;
+    const double temp = p.temps_mh[t];
+    const bool warm = temp <= 100.0;
+    const double sT = warm ? det_sqrt(temp) : 1.0;
+    const double base = plo > T97 ? 10.0 : (plo > T90 ? 0.2 : 1.0);
+    e.it = it; e.sid = sid; e.pad = 0;
+    e.cd = p.gcn * (warm ? base * sT : base);
+    return true;
+}
+__global__ void am_count_kernel(const AmArgs p, int32_t *count)
+{
+    const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= p.nch) return;
+    int n = 0;
+    AmEvent e;
+    for (int s = 0; s < p.nsteps; ++s) n += am_pick(p, ch, p.iter0 + s, e) ? 1 : 0;
+    count[ch] = n;
+}
+// exclusive prefix sums of the chains' counts (one block); base[nch] = the number of events
+__global__ __launch_bounds__(1024) void am_scan_kernel(const int32_t *count, long long *base, long long nch)
+{
+    __shared__ long long part[1024];
+    const long long per = (nch + 1023) / 1024, lo = (long long)threadIdx.x * per, hi = lo + per < nch ? lo + per : nch;
+    long long sum = 0;
+    for (long long i = lo; i < hi; ++i) sum += count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+        base[nch] = run;
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (long long i = lo; i < hi; ++i) { base[i] = run; run += count[i]; }
+}
+__global__ void am_fill_kernel(const AmArgs p, const long long *base, AmEvent *ev)
+{
+    const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= p.nch) return;
+    long long at = base[ch];
+    AmEvent e;
+    for (int s = 0; s < p.nsteps; ++s)
+        if (am_pick(p, ch, p.iter0 + s, e)) ev[at++] = e;
+}
+// 64 events per block of four waves; wave v holds the output tiles v, v + 4, ... (16 rows of the increment each) of all four event
+// tiles: at most 8 x 4 tiles of 8 registers = the 256 accumulation registers, i.e. 512 rows of the increment per block.  Beyond
+// (ndim <= 1024) two blocks (blockIdx.y) share an event tile, each with half of the output rows and its own copy of the weights.
+// The weights of 2 G consecutive directions -- G Box-Muller pairs (k, k + G) per event, the pairing of the step kernels -- are
+// generated into LDS one super-chunk ahead of the products that use them.
+template <int G, int MAXT>
+__global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, const long long *base, long long nch, int d, const double *Ut,
+                                                        const double *S, u64 seed, double *inc)
+{
+    constexpr int NEV = 64, K2 = 2 * G;
+    extern __shared__ __attribute__((aligned(16))) double Wl[];          // [2][K2][NEV]
+    const long long nev = base[nch], e0 = (long long)blockIdx.x * NEV;
+    if (e0 >= nev) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const bool ev_on = e0 + lane < nev;
+    const AmEvent me = ev[ev_on ? e0 + lane : e0];
+    ps_d4 acc[MAXT][4];
+#pragma unroll
+    for (int tt = 0; tt < MAXT; ++tt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[tt][ct] = ps_d4{0.0, 0.0, 0.0, 0.0};
+    const int ntile = (d + 15) / 16, nsup = (d + K2 - 1) / K2;
+    const int tile0 = (int)blockIdx.y * 4 * MAXT + wave;               // this wave's first output tile
+    auto gen = [&](int m, int buf) {
+        for (int kk = wave; kk < G; kk += 4) {                          // pair (k, k + G) of event `lane`
+            const int k = m * K2 + kk;
+            double wa = 0.0, wb = 0.0;
+            if (ev_on && k < d) {
+                u64 w0, w1;
+                philox_words(seed, (u64)me.it, me.sid, SLOT_AM + (u32)k, w0, w1);
+                const double r = det_sqrt(-2.0 * unit_log<0>(w0));
+                u32 aj;
+                double at, sn, cs;
+                unit_angle64(w1, aj, at);
+                unit_sincos<0>(aj, at, sn, cs);
+                wa = (r * cs) * me.cd * det_sqrt(S[k]);                   // PT:930
+                if (k + G < d) wb = (r * sn) * me.cd * det_sqrt(S[k + G]);
+            }
+            Wl[((size_t)buf * K2 + kk) * NEV + lane] = wa;
+            Wl[((size_t)buf * K2 + kk + G) * NEV + lane] = wb;
+        }
+    };
+    gen(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int m = 0; m < nsup; ++m) {
+        if (m + 1 < nsup) gen(m + 1, buf ^ 1);
+        const double *Wb = Wl + (size_t)buf * K2 * NEV + (size_t)g * NEV + c;
+        // The table values go four output tiles at a time: the next group's (the next k-step's first group after the last) are
+        // requested before the 16 matrix instructions of this one -- one wave per SIMD, nothing else hides the round trip, and
+        // the 256 accumulation registers leave no room to hold a whole k-step ahead.
+        auto rows_of = [&](int k0, int grp, double (&dst)[4]) {
+            const int kr = k0 + g < d ? k0 + g : d - 1;                  // rows past the end: their weights are zero
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = 16 * (tile0 + 4 * (4 * grp + u)) + c;
+                dst[u] = Ut[(size_t)kr * d + (col < d ? col : d - 1)];
+            }
+        };
+        double ga[4], gn[4];
+        rows_of(m * K2, 0, ga);
+#pragma unroll 1
+        for (int ks = 0; ks < K2 / 4; ++ks) {
+            const int k0 = m * K2 + 4 * ks;
+            if (k0 >= d) break;                                          // uniform
+            double bq[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) bq[ct] = Wb[(size_t)(4 * ks) * NEV + 16 * ct];
+#pragma unroll
+            for (int grp = 0; grp < MAXT / 4; ++grp) {
+                if (grp + 1 < MAXT / 4) rows_of(k0, grp + 1, gn);
+                else rows_of(k0 + 4 < d ? k0 + 4 : k0, 0, gn);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (tile0 + 4 * (4 * grp + u) < ntile) {
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+                            acc[4 * grp + u][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[u], bq[ct], acc[4 * grp + u][ct], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ga[u] = gn[u];
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int tt = 0; tt < MAXT; ++tt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * (tile0 + 4 * tt) + g + 4 * r;
+                const long long e = e0 + 16 * ct + c;
+                if (i < d && e < nev) inc[(size_t)e * d + i] = acc[tt][ct][r];
+            }
+}
+
 // DE history ring: rows [head, head+mem) are the oldest; overwrite them with the AM buffer.
 // Row layout (ptmi_de_row_stride): with 4 lanes per chain a row is stored in 16-byte PIECES dealt to the lanes in turn --
 // position 8 (e / 2) + 2 lane + e % 2 holds element lane + 4 e, zero where that is past ndim -- so that one read
@@ -835,6 +1014,30 @@ static int chains_grid(const ptmi_engine *h)
     return (int)((nch + cpb - 1) / cpb);
 }
 
+// am_gemm_kernel for up to max_events events (blocks beyond the actual count leave at once: no host round trip for it)
+template <int G, int MAXT>
+static int launch_am_gemm_t(ptmi_engine *h, long long max_events)
+{
+    const size_t lds = sizeof(double) * 2 * (2 * G) * 64;
+    auto kern = am_gemm_kernel<G, MAXT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
+    }
+    const int ntile = (h->cfg.ndim + 15) / 16, parts = (ntile + 4 * MAXT - 1) / (4 * MAXT);      // blocks per event tile
+    hipLaunchKernelGGL(kern, dim3((unsigned)((max_events + 63) / 64), parts), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
+                       (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, h->cfg.ndim, (const double *)h->buf.Ut,
+                       (const double *)h->buf.S, h->cfg.seed, h->d_am_inc);
+    return PTMI_OK;
+}
+static int launch_am_gemm(ptmi_engine *h, long long max_events)
+{
+    const int ntile = (h->cfg.ndim + 15) / 16;                          // output tiles of an increment
+    if (h->G == 16) return ntile <= 16 ? launch_am_gemm_t<16, 4>(h, max_events) : launch_am_gemm_t<16, 8>(h, max_events);
+    if (h->G == 64) return launch_am_gemm_t<64, 8>(h, max_events);
+    return fail(PTMI_EINVAL, "AM increments ahead of the launch are built for the 16- and 64-lane shapes");
+}
+
 extern "C" {
 
 const char *ptmi_last_error(void) { return g_err; }
@@ -985,6 +1188,21 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         e = hipMalloc((void **)&h->d_pool_part, sizeof(double) * (size_t)nslab * c.ndim * (c.ndim + 1));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_pool_T, sizeof(double) * (size_t)c.ndim * (c.ndim + 1));
     }
+    // AM increments ahead of the launch (am_gemm_kernel): the 16- and 64-lane shapes with one pooled table, ndim <= 1024
+    if (e == hipSuccess && !gj && c.w_am > 0 && !c.cov_per_walker && c.ngroups <= 1 && s.G > 4 && c.ndim <= 1024 && c.w_host == 0 &&
+        !getenv("PTMI_NO_AM_AHEAD")) {
+        const long long nch = (long long)c.nwalkers * c.ntemps;
+        const char *mb = getenv("PTMI_AM_BUDGET_MB");                    // scratch for the increments of one piece of a launch (default 6 GB)
+        const double budget = (mb ? atof(mb) : 6144.0) * 1048576.0;
+        long long piece = (long long)(budget / ((double)c.ndim * 8.0 * (double)nch));
+        piece = piece < 1 ? 1 : (piece > 64 ? 64 : piece);
+        h->am_piece = (int)piece;
+        h->am_cap = nch * piece;
+        e = hipMalloc((void **)&h->d_am_ev, sizeof(AmEvent) * (size_t)h->am_cap);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_count, sizeof(int32_t) * (size_t)nch);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_base, sizeof(long long) * (size_t)(nch + 1));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_inc, sizeof(double) * (size_t)h->am_cap * c.ndim);
+    }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) { ptmi_destroy(h); return fail(PTMI_EHIP, "create: %s", hipGetErrorString(e)); }
@@ -998,6 +1216,7 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
+    (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1060,6 +1279,31 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     const bool full = h->cfg.w_am > 0 || (h->de_on && h->cfg.w_de > 0);
     if (!full && h->cfg.w_scam <= 0) return fail(PTMI_EINVAL, "empty proposal cycle");
     const int grid = chains_grid(h);
+    if (h->am_piece > 0) {
+        // large ndim: the launch goes in pieces, each behind the matrix product that computes its AM increments
+        const ptmi_config &c = h->cfg;
+        const long long nch = (long long)c.nwalkers * c.ntemps;
+        for (int s0 = 0; s0 < nsteps; s0 += h->am_piece) {
+            const int ns = nsteps - s0 < h->am_piece ? nsteps - s0 : h->am_piece;
+            AmArgs p;
+            p.seed = c.seed; p.iter0 = iter0 + s0; p.nch = nch; p.nsteps = ns; p.nt = c.ntemps; p.ntg = c.ntemps_global; p.temp0 = c.temp0;
+            p.walker0 = c.walker0; p.w_host = c.w_host; p.w_scam = c.w_scam; p.w_am = c.w_am; p.w_de = h->de_on ? c.w_de : 0;
+            p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.gcn = 2.4 / sqrt(2.0 * (double)c.ndim);
+            p.temp_of = h->buf.temp_of; p.temps_mh = h->d_temps;
+            const unsigned gch = (unsigned)((nch + 255) / 256);
+            hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count);
+            hipLaunchKernelGGL(am_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, h->d_am_base, nch);
+            hipLaunchKernelGGL(am_fill_kernel, dim3(gch), dim3(256), 0, h->stream, p, (const long long *)h->d_am_base, (AmEvent *)h->d_am_ev);
+            if (int rc = launch_am_gemm(h, nch * ns)) return rc;
+            KArgs ap = make_args(h);
+            ap.iter0 = iter0 + s0; ap.nsteps = ns;
+            if (int rc = set_step_args(h, &ap)) return rc;
+            ap.am_inc = h->d_am_inc; ap.am_base = h->d_am_base;
+            if (int rc = run_shape(h, PTMI_OP_MH, ap, grid, full)) return rc;
+        }
+        HIPCHK(hipGetLastError());
+        return PTMI_OK;
+    }
     if (int rc = run_shape(h, PTMI_OP_MH, a, grid, full)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;

@@ -49,6 +49,10 @@ struct KArgs {
     int amq_on;                  // ... and whether this launch takes its AM increments from the queue (launch_mh_k)
     int box_off;                 // box prior: offset (doubles, even) of the bounds table in the block's LDS, or -1: bounds read from global
     int tab_off;                 // step kernels: offset (doubles, even) of the block's LDS copy of the draw tables (ptmi_tables.h), or -1: read from global
+    // AM increments computed ahead of the launch by am_gemm_kernel (ptmi_abi.hip; the 16- and 64-lane shapes): increment j of the
+    // chain's AM picks of this launch is am_inc[(am_base[chain] + j) * d ...]; nullptr: the kernel computes its own
+    const double *am_inc;
+    const long long *am_base;
     // gradient jumps (ptmi_gj.inc.h)
     int w_nuts, w_hmc, gj_nburn, hmc_min, hmc_max, nuts_maxdepth;
     double hmc_eps, nuts_delta;
@@ -89,6 +93,13 @@ struct ptmi_engine {
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
     int32_t *d_gj_order, *d_gj_bucket;         // launch order of the chains ([nch]) and its counting-sort scratch ([3][GJ_BUCKETS])
+    // AM increments ahead of the launch (large ndim): events of a piece of the launch, their increments [am_cap][ndim]
+    void *d_am_ev;
+    int32_t *d_am_count;
+    long long *d_am_base;
+    double *d_am_inc;
+    long long am_cap;
+    int am_piece;       // steps per piece (0: the path is off for this engine)
     double *d_pool_part, *d_pool_T;  // pooled covariance: the slabs' partial sums [nslab][d][d+1] and their total [d][d+1] (column d: the column sums)
     int G, EPL;
     int de_on, de_head;

@@ -613,7 +613,8 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
 template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, const Draws &dr,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
-                                       double (&dq)[EPL], bool s_sqrt = false, bool am_here = true, const double *tsm = nullptr)
+                                       double (&dq)[EPL], bool s_sqrt = false, bool am_here = true, const double *tsm = nullptr,
+                                       long long *am_next = nullptr /* where the chain's next precomputed AM increment is (a.am_inc) */)
 {
     // s_sqrt: S holds sqrt(eigenvalue) already (the block's LDS copy; sqrt is correctly rounded, so the bits are the same)
     auto root_s = [&](int k) { const double v = S[k]; return s_sqrt ? v : det_sqrt(v); };
@@ -737,6 +738,15 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
 #pragma unroll
                         for (int e = 0; e < EPL; ++e) dq[e] = acc.at(e);
                     }
+                }
+            } else if (a.am_inc != nullptr && am_next != nullptr) {
+                // the increment U (cd sqrt(S) z) was computed ahead of the launch on the matrix cores (am_gemm_kernel: the same
+                // k-ascending fma chain from the same weights)
+                if (is_am) {
+                    const double *inc = a.am_inc + (size_t)(*am_next) * d;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD_S(PSAFE, dq[e], inc, e);
+                    *am_next += 1;
                 }
             } else {
                 double wk[EPL];
@@ -916,6 +926,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
     double lnL = a.lnL[ch], lp = a.lp[ch];
     u32 nacc = 0, jp[PTMI_J_FUSED] = {0, 0, 0}, ja[PTMI_J_FUSED] = {0, 0, 0};
+    long long am_next = (FULL && a.am_base != nullptr) ? a.am_base[ch] : 0;      // the chain's next precomputed AM increment
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
 
@@ -1011,7 +1022,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         else if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
         else if (STAGE && FULL && (UT_ALWAYS_LDS || a.lds_u)) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, PTMI_UL, true, PTMI_SQ, DE, dq, true, !amq_on, tsm);
         else if (STAGE && FULL) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, PTMI_SQ, DE, dq, true, !amq_on, tsm);
-        else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq);
+        else jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, UtBlock, false, S, DE, dq, false, true, nullptr, &am_next);
         }
         if constexpr (AMQ) {
             // the rank of this chain's event of this step is held by its lane of row (k & 3)

@@ -354,6 +354,26 @@ def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior):
     assert_same(g.get("Ut"), o.Ut, "Ut")
 
 
+@pytest.mark.parametrize("d,nt,W,pick", [(130, 3, 7, "chain"), (300, 2, 5, "chain"), (417, 3, 3, "walker"), (640, 2, 3, "chain"), (1000, 3, 2, "chain")])
+def test_am_increments_ahead_of_the_launch_large_ndim(mods, d, nt, W, pick):
+    """ndim > 104 with one pooled table: the AM increments U (cd sqrt(S) z) (PTMCMCSampler.py:879-933) of a piece of the launch
+    are computed ahead of it by am_gemm_kernel on the matrix cores (16- and 64-lane shapes; one and two blocks per event
+    tile), the step kernel reads them.  Same weights, same k-ascending fma chain as the oracle's: bit for bit, through
+    covariance epochs that change the table, DE activation, launches of odd lengths and a scratch budget that cuts the
+    launches into pieces of a few steps."""
+    orc, _lib, _ = mods
+    g, o = _pair(mods, d, nt, W, weights=(20, 20, 20), cov_update=30, burn=60, tskip=7, seed=d, cov_mode="pooled", pick_mode=pick,
+                 cov0=np.eye(d) * 0.01)
+    for n in (33, 5, 52):
+        g.run(n)
+        o.run(n)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_FULL and G == (16 if d <= 416 else 64)
+    _compare(g, o, "AM ahead d=%d " % d)
+    assert_same(g.get("Ut"), o.Ut, "Ut")
+    assert o.jstat[..., 1, 0].sum() > 0 and o.jstat[..., 1, 1].sum() > 0 and o.jstat[..., 2, 0].sum() > 0
+
+
 def test_minus_inf_start_and_nan_safety(mods):
     """A start outside the prior (lnL = lp = -inf, PTMCMCSampler.py:481-483) can only leave through a finite proposal."""
     d = 4

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes, one JSON line per workload, into gpurun_out/sweep_<tag>/ (copy the merged file to
-# profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r02'
-TAG=${1:-r02}
+# profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r03'
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sweep_$TAG
 mkdir -p $OUT
@@ -16,7 +16,8 @@ b dense_mix_walker --no-cpu-baseline --logl dense --mix default --pick walker --
 b per_walker_lapack --no-cpu-baseline --cov-mode per_walker --steps 20 --warmup 10
 b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10
 b callback --no-cpu-baseline --callback --steps 10 --warmup 2
-b c4_share --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 20 --warmup 10
+b c4_share --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 40 --warmup 20 --ess-window 0
+b c4_share_lapack --no-cpu-baseline --ndim 1000 --nwalkers 512 --cov-mode pooled_device --steps 1 --warmup 0 --ess-window 0 || true
 b c5_share --no-cpu-baseline --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 6 --warmup 4
 b oddeven --no-cpu-baseline --swap-mode oddeven --steps 100 --warmup 20
 python - <<PY
