@@ -45,7 +45,8 @@ enum { PTMI_OK = 0, PTMI_EINVAL = -1, PTMI_EHIP = -2, PTMI_EUNSUPPORTED = -3, PT
 /* built-in device likelihoods / priors (a Python callback cannot run in a kernel;
  * user callbacks go through ptmi_propose / ptmi_accept instead) */
 enum { PTMI_LOGL_ISO = 0,      /* -1/2 sum x^2 */
-       PTMI_LOGL_DENSE = 1,    /* -(x-mu)^T P (x-mu) / 2 ; par = mu[d], Pt[d*d] (Pt[j*d+i] = P[i][j]) */
+       PTMI_LOGL_DENSE = 1,    /* -(x-mu)^T P (x-mu) / 2 ; par = mu[d], Pt[d*d] (Pt[j*d+i] = P[i][j]).  P is a precision matrix:
+                                * the value is summed over the lower half of its symmetric part (half the products) */
        PTMI_LOGL_CURVED = 2 }; /* d/2 copies of examples/curved_likelihood.ipynb's 2-d likelihood */
 enum { PTMI_LOGP_FLAT = 0,     /* 0 everywhere */
        PTMI_LOGP_BOX = 1 };    /* 0 inside [lo,hi], -inf outside ; par = lo[d], hi[d] */

@@ -112,6 +112,16 @@ def _p(a, t=_dp):
     return a.ctypes.data_as(t)
 
 
+def dense_par(mu, P):
+    """Parameter block of the dense likelihood: mu | Pt (Pt[j][i] = P[i][j], the gradient's table) | Tl (the half of the
+    symmetric part of P the VALUE is summed over: Tl[k][i] = Ps[k][i] for k > i, Ps[i][i] / 2 for k == i, else 0)."""
+    mu, P = np.asarray(mu, dtype=np.float64), np.asarray(P, dtype=np.float64)
+    Pt = np.ascontiguousarray(P.T)
+    Ps = (Pt + Pt.T) * 0.5
+    Tl = np.tril(Ps, -1) + np.diag(np.diag(Ps) * 0.5)
+    return np.concatenate([mu, Pt.ravel(), Tl.ravel()])
+
+
 def lanes_for(ndim, grad=False):
     """Lanes that share one chain in the HIP kernels (fixes the summation order); grad: with NUTS / HMC in the cycle."""
     if grad:
@@ -238,7 +248,7 @@ def gradjump(kind, x, it, beta, state, cov, logl=("iso",), logp=("flat",), nburn
     d = len(x)
     par_l, par_p = np.zeros(1), np.zeros(1)
     if logl[0] == "dense":
-        par_l = np.concatenate([np.asarray(logl[1], float), np.ascontiguousarray(np.asarray(logl[2], float).T).ravel()])
+        par_l = dense_par(logl[1], logl[2])
     if logp[0] == "box":
         par_p = np.concatenate([np.asarray(logp[1], float), np.asarray(logp[2], float)])
     tab = gj_tables(cov)
@@ -330,8 +340,7 @@ class OracleEngine(object):
         self._par_l = np.zeros(1)
         self._par_p = np.zeros(1)
         if logl[0] == "dense":
-            mu, P = np.asarray(logl[1], float), np.asarray(logl[2], float)
-            self._par_l = np.concatenate([mu, np.ascontiguousarray(P.T).ravel()])
+            self._par_l = dense_par(logl[1], logl[2])
         if logp[0] == "box":
             self._par_p = np.concatenate([np.asarray(logp[1], float), np.asarray(logp[2], float)])
         self.cfg = Cfg(ndim=d, ntemps=nt, nwalkers=W, lanes=self.lanes, logl_kind=LOGL[logl[0]],

@@ -308,7 +308,8 @@ typedef struct {
     int32_t cov_per_walker;           /* 1: Ut/S/DE per walker, 0: one shared set */
     int32_t ntemps_global, temp0, walker0, ngroups;   /* ngroups: parameter groups (PT:129-145); 0 or 1 = one full group */
     uint64_t seed;
-    const double *logl_par;           /* DENSE: mu[d], Pt[d*d] (Pt[j*d+i] = P[i][j]) */
+    const double *logl_par;           /* DENSE: mu[d], Pt[d*d] (Pt[j*d+i] = P[i][j]), Tl[d*d] (the half of the symmetric P the value is summed over:
+                                       * Tl[k*d+i] = P[k][i] for k > i, P[i][i] / 2 for k == i, 0 for k < i) */
     const double *logp_par;           /* BOX: lo[d], hi[d] */
     const double *temps_mh;           /* [ntemps] temperature of each local rank as the MH step sees it (PT:278-282) */
     const double *beta;               /* [ntemps] 1/temps_mh */
@@ -388,13 +389,15 @@ static double eval_logl(const orc_cfg *c, const double *q, double *tmp /* 2d */)
     int d = c->ndim;
     if (c->logl_kind == LOGL_ISO)
         return -0.5 * lane_dot(q, q, d, c->lanes);
-    if (c->logl_kind == LOGL_DENSE) {        /* -(x-mu)^T P (x-mu) / 2 */
-        const double *mu = c->logl_par, *Pt = c->logl_par + d;
+    if (c->logl_kind == LOGL_DENSE) {
+        /* -(x-mu)^T P (x-mu) / 2 with P symmetric = -sum_i r_i (P_ii r_i / 2 + sum_{k > i} P_ki r_k): half the products of the
+         * full form.  v_i is the k-ascending fma chain over column i of Tl (its zeros leave the sum untouched). */
+        const double *mu = c->logl_par, *Tl = c->logl_par + d + (size_t)d * d;
         double *r = tmp, *v = tmp + d;
         for (int i = 0; i < d; ++i) { r[i] = q[i] - mu[i]; v[i] = 0.0; }
         for (int j = 0; j < d; ++j)
-            for (int i = 0; i < d; ++i) v[i] = fma(Pt[(size_t)j * d + i], r[j], v[i]);
-        return -0.5 * lane_dot(r, v, d, c->lanes);
+            for (int i = 0; i < d; ++i) v[i] = fma(Tl[(size_t)j * d + i], r[j], v[i]);
+        return -lane_dot(r, v, d, c->lanes);
     }
     if (c->logl_kind == LOGL_CURVED) {
         /* d/2 independent copies of the 2-d curved likelihood of the reference's
@@ -472,7 +475,11 @@ static double eval_logl_grad(const orc_cfg *c, const double *q, double *tmp /* 2
     const double ll = eval_logl(c, q, tmp);
     if (c->logl_kind == LOGL_ISO) {
         for (int i = 0; i < d; ++i) g[i] = -q[i];
-    } else if (c->logl_kind == LOGL_DENSE) {                   /* symmetric P: grad = -P (x - mu); tmp + d holds P r */
+    } else if (c->logl_kind == LOGL_DENSE) {                   /* symmetric P: grad = -P (x - mu), the full product (tmp holds r) */
+        const double *Pt = c->logl_par + d;
+        for (int i = 0; i < d; ++i) tmp[d + i] = 0.0;
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i < d; ++i) tmp[d + i] = fma(Pt[(size_t)j * d + i], tmp[j], tmp[d + i]);
         for (int i = 0; i < d; ++i) g[i] = -tmp[d + i];
     } else {
         for (int i = 0; i < d; ++i) g[i] = 0.0;

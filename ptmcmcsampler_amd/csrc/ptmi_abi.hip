@@ -1141,9 +1141,24 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     h->cfg = c; h->buf = *buf; h->stream = (hipStream_t)c.stream; h->G = s.G; h->EPL = s.EPL;
     std::vector<double> beta((size_t)c.ntemps);
     for (int t = 0; t < c.ntemps; ++t) beta[(size_t)t] = 1.0 / c.temps_mh[t];   // 1/self.temp, PT:612
+    // likelihood parameters on the device.  Dense: mu | Pt | Tl, Tl = the half of the symmetric part of P the VALUE is summed over
+    // (Tl[k][i] = Ps[k][i] for k > i, Ps[i][i] / 2 for k == i, 0 for k < i: -r^T P r / 2 = -sum_i r_i sum_{k >= i} Tl[k][i] r_k,
+    // half the products of the full form; the oracle's dense_par builds the same table); Pt stays for the gradient -P r
+    std::vector<double> loglpar(c.logl_par, c.logl_par + (c.logl_par ? c.logl_par_len : 0));
+    if (c.logl_kind == PTMI_LOGL_DENSE) {
+        const size_t d = (size_t)c.ndim;
+        loglpar.resize(d + 2 * d * d, 0.0);
+        const double *Pt = loglpar.data() + d;
+        double *Tl = loglpar.data() + d + d * d;
+        for (size_t k = 0; k < d; ++k)
+            for (size_t i = 0; i <= k; ++i) {
+                const double ps = (Pt[k * d + i] + Pt[i * d + k]) * 0.5;
+                Tl[k * d + i] = k == i ? ps * 0.5 : ps;
+            }
+    }
     int rc;
     if ((rc = upload(&h->d_ladder, c.ladder, c.ntemps_global)) || (rc = upload(&h->d_temps, c.temps_mh, c.ntemps)) ||
-        (rc = upload(&h->d_beta, beta.data(), c.ntemps)) || (rc = upload(&h->d_loglpar, c.logl_par, c.logl_par_len)) ||
+        (rc = upload(&h->d_beta, beta.data(), c.ntemps)) || (rc = upload(&h->d_loglpar, loglpar.data(), (long long)loglpar.size())) ||
         (rc = upload(&h->d_logppar, c.logp_par, c.logp_par_len))) {
         ptmi_destroy(h);
         return rc;

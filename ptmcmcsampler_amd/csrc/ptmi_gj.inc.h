@@ -128,10 +128,12 @@ struct GradJump {
                 const int i = gl + G * e;
                 r[e] = i < d ? x[e] - mu[i] : 0.0;
             }
-            tab_vec<-1>(Pt, r, v);
+            tab_vec<-1>(Pt, r, v);                                        // the gradient -P r: the full product
 #pragma unroll
             for (int e = 0; e < EPL; ++e) g[e] = -v[e];
-            return -0.5 * dot(r, v);
+            double vh[EPL];
+            tab_vec<-1>(Pt + (size_t)d * d, r, vh);                        // the value: eval_logl's half table Tl
+            return -dot(r, vh);
         } else {
             double p = 0.0;
 #pragma unroll
@@ -625,9 +627,10 @@ struct GradJumpWide {
             return r;
         } else if (LOGL == PTMI_LOGL_DENSE) {
             const double r = act ? x - a.logl_par[col] : 0.0;
-            const double v = tab_vec<-1>(a.logl_par + d, r);
+            const double v = tab_vec<-1>(a.logl_par + d, r);                 // the gradient -P r: the full product
             g = -v;
-            const double rr = -0.5 * dot(r, v);
+            const double vh = tab_vec<-1>(a.logl_par + d + (size_t)d * d, r);  // the value: eval_logl's half table Tl
+            const double rr = -dot(r, vh);
             GJP_ADD(GJP_LOGL, t0);
             return rr;
         } else {
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? 2 : 1) void mh_ste
     const size_t wc = a.per_walker ? (size_t)w : 0;
     const double *Ut = a.Ut + wc * d * d, *S = a.S + wc * d;
     const double *DE = a.DE ? a.DE + wc * (size_t)a.de_size * a.de_ld : nullptr;
-    const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr;
+    const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d + (size_t)a.d * a.d : nullptr;   // eval_logl's half table Tl
     double *xrow = a.X + (size_t)ch * d;
     double *stg = a.gj + ((size_t)w * nt + t) * GJ_NSTATE;
 

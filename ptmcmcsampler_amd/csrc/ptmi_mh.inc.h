@@ -63,7 +63,8 @@ struct MfmaAcc {
     ptmi_d4 t[NT];
     __device__ __forceinline__ double at(int e) const { return t[e >> 2][e & 3]; }   // element gl + 4e (compile-time e)
 };
-template <int EPL, bool PADDED>
+// LOWER: T[k][i] = 0 for k < i (the dense likelihood's half table): the matrix tiles above the diagonal are skipped.
+template <int EPL, bool PADDED, bool LOWER = false>
 __device__ __forceinline__ void mfma_tab_vec(const double *T, int ld, int d, const double (&vec)[EPL], MfmaAcc<EPL> &acc)
 {
     constexpr int NT = MfmaAcc<EPL>::NT;
@@ -78,6 +79,7 @@ __device__ __forceinline__ void mfma_tab_vec(const double *T, int ld, int d, con
         const double *row = T + (size_t)k * ld + c;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (LOWER && 16 * t > 4 * e + 3) continue;      // rows 4e .. 4e+3 of this tile are all zero
             if (PADDED) dst[t] = row[16 * t];
             else dst[t] = (k < d && 16 * t + c < d) ? row[16 * t] : 0.0;
         }
@@ -88,7 +90,8 @@ __device__ __forceinline__ void mfma_tab_vec(const double *T, int ld, int d, con
         if (4 * e < d) {                                   // wave-uniform
             if (e + 1 < EPL && 4 * (e + 1) < d) fetch(e + 1, nxt);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t], vec[e], acc.t[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                if (!LOWER || 16 * t <= 4 * e + 3) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t], vec[e], acc.t[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
             __builtin_amdgcn_sched_barrier(0);
@@ -118,13 +121,14 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
             r[e] = i < d ? q[e] - mu[i] : 0.0;
             v[e] = 0.0;
         }
+        // Pt here is the HALF table Tl (k >= i; diagonal halved): -r^T P r / 2 = -sum_i r_i sum_{k >= i} Tl[k][i] r_k
         if (STR) {
             MfmaAcc<EPL> acc;
-            mfma_tab_vec<EPL, true>(Pt, mfma_ld(EPL), d, r, acc);
+            mfma_tab_vec<EPL, true, true>(Pt, mfma_ld(EPL), d, r, acc);
             double p = 0.0;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) p = __builtin_fma(r[e], acc.at(e), p);
-            return -0.5 * grp_sum<G, STR>(p);
+            return -grp_sum<G, STR>(p);
         }
 #pragma unroll
         for (int e2 = 0; e2 < EPL; ++e2) {
@@ -144,7 +148,7 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
         double p = 0.0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) p = __builtin_fma(r[e], v[e], p);
-        return -0.5 * grp_sum<G, STR>(p);
+        return -grp_sum<G, STR>(p);
     } else {  // PTMI_LOGL_CURVED: pairs (2m, 2m+1); G is even so a pair lives in lanes (gl, gl+1) of one slot
         double p = 0.0;
 #pragma unroll
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = mfma_ld(EPL);
     const int tab_n = 4 * ((d + 3) / 4) * LD;                      // doubles of one zero-padded LDS table
-    const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr;
+    const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d + (size_t)d * d : nullptr;       // the half table Tl
     // LDS pointers are derived from smem at their use so that they stay LDS (ds_read) accesses
 #define PTMI_PL (smem)
 #define PTMI_UL (smem + (LOGL == PTMI_LOGL_DENSE ? (size_t)tab_n : 0))
@@ -1150,7 +1154,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
     {
         const long long ch0 = (long long)logical_block() * CPB;
         const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
-        const double *Pg = a.logl_par + d, *Ug = a.Ut + w0 * d * d, *Sg = a.S + w0 * d, *mug = a.logl_par;
+        const double *Pg = a.logl_par + d + (size_t)d * d /* the half table Tl */, *Ug = a.Ut + w0 * d * d, *Sg = a.S + w0 * d, *mug = a.logl_par;
         for (int i = (int)threadIdx.x; i < d * d; i += BLK) {
             const int r = i / d, c = i % d;
             PTMI_D_P[((r & 1) ? podd : 0) + (r >> 1) * d + c] = Pg[i];
@@ -1189,10 +1193,13 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         // software pipeline of depth one (the row block of step e + 1 is in flight while step e multiplies); the scheduling
         // barrier keeps the compiler from hoisting all 7 * 26 table reads to the top
         double cur[NT], nxt[NT];
+        // the table is the half Tl (k >= i): in k-step e the tiles with 16 tt > 4 e + 3 hold zeros only and are skipped --
+        // 91 matrix instructions per likelihood instead of 175
         auto fetch = [&](int e, double (&dst)[NT]) {
             const double *row = PTMI_D_P + ((g4 & 1) ? podd : 0) + (2 * e + (g4 >> 1)) * d + c16;
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) dst[tt] = row[16 * tt];
+            for (int tt = 0; tt < NT; ++tt)
+                if (16 * tt <= 4 * e + 3) dst[tt] = row[16 * tt];
         };
         fetch(0, cur);
 #pragma unroll
@@ -1201,7 +1208,8 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
                 if (e + 1 < EPL && e + 1 < esteps) fetch(e + 1, nxt);
                 const double re = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc.t[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[tt], re, acc.t[tt], 0, 0, 0);
+                for (int tt = 0; tt < NT; ++tt)
+                    if (16 * tt <= 4 * e + 3) acc.t[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[tt], re, acc.t[tt], 0, 0, 0);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) cur[tt] = nxt[tt];
                 __builtin_amdgcn_sched_barrier(0);
@@ -1214,7 +1222,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
             const double ve = (gl + G * e) < d ? acc.at(e) : 0.0;          // outputs past the row are padding
             p = __builtin_fma(re, ve, p);
         }
-        const double nlnL = -0.5 * grp_sum<G, true>(p);
+        const double nlnL = -grp_sum<G, true>(p);
         const double nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
         // PT:615-622
         const double lnprob0 = beta * lnL + lp;
@@ -1374,7 +1382,7 @@ __global__ __launch_bounds__(256) void eval_state_kernel(const KArgs a)
     }
     const double lp = eval_logp<G, EPL, false>(a, x, gl);
     double lnL = -__builtin_inf();
-    if (lp != -__builtin_inf()) lnL = eval_logl<G, EPL, LOGL, false>(a, x, gl, LOGL == PTMI_LOGL_DENSE ? a.logl_par + d : nullptr);
+    if (lp != -__builtin_inf()) lnL = eval_logl<G, EPL, LOGL, false>(a, x, gl, LOGL == PTMI_LOGL_DENSE ? a.logl_par + a.d + (size_t)a.d * a.d : nullptr);
     if (live && gl == 0) {
         a.lp[ch] = lp;
         a.lnL[ch] = lnL;

@@ -85,7 +85,7 @@ class PTEngine(object):
     Tskip.  ``cov_mode``: ``"per_walker"`` makes every walker a faithful replica of a
     reference run (own covariance, eigenvectors and DE history); ``"pooled"`` adapts one
     covariance from all walkers' rank-0 samples.  ``logl`` / ``logp`` select the built-in
-    device likelihood / prior: ("iso",), ("dense", mu, P), ("curved",); ("flat",),
+    device likelihood / prior: ("iso",), ("dense", mu, P) with P a (symmetric) precision matrix, ("curved",); ("flat",),
     ("box", lo, hi).  ``swap_mode``: ``"sweep"`` is the reference's hot -> cold PTswap; ``"oddeven"`` tries
     the disjoint pairs (k, k+1), k = swap epoch (mod 2), all at once (see include/ptmi.h).  ``pick_mode``: ``"chain"`` =
     every chain draws its own entry of the proposal cycle (the reference's ``_jump``); ``"walker"`` = one draw per walker

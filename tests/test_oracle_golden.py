@@ -223,7 +223,7 @@ def test_builtin_likelihood_gradients():
     d = 6
     A = rng.normal(size=(d, d))
     P, mu = A @ A.T / d + np.eye(d), rng.normal(size=d)
-    par = np.concatenate([mu, np.ascontiguousarray(P.T).ravel()])
+    par = orc.dense_par(mu, P)
     for kind, p, f in (("iso", None, lambda x: -0.5 * x @ x), ("dense", par, lambda x: -0.5 * (x - mu) @ P @ (x - mu))):
         x = rng.normal(size=d)
         v, g = oracle(kind, x, p)
