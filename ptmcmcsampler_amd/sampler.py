@@ -275,21 +275,33 @@ class PTSampler(object):
             if self.verbose:
                 print("Resuming run from chain file {0}".format(self.fname))
         if self._replaying:
-            # PTMCMCSampler.py:290-313: the text rows are all there is (a chain the reference wrote, or a run of ours
-            # without checkpoints).  One chain only: a file holds one rank of one walker.
-            if self.nchain != 1 or self.nwalkers != 1:
-                raise Exception("Couldn't resume: {0} exists but the device checkpoint {1} does not, and a chain file alone can "
-                                "only be replayed for one chain (ntemps = nwalkers = 1): runs with several chains are resumable "
-                                "when they were started with checkpoint=True (or resume=True).  Refusing to overwrite it.".format(
-                                    self.fname, self._ckpt))
+            # PTMCMCSampler.py:290-313: the text rows are all there is (chains the reference wrote, or a run of ours without
+            # checkpoints).  In the reference every MPI rank replays its own chain_<T>.txt; here the one process replays
+            # all of a ladder's files (one walker: a file holds one rank of one reference run).
+            rank_files = [self.fname]
+            for r in range(1, self.nchain):
+                last_hot = hotChain and r == self.nchain - 1
+                rank_files.append(self.outDir + ("/chain_hot.txt" if last_hot else "/chain_{0}.txt".format(self.ladder[r])))
+            missing = [f for f in rank_files if not os.path.isfile(f)]
+            if self.nwalkers != 1 or missing:
+                raise Exception("Couldn't resume: {0} exists but the device checkpoint {1} does not, and chain files alone can only be "
+                                "replayed for one walker with the file of every temperature present ({2}): runs of several "
+                                "walkers are resumable when they were started with checkpoint=True (or resume=True).  Refusing to "
+                                "overwrite it.".format(self.fname, self._ckpt, "missing: " + ", ".join(missing) if missing else
+                                                       "nwalkers = %d" % self.nwalkers))
             try:
-                self.resumechain = np.loadtxt(self.fname, ndmin=2)
+                self._resume_rows = [np.loadtxt(f, ndmin=2) for f in rank_files]
             except ValueError as error:
                 print("Reading old chain files failed with error", error)
                 raise Exception("Couldn't read old chain to resume")
+            self.resumechain = self._resume_rows[0]
             self.resumeLength = self.resumechain.shape[0]
-            if self.resumechain.shape[1] != self.ndim + 4:
-                raise Exception("Old chain has {0} columns, expected ndim + 4 = {1}".format(self.resumechain.shape[1], self.ndim + 4))
+            for f, rows in zip(rank_files, self._resume_rows):
+                if rows.shape[1] != self.ndim + 4:
+                    raise Exception("Old chain {0} has {1} columns, expected ndim + 4 = {2}".format(f, rows.shape[1], self.ndim + 4))
+                if rows.shape[0] != self.resumeLength:
+                    raise Exception("Old chains differ in length: {0} has {1} rows, {2} has {3}".format(f, rows.shape[0], self.fname,
+                                                                                                      self.resumeLength))
             if self.isave != self.thin and self.resumeLength % (self.isave / self.thin) != 1:
                 raise Exception("Old chain has {0} rows, which is not the initial sample plus a multiple of isave/thin = {1}".format(
                     self.resumeLength, self.isave // self.thin))
@@ -477,21 +489,39 @@ class PTSampler(object):
         return i0
 
     def _replay_chain_file(self):
-        """Resume as the reference does (PTMCMCSampler.py:591-599): for iterations below resumeLength * thin the chain
-        does not jump but takes row iter // thin of the old file as its state, so the AM buffer, the covariance epochs
-        (:545-560) and the DE history (:563-571) are rebuilt from the file.  Returns the last replayed iteration."""
+        """Resume as the reference does (PTMCMCSampler.py:591-599): for iterations below resumeLength * thin a chain does
+        not jump but takes row iter // thin of its old file as its state, so the AM buffer, the covariance epochs
+        (:545-560) and the DE history (:563-571) are rebuilt from the files.  With a ladder every rank replays its own
+        file and the swaps of the replayed iterations still run (:624-627 follows the replay branch): PTswap acts on the
+        replayed states, its result is what the AM buffer of that iteration holds and what the swap counters count, and the
+        next iteration takes the files' rows again.  Returns the last replayed iteration."""
         import torch
-        eng, rows, thin, cu = self.engine, self.resumechain, self.thin, self.covUpdate
-        d = self.ndim
+        eng, thin, cu = self.engine, self.thin, self.covUpdate
+        d, n = self.ndim, self.nchain
         last = self.resumeLength * thin - 1                         # iterations 1 .. last are replayed
-        X, lnl, lnp = rows[:, :d], rows[:, -3], rows[:, -4]
-        beta0 = 1.0 / eng.temps_mh[0]
-        with np.errstate(invalid="ignore"):
-            lpr = np.where(np.isneginf(lnp), -np.inf, lnp - beta0 * lnl)      # log-prior of a row (a -inf row: lnlike may be -inf too)
+        betas = 1.0 / eng.temps_mh
+        Xs = [rows[:, :d] for rows in self._resume_rows]
+        lnls = [rows[:, -3] for rows in self._resume_rows]
+        lnps = [rows[:, -4] for rows in self._resume_rows]
+        with np.errstate(invalid="ignore"):                        # log-prior of a row (a -inf row: lnlike may be -inf too)
+            lprs = [np.where(np.isneginf(lnps[r]), -np.inf, lnps[r] - betas[r] * lnls[r]) for r in range(n)]
+        X, lnl, lnp, lpr = Xs[0], lnls[0], lnps[0], lprs[0]
+
+        def set_state(k):
+            """every rank holds row k of its file (by rank: a swap may have permuted the slots)"""
+            so = eng.get("slot_of")[0].astype(np.int64)
+            state, sl, sp = np.zeros((1, n, d)), np.zeros((1, n)), np.zeros((1, n))
+            for r in range(n):
+                state[0, so[r]], sl[0, so[r]], sp[0, so[r]] = Xs[r][k], lnls[r][k], lprs[r][k]
+            eng.t["X"].copy_(torch.from_numpy(state))
+            eng.put("lnL", sl)
+            eng.put("lp", sp)
+
         # iteration 0: the first row (:474-476, :491)
         eng.t["AM"][0, 0] = torch.from_numpy(X[0].copy())
         eng.t["AMaux"][0, 0, 0], eng.t["AMaux"][0, 0, 1] = float(lnl[0]), float(lpr[0])
         self._chains[0, 0], self._lnlikes[0, 0], self._lnprobs[0, 0] = X[0], lnl[0], lnp[0]
+        swapped_last = False
         it = 1
         while it <= last:
             before = eng.eig_epochs
@@ -510,15 +540,20 @@ class PTSampler(object):
             keep = its[its % thin == 0]
             self._chains[0, keep // thin], self._lnlikes[0, keep // thin], self._lnprobs[0, keep // thin] = (
                 X[keep // thin], lnl[keep // thin], lnp[keep // thin])
+            swapped_last = False
+            if n > 1 and self.Tskip > 0 and end % self.Tskip == 0:   # PTswap of a replayed iteration (:624-627)
+                set_state(end // thin)
+                eng.swap(end)                                       # also stores the AM row of the state now at rank 0
+                swapped_last = end == last
             it = end + 1
-        # the chain's state after the replay, its acceptance counter (:597-599), and what is on file already
+        # the chains' states after the replay, their acceptance counters (:597-599), and what is on file already
         k = last // thin
-        state = np.broadcast_to(X[k], (eng.W, eng.nt, d)).copy()
-        eng.t["X"].copy_(torch.from_numpy(state))
-        eng.put("lnL", np.full((eng.W, eng.nt), lnl[k]))
-        eng.put("lp", np.full((eng.W, eng.nt), lpr[k]))
+        if not swapped_last:
+            set_state(k)
+        so = eng.get("slot_of")[0].astype(np.int64)
         nacc = eng.get("nacc")
-        nacc[0, 0] = int(round(last * rows[k, -2]))
+        for r in range(n):
+            nacc[0, r] = int(round(last * self._resume_rows[r][k, -2]))
         eng.put("nacc", nacc.astype(np.int64))
         self.ind_next_write = self.resumeLength
         eng.iter = last

@@ -322,6 +322,85 @@ def test_resume_from_a_chain_file_the_reference_wrote(tmp_path, golden, capsys):
     assert s.DEJump in s.propCycle and s.jumpDict["DEJump"][0] > 0
 
 
+def test_resume_a_ladder_from_its_chain_files(tmp_path, capsys):
+    """PTMCMCSampler.py:290-319, 591-599 for a LADDER: in the reference every MPI rank replays its own chain_<T>.txt, and the swaps
+    of the replayed iterations still run on the replayed states (:624-627).  Here the one process replays all the files.  The
+    procedure is checked against the oracle's pieces: AM rows = the cold file's rows, at swap iterations the state the
+    oracle's sweep (same Philox uniforms) puts at rank 0; covariance epochs = the oracle's Welford over those rows; swap
+    credits = the sweep's; then sampling continues and every file grows."""
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd import PTSampler
+    d, nt = 4, 3
+    kw = dict(burn=200, thin=2, covUpdate=50, isave=100, Tskip=10, writeHotChains=True)
+    p0 = np.full(d, 0.1)
+
+    def make(resume):
+        return PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path), verbose=False, seed=21, ntemps=nt, resume=resume,
+                         checkpoint=False)
+    a = make(False)
+    a.sample(p0, 400, **kw)
+    assert not os.path.exists(tmp_path / "ptmi_checkpoint.npz")
+    names = ["chain_1.0.txt"] + ["chain_{0}.txt".format(a.ladder[r]) for r in range(1, nt)]
+    old = {f: open(tmp_path / f).read() for f in names}
+    rows = [np.loadtxt(tmp_path / f) for f in names]
+    assert all(r.shape == (201, d + 4) for r in rows)
+    b = make(True)
+    snaps, end = [], {}
+    replay = b._replay_chain_file
+
+    def watched():
+        eng = b.engine
+        upd = eng.update_cov
+
+        def update_cov(it_done):
+            upd(it_done)
+            snaps.append((it_done, eng.get("mu")[0].copy(), eng.get("M2")[0].copy(), eng.get("cov")[0].copy()))
+
+        eng.update_cov = update_cov
+        last = replay()
+        eng.update_cov = upd
+        eng.sync()
+        end.update(last=last, AM=eng.get("AM")[0].copy(), X=eng.by_temp("X")[0].copy(), lnL=eng.by_temp("lnL")[0].copy(),
+                   nswap=eng.get("nswap")[0].astype(np.int64).copy(), nacc=eng.get("nacc")[0].astype(np.int64).copy(), swaps=eng.swap_proposed)
+        return last
+
+    b._replay_chain_file = watched
+    b.sample(p0, 600, **kw)
+    assert "Resuming with 201 samples from file representing 401 original samples" in capsys.readouterr().out
+    # the same procedure from the oracle's pieces
+    thin, cu, last = kw["thin"], kw["covUpdate"], 201 * kw["thin"] - 1
+    mu, M2, AM = np.zeros(d), np.zeros((d, d)), np.zeros((cu, d))
+    nswap, nsw, want = np.zeros(nt, dtype=np.int64), 0, []
+    AM[0] = rows[0][0, :d]
+    for it in range(1, last + 1):
+        if (it - 1) % cu == 0 and it - 1 != 0:
+            cov = orc.welford(AM, mu, M2, it - 1)
+            want.append((it - 1, mu.copy(), M2.copy(), cov.copy()))
+        k = it // thin
+        cold = rows[0][k, :d]
+        if it % kw["Tskip"] == 0:
+            lnl_pos = np.array([[rows[r][k, -3] for r in range(nt)]])
+            m, acc = orc.swap_sweep(b.ladder, lnl_pos, it=it, seed=b.seed, walker0=0)
+            cold = rows[int(m[0, 0])][k, :d]
+            nswap += acc[0].astype(np.int64)
+            nsw += 1
+        AM[it % cu] = cold
+    assert end["last"] == last == 401 and len(snaps) == len(want) == 8
+    for (it, mu_g, M2_g, cov_g), (it_o, mu_o, M2_o, cov_o) in zip(snaps, want):
+        assert it == it_o
+        for name, x, y in (("mu", mu_g, mu_o), ("M2", M2_g, M2_o), ("cov", cov_g, cov_o)):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64)), (name, it)
+    assert np.array_equal(end["AM"], AM)
+    assert np.array_equal(end["nswap"], nswap) and end["swaps"] == nsw == 40 and nswap.sum() > 0
+    for r in range(nt):                                       # 401 is no swap iteration: every rank holds its file's last row
+        assert np.array_equal(end["X"][r], rows[r][200, :d]) and end["lnL"][r] == rows[r][200, -3]
+        assert abs(end["nacc"][r] - last * rows[r][200, -2]) <= 1.0
+    # the files: old rows untouched, 100 new rows each
+    for f in names:
+        new = open(tmp_path / f).read()
+        assert new.startswith(old[f]) and len(new.splitlines()) == 301, f
+
+
 def test_neff_stops_the_run_early(tmp_path, capsys):
     """neff (PTMCMCSampler.py:510-521): every 1000 iterations past 2 * burn the effective sample size of the cold chain
     is estimated (the restated acor, ess.acor) and the run ends once it reaches the request; the partial block is written.
