@@ -11,15 +11,15 @@ b driver --steps 20 --warmup 5                                   # exactly what 
 b scam --no-cpu-baseline                                         # config 2, default length (200 steps after 100)
 b mix_chain --no-cpu-baseline --mix default --steps 100 --warmup 110
 b mix_walker --no-cpu-baseline --mix default --pick walker --steps 100 --warmup 110
-b dense --no-cpu-baseline --logl dense --steps 50 --warmup 20    # config 3, SCAM cycle
-b dense_mix_walker --no-cpu-baseline --logl dense --mix default --pick walker --steps 30 --warmup 110
-b per_walker_lapack --no-cpu-baseline --cov-mode per_walker --steps 20 --warmup 10
-b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10
-b callback --no-cpu-baseline --callback --steps 10 --warmup 2
+b dense --no-cpu-baseline --logl dense --steps 50 --warmup 20 --ess-window 0   # config 3, SCAM cycle
+b dense_mix_walker --no-cpu-baseline --logl dense --mix default --pick walker --steps 30 --warmup 110 --ess-window 0
+b per_walker_lapack --no-cpu-baseline --cov-mode per_walker --steps 20 --warmup 10 --ess-window 0
+b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10 --ess-window 0
+b callback --no-cpu-baseline --callback --steps 10 --warmup 2 --ess-window 0
 b c4_share --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 40 --warmup 20 --ess-window 0
-b c4_share_lapack --no-cpu-baseline --ndim 1000 --nwalkers 512 --cov-mode pooled_device --steps 1 --warmup 0 --ess-window 0 || true
-b c5_share --no-cpu-baseline --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 6 --warmup 4
-b oddeven --no-cpu-baseline --swap-mode oddeven --steps 100 --warmup 20
+b c4_mix --no-cpu-baseline --ndim 1000 --nwalkers 512 --mix default --steps 6 --warmup 2 --ess-window 0
+b c5_share --no-cpu-baseline --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 6 --warmup 4 --ess-window 0
+b oddeven --no-cpu-baseline --swap-mode oddeven --steps 100 --warmup 20 --ess-window 0
 python - <<PY
 import json, glob, os
 out = {}
