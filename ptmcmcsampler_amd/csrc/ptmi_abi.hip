@@ -959,6 +959,8 @@ static KArgs make_args(ptmi_engine *h)
     const ptmi_buffers &b = h->buf;
     a.X = b.X; a.lnL = b.lnL; a.lp = b.lp; a.temp_of = b.temp_of; a.slot_of = b.slot_of;
     a.Ut = b.Ut; a.S = b.S; a.DE = b.DE; a.AM = c.temp0 == 0 ? b.AM : nullptr; a.AMaux = c.temp0 == 0 ? b.AMaux : nullptr;
+    static const bool no_am = getenv("PTMI_MEASURE_NO_AM") != nullptr;   // MEASUREMENT ONLY (results are wrong): what the AM-row stores of the step kernels cost
+    if (no_am) a.AM = nullptr;
     a.nacc = (u64 *)b.nacc; a.jstat = (u64 *)b.jstat;
     a.temps_mh = h->d_temps; a.beta = h->d_beta; a.logl_par = h->d_loglpar; a.logp_par = h->d_logppar;
     a.gsize = h->d_gsize; a.gmask = h->d_gmask; a.gcn = h->d_gcn; a.gdiv = h->d_gdiv; a.ngroups = c.ngroups > 1 ? c.ngroups : 1;
