@@ -437,8 +437,9 @@ struct ScamBatch {
         else return (int)dpp32<0x4E>((u32)v);
     }
     // root_s(k): sqrt of the k-th eigenvalue of the chain's table; ng: directions to pick from
-    template <class RS>
-    __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, int ng, RS root_s)
+    // TM / tsm: where the draw tables are read (draw_table): 0 = global memory, 2 = the block's LDS copy when a.tab_off >= 0
+    template <int TM, class RS>
+    __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, int ng, RS root_s, const double *tsm)
     {
         const int j = gl & 3;
         u64 w0, w1;
@@ -448,7 +449,7 @@ struct ScamBatch {
         unit_angle32((u32)w1, aj, at);
         const UnitLogArg g = unit_log_arg((j & 1) ? w0 : w1);       // both uniforms are (0,1] ones
         double sb, cb;
-        const ptmi_dev_d2 te = draw_table<0>(nullptr, -1, g.slice), tb = draw_table<0>(nullptr, -1, 32u + aj);   // both reads first
+        const ptmi_dev_d2 te = draw_table<TM>(tsm, a.tab_off, g.slice), tb = draw_table<TM>(tsm, a.tab_off, 32u + aj);   // both reads first
         kdir = (int)h2index((u32)(w1 >> 32), (u32)ng);              // PT:868 (odd lanes)
         const double rs = root_s(kdir);
         // the scale branch comes from the iteration's P word, which the chain's lane j - 1 holds (PT:843-858)
@@ -474,11 +475,11 @@ struct ScamBatch {
         else d.k = (int)dpp32<0x55>((u32)kdir);
     }
 };
-template <bool STR, class RS>
+template <bool STR, int TM = 0, class RS>
 __device__ __forceinline__ void scam_draws_for_step(ScamBatch<STR> &b, ScamDraw &dr, const KArgs &a, int k, u32 sid, int gl,
-                                                    const ChainConst &cc, int ng, RS root_s)
+                                                    const ChainConst &cc, int ng, RS root_s, const double *tsm = nullptr)
 {
-    if ((k & 1) == 0) b.refill(a, a.iter0 + k, sid, gl, cc, ng, root_s);
+    if ((k & 1) == 0) b.template refill<TM>(a, a.iter0 + k, sid, gl, cc, ng, root_s, tsm);
     else b.advance();
     b.take(dr);
 }
@@ -902,6 +903,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
     }
     box_table_fill<G, EPL>(a, smem, BLK);
+    if (ULDS) draw_table_fill(smem, a.tab_off, BLK);
     if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
 
     // ---- AM queue (staged full kernels).  An AM increment U (cd sqrt(S) z) does not depend on the chain's state, only on
@@ -995,10 +997,13 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         if constexpr (SCAMFAST) {
             ScamDraw sd;
             // sqrt(S_k): from the block's LDS copy where it has one, else from the chain's table (sqrt is correctly rounded: same bits)
-            scam_draws_for_step<STR>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
+            // ULDS: the draw tables too come from the block's LDS when the host found room (a.tab_off >= 0).  Global reads share
+            // the in-order vector-memory counter with the cold chain's AM-row stores: in the block's one cold wave every draw
+            // pass waited for 25 stores to retire first
+            scam_draws_for_step<STR, ULDS ? 2 : 0>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
                 if (ULDS && !ulds_box) return smem[d * d + kk];
                 return det_sqrt(S[kk]);
-            });
+            }, smem);
             log_u = sd.log_u;
             if constexpr (PAIRED) {
                 const double *row = smem + (size_t)sd.k * d;
@@ -1072,7 +1077,10 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
                 for (int j = 0; j < PTMI_J_FUSED; ++j) ja[j] += (jt == j);
             }
         }
-        // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
+        // PT:327-328 (the post-swap row of a swap iteration is written by the swap).  These 25 stores of four active lanes, in ONE
+        // wave of every block, are 15 % of the config-2 kernel (0.90 -> 0.77 ms without them, PTMI_MEASURE_NO_AM): the wave is its
+        // block's straggler.  Sending the row through LDS and out as two coalesced stores of the whole wave was built and measured
+        // slower (1.00 ms: the round trip sits on the wave's critical path).
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
             double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
 #pragma unroll
@@ -1481,13 +1489,18 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             }
         }
         if (one_table && 2 * tab <= 160 * 1024 && !off) {
+            static const bool no_ldst = getenv("PTMI_NO_ULDS_DRAWT") != nullptr;     // measurement switch: same results either way
+            if (!no_ldst && 2 * (sizeof(double) * even(tab / sizeof(double)) + DRAWT) <= 160 * 1024) {
+                a.tab_off = (int)even(tab / sizeof(double));
+                tab = sizeof(double) * (size_t)a.tab_off + DRAWT;
+            }
             auto kern = mh_steps_kernel<G, EPL, LOGL, false, false, false, true>;
             if (tab > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab);
                 if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", tab, hipGetErrorString(e));
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), tab, h->stream, a);
-            h->last_variant = PTMI_VAR_LDS_UT | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
+            h->last_variant = PTMI_VAR_LDS_UT | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | (a.tab_off >= 0 ? PTMI_VAR_LDS_DRAWT : 0);
             return PTMI_OK;
         }
     }
