@@ -89,7 +89,9 @@ template <bool STG>
 __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n, const double *ladder, const SwapPre *pre,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
                                   int parity, int32_t *inv /* with map: inv[w][map[w][j]] = j */,
-                                  int wpb /* walkers per block: 64, fewer when a long ladder's tables would not fit the LDS */)
+                                  int wpb /* walkers per block: 64, fewer when a long ladder's tables would not fit the LDS */,
+                                  int hop_nt, int32_t *hop_flag /* hop_nt > 0 (STG, map form): set *hop_flag when a state moves beyond a
+                                                                 * neighbouring block of hop_nt ranks (ptmi_exchange_multihop) */)
 {
     // STG blocks have four waves: the first runs the recurrence (a lane per walker), all four write the tables out
     extern __shared__ int32_t sw_lds[];
@@ -162,22 +164,29 @@ __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n
     fw[0] = crow;
     if (!STG) bw[crow] = 0;
     }
+    // block of a position (the multi-hop scan of the write-out): filled by the waves that sit out the recurrence
+    int32_t *const blk = sw_lds + (size_t)2 * wpb * ld;
+    if (STG && hop_nt > 0 && wave > 0)
+        for (int k = (int)threadIdx.x - 64; k < n; k += 192) blk[k] = k / hop_nt;
     if (STG) {
         __syncthreads();
         const int w0 = (int)blockIdx.x * wpb;
         int32_t *g0 = fused ? slot_of : map, *g1 = fused ? temp_of : inv;
         const int nw = W - w0 < wpb ? W - w0 : wpb;
+        bool far = false;
         for (int wl = wave; wl < nw; wl += 4) {                        // a wave per walker, the lanes along the position
             const size_t row = (size_t)(w0 + wl) * n;
             for (int k = lane; k < n; k += 64) {
                 const int f = sw_lds[(size_t)wl * ld + k];
                 g0[row + k] = f;
                 g1[row + f] = k;                                       // the inverse table: a scatter inside the walker's own row
+                if (hop_nt > 0) { const int hop = blk[f] - blk[k]; far = far || hop > 1 || hop < -1; }
                 // a no-return atomic: fire and forget (a read-modify-write would wait for its load in every trip: 37 against 24 us)
                 if (k < n - 1 && k >= local0 && k < local0 + nlocal && sw_lds[(size_t)(wpb + wl) * ld + k])
                     atomicAdd((unsigned long long *)&nswap[row + k], 1ull);
             }
         }
+        if (hop_nt > 0 && __ballot(far) != 0 && lane == 0) atomicOr(hop_flag, 1);   // once per wave at most
     }
 }
 
@@ -1378,21 +1387,26 @@ static int swap_parity(const ptmi_config &c, int64_t iter)
 }
 
 static int launch_swap_sweep(ptmi_engine *h, int W, int n, const SwapPre *pre, int32_t *slot_of, int32_t *temp_of,
-                             int32_t *map, u64 *nswap, int local0, int nlocal, int parity, int32_t *inv)
+                             int32_t *map, u64 *nswap, int local0, int nlocal, int parity, int32_t *inv, int hop_nt = 0, bool *hop_done = nullptr)
 {
+    if (hop_done) *hop_done = false;
     int wpb = 64;                                                      // 2 tables of wpb x (n + 1) ints must fit the CU's LDS
-    while (wpb > 8 && sizeof(int32_t) * 2 * (size_t)wpb * (size_t)(n + 1) > 160 * 1024) wpb /= 2;
-    const size_t lds = sizeof(int32_t) * 2 * (size_t)wpb * (size_t)(n + 1);
+    while (wpb > 8 && sizeof(int32_t) * (2 * (size_t)wpb * (size_t)(n + 1) + n) > 160 * 1024) wpb /= 2;
+    const size_t lds = sizeof(int32_t) * (2 * (size_t)wpb * (size_t)(n + 1) + n);      // forward table, flags, block of a position
     if (lds <= 160 * 1024) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)swap_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
         }
+        if (hop_nt > 0) {                                              // the multi-hop scan rides on the write-out
+            HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
+            if (hop_done) *hop_done = true;
+        }
         hipLaunchKernelGGL(swap_sweep_kernel<true>, dim3((unsigned)((W + wpb - 1) / wpb)), dim3(256), lds, h->stream, W, n, h->d_ladder, pre,
-                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, wpb);
+                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, wpb, hop_nt, h->d_hop);
     } else {
         hipLaunchKernelGGL(swap_sweep_kernel<false>, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, h->stream, W, n, h->d_ladder, pre,
-                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, 64);
+                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, 64, 0, (int32_t *)nullptr);
     }
     return PTMI_OK;
 }
@@ -1464,7 +1478,8 @@ static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t 
                        (long long)iter, c.seed, c.walker0, block_nt);
     if (int rc = launch_swap_sweep(h, W, c.ntemps_global, (const SwapPre *)h->d_pre, (int32_t *)nullptr,
                                    (int32_t *)nullptr, map, (u64 *)h->buf.nswap, c.temp0, c.ntemps,
-                                   c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1, h->d_xint /* inv[W][ntemps_global] */)) return rc;
+                                   c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1, h->d_xint /* inv[W][ntemps_global] */,
+                                   block_nt, &h->hop_from_sweep)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -1608,10 +1623,13 @@ int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send)
                        map, h->buf.slot_of, h->buf.temp_of, (const int32_t *)inv, newslot, arr, lvs, lvr, err);
     hipLaunchKernelGGL(exchange_pack_kernel, dim3(W, 2), dim3(64), 0, h->stream, W, c.ntemps, c.ndim, (const double *)h->buf.X,
                        (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)lvs, (const int32_t *)lvr, send);
-    HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
-    const long long tot = (long long)W * c.ntemps_global;
-    hipLaunchKernelGGL(exchange_multihop_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global, c.ntemps,
-                       map, h->d_hop);
+    if (!h->hop_from_sweep) {                                          // the sweep's write-out did not look (tables beyond the LDS)
+        HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
+        const long long tot = (long long)W * c.ntemps_global;
+        hipLaunchKernelGGL(exchange_multihop_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global, c.ntemps,
+                           map, h->d_hop);
+    }
+    h->hop_from_sweep = false;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -89,7 +89,8 @@ struct ptmi_engine {
     double *d_ladder, *d_temps, *d_beta, *d_loglpar, *d_logppar, *d_gmask, *d_gcn, *d_gdiv;
     int32_t *d_gsize;
     void *d_pre;        // [ntg][W] records of the swap (log uniform, likelihood, own-likelihood quotients, row: swap_prepare_kernel)
-    int32_t *d_hop;     // set by ptmi_exchange_pack when a row of the last sweep travels beyond a neighbouring block
+    int32_t *d_hop;     // set when a row of the last sweep travels beyond a neighbouring block (by the sweep's write-out, else by ptmi_exchange_pack)
+    bool hop_from_sweep;
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
     int32_t *d_gj_order, *d_gj_bucket;         // launch order of the chains ([nch]) and its counting-sort scratch ([3][GJ_BUCKETS])
