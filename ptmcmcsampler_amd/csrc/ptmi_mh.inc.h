@@ -50,6 +50,17 @@ __device__ __forceinline__ double grp_xor1(double v)
     return dppf64<0xB1>(v);
 }
 
+// Kernel shapes: (lanes per chain G, register slots per lane EPL); a shape serves
+// G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
+// lane for every ndim the shape serves and need no bounds check.
+// Shape (4, 25) is EXACT: it serves ndim = 100 only (ptmi_abi.hip pick_shape), so every slot of every lane is valid.
+constexpr int safe_slots(int G, int EPL)
+{
+    return G == 4 ? (EPL == 26 ? 20 : EPL == 25 ? 25 : EPL == 20 ? 14 : EPL == 14 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
+         : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
+         : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
+}
+
 // out[e] = sum_k T[k][i] * vec_k  for the caller's elements i = gl + 4 e, all 16 chains of the wave at once, on
 // v_mfma_f64_16x16x4_f64 (strided layout).  The instruction is a k-ascending fma chain (tools/mfma_probe.hip),
 // i.e. exactly the order of the scalar definition.  T is row-major with leading dimension ld.  PADDED: T has
@@ -85,10 +96,11 @@ __device__ __forceinline__ void mfma_tab_vec(const double *T, int ld, int d, con
         }
     };
     fetch(0, cur);
+    constexpr bool EXACT = safe_slots(4, EPL) == EPL;      // ndim = 4 EPL: every k-step exists, the product is one straight-line block
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        if (4 * e < d) {                                   // wave-uniform
-            if (e + 1 < EPL && 4 * (e + 1) < d) fetch(e + 1, nxt);
+        if (EXACT || 4 * e < d) {                          // wave-uniform
+            if (e + 1 < EPL && (EXACT || 4 * (e + 1) < d)) fetch(e + 1, nxt);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (!LOWER || 16 * t <= 4 * e + 3) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t], vec[e], acc.t[t], 0, 0, 0);
@@ -168,17 +180,6 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
         }
         return grp_sum<G, STR>(p);
     }
-}
-
-// Kernel shapes: (lanes per chain G, register slots per lane EPL); a shape serves
-// G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
-// lane for every ndim the shape serves and need no bounds check.
-// Shape (4, 25) is EXACT: it serves ndim = 100 only (ptmi_abi.hip pick_shape), so every slot of every lane is valid.
-constexpr int safe_slots(int G, int EPL)
-{
-    return G == 4 ? (EPL == 26 ? 20 : EPL == 25 ? 25 : EPL == 20 ? 14 : EPL == 14 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
-         : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
-         : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
 }
 
 // Box prior (the reference's usual lnpriorfn: -inf outside [pmin, pmax]): true when every element of the row lies inside.
@@ -1183,9 +1184,12 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
     const int esteps = (d + 3) / 4 < EPL ? (d + 3) / 4 : EPL;
+    // the exact shape (ndim = 4 EPL): every k-step and every output exists, so the product is ONE straight-line block -- with a
+    // wave-uniform test around each k-step the software pipeline's row blocks were copied from "next" to "current" in every one
+    // of them (7 v_mov_b64 per k-step: 160 of the step's 617 vector instructions)
+    constexpr bool EXACT = safe_slots(G, EPL) == EPL;
 
     for (int k = 0; k < a.nsteps; ++k) {
-        const long long it = a.iter0 + k;
         ScamDraw sd;
         scam_draws_for_step<true>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) { return PTMI_D_SQ[kk]; });
         const double log_u = sd.log_u;
@@ -1212,8 +1216,8 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         fetch(0, cur);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            if (e < esteps) {                                              // wave-uniform
-                if (e + 1 < EPL && e + 1 < esteps) fetch(e + 1, nxt);
+            if (EXACT || e < esteps) {                                     // wave-uniform
+                if (e + 1 < EPL && (EXACT || e + 1 < esteps)) fetch(e + 1, nxt);
                 const double re = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
@@ -1227,7 +1231,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const double re = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
-            const double ve = (gl + G * e) < d ? acc.at(e) : 0.0;          // outputs past the row are padding
+            const double ve = (EXACT || (gl + G * e) < d) ? acc.at(e) : 0.0;   // outputs past the row are padding
             p = __builtin_fma(re, ve, p);
         }
         const double nlnL = -grp_sum<G, true>(p);
