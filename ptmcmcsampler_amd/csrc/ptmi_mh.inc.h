@@ -1080,8 +1080,8 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         }
         // PT:327-328 (the post-swap row of a swap iteration is written by the swap).  These 25 stores of four active lanes, in ONE
         // wave of every block, are 15 % of the config-2 kernel (0.90 -> 0.77 ms without them, PTMI_MEASURE_NO_AM): the wave is its
-        // block's straggler.  Sending the row through LDS and out as two coalesced stores of the whole wave was built and measured
-        // slower (1.00 ms: the round trip sits on the wave's critical path).
+        // block's straggler.  Sending the row through LDS and out as two coalesced stores of the whole wave was built twice -- stored
+        // in the same step, and one step late so that no wait sits on the critical path -- and measured slower both times (1.00 ms).
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
             double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
 #pragma unroll

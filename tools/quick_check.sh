@@ -7,7 +7,6 @@ import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-12s %.4g upd/s  launch %.3f ms  step %.3f ms' % ('$name', j['value'], j['roofline']['avg_launch_ms'], j['ms_per_step']))"; }
 run scam --steps 100 --warmup 20
 run am_only --weights 0,20,0 --steps 30 --warmup 10
-run de_only --weights 0,0,20 --steps 30 --warmup 105
 run mix_chain --mix default --steps 60 --warmup 110
 run mix_walker --mix default --pick walker --steps 60 --warmup 110
 run dense --logl dense --steps 40 --warmup 10
