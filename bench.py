@@ -125,7 +125,7 @@ class ColdSamples(object):
         out = None
         have = np.zeros(last - first + 1, dtype=bool)
         for it_done, ring in self.snaps:
-            ring = ring.cpu().numpy()
+            ring = self.eng.am_params(ring.cpu().numpy())             # parameter order whatever the buffer's row format
             if out is None:
                 out = np.zeros((ring.shape[0], last - first + 1, ring.shape[2]))
             its = np.arange(max(first, it_done - cu + 1), min(last, it_done) + 1)

@@ -128,7 +128,7 @@ typedef struct ptmi_buffers {
                          *              beyond its size) */
     double *S;          /* [Wc][Ng][d]  eigenvalues (zero beyond the group's size) */
     double *DE;         /* [Wc][de_size][stride]  DE history ring (optional); row format: ptmi_de_row_stride */
-    double *AM;         /* [W][cov_update][d] samples of the rank-0 chain (:327-328); only where temp0 == 0 */
+    double *AM;         /* [W][cov_update][d] samples of the rank-0 chain (:327-328); only where temp0 == 0; row format: ptmi_am_row_format */
     uint64_t *nacc;     /* [W][T]      accepted MH updates per rank (:621) */
     uint64_t *jstat;    /* [W][T][PTMI_J_NTYPES][2]  proposed, accepted per jump type (:602,622) */
     uint64_t *nswap;    /* [W][ntemps_global]  accepted swaps credited to the lower rank (:681) */
@@ -165,6 +165,12 @@ int ptmi_temperature_ladder(int nchain, int ndim, double Tmin, double Tmax, doub
  * row is dealt to the lanes in 16-byte pieces, row[8 * (e / 2) + 2 * lane + e % 2] = parameter lane + 4 e (zero past ndim
  * and for e >= *epl), stride == 8 * ((*epl + 1) / 2) -- one read instruction of the kernel takes 64 contiguous bytes per chain. */
 int ptmi_de_row_stride(int ndim, int grad, int *stride, int *epl);
+
+/* Row format of the AM buffer for a given ndim (grad != 0: with gradient jumps in the cycle).  *epl == 0: a row holds the parameters
+ * in order.  *epl > 0 (the exact 4-lane shape: ndim = 4 * *epl = 100): the lanes' order -- position 8 * (e / 2) + 2 * lane + e % 2
+ * holds parameter lane + 4 e, the odd last slot e = *epl - 1 at 8 * (*epl / 2) + lane -- so that the rank-0 chain's four lanes store
+ * their row 16 bytes at a time.  Every kernel that reads the buffer goes through the same map. */
+int ptmi_am_row_format(int ndim, int grad, int *epl);
 
 int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out);
 int ptmi_destroy(ptmi_handle h);

@@ -42,7 +42,7 @@ class Buffers(C.Structure):
 
 # every symbol include/ptmi.h declares
 SYMBOLS = (
-    "ptmi_last_error", "ptmi_version", "ptmi_device_count", "ptmi_lanes_for", "ptmi_lanes_for_grad", "ptmi_temperature_ladder", "ptmi_de_row_stride", "ptmi_create", "ptmi_destroy",
+    "ptmi_last_error", "ptmi_version", "ptmi_device_count", "ptmi_lanes_for", "ptmi_lanes_for_grad", "ptmi_temperature_ladder", "ptmi_de_row_stride", "ptmi_am_row_format", "ptmi_create", "ptmi_destroy",
     "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_last_mh_variant", "ptmi_swap", "ptmi_swap_gather_lnl",
     "ptmi_swap_sweep", "ptmi_swap_sweep_blocks", "ptmi_exchange_pack", "ptmi_exchange_apply", "ptmi_exchange_status", "ptmi_exchange_multihop",
     "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_eig_jacobi", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept",
@@ -81,6 +81,7 @@ def load():
     L.ptmi_lanes_for_grad.argtypes = [C.c_int]
     L.ptmi_temperature_ladder.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp]
     L.ptmi_de_row_stride.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ptmi_am_row_format.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.ptmi_create.argtypes = [C.POINTER(Config), C.POINTER(Buffers), C.POINTER(H)]
     for n in ("ptmi_destroy", "ptmi_sync", "ptmi_eval_state", "ptmi_update_de", "ptmi_timer_start", "ptmi_eig_jacobi"):
         getattr(L, n).argtypes = [H]

@@ -221,13 +221,13 @@ __global__ void swap_oddeven_kernel(int W, int n, const double *ladder, const do
 
 // AM-buffer row of a swap iteration: the state that now sits at rank 0 (PT:624-627, 327-328)
 __global__ void am_write_kernel(const double *X, const double *lnL, const double *lp, const int32_t *slot_of, double *AM,
-                                double *AMaux, int W, int nt, int d, int cov_update, long long iter)
+                                double *AMaux, int W, int nt, int d, int cov_update, long long iter, int am_epl)
 {
     const int w = (int)blockIdx.x;
     const size_t r = (size_t)w * nt + slot_of[(size_t)w * nt];
     const double *row = X + r * d;
     double *am = AM + ((size_t)w * cov_update + (size_t)(iter % cov_update)) * d;
-    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) am[i] = row[i];
+    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) am[am_pos(i, am_epl)] = row[i];
     if (AMaux && threadIdx.x == 0) {
         double *ax = AMaux + ((size_t)w * cov_update + (size_t)(iter % cov_update)) * 2;
         ax[0] = lnL[r];
@@ -244,7 +244,7 @@ __global__ void am_write_kernel(const double *X, const double *lnL, const double
 constexpr int WT = 7, WTILE = 16 * WT;
 template <bool FUSED>
 __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *mu, double *M2, double *cov, int d, int mem,
-                                                     long long iter, int cov_stride_per_walker)
+                                                     long long iter, int cov_stride_per_walker, int am_epl)
 {
     constexpr int PF = 8;       // rows fetched ahead by the carrier threads (one HBM latency per PF rows)
     constexpr int RB = 4;       // rows handed to the tile per barrier
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
     for (int ii0 = 0; ii0 < mem; ii0 += PF) {
         double vpre[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) vpre[u] = (carrier && ii0 + u < mem) ? am[(size_t)(ii0 + u) * d + rel] : 0.0;
+        for (int u = 0; u < PF; ++u) vpre[u] = (carrier && ii0 + u < mem) ? am[(size_t)(ii0 + u) * d + am_pos(rel < d ? rel : 0, am_epl)] : 0.0;
 #pragma unroll
         for (int u0 = 0; u0 < PF; u0 += RB) {
             if (ii0 + u0 >= mem) break;
@@ -361,7 +361,8 @@ __host__ __device__ inline int pool_groups(int d) { return (d + 1 + PS_W - 1) / 
 static inline int pool_slab(int nwalkers, int d) { const int target = d + 1 <= PS_W ? 512 : 32; const int s = (nwalkers + target - 1) / target; return s < 1 ? 1 : s; }
 template <bool DIAG>
 __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, long long nrows, int d, const double *shift,
-                                                                     long long rows_per_slab, double *part)
+                                                                     long long rows_per_slab, double *part, int am_epl,
+                                                                     int shift_epl /* row format of `shift` (an AM row at the first epoch) */)
 {
     constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG);
     __shared__ double Dl[NA][2][PS_RC][PS_W];
@@ -408,14 +409,14 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
 #pragma unroll
     for (int a2 = 0; a2 < NA; ++a2) {
         gc[a2] = (a2 == 0 ? I : J) * PS_W + scol;
-        sh[a2] = (stager && gc[a2] < d) ? shift[gc[a2]] : 0.0;
+        sh[a2] = (stager && gc[a2] < d) ? shift[am_pos(gc[a2], shift_epl)] : 0.0;
     }
     // Loads are unconditional (row and column clamped into the slab: a branch per load made every one of them wait for its
     // own round trip, 2.6 ms per epoch); what a slot really holds is decided when it is staged.
     double v[NA][PS_RC / 2];
     int gcl[NA];
 #pragma unroll
-    for (int a2 = 0; a2 < NA; ++a2) gcl[a2] = gc[a2] < d ? gc[a2] : d - 1;
+    for (int a2 = 0; a2 < NA; ++a2) gcl[a2] = am_pos(gc[a2] < d ? gc[a2] : d - 1, am_epl);      // where the column sits in a buffered row
     long long vr0 = beg;
     auto fetch = [&](long long r0) {
         vr0 = r0;
@@ -491,7 +492,7 @@ __global__ void pool_reduce_kernel(const double *part, int nslab, int d, double 
     Tsum[idx] = sum;
 }
 // Chan's combination of the chunk (nb samples, sums about the shift) with the running pooled statistics (nprev samples)
-__global__ void pool_finish_kernel(const double *Tsum, const double *shift, double *mu, double *M2, double *cov, int d, int first,
+__global__ void pool_finish_kernel(const double *Tsum, const double *shift, int shift_epl, double *mu, double *M2, double *cov, int d, int first,
                                    double nb, double f /* nprev nb / (nprev + nb) */, double gw /* nb / (nprev + nb) */, double den)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,10 +509,10 @@ __global__ void pool_finish_kernel(const double *Tsum, const double *shift, doub
     const double cv = m / den;
     cov[idx] = cv;
     cov[(size_t)j * d + i] = cv;
-    if (i == j) mu[i] = first ? shift[i] + ti / nb : mu[i] + (ti / nb) * gw;
+    if (i == j) mu[i] = first ? shift[am_pos(i, shift_epl)] + ti / nb : mu[i] + (ti / nb) * gw;
 }
 
-__global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem, long long iter, int fused)
+__global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem, long long iter, int fused, int am_epl)
 {
     const int w = (int)blockIdx.y;
     const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -521,7 +522,7 @@ __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem
     double m = it == 0 ? 0.0 : mu[(size_t)w * d + j];
     for (int ii = 0; ii < mem; ++ii) {
         it += 1;
-        const double df = am[(size_t)ii * d + j] - m;
+        const double df = am[(size_t)ii * d + am_pos(j, am_epl)] - m;
         if (fused) m = m + df * (1.0 / (double)it);
         else m += df / (double)it;
     }
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, cons
 // again by the next instruction).  Round-2 history: in element order the four lanes pulled 8 B each out of 26 x 32-B
 // pieces (140 us per step of 262 144 chains); lane-major rows (a lane's 26 values contiguous, 208 B) made every
 // instruction touch 64 different lines and a piece straddle 2-3 of them (85 us).
-__global__ void de_update_kernel(double *DE, const double *AM, int d, int de_size, int mem, int head, int W, int pooled, int ld, int epl)
+__global__ void de_update_kernel(double *DE, const double *AM, int d, int de_size, int mem, int head, int W, int pooled, int ld, int epl, int am_epl)
 {
     const int r = (int)blockIdx.x;   // new row index 0..mem-1 (or the tail when mem > de_size)
     const int wc = (int)blockIdx.y;
@@ -730,7 +731,7 @@ __global__ void de_update_kernel(double *DE, const double *AM, int d, int de_siz
             const int e = 2 * (j / 8) + (j & 1);
             i = e < epl ? ((j & 7) >> 1) + 4 * e : d;
         }
-        dst[j] = i < d ? src[i] : 0.0;
+        dst[j] = i < d ? src[am_pos(i, am_epl)] : 0.0;
     }
 }
 
@@ -980,6 +981,7 @@ static KArgs make_args(ptmi_engine *h)
     a.cov_update = c.cov_update; a.tskip = c.tskip; a.per_walker = c.cov_per_walker; a.logp_kind = c.logp_kind;
     a.pick_walker = c.pick_mode == PTMI_PICK_WALKER;
     a.de_ld = h->G == 4 ? 8 * ((h->EPL + 1) / 2) : c.ndim;
+    a.am_epl = am_row_epl(h->G, h->EPL);
     a.w_nuts = c.w_nuts; a.w_hmc = c.w_hmc; a.gj_nburn = c.gj_nburn; a.hmc_min = c.hmc_min; a.hmc_max = c.hmc_max;
     a.nuts_maxdepth = c.nuts_maxdepth; a.hmc_eps = c.hmc_eps; a.nuts_delta = c.nuts_delta;
     a.gj_tab = h->d_gj_tab; a.gj = b.gj; a.gj_scr = h->d_gj_scr; a.gj_scal = h->d_gj_scal;
@@ -1076,6 +1078,17 @@ int ptmi_de_row_stride(int ndim, int grad, int *stride, int *epl)
     if (!pick_shape(ndim, grad != 0, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported", ndim);
     *stride = s.G == 4 ? 8 * ((s.EPL + 1) / 2) : ndim;
     *epl = s.G == 4 ? s.EPL : 0;
+    return PTMI_OK;
+}
+
+// row format of the AM buffer for a given ndim (grad != 0: with gradient jumps in the cycle): *epl == 0: parameter order; *epl > 0:
+// the lanes' order of the exact 4-lane shape (include/ptmi.h)
+int ptmi_am_row_format(int ndim, int grad, int *epl)
+{
+    Shape s;
+    if (!epl) return fail(PTMI_EINVAL, "NULL argument");
+    if (!pick_shape(ndim, grad != 0, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported", ndim);
+    *epl = am_row_epl(s.G, s.EPL);
     return PTMI_OK;
 }
 
@@ -1375,7 +1388,7 @@ int ptmi_swap_write_am(ptmi_handle h, int64_t iter)
     if (h->cfg.temp0 != 0 || !h->buf.AM) return PTMI_OK;
     hipLaunchKernelGGL(am_write_kernel, dim3(h->cfg.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.X,
                        (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)h->buf.slot_of, h->buf.AM,
-                       h->buf.AMaux, h->cfg.nwalkers, h->cfg.ntemps, h->cfg.ndim, h->cfg.cov_update, (long long)iter);
+                       h->buf.AMaux, h->cfg.nwalkers, h->cfg.ntemps, h->cfg.ndim, h->cfg.cov_update, (long long)iter, am_row_epl(h->G, h->EPL));
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -1674,10 +1687,10 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
     const int d = c.ndim, nt = (d + WTILE - 1) / WTILE;
     if (c.cov_per_walker) {
         hipLaunchKernelGGL(welford_kernel<false>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
-                           h->buf.mu, h->buf.M2, h->buf.cov, d, c.cov_update, (long long)iter, d * d);
+                           h->buf.mu, h->buf.M2, h->buf.cov, d, c.cov_update, (long long)iter, d * d, am_row_epl(h->G, h->EPL));
         if (nt > 1)
             hipLaunchKernelGGL(welford_mean_kernel, dim3((d + 63) / 64, c.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.AM,
-                               h->buf.mu, d, c.cov_update, (long long)iter, 0);
+                               h->buf.mu, d, c.cov_update, (long long)iter, 0, am_row_epl(h->G, h->EPL));
     } else {
         // pooled statistics (orc_pool_update): mu[0 .. d), M2[0 .. d*d) of the buffers are the pooled state
         const int W = c.nwalkers, SL = pool_slab(W, d), nslab = (W + SL - 1) / SL, ng = pool_groups(d);
@@ -1685,16 +1698,16 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
         const bool first = iter == c.cov_update;
         const double *shift = first ? (const double *)h->buf.AM : (const double *)h->buf.mu;     // the first epoch: walker 0's row 0
         hipLaunchKernelGGL(pool_syrk_kernel<true>, dim3(nslab, ng), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d, shift,
-                           (long long)SL * c.cov_update, h->d_pool_part);
+                           (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
         if (ng > 1)
             hipLaunchKernelGGL(pool_syrk_kernel<false>, dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
-                               shift, (long long)SL * c.cov_update, h->d_pool_part);
+                               shift, (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
         const long long nel = (long long)d * (d + 1);
         hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->d_pool_part, nslab, d,
                            h->d_pool_T);
         const double nb = (double)W * (double)c.cov_update, nprev = (double)W * (double)(iter - c.cov_update);
         hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)(((long long)d * d + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->d_pool_T,
-                           shift, h->buf.mu, h->buf.M2, h->buf.cov, d, first ? 1 : 0, nb, nprev * nb / (nprev + nb), nb / (nprev + nb),
+                           shift, first ? am_row_epl(h->G, h->EPL) : 0, h->buf.mu, h->buf.M2, h->buf.cov, d, first ? 1 : 0, nb, nprev * nb / (nprev + nb), nb / (nprev + nb),
                            nprev + nb - 1.0);
     }
     HIPCHK(hipGetLastError());
@@ -1727,7 +1740,7 @@ int ptmi_update_de(ptmi_handle h)
     const int wc = c.cov_per_walker ? c.nwalkers : 1;
     hipLaunchKernelGGL(de_update_kernel, dim3(c.cov_update, wc), dim3(64), 0, h->stream, h->buf.DE, (const double *)h->buf.AM,
                        c.ndim, c.de_size, c.cov_update, h->de_head, c.nwalkers, c.cov_per_walker ? 0 : 1,
-                       h->G == 4 ? 8 * ((h->EPL + 1) / 2) : c.ndim, h->G == 4 ? h->EPL : 0);
+                       h->G == 4 ? 8 * ((h->EPL + 1) / 2) : c.ndim, h->G == 4 ? h->EPL : 0, am_row_epl(h->G, h->EPL));
     HIPCHK(hipGetLastError());
     const int adv = c.cov_update < c.de_size ? c.cov_update : c.de_size;
     h->de_head = (h->de_head + adv) % c.de_size;

@@ -19,6 +19,18 @@ int ptmi_fail(int code, const char *fmt, ...);
         if (e_ != hipSuccess) return fail(PTMI_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Position of parameter i inside a row of the AM buffer.  epl == 0: parameter order.  epl > 0 (the exact 4-lane shape, ndim = 4 epl,
+// epl odd): the lanes' order -- 16-byte pieces dealt to the four lanes in turn, position 8 (e / 2) + 2 lane + e % 2 holds
+// parameter lane + 4 e, the odd last slot at 8 (epl / 2) + lane -- so that the cold chain's four lanes store their row with
+// 16-byte instructions (13 instead of 25: the stores are 15 % of the config-2 kernel).  Every reader goes through this map.
+__host__ __device__ inline int am_pos(int i, int epl)
+{
+    if (epl == 0) return i;
+    const int e = i >> 2, ln = i & 3;
+    return e < 2 * (epl / 2) ? 8 * (e >> 1) + 2 * ln + (e & 1) : 8 * (epl / 2) + ln;
+}
+constexpr int am_row_epl(int G, int EPL) { return (G == 4 && EPL == 25) ? EPL : 0; }      // = ptmi_shape_exact (declared below)
+
 // ------------------------------------------------------------- kernel args
 struct KArgs {
     // state
@@ -42,6 +54,7 @@ struct KArgs {
     int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
     int cov_update, tskip, per_walker, logp_kind, ngroups;
     int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
+    int am_epl;                  // row format of the AM buffer (am_pos): 0 = parameter order, 25 = the lanes' order of the exact shape
     int de_ld;                   // doubles per row of the DE buffer (ptmi_de_row_stride: 8 * ceil(EPL / 2) with 4 lanes per chain, else ndim)
     int pick_walker;             // pick_mode WALKER: the cycle entry comes from the stream of the walker's rank 0
     int lds_u;                   // staged kernels: the block's Ut is copied to LDS (else read from global)

@@ -792,6 +792,24 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
     return jt;
 }
 
+// The rank-0 chain's row into the AM buffer (PT:327-328), in the buffer's row format (ptmi_common.h am_pos)
+template <int G, int EPL>
+__device__ __forceinline__ void am_store_row(double *am, const double (&x)[EPL], int gl, int d)
+{
+    if constexpr (am_row_epl(G, EPL) != 0) {
+        ptmi_d2 *ap = reinterpret_cast<ptmi_d2 *>(am) + gl;
+#pragma unroll
+        for (int e2 = 0; e2 < EPL / 2; ++e2) ap[4 * e2] = ptmi_d2{x[2 * e2], x[2 * e2 + 1]};
+        if (EPL & 1) am[8 * (EPL / 2) + gl] = x[EPL - 1];
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = gl + G * e;
+            if (e < safe_slots(G, EPL) || i < d) am[i] = x[e];
+        }
+    }
+}
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; make consecutive
 // logical blocks (chains of one walker, sharing its Ut) land on one XCD's L2.
 __device__ __forceinline__ int logical_block()
@@ -1084,11 +1102,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         // in the same step, and one step late so that no wait sits on the critical path -- and measured slower both times (1.00 ms).
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
             double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int i = gl + G * e;
-                if (e < safe_slots(G, EPL) || i < d) am[i] = x[e];
-            }
+            am_store_row<G, EPL>(am, x, gl, d);
             if (a.AMaux && gl == 0) {
                 double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
                 ax[0] = lnL;
@@ -1253,11 +1267,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
             double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int i = gl + G * e;
-                if (e < safe_slots(G, EPL) || i < d) am[i] = x[e];
-            }
+            am_store_row<G, EPL>(am, x, gl, d);
             if (a.AMaux && gl == 0) {
                 double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
                 ax[0] = lnL;
@@ -1354,7 +1364,7 @@ __global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
         if (i < d) {
             const double v = acc ? a.Q[(size_t)ch * d + i] : a.X[(size_t)ch * d + i];
             if (acc) a.X[(size_t)ch * d + i] = v;
-            if (am) am[i] = v;
+            if (am) am[am_pos(i, a.am_epl)] = v;
         }
     }
     if (gl == 0) {

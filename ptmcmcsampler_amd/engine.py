@@ -163,6 +163,13 @@ class PTEngine(object):
         st, ep = C.c_int(0), C.c_int(0)                                # row format of the DE buffer (include/ptmi.h)
         _lib.check(self.lib.ptmi_de_row_stride(d, int(has_gj), C.byref(st), C.byref(ep)))
         self.de_ld, self.de_epl = st.value, ep.value
+        _lib.check(self.lib.ptmi_am_row_format(d, int(has_gj), C.byref(ep)))         # row format of the AM buffer (include/ptmi.h)
+        self.am_epl = ep.value
+        self.am_pos = self.am_inv = None
+        if self.am_epl:
+            e_, ln_ = np.arange(d) // 4, np.arange(d) % 4
+            self.am_pos = np.where(e_ < 2 * (self.am_epl // 2), 8 * (e_ // 2) + 2 * ln_ + e_ % 2, 8 * (self.am_epl // 2) + ln_)   # where parameter i sits
+            self.am_inv = np.argsort(self.am_pos)                                   # which parameter sits at position p
         self.owns_cold = self.temp0 == 0
         self.t = dict(
             X=z((W, nt, d)), lnL=z((W, nt)), lp=z((W, nt)),
@@ -237,10 +244,14 @@ class PTEngine(object):
             lane, slot = np.arange(self.d) % 4, np.arange(self.d) // 4
             pos = 8 * (slot // 2) + 2 * lane + slot % 2                # where parameter i sits in a row (ptmi_de_row_stride)
             return np.ascontiguousarray(a[..., pos])
+        if name == "AM" and self.am_pos is not None:
+            return np.ascontiguousarray(a[..., self.am_pos])              # parameter order whatever the device format
         return a.view(np.uint64) if name in ("nacc", "jstat", "nswap") else a
 
     def put(self, name, value):
         torch = _torch()
+        if name == "AM":
+            value = self.am_rows(np.asarray(value))                      # parameter order in, the buffer's row format on the device
         self.t[name].copy_(torch.from_numpy(np.ascontiguousarray(value)).to(self.t[name].dtype))
 
     def by_temp(self, name):
@@ -312,6 +323,22 @@ class PTEngine(object):
         self._store_initial(i0)
         self.iter = int(i0)
 
+    def am_rows(self, rows):
+        """Rows in parameter order (last axis) -> the AM buffer's row format (a torch tensor or a numpy array)."""
+        if self.am_inv is None:
+            return rows
+        if isinstance(rows, np.ndarray):
+            return rows[..., self.am_inv]
+        return rows[..., _torch().from_numpy(self.am_inv).to(rows.device)]
+
+    def am_params(self, rows):
+        """Rows of the AM buffer (last axis in its row format) -> parameter order."""
+        if self.am_pos is None:
+            return rows
+        if isinstance(rows, np.ndarray):
+            return rows[..., self.am_pos]
+        return rows[..., _torch().from_numpy(self.am_pos).to(rows.device)]
+
     def _store_initial(self, i0=0):
         """updateChains(p0, lnlike0, lnprob0, i0), :491: row i0 % covUpdate of the AM ring holds the point."""
         torch = _torch()
@@ -319,7 +346,7 @@ class PTEngine(object):
             ar = torch.arange(self.W, device=self.device)
             idx = self.t["slot_of"][:, 0].long()
             row = int(i0) % self.cov_update
-            self.t["AM"][:, row, :] = self.t["X"][ar, idx]
+            self.t["AM"][:, row, :] = self.am_rows(self.t["X"][ar, idx])
             if self.t["AMaux"] is not None:
                 self.t["AMaux"][:, row, 0] = self.t["lnL"][ar, idx]
                 self.t["AMaux"][:, row, 1] = self.t["lp"][ar, idx]

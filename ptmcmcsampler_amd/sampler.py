@@ -105,7 +105,7 @@ class _PerRankJump(object):
         return j(x, iter, beta)
 
 
-_CKPT_FORMAT = 3      # ptmi_checkpoint.npz: 2 = DE rows in the piece-cyclic device format + run fingerprint; 3 = pooled mode keeps ONE (mu, M2)
+_CKPT_FORMAT = 4      # ptmi_checkpoint.npz: 2 = DE rows in the piece-cyclic device format + run fingerprint; 3 = pooled mode keeps ONE (mu, M2); 4 = AM rows in the device's row format
 
 
 class PTSampler(object):
@@ -446,7 +446,7 @@ class PTSampler(object):
         """What a checkpoint must agree on with the run that loads it."""
         eng = self.engine
         return np.asarray([self.seed & 0x7FFFFFFFFFFFFFFF, self.ndim, self.nchain, self.nwalkers, self.thin, self.covUpdate, self.burn,
-                           eng.de_ld, eng.de_epl, self.keep_walkers], dtype=np.int64)
+                           eng.de_ld, eng.de_epl, self.keep_walkers, eng.am_epl], dtype=np.int64)
 
     def _load_checkpoint(self):
         st = np.load(self._ckpt, allow_pickle=False)
@@ -455,7 +455,7 @@ class PTSampler(object):
                             "changed): it cannot be resumed from".format(self._ckpt, int(st["f_format"]) if "f_format" in st.files else 1, _CKPT_FORMAT))
         fp = self._fingerprint()
         if not np.array_equal(st["f_fingerprint"], fp):
-            names = ("seed", "ndim", "ntemps", "nwalkers", "thin", "covUpdate", "burn", "DE row stride", "DE row format", "keep_walkers")
+            names = ("seed", "ndim", "ntemps", "nwalkers", "thin", "covUpdate", "burn", "DE row stride", "DE row format", "keep_walkers", "AM row format")
             bad = [n for n, a, b in zip(names, st["f_fingerprint"], fp) if a != b]
             raise Exception("{0} belongs to a different run ({1} differ): refusing to resume from it".format(self._ckpt, ", ".join(bad)))
         self.engine.restore(st)
@@ -518,7 +518,7 @@ class PTSampler(object):
             eng.put("lp", sp)
 
         # iteration 0: the first row (:474-476, :491)
-        eng.t["AM"][0, 0] = torch.from_numpy(X[0].copy())
+        eng.t["AM"][0, 0] = torch.from_numpy(eng.am_rows(X[0]).copy())
         eng.t["AMaux"][0, 0, 0], eng.t["AMaux"][0, 0, 1] = float(lnl[0]), float(lpr[0])
         self._chains[0, 0], self._lnlikes[0, 0], self._lnprobs[0, 0] = X[0], lnl[0], lnp[0]
         swapped_last = False
@@ -534,7 +534,7 @@ class PTSampler(object):
             end = min(eng._segment_end(it, last), last)
             its = np.arange(it, end + 1)
             src = its // thin
-            eng.t["AM"][0, torch.from_numpy(its % cu).to(eng.device)] = torch.from_numpy(X[src]).to(eng.device)
+            eng.t["AM"][0, torch.from_numpy(its % cu).to(eng.device)] = torch.from_numpy(np.ascontiguousarray(eng.am_rows(X[src]))).to(eng.device)
             aux = np.stack([lnl[src], lpr[src]], 1)
             eng.t["AMaux"][0, torch.from_numpy(its % cu).to(eng.device)] = torch.from_numpy(aux).to(eng.device)
             keep = its[its % thin == 0]
@@ -589,7 +589,7 @@ class PTSampler(object):
             return
         eng, kw = self.engine, self.keep_walkers
         rows = [i % eng.cov_update for i in iters]
-        X = eng.t["AM"][:kw][:, rows].cpu().numpy()
+        X = eng.am_params(eng.t["AM"][:kw][:, rows].cpu().numpy())
         aux = eng.t["AMaux"][:kw][:, rows].cpu().numpy()
         beta0 = 1.0 / eng.temps_mh[0]
         for n, i in enumerate(iters):

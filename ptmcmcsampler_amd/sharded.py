@@ -149,6 +149,9 @@ class ShardedPTEngine(object):
     def get(self, name):
         return self.local.get(name)
 
+    def am_params(self, rows):
+        return self.local.am_params(rows) if hasattr(self.local, "am_params") else rows
+
     def init_state(self, p0):
         p0 = np.asarray(p0, dtype=np.float64)
         if p0.ndim == 3:                                                      # [W][ntemps_global][d] -> my block
