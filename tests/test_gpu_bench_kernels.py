@@ -332,3 +332,33 @@ def test_walker_pick_mode_with_gradient_jumps(mods):
     assert_same(g.get("gj"), o.gj, "gj")
     js = g.get("jstat").astype(np.int64)[..., 0]
     assert (js == js[:, :1]).all() and js[..., 3].sum() > 0 and js[..., 4].sum() > 0
+
+
+def test_full_size_stationary_distribution_at_every_temperature(mods):
+    """BASELINE configs[1] as benchmarked (64 temps x 4096 walkers x 100-d, SCAM cycle, pooled covariance, swaps every 100):
+    after 40 000 iterations from p0 = 0 the batch samples what it should.  Rank t of an isotropic Gaussian at temperature T_t
+    holds x ~ N(0, T_t I), so <lnL> = -d T_t / 2 with standard deviation sqrt(d / 2) T_t -- checked across the 4096 independent
+    walkers for every rank up to T = 100 (above, the reference does not scale its jumps with sqrt(T), PTMCMCSampler.py:861-862,
+    and the hot chains need far longer) -- and the cold chains have mean 0 and variance 1 in every parameter.  A property of
+    the whole path at full size: proposals, accept test, swaps and adaptation together (the oracle cannot run this size)."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=1000, burn=10000, tskip=100, seed=11, cov_mode="pooled")
+    g.init_state(np.zeros(d))
+    g.run(40000)
+    g.sync()
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_LDS_UT and (G, E) == (4, 25)
+    lnL, T = g.by_temp("lnL"), g.ladder
+    warm = T <= 100.0
+    assert warm.sum() >= 30
+    z = (lnL.mean(0) + 0.5 * d * T) / (lnL.std(0) / np.sqrt(W))
+    assert np.abs(z[warm]).max() < 5.0, z[warm]
+    assert np.allclose(lnL.std(0)[warm], np.sqrt(d / 2.0) * T[warm], rtol=0.06)
+    X = g.by_temp("X")[:, 0]                                  # the 4096 cold states
+    assert np.abs(X.mean(0)).max() < 5.0 / np.sqrt(W)
+    assert np.abs(X.var(0) - 1.0).max() < 5.0 * np.sqrt(2.0 / W)
+    S = g.get("S")[0, 0]
+    assert 0.9 < S.min() and S.max() < 1.1                    # the adapted covariance found the unit target
+    acc = g.get("nswap").astype(np.float64)[:, :nt - 1].mean(0) / g.swap_proposed
+    assert 0.2 < acc[:30].min() and acc[:30].max() < 0.8      # the ladder's design acceptance (tstep = 1 + sqrt(2 / d), :711)
