@@ -362,3 +362,31 @@ def test_full_size_stationary_distribution_at_every_temperature(mods):
     assert 0.9 < S.min() and S.max() < 1.1                    # the adapted covariance found the unit target
     acc = g.get("nswap").astype(np.float64)[:, :nt - 1].mean(0) / g.swap_proposed
     assert 0.2 < acc[:30].min() and acc[:30].max() < 0.8      # the ladder's design acceptance (tstep = 1 + sqrt(2 / d), :711)
+
+
+def test_full_size_dense_target_covariance(mods):
+    """BASELINE configs[2] as benchmarked (100-d dense Gaussian, 64 x 4096 chains, the 512-thread matrix-core kernel with the
+    half-matrix quadratic form): after 30 000 iterations the 4096 cold states have the target's covariance P^-1, entry by entry
+    within five standard errors, and <lnL> = -d T / 2 holds down the warm part of the ladder."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    A = np.random.default_rng(0).standard_normal((d, d))
+    Ctrue = A @ A.T / d + np.eye(d)
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=1000, burn=10000, tskip=100, seed=5, cov_mode="pooled",
+                 logl=("dense", np.zeros(d), np.linalg.inv(Ctrue)))
+    g.init_state(np.zeros(d))
+    g.run(30000)
+    g.sync()
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_DENSE_SCAM and (G, E) == (4, 25)
+    X = g.by_temp("X")[:, 0]
+    Chat = X.T @ X / W
+    se = np.sqrt((np.outer(np.diag(Ctrue), np.diag(Ctrue)) + Ctrue ** 2) / W)
+    assert np.abs((Chat - Ctrue) / se).max() < 5.5, np.abs((Chat - Ctrue) / se).max()
+    assert np.abs(X.mean(0) / np.sqrt(np.diag(Ctrue) / W)).max() < 5.0
+    lnL, T = g.by_temp("lnL"), g.ladder
+    warm = T <= 100.0
+    z = (lnL.mean(0) + 0.5 * d * T) / (lnL.std(0) / np.sqrt(W))
+    assert np.abs(z[warm]).max() < 5.0, z[warm]
+    # the pooled adaptive covariance (cumulative since p0 = 0, transient included) is on its way to the target's
+    assert np.linalg.norm(g.get("cov")[0] - Ctrue) < 0.3 * np.linalg.norm(Ctrue)
