@@ -1142,11 +1142,20 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
 // next row; those columns only feed the padding outputs i >= d, which are masked.  Strided lane layout as STAGE.
 // doubles from the first even row to the first odd row of the dense kernel's LDS copy of P: past the even rows, = 16 (mod 32)
 __host__ __device__ constexpr int dense_podd(int d) { return ((d + 1) / 2) * d + ((16 - (((d + 1) / 2) * d) % 32) + 32) % 32; }
-template <int EPL, int BLK>
+#ifndef PTMI_DENSE_PF
+#define PTMI_DENSE_PF 6
+#endif
+// matrix instructions of the half-table product (k-steps ascending, tiles 0 .. (4e+3)/16 within one)
+constexpr int dense_pairs(int EPL) { int n = 0; for (int e = 0; e < EPL; ++e) n += (4 * e + 3) / 16 + 1; return n; }
+template <int EPL, int BLK, bool BOX>
 __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KArgs a)
 {
     constexpr int G = 4, CPB = BLK / G, NT = MfmaAcc<EPL>::NT;
-    const int d = a.d, nt = a.nt;
+    // the exact shape serves ndim = 4 EPL only: a compile-time d turns every table address of the step into one base register
+    // plus an immediate offset (with a run-time d the 25 row addresses were loop invariants, hoisted and spilled: a scratch read
+    // in front of the LDS read in front of the matrix instruction)
+    constexpr bool EXACT = safe_slots(G, EPL) == EPL;
+    const int d = EXACT ? 4 * EPL : a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int cib = wave * 16 + (lane & 15), gl = lane >> 4;
@@ -1201,7 +1210,6 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
     // the exact shape (ndim = 4 EPL): every k-step and every output exists, so the product is ONE straight-line block -- with a
     // wave-uniform test around each k-step the software pipeline's row blocks were copied from "next" to "current" in every one
     // of them (7 v_mov_b64 per k-step: 160 of the step's 617 vector instructions)
-    constexpr bool EXACT = safe_slots(G, EPL) == EPL;
 
     for (int k = 0; k < a.nsteps; ++k) {
         ScamDraw sd;
@@ -1211,40 +1219,78 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], PTMI_D_U + (size_t)sd.k * d, e);       // PT:868-873
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dq[e] = sd.amp * dq[e];
-        // PT:605-612: prior on q = x + dq, then -1/2 r^T P r with r = q - mu
-        const double nlp = eval_logp_q<G, EPL, true>(a, smem, gl, [&](int e) { return x[e] + dq[e]; });
+        // PT:605-612: prior on q = x + dq (BOX: the kernel is instantiated per prior kind -- the flat prior's dead test cost 7 %),
+        // then -1/2 r^T P r with r = q - mu, formed ONCE (bit-identical wherever it is used)
+        double nlp = 0.0;
+        if (BOX) nlp = eval_logp_q<G, EPL, true>(a, smem, gl, [&](int e) { return x[e] + dq[e]; });
         MfmaAcc<EPL> acc;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) acc.t[tt] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
-        // software pipeline of depth one (the row block of step e + 1 is in flight while step e multiplies); the scheduling
-        // barrier keeps the compiler from hoisting all 7 * 26 table reads to the top
-        double cur[NT], nxt[NT];
         // the table is the half Tl (k >= i): in k-step e the tiles with 16 tt > 4 e + 3 hold zeros only and are skipped --
         // 91 matrix instructions per likelihood instead of 175
-        auto fetch = [&](int e, double (&dst)[NT]) {
-            const double *row = PTMI_D_P + ((g4 & 1) ? podd : 0) + (2 * e + (g4 >> 1)) * d + c16;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-                if (16 * tt <= 4 * e + 3) dst[tt] = row[16 * tt];
+        auto tile = [&](int e, int tt) -> double {
+            return PTMI_D_P[((g4 & 1) ? podd : 0) + (2 * e + (g4 >> 1)) * d + c16 + 16 * tt];
         };
-        fetch(0, cur);
+        double rr[EPL];
+        if constexpr (EXACT) {
+            // the table operand of matrix instruction i + PF is requested before instruction i is issued (PF instructions =
+            // 300+ cycles of LDS latency covered from the first k-step on, where a k-step is ONE instruction); the scheduling
+            // barriers pin that order -- left alone the compiler put every read directly in front of its consumer
+            constexpr int NP = dense_pairs(EPL), PF = PTMI_DENSE_PF;
+            double av[NP];
+            int pe = 0, pt = 0, pi = 0;                        // cursor of the requests (all compile-time after unrolling)
+            auto request = [&]() {
+                av[pi] = tile(pe, pt);
+                ++pi;
+                if (16 * (pt + 1) <= 4 * pe + 3) ++pt;
+                else { pt = 0; ++pe; }
+            };
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            if (EXACT || e < esteps) {                                     // wave-uniform
-                if (e + 1 < EPL && (EXACT || e + 1 < esteps)) fetch(e + 1, nxt);
-                const double re = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
+            for (int i = 0; i < PF; ++i) request();
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) rr[e] = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
+            __builtin_amdgcn_sched_barrier(0);
+            int i = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    if (16 * tt > 4 * e + 3) continue;
+                    if (pi < NP) request();
+                    acc.t[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], rr[e], acc.t[tt], 0, 0, 0);
+                    ++i;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // software pipeline of depth one (the row block of step e + 1 is in flight while step e multiplies); the scheduling
+            // barrier keeps the compiler from hoisting all 7 * 26 table reads to the top
+            double cur[NT], nxt[NT];
+            auto fetch = [&](int e, double (&dst)[NT]) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
-                    if (16 * tt <= 4 * e + 3) acc.t[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[tt], re, acc.t[tt], 0, 0, 0);
+                    if (16 * tt <= 4 * e + 3) dst[tt] = tile(e, tt);
+            };
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) cur[tt] = nxt[tt];
-                __builtin_amdgcn_sched_barrier(0);
+            for (int e = 0; e < EPL; ++e) rr[e] = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
+            fetch(0, cur);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (e < esteps) {                                     // wave-uniform
+                    if (e + 1 < EPL && e + 1 < esteps) fetch(e + 1, nxt);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+                        if (16 * tt <= 4 * e + 3) acc.t[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[tt], rr[e], acc.t[tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) cur[tt] = nxt[tt];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         double p = 0.0;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const double re = (x[e] + dq[e]) - PTMI_D_MU[gl + G * e];
+            const double re = rr[e];
             const double ve = (EXACT || (gl + G * e) < d) ? acc.at(e) : 0.0;   // outputs past the row are padding
             p = __builtin_fma(re, ve, p);
         }
@@ -1445,7 +1491,9 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_LDS_UT | PTMI_VAR_DENSE_SCAM | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
                 return PTMI_OK;
             };
-            return want == 256 ? launch(mh_dense_scam_kernel<EPL, 256>, 256) : launch(mh_dense_scam_kernel<EPL, 512>, 512);
+            if (c.logp_kind == PTMI_LOGP_BOX)
+                return want == 256 ? launch(mh_dense_scam_kernel<EPL, 256, true>, 256) : launch(mh_dense_scam_kernel<EPL, 512, true>, 512);
+            return want == 256 ? launch(mh_dense_scam_kernel<EPL, 256, false>, 256) : launch(mh_dense_scam_kernel<EPL, 512, false>, 512);
         }
     }
     if constexpr (WANTS) {

@@ -115,6 +115,8 @@ def test_box_prior_from_lds_table(mods, kind):
     assert flags & _lib.VAR_LDS_BOX and (G, E) == (4, 25)
     if kind == "scam":
         assert flags & _lib.VAR_LDS_UT and not flags & _lib.VAR_STAGED
+    if kind == "dense":
+        assert flags & _lib.VAR_DENSE_SCAM              # the box-prior instantiation of the 512-thread kernel
     _compare(g, o, "box %s " % kind)
     rej = o.jstat[..., 0, 0].sum() - o.jstat[..., 0, 1].sum()
     assert np.isinf(o.lp).sum() == 0 and rej > 0                # proposals did leave the box and were refused
