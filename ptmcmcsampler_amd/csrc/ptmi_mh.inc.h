@@ -824,15 +824,20 @@ __device__ __forceinline__ int logical_block()
 // table-times-vector products of the AM proposal and of the dense likelihood run on the matrix cores.
 // ULDS (SCAM-only cycles whose block shares one eigenvector table that fits LDS twice per CU): contiguous lane layout,
 // the table copied to LDS unpadded, so the one row a step reads comes at LDS latency instead of L2 latency.
-template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false>
-__global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
+// PERS > 0 (ULDS with ONE table for the whole launch, i.e. a pooled covariance): persistent blocks of PERS threads, one per CU,
+// over one LDS copy of the table; every wave walks over units of 16 chains on its own (no barrier after the set-up), so the
+// occupancy is what the registers allow -- three waves per SIMD at 768 threads -- instead of what two table copies allow,
+// the table is staged 256 times per launch instead of 4096 times, and a block's waves do not wait for its cold wave.
+template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false, int PERS = 0, int PRI = -1 /* PERS: the prior kind */>
+__global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
 {
     static_assert(!ULDS || (!STAGE && !FULL && !GRP), "ULDS is the SCAM-only contiguous-layout kernel");
+    static_assert(!PERS || (ULDS && G == 4), "persistent blocks are a variant of the ULDS kernel");
     // the draw tables (ptmi_tables.h, 1 KB): the staged full kernels read them from an LDS copy when the host found room
     // (a.tab_off >= 0: 13.0 instead of 14.1 ms per 100 steps of the default mix); the SCAM-only kernels from global memory --
     // measured in the ULDS kernel: 1.14 ms per 100 steps from global, 1.20 from LDS, whose pipe serves the direction rows
     constexpr int TM = (STAGE && FULL) ? 2 : 0;
-    constexpr int BLK = 256;
+    constexpr int BLK = PERS ? PERS : 256;
     constexpr int CPB = BLK / G;
     constexpr bool STR = STAGE;
     const int d = a.d, nt = a.nt;
@@ -840,7 +845,27 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int cib = STR ? wave * 16 + (lane & 15) : (int)(threadIdx.x / G);       // chain in block
     const int gl = STR ? lane >> 4 : (int)(threadIdx.x % G);
-    long long ch = (long long)logical_block() * CPB + cib;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if constexpr (PERS != 0) {
+        // set-up of the persistent block: the launch's one table (rows in the lanes' order for the exact shape), sqrt(S) or the
+        // bounds, the draw tables -- what the ULDS set-up below does per block of 64 chains
+        constexpr bool PAIRED_P = EPL == 25;
+        if constexpr (PAIRED_P) {
+            for (int i = (int)threadIdx.x; i < d * d; i += BLK) {
+                const int r = i / d, c = i % d, ln = c & 3, e = c >> 2;
+                smem[r * d + (e < 2 * (EPL / 2) ? 8 * (e >> 1) + 2 * ln + (e & 1) : 8 * (EPL / 2) + ln)] = a.Ut[i];
+            }
+        } else {
+            for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = a.Ut[i];
+        }
+        for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(a.S[i]);      // one copy per CU: room for sqrt(S) AND the bounds
+        if constexpr (PRI == PTMI_LOGP_BOX) box_table_fill<G, EPL>(a, smem, BLK);
+        draw_table_fill(smem, a.tab_off, BLK);
+        __syncthreads();
+    }
+    const long long nunits = (nch + 15) / 16, ustride = PERS ? (long long)gridDim.x * (BLK / 64) : nunits;
+    for (long long unit = PERS ? (long long)blockIdx.x * (BLK / 64) + wave : 0; unit < nunits; unit += ustride) {
+    long long ch = PERS ? unit * 16 + (lane >> 2) : (long long)logical_block() * CPB + cib;
     const bool live = ch < nch;
     if (!live) ch = nch - 1;
     const int w = (int)(ch / nt);
@@ -864,7 +889,6 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
     // 61 % of the LDS cycles of that kernel were bank conflicts of the 8-byte reads (profiles/r03_scam_lds.txt)
     constexpr bool PAIRED = ULDS && G == 4 && EPL == 25;
 
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = mfma_ld(EPL);
     const int tab_n = 4 * ((d + 3) / 4) * LD;                      // doubles of one zero-padded LDS table
     const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d + (size_t)d * d : nullptr;       // the half table Tl
@@ -905,8 +929,8 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         __syncthreads();
     }
     // ULDS with a box prior: the bounds table takes the place of sqrt(S) (both do not fit twice per CU at d = 100)
-    const bool ulds_box = ULDS && a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0 && a.box_off < d * d + d;
-    if (ULDS) {
+    const bool ulds_box = ULDS && !PERS && a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0 && a.box_off < d * d + d;
+    if (ULDS && !PERS) {
         const long long ch0 = (long long)logical_block() * CPB;
         const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
         const double *src = a.Ut + w0 * d * d, *srcS = a.S + w0 * d;
@@ -921,9 +945,11 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
         if (!ulds_box)
             for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
     }
-    box_table_fill<G, EPL>(a, smem, BLK);
-    if (ULDS) draw_table_fill(smem, a.tab_off, BLK);
-    if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
+    if constexpr (PERS == 0) {
+        box_table_fill<G, EPL>(a, smem, BLK);
+        if (ULDS) draw_table_fill(smem, a.tab_off, BLK);
+        if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
+    }
 
     // ---- AM queue (staged full kernels).  An AM increment U (cd sqrt(S) z) does not depend on the chain's state, only on
     // its stream, the iteration and the scale branch -- all known from the draws -- and the matrix instruction computes 16
@@ -1070,7 +1096,10 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             double q[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
-            nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
+            if constexpr (PERS != 0 && PRI == PTMI_LOGP_FLAT) nlp = 0.0;
+            else if constexpr (PERS != 0 && PRI == PTMI_LOGP_BOX)
+                nlp = grp_all<G, STR>(box_inside_lds<G, EPL>(smem, a.box_off, gl, [&](int e) { return q[e]; })) ? 0.0 : -__builtin_inf();
+            else nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
             // the reference skips logl when the prior is -inf (PT:607-608); the value is unused then, and the
             // matrix-core path needs every lane, so it is evaluated unconditionally
             if (STAGE) nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, PTMI_PL);
@@ -1130,6 +1159,7 @@ __global__ __launch_bounds__(256, (STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1
             }
         }
     }
+    }       // units of a persistent block (one trip otherwise)
 }
 
 // Dense Gaussian likelihood, SCAM-only cycle, one eigenvector table for the whole block (pooled covariance, or the ranks of
@@ -1539,6 +1569,45 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
         size_t tab = sizeof(double) * ((size_t)c.ndim * c.ndim + c.ndim);
         const bool one_table = c.ngroups <= 1 && (!c.cov_per_walker || c.ntemps % (256 / G) == 0);
         static const bool off = getenv("PTMI_NO_ULDS") != nullptr;      // measurement switch: same results either way
+        // ONE table for the whole launch (pooled covariance): persistent blocks, one per CU over one LDS copy of the table
+        // (PTMI_ULDS_PERS = 0 / 512 / 768: measurement switch, same results for any value)
+        if constexpr (G == 4) {
+            const char *pe = getenv("PTMI_ULDS_PERS");       // read per launch: the tests switch it
+            const int pers = pe ? atoi(pe) : 512;
+            if (c.ngroups <= 1 && !c.cov_per_walker && pers && !off && (c.logp_kind == PTMI_LOGP_FLAT || c.logp_kind == PTMI_LOGP_BOX)) {
+                static int ncu = 0;
+                if (!ncu) {
+                    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || ncu < 1) ncu = 256;
+                }
+                // table | sqrt(S) | bounds | draw tables
+                size_t tp = sizeof(double) * even((size_t)c.ndim * c.ndim + c.ndim);
+                a.box_off = -1;
+                if (box_bytes) { a.box_off = (int)(tp / sizeof(double)); tp += box_bytes; }
+                a.tab_off = (int)(tp / sizeof(double));
+                tp += DRAWT;
+                auto launch_p = [&](auto kernp, int BLKv) -> int {
+                    if (tp > 64 * 1024) {
+                        hipError_t e = hipFuncSetAttribute((const void *)kernp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp);
+                        if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", tp, hipGetErrorString(e));
+                    }
+                    const long long nunits = ((long long)c.nwalkers * c.ntemps + 15) / 16, wpb = BLKv / 64;
+                    const long long nb = (nunits + wpb - 1) / wpb;
+                    hipLaunchKernelGGL(kernp, dim3((unsigned)(nb < ncu ? nb : ncu)), dim3(BLKv), tp, h->stream, a);
+                    h->last_variant = PTMI_VAR_LDS_UT | PTMI_VAR_PERSISTENT | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | PTMI_VAR_LDS_DRAWT;
+                    return PTMI_OK;
+                };
+                if (tp <= 160 * 1024) {
+                    if (c.logp_kind == PTMI_LOGP_BOX) {
+                        if (pers == 768) return launch_p(mh_steps_kernel<G, EPL, LOGL, false, false, false, true, 768, PTMI_LOGP_BOX>, 768);
+                        return launch_p(mh_steps_kernel<G, EPL, LOGL, false, false, false, true, 512, PTMI_LOGP_BOX>, 512);
+                    }
+                    if (pers == 768) return launch_p(mh_steps_kernel<G, EPL, LOGL, false, false, false, true, 768, PTMI_LOGP_FLAT>, 768);
+                    return launch_p(mh_steps_kernel<G, EPL, LOGL, false, false, false, true, 512, PTMI_LOGP_FLAT>, 512);
+                }
+                a.box_off = -1;
+                a.tab_off = -1;
+            }
+        }
         if (box_bytes) {
             // the bounds table instead of sqrt(S) when both do not fit twice per CU (the kernel then takes the root per step)
             const size_t ut = sizeof(double) * even((size_t)c.ndim * c.ndim);

@@ -350,7 +350,7 @@ def test_full_size_stationary_distribution_at_every_temperature(mods):
     g.run(40000)
     g.sync()
     flags, G, E = g.last_variant()
-    assert flags & _lib.VAR_LDS_UT and (G, E) == (4, 25)
+    assert flags & _lib.VAR_LDS_UT and flags & _lib.VAR_PERSISTENT and (G, E) == (4, 25)
     lnL, T = g.by_temp("lnL"), g.ladder
     warm = T <= 100.0
     assert warm.sum() >= 30

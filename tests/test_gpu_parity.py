@@ -294,6 +294,9 @@ def test_full_size_properties_and_subset_parity(mods):
     n = 200
     g.run(n)
     g.sync()
+    flags, G, E = g.last_variant()
+    # what bench.py times: persistent blocks over one LDS copy of the pooled table, exact shape
+    assert flags & _lib.VAR_PERSISTENT and flags & _lib.VAR_LDS_UT and flags & _lib.VAR_LDS_DRAWT and (G, E) == (4, 25)
     so, to = g.get("slot_of"), g.get("temp_of")
     assert (np.sort(so, axis=1) == np.arange(nt)).all()                       # tables stay permutations
     assert (np.take_along_axis(to, so.astype(np.int64), 1) == np.arange(nt)).all()
@@ -332,13 +335,18 @@ def test_ragged_and_boundary_sizes(mods, d, nt, W):
     assert_same(g.get("cov"), o.cov, "cov")
 
 
+@pytest.mark.parametrize("pers", [512, 0, 768])
 @pytest.mark.parametrize("d,prior", [(99, "flat"), (100, "flat"), (100, "box"), (101, "flat"), (104, "box"), (81, "flat")])
-def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior):
+def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior, pers, monkeypatch):
     """SCAM-only cycle with the eigenvector table in LDS (the config-2 bench kernel) on both sides of ndim = 100: 100 runs the
     EXACT shape (4, 25) -- no bounds checks, table rows stored in lane order and read 16 bytes at a time, chain-scalar half of
     the proposal computed in the draw pass -- its neighbours the general shape (4, 26).  Pooled covariance epochs in between
-    change the table; 70 walkers x 4 ranks fill more than one block (PTMCMCSampler.py:820-876, 605-622)."""
+    change the table; 70 walkers x 4 ranks fill more than one block (PTMCMCSampler.py:820-876, 605-622).
+    ``pers``: with one table for the whole launch (pooled covariance) the launch goes to PERSISTENT blocks of that many threads,
+    one per CU over one LDS copy of the table, every wave walking over units of 16 chains (512 is the default and what bench.py
+    times); 0 = the kernel with a table copy per block of 64 chains, which per-walker tables keep."""
     orc, _lib, _ = mods
+    monkeypatch.setenv("PTMI_ULDS_PERS", str(pers))
     kw = dict(weights=(20, 0, 0), cov_update=40, burn=1000, tskip=10, seed=d, cov_mode="pooled", cov0=np.eye(d) * 0.02)
     if prior == "box":
         kw.update(logp=("box", -0.4 * np.ones(d), 0.5 * np.ones(d)), p0=np.random.RandomState(d).uniform(-0.1, 0.1, (70, 4, d)))
@@ -348,9 +356,11 @@ def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior):
         o.run(n)
     flags, G, E = g.last_variant()
     assert not flags & _lib.VAR_STAGED and not flags & _lib.VAR_FULL
-    assert bool(flags & _lib.VAR_LDS_UT) == (d <= 100)             # two blocks' tables (+ sqrt(S) or the bounds) fit the CU up to ndim = 100
+    assert bool(flags & _lib.VAR_PERSISTENT) == (pers != 0)
+    # a copy per block: two blocks' tables (+ sqrt(S) or the bounds) fit the CU up to ndim = 100; one copy per CU: every 4-lane shape
+    assert bool(flags & _lib.VAR_LDS_UT) == (d <= 100 or pers != 0)
     assert (G, E) == ((4, 25) if d == 100 else (4, 26) if d > 80 else (4, 20))
-    _compare(g, o, "scam table d=%d %s " % (d, prior))
+    _compare(g, o, "scam table d=%d %s pers=%d " % (d, prior, pers))
     assert_same(g.get("Ut"), o.Ut, "Ut")
 
 
