@@ -846,26 +846,78 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
     const int cib = STR ? wave * 16 + (lane & 15) : (int)(threadIdx.x / G);       // chain in block
     const int gl = STR ? lane >> 4 : (int)(threadIdx.x % G);
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if constexpr (PERS != 0) {
-        // set-up of the persistent block: the launch's one table (rows in the lanes' order for the exact shape), sqrt(S) or the
-        // bounds, the draw tables -- what the ULDS set-up below does per block of 64 chains
-        constexpr bool PAIRED_P = EPL == 25;
-        if constexpr (PAIRED_P) {
-            for (int i = (int)threadIdx.x; i < d * d; i += BLK) {
-                const int r = i / d, c = i % d, ln = c & 3, e = c >> 2;
-                smem[r * d + (e < 2 * (EPL / 2) ? 8 * (e >> 1) + 2 * ln + (e & 1) : 8 * (EPL / 2) + ln)] = a.Ut[i];
+    // SCAM-only cycle, one parameter group: the chain-scalar half of the proposal moves into the draw pass (ScamBatch)
+    constexpr bool SCAMFAST = !FULL && !GRP;
+    // ULDS with the exact shape (4, 25) (ndim = 100): the table rows are stored in the lanes' order, 16-byte pieces dealt to
+    // the four lanes in turn (position 8 (e / 2) + 2 lane + e % 2 holds element lane + 4 e; the odd last slot at 96 + lane), so
+    // that a step reads its direction with 12 ds_read_b128 + 1 ds_read_b64 instead of 10 ds_read2_b64 + 6 ds_read_b64:
+    // 61 % of the LDS cycles of that kernel were bank conflicts of the 8-byte reads (profiles/r03_scam_lds.txt)
+    constexpr bool PAIRED = ULDS && G == 4 && EPL == 25;
+    constexpr int LD = mfma_ld(EPL);
+    const int tab_n = 4 * ((d + 3) / 4) * LD;                      // doubles of one zero-padded LDS table
+    const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d + (size_t)d * d : nullptr;       // the half table Tl
+    // LDS pointers are derived from smem at their use so that they stay LDS (ds_read) accesses
+#define PTMI_PL (smem)
+#define PTMI_UL (smem + (LOGL == PTMI_LOGL_DENSE ? (size_t)tab_n : 0))
+    // FULL staged kernels: sqrt of the block's eigenvalues, behind the tables (d doubles)
+#define PTMI_SQ (smem + (size_t)tab_n * ((LOGL == PTMI_LOGL_DENSE ? 1 : 0) + ((UT_ALWAYS_LDS || a.lds_u) ? 1 : 0)))
+    // with the dense likelihood both tables may not fit: then Ut stays in global memory (host decides, a.lds_u)
+    constexpr bool UT_ALWAYS_LDS = LOGL != PTMI_LOGL_DENSE;
+    const double *const tsm = TM ? smem : nullptr;
+    // ---- set-up of the block: its tables into LDS.  The block's table: the launch's one table (PERS, pooled covariance), else
+    // the table of the walker its first chain belongs to (the host checks that all its chains share it, launch_mh_k)
+    size_t w0 = 0;
+    if (!PERS && a.per_walker) {
+        const long long ch0 = (long long)logical_block() * CPB;
+        w0 = (size_t)((ch0 < nch ? ch0 : nch - 1) / nt);
+    }
+    const double *const UtBlk = a.Ut + w0 * d * d;
+    if (TM) draw_table_fill(smem, a.tab_off, BLK);
+    if (STAGE) {
+        if (LOGL == PTMI_LOGL_DENSE) {
+            for (int i = (int)threadIdx.x; i < tab_n; i += BLK) {
+                const int r = i / LD, c = i % LD;
+                PTMI_PL[i] = (r < d && c < d) ? PtG[(size_t)r * d + c] : 0.0;
             }
-        } else {
-            for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = a.Ut[i];
         }
-        for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(a.S[i]);      // one copy per CU: room for sqrt(S) AND the bounds
-        if constexpr (PRI == PTMI_LOGP_BOX) box_table_fill<G, EPL>(a, smem, BLK);
-        draw_table_fill(smem, a.tab_off, BLK);
+        // FULL: the block's table serves all its chains.  SCAM-only cycles read one row per step from the chain's OWN table.
+        if (FULL) {
+            const double *Sb = a.S + w0 * d;                                               // the eigenvalues that go with UtBlk
+            for (int i = (int)threadIdx.x; i < d; i += BLK) PTMI_SQ[i] = det_sqrt(Sb[i]);
+        }
+        if (FULL && (UT_ALWAYS_LDS || a.lds_u)) {
+            for (int i = (int)threadIdx.x; i < tab_n; i += BLK) {
+                const int r = i / LD, c = i % LD;
+                PTMI_UL[i] = (r < d && c < d) ? UtBlk[(size_t)r * d + c] : 0.0;
+            }
+        }
         __syncthreads();
     }
+    // ULDS with a box prior and a table copy per block: the bounds table takes the place of sqrt(S) (both do not fit twice per
+    // CU at d = 100); a persistent block (one copy per CU) has room for both
+    const bool ulds_box = ULDS && !PERS && a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0 && a.box_off < d * d + d;
+    if (ULDS) {
+        const double *src = UtBlk, *srcS = a.S + w0 * d;
+        if constexpr (PAIRED) {
+            for (int i = (int)threadIdx.x; i < d * d; i += BLK) {
+                const int r = i / d, c = i % d, ln = c & 3, e = c >> 2;
+                smem[r * d + (e < 2 * (EPL / 2) ? 8 * (e >> 1) + 2 * ln + (e & 1) : 8 * (EPL / 2) + ln)] = src[i];
+            }
+        } else {
+            for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = src[i];
+        }
+        if (!ulds_box)
+            for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
+    }
+    if (!(ULDS && PERS && PRI == PTMI_LOGP_FLAT)) box_table_fill<G, EPL>(a, smem, BLK);
+    if (ULDS) draw_table_fill(smem, a.tab_off, BLK);
+    if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
+
+    // ---- the chains.  A block of 256 threads serves its 64 chains; a persistent block's waves walk over units of 16 chains on
+    // their own (no barrier from here on)
     const long long nunits = (nch + 15) / 16, ustride = PERS ? (long long)gridDim.x * (BLK / 64) : nunits;
     for (long long unit = PERS ? (long long)blockIdx.x * (BLK / 64) + wave : 0; unit < nunits; unit += ustride) {
-    long long ch = PERS ? unit * 16 + (lane >> 2) : (long long)logical_block() * CPB + cib;
+    long long ch = PERS ? unit * 16 + (STR ? (lane & 15) : (lane >> 2)) : (long long)logical_block() * CPB + cib;
     const bool live = ch < nch;
     if (!live) ch = nch - 1;
     const int w = (int)(ch / nt);
@@ -880,76 +932,8 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
     const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * a.de_ld : nullptr;
     double *xrow = a.X + (size_t)ch * d;
     DrawBatch<STR> batch;
-    // SCAM-only cycle, one parameter group: the chain-scalar half of the proposal moves into the draw pass (ScamBatch)
-    constexpr bool SCAMFAST = !FULL && !GRP;
     ScamBatch<STR> sbatch;
-    // ULDS with the exact shape (4, 25) (ndim = 100): the table rows are stored in the lanes' order, 16-byte pieces dealt to
-    // the four lanes in turn (position 8 (e / 2) + 2 lane + e % 2 holds element lane + 4 e; the odd last slot at 96 + lane), so
-    // that a step reads its direction with 12 ds_read_b128 + 1 ds_read_b64 instead of 10 ds_read2_b64 + 6 ds_read_b64:
-    // 61 % of the LDS cycles of that kernel were bank conflicts of the 8-byte reads (profiles/r03_scam_lds.txt)
-    constexpr bool PAIRED = ULDS && G == 4 && EPL == 25;
-
-    constexpr int LD = mfma_ld(EPL);
-    const int tab_n = 4 * ((d + 3) / 4) * LD;                      // doubles of one zero-padded LDS table
-    const double *PtG = LOGL == PTMI_LOGL_DENSE ? a.logl_par + d + (size_t)d * d : nullptr;       // the half table Tl
-    // LDS pointers are derived from smem at their use so that they stay LDS (ds_read) accesses
-#define PTMI_PL (smem)
-#define PTMI_UL (smem + (LOGL == PTMI_LOGL_DENSE ? (size_t)tab_n : 0))
-    // FULL staged kernels: sqrt of the block's eigenvalues, behind the tables (d doubles)
-#define PTMI_SQ (smem + (size_t)tab_n * ((LOGL == PTMI_LOGL_DENSE ? 1 : 0) + ((UT_ALWAYS_LDS || a.lds_u) ? 1 : 0)))
-    // with the dense likelihood both tables may not fit: then Ut stays in global memory (host decides, a.lds_u)
-    constexpr bool UT_ALWAYS_LDS = LOGL != PTMI_LOGL_DENSE;
-    const double *UtBlock = Ut;
-    const double *const tsm = TM ? smem : nullptr;
-    if (TM) draw_table_fill(smem, a.tab_off, BLK);
-    if (STAGE) {
-        if (LOGL == PTMI_LOGL_DENSE) {
-            for (int i = (int)threadIdx.x; i < tab_n; i += BLK) {
-                const int r = i / LD, c = i % LD;
-                PTMI_PL[i] = (r < d && c < d) ? PtG[(size_t)r * d + c] : 0.0;
-            }
-        }
-        // FULL: all chains of the block belong to one walker (or the table is pooled; the host checks, launch_mh_k): the
-        // first chain's table serves the block.  SCAM-only cycles read one row per step from the chain's OWN table.
-        if (FULL) {
-            const long long ch0 = (long long)logical_block() * CPB;
-            const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
-            UtBlock = a.Ut + w0 * d * d;
-        }
-        if (FULL) {
-            const double *Sb = a.S + (size_t)((UtBlock - a.Ut) / ((size_t)d * d)) * d;     // the eigenvalues that go with UtBlock
-            for (int i = (int)threadIdx.x; i < d; i += BLK) PTMI_SQ[i] = det_sqrt(Sb[i]);
-        }
-        if (FULL && (UT_ALWAYS_LDS || a.lds_u)) {
-            for (int i = (int)threadIdx.x; i < tab_n; i += BLK) {
-                const int r = i / LD, c = i % LD;
-                PTMI_UL[i] = (r < d && c < d) ? UtBlock[(size_t)r * d + c] : 0.0;
-            }
-        }
-        __syncthreads();
-    }
-    // ULDS with a box prior: the bounds table takes the place of sqrt(S) (both do not fit twice per CU at d = 100)
-    const bool ulds_box = ULDS && !PERS && a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0 && a.box_off < d * d + d;
-    if (ULDS && !PERS) {
-        const long long ch0 = (long long)logical_block() * CPB;
-        const size_t w0 = a.per_walker ? (size_t)((ch0 < nch ? ch0 : nch - 1) / nt) : 0;
-        const double *src = a.Ut + w0 * d * d, *srcS = a.S + w0 * d;
-        if constexpr (PAIRED) {
-            for (int i = (int)threadIdx.x; i < d * d; i += BLK) {
-                const int r = i / d, c = i % d, ln = c & 3, e = c >> 2;
-                smem[r * d + (e < 2 * (EPL / 2) ? 8 * (e >> 1) + 2 * ln + (e & 1) : 8 * (EPL / 2) + ln)] = src[i];
-            }
-        } else {
-            for (int i = (int)threadIdx.x; i < d * d; i += BLK) smem[i] = src[i];
-        }
-        if (!ulds_box)
-            for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
-    }
-    if constexpr (PERS == 0) {
-        box_table_fill<G, EPL>(a, smem, BLK);
-        if (ULDS) draw_table_fill(smem, a.tab_off, BLK);
-        if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
-    }
+    const double *UtBlock = (STAGE && FULL) ? UtBlk : Ut;
 
     // ---- AM queue (staged full kernels).  An AM increment U (cd sqrt(S) z) does not depend on the chain's state, only on
     // its stream, the iteration and the scale branch -- all known from the draws -- and the matrix instruction computes 16
