@@ -309,6 +309,8 @@ def main():
     nchains_total = nt * world * W
     value = nchains_total * it_timed / wall
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    if os.environ.get("PTMI_BENCH_LAUNCHES"):                        # developer switch: every timed launch
+        log("launch ms: " + " ".join("%.3f" % e0.elapsed_time(e1) for e0, e1, _ in events))
     kern_steps = sum(n for _, _, n in events)
     avg_launch_ms = kern_ms / max(1, len(events))
     avg_steps = kern_steps / max(1, len(events))
