@@ -85,13 +85,16 @@ __global__ void swap_prepare_kernel(int W, int n, const double *ladder, const do
 #ifndef PTMI_SWEEP_BATCH
 #define PTMI_SWEEP_BATCH 8
 #endif
+// the AM-buffer row of a swap iteration (PT:624-627, 327-328): the state that sits at rank 0 after the sweep
+struct SwapAmRow { const double *X, *lnL, *lp; double *AM, *AMaux; int d, cov_update, am_epl; long long iter; };
 template <bool STG>
 __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n, const double *ladder, const SwapPre *pre,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
                                   int parity, int32_t *inv /* with map: inv[w][map[w][j]] = j */,
                                   int wpb /* walkers per block: 64, fewer when a long ladder's tables would not fit the LDS */,
                                   int hop_nt, int32_t *hop_flag /* hop_nt > 0 (STG, map form): set *hop_flag when a state moves beyond a
-                                                                 * neighbouring block of hop_nt ranks (ptmi_exchange_multihop) */)
+                                                                 * neighbouring block of hop_nt ranks (ptmi_exchange_multihop) */,
+                                  SwapAmRow amr /* STG, fused: the write-out also stores the swap iteration's AM row (am_write_kernel) */)
 {
     // STG blocks have four waves: the first runs the recurrence (a lane per walker), all four write the tables out
     extern __shared__ int32_t sw_lds[];
@@ -187,6 +190,34 @@ __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n
             }
         }
         if (hop_nt > 0 && __ballot(far) != 0 && lane == 0) atomicOr(hop_flag, 1);   // once per wave at most
+        if (amr.AM != nullptr) {
+            // the rows now at rank 0 into the AM ring (am_write_kernel's copy): the block's nw rows as one list of elements, six
+            // reads in flight per thread (a wave per walker waited for sixteen round trips in turn)
+            constexpr int NB = 6;
+            const int tot = nw * amr.d, ring = (int)(amr.iter % amr.cov_update);
+            for (int base = (int)threadIdx.x; base < tot; base += 256 * NB) {
+                double v[NB];
+                size_t dst[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int idx = base + 256 * u, ic = idx < tot ? idx : tot - 1;
+                    const int wl = ic / amr.d, i = ic % amr.d;
+                    const size_t r = (size_t)(w0 + wl) * n + (size_t)sw_lds[(size_t)wl * ld];
+                    v[u] = amr.X[r * amr.d + i];
+                    dst[u] = ((size_t)(w0 + wl) * amr.cov_update + (size_t)ring) * amr.d + (size_t)am_pos(i, amr.am_epl);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (base + 256 * u < tot) amr.AM[dst[u]] = v[u];
+            }
+            if (amr.AMaux)
+                for (int wl = (int)threadIdx.x; wl < nw; wl += 256) {
+                    const size_t r = (size_t)(w0 + wl) * n + (size_t)sw_lds[(size_t)wl * ld];
+                    const size_t arow = (size_t)(w0 + wl) * amr.cov_update + (size_t)ring;
+                    amr.AMaux[arow * 2] = amr.lnL[r];
+                    amr.AMaux[arow * 2 + 1] = amr.lp[r];
+                }
+        }
     }
 }
 
@@ -1400,9 +1431,12 @@ static int swap_parity(const ptmi_config &c, int64_t iter)
 }
 
 static int launch_swap_sweep(ptmi_engine *h, int W, int n, const SwapPre *pre, int32_t *slot_of, int32_t *temp_of,
-                             int32_t *map, u64 *nswap, int local0, int nlocal, int parity, int32_t *inv, int hop_nt = 0, bool *hop_done = nullptr)
+                             int32_t *map, u64 *nswap, int local0, int nlocal, int parity, int32_t *inv, int hop_nt = 0, bool *hop_done = nullptr,
+                             const SwapAmRow *amr = nullptr, bool *am_done = nullptr)
 {
     if (hop_done) *hop_done = false;
+    if (am_done) *am_done = false;
+    SwapAmRow none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0};
     int wpb = 64;                                                      // 2 tables of wpb x (n + 1) ints must fit the CU's LDS
     while (wpb > 8 && sizeof(int32_t) * (2 * (size_t)wpb * (size_t)(n + 1) + n) > 160 * 1024) wpb /= 2;
     const size_t lds = sizeof(int32_t) * (2 * (size_t)wpb * (size_t)(n + 1) + n);      // forward table, flags, block of a position
@@ -1415,11 +1449,13 @@ static int launch_swap_sweep(ptmi_engine *h, int W, int n, const SwapPre *pre, i
             HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
             if (hop_done) *hop_done = true;
         }
+        const bool with_am = amr != nullptr && slot_of != nullptr;
         hipLaunchKernelGGL(swap_sweep_kernel<true>, dim3((unsigned)((W + wpb - 1) / wpb)), dim3(256), lds, h->stream, W, n, h->d_ladder, pre,
-                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, wpb, hop_nt, h->d_hop);
+                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, wpb, hop_nt, h->d_hop, with_am ? *amr : none);
+        if (am_done) *am_done = with_am;
     } else {
         hipLaunchKernelGGL(swap_sweep_kernel<false>, dim3((unsigned)((W + 63) / 64)), dim3(64), 0, h->stream, W, n, h->d_ladder, pre,
-                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, 64, 0, (int32_t *)nullptr);
+                           slot_of, temp_of, map, nswap, local0, nlocal, parity, inv, 64, 0, (int32_t *)nullptr, none);
     }
     return PTMI_OK;
 }
@@ -1446,10 +1482,15 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
     hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps, h->d_ladder,
                        (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, (SwapPre *)h->d_pre,
                        (long long)iter, c.seed, c.walker0, 0);
+    // the sweep's write-out also stores the swap iteration's AM row (one kernel and one launch gap less per swap epoch)
+    const SwapAmRow amr = {(const double *)h->buf.X, (const double *)h->buf.lnL, (const double *)h->buf.lp, h->buf.AM, h->buf.AMaux,
+                           c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (long long)iter};
+    bool am_done = false;
     if (int rc = launch_swap_sweep(h, W, c.ntemps, (const SwapPre *)h->d_pre, h->buf.slot_of, h->buf.temp_of,
-                                   (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1, (int32_t *)nullptr)) return rc;
+                                   (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1, (int32_t *)nullptr, 0, nullptr,
+                                   (c.temp0 == 0 && h->buf.AM) ? &amr : nullptr, &am_done)) return rc;
     HIPCHK(hipGetLastError());
-    return ptmi_swap_write_am(h, iter);
+    return am_done ? PTMI_OK : ptmi_swap_write_am(h, iter);
 }
 
 int ptmi_swap_gather_lnl(ptmi_handle h, double *out)

@@ -916,7 +916,20 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
     // ---- the chains.  A block of 256 threads serves its 64 chains; a persistent block's waves walk over units of 16 chains on
     // their own (no barrier from here on)
     const long long nunits = (nch + 15) / 16, ustride = PERS ? (long long)gridDim.x * (BLK / 64) : nunits;
-    for (long long unit = PERS ? (long long)blockIdx.x * (BLK / 64) + wave : 0; unit < nunits; unit += ustride) {
+    // The unit that holds a walker's rank-0 chain stores an AM row per step and takes ~13 % longer; which of the walker's units
+    // that is changes with every swap.  The waves therefore walk over the units in an order that lists the W cold units first
+    // (position p < W: walker p's cold unit), then the others walker by walker: a wave's positions p, p + stride, ... hold the same
+    // number of cold units for every wave (two of eight at 64 x 4096), where the plain order gave it a binomial draw.
+    const int upw = nt / 16, upw1 = upw > 1 ? upw - 1 : 1;               // units per walker
+    const bool cold_first = PERS && a.AM != nullptr && a.temp0 == 0 && nt % 16 == 0;
+    for (long long upos = PERS ? (long long)blockIdx.x * (BLK / 64) + wave : 0; upos < nunits; upos += ustride) {
+    long long unit = upos;
+    if (cold_first) {
+        const long long r = upos - a.W;
+        const int wq = upos < a.W ? (int)upos : (int)(r / upw1);
+        const int cq = __builtin_amdgcn_readfirstlane(a.slot_of[(size_t)wq * nt]) >> 4;        // the unit of the walker's rank 0
+        unit = (long long)wq * upw + (upos < a.W ? cq : (cq + 1 + (int)(r % upw1)) % upw);
+    }
     long long ch = PERS ? unit * 16 + (STR ? (lane & 15) : (lane >> 2)) : (long long)logical_block() * CPB + cib;
     const bool live = ch < nch;
     if (!live) ch = nch - 1;
