@@ -364,6 +364,27 @@ def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior, pers, mon
     assert_same(g.get("Ut"), o.Ut, "Ut")
 
 
+@pytest.mark.parametrize("d,nt,W", [(100, 16, 37), (100, 32, 70), (100, 48, 19), (64, 64, 9), (100, 64, 130)])
+def test_persistent_kernel_cold_first_walk(mods, d, nt, W):
+    """The persistent SCAM kernel walks its units of 16 chains cold-first when a walker's ranks fill whole units (ntemps a
+    multiple of 16): position p < W of the order is walker p's cold unit (``slot_of[p][0] >> 4``: it moves with every swap), the
+    others follow walker by walker.  One, two, three and four units per walker, more units than the 2048 waves of a launch
+    (130 walkers x 4) and fewer; swaps every 7 iterations move the cold chain between the units; the AM ring (written by the
+    cold units and by the sweep's write-out at swap iterations) and the pooled covariance it feeds are compared bit for bit
+    (PTMCMCSampler.py:327-328, 624-627, 820-876)."""
+    orc, _lib, _ = mods
+    g, o = _pair(mods, d, nt, W, weights=(20, 0, 0), cov_update=30, burn=1000, tskip=7, seed=5 * d + nt, cov_mode="pooled",
+                 cov0=np.eye(d) * 0.02)
+    for n in (29, 40, 31):
+        g.run(n)
+        o.run(n)
+        flags, G, E = g.last_variant()
+        assert flags & _lib.VAR_PERSISTENT and flags & _lib.VAR_LDS_UT
+        _compare(g, o, "cold first d=%d nt=%d W=%d " % (d, nt, W))
+    assert_same(g.get("cov"), o.cov, "cov")
+    assert o.nswap[:, 0].sum() > 0                              # the cold chain did change places
+
+
 @pytest.mark.parametrize("d,nt,W,pick", [(130, 3, 7, "chain"), (300, 2, 5, "chain"), (417, 3, 3, "walker"), (640, 2, 3, "chain"), (1000, 3, 2, "chain")])
 def test_am_increments_ahead_of_the_launch_large_ndim(mods, d, nt, W, pick):
     """ndim > 104 with one pooled table: the AM increments U (cd sqrt(S) z) (PTMCMCSampler.py:879-933) of a piece of the launch
