@@ -53,6 +53,16 @@ def test_struct_layouts_match_the_header(lib):
     assert [lib.lanes_for(d, grad=True) for d in dims] == [lib.load().ptmi_lanes_for_grad(d) for d in dims]
 
 
+def test_variant_flags_match_the_header(lib):
+    """The PTMI_VAR_* flags the GPU tests assert on (which instantiation of the fused kernel ran) are the header's."""
+    hdr = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    flags = {n: int(v) for n, v in re.findall(r"\bPTMI_(VAR_[A-Z_]+)\s*=\s*(\d+)", hdr)}
+    assert len(flags) >= 11 and sorted(flags.values()) == [1 << k for k in range(len(flags))]      # distinct bits, none skipped
+    assert max(flags.values()) < 1 << 12                                                           # bits 12+ carry the shape
+    for n, v in flags.items():
+        assert getattr(lib, n) == v, n
+
+
 def test_no_cpu_fallback(lib):
     """Without a device the product path refuses to run instead of computing on the host."""
     import numpy as np
