@@ -43,29 +43,40 @@ struct __attribute__((aligned(16))) SwapPre {
     int32_t row, pad;    // the slot that holds the position (whole ladder local)
 };
 static_assert(sizeof(SwapPre) == 48, "three 16-byte loads");
-__global__ void swap_prepare_kernel(int W, int n, const double *ladder, const double *lnL_pos, const double *lnL_rows,
-                                    const int32_t *slot_of, SwapPre *pre, long long iter, u64 seed, int walker0,
-                                    int block_nt /* > 0: lnL_pos is [n / block_nt][W][block_nt], as all-gathered */)
+// what a record is made from
+struct SwapSrc {
+    const double *ladder, *lnL_pos, *lnL_rows;
+    const int32_t *slot_of;      // whole ladder local: the slot tables (else nullptr: lnL_pos holds the likelihoods by position)
+    long long iter;
+    u64 seed;
+    int walker0;
+    int block_nt;                // > 0: lnL_pos is [n / block_nt][W][block_nt], as all-gathered
+};
+__device__ __forceinline__ SwapPre swap_record(const SwapSrc &p, int W, int n, int k, int w)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)n * W) return;
-    const int k = (int)(idx / W), w = (int)(idx % W);
-    const bool fused = slot_of != nullptr;
-    const int row = fused ? slot_of[(size_t)w * n + k] : 0;
-    const double L = fused ? lnL_rows[(size_t)w * n + row]
-                   : (block_nt > 0 ? lnL_pos[((size_t)(k / block_nt) * W + w) * block_nt + k % block_nt] : lnL_pos[(size_t)w * n + k]);
+    const bool fused = p.slot_of != nullptr;
+    const int row = fused ? p.slot_of[(size_t)w * n + k] : 0;
+    const double L = fused ? p.lnL_rows[(size_t)w * n + row]
+                   : (p.block_nt > 0 ? p.lnL_pos[((size_t)(k / p.block_nt) * W + w) * p.block_nt + k % p.block_nt] : p.lnL_pos[(size_t)w * n + k]);
     double u = 0.0, b = 0.0, c = 0.0;
     if (k < n - 1) {
-        const u32 sid = (u32)((u64)(walker0 + w) * (u32)n + 0u);      // rank 0's stream (PT:679)
+        const u32 sid = (u32)((u64)(p.walker0 + w) * (u32)n + 0u);    // rank 0's stream (PT:679)
         u64 w0, w1;
-        philox_words(seed, (u64)iter, sid, SLOT_SWAP + (u32)k, w0, w1);
+        philox_words(p.seed, (u64)p.iter, sid, SLOT_SWAP + (u32)k, w0, w1);
         u = det_log(w2uniform(w0));                                   // log of the [0,1) uniform; -inf for u = 0: always accepted
-        b = L / ladder[k + 1];
+        b = L / p.ladder[k + 1];
     }
-    if (k > 0) c = L / ladder[k - 1];
+    if (k > 0) c = L / p.ladder[k - 1];
     SwapPre r;
-    r.lu = u; r.L = L; r.a = -L / ladder[k]; r.b = b; r.c = c; r.row = fused ? row : k; r.pad = 0;
-    pre[idx] = r;
+    r.lu = u; r.L = L; r.a = -L / p.ladder[k]; r.b = b; r.c = c; r.row = fused ? row : k; r.pad = 0;
+    return r;
+}
+__global__ void swap_prepare_kernel(int W, int n, SwapSrc src, SwapPre *pre)
+{
+    // grid (walkers, positions); the 2 M records of a 512-rank ladder are 100 MB: this kernel is bound by writing them
+    const int k = (int)blockIdx.y, w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= W) return;
+    pre[(size_t)k * W + (size_t)w] = swap_record(src, W, n, k, w);
 }
 
 // The recurrence of pair k (positions k, k+1; carried state of likelihood Lc at k+1) is the reference's four-term sum in
@@ -218,6 +229,149 @@ __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n
                     amr.AMaux[arow * 2 + 1] = amr.lp[r];
                 }
         }
+    }
+}
+
+// The sweep with its records made in the block (no scratch in memory: the 48-byte records of a 512-rank ladder are 100 MB
+// written and read back, 34 us of the 160 us a swap epoch takes on one of eight GPUs; with 64 ranks the prepare kernel and its
+// launch gap are a third of the epoch).  Blocks of 512 threads: wave 0 runs the recurrence as in swap_sweep_kernel<true>, six
+// of the others (not wave 4, which sits on the recurrence's SIMD) make the records of the batch after next (eight pairs) into a
+// three-slot LDS ring while it works through the current one and reads the next into its second register set; one barrier
+// per batch.  Same records, same recurrence, same write-out: bit-identical.
+constexpr int SWF_BLK = 512;
+__host__ __device__ inline size_t swf_ring_offset(int wpb, int n) { return ((sizeof(int32_t) * (2 * (size_t)wpb * (size_t)(n + 1) + (size_t)n)) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t swf_lds_bytes(int wpb, int n) { return swf_ring_offset(wpb, n) + sizeof(SwapPre) * (size_t)(3 * PTMI_SWEEP_BATCH + 1) * (size_t)wpb; }
+__global__ __launch_bounds__(SWF_BLK) void swap_fused_kernel(int W, int n, SwapSrc src, int32_t *slot_of, int32_t *temp_of, int32_t *map,
+                                                          u64 *nswap, int local0, int nlocal, int parity, int32_t *inv, int wpb, int wpb_log2,
+                                                          int hop_nt, int32_t *hop_flag, SwapAmRow amr)
+{
+    extern __shared__ int32_t sw_lds[];
+    constexpr int SW = PTMI_SWEEP_BATCH;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w0 = (int)blockIdx.x * wpb, w = w0 + lane;
+    const bool fused = slot_of != nullptr;
+    const int ld = n + 1;
+    int32_t *const fw = sw_lds + (size_t)lane * ld;                    // slot_of / map of this lane's walker
+    int32_t *const lf = sw_lds + (size_t)(wpb + lane) * ld;            // pair k accepted
+    int32_t *const blk = sw_lds + (size_t)2 * wpb * ld;
+    SwapPre *const ring = reinterpret_cast<SwapPre *>(reinterpret_cast<char *>(sw_lds) + swf_ring_offset(wpb, n));   // [3][SW][wpb]
+    SwapPre *const topr = ring + (size_t)3 * SW * wpb;                 // [wpb]: the records of position n - 1
+    const int NB = (n - 1 + SW - 1) / SW;                              // batches of the pairs n - 2 .. 0
+    auto produce = [&](int b, int t0, int nthr) {                      // batch b by the threads t0 .. t0 + nthr - 1
+        const int k0 = n - 2 - b * SW;
+        for (int idx = tid - t0; idx < SW * wpb; idx += nthr) {
+            const int j = idx >> wpb_log2, wl = idx & (wpb - 1), k = k0 - j;
+            if (k >= 0 && w0 + wl < W) ring[((size_t)(b % 3) * SW + j) * wpb + wl] = swap_record(src, W, n, k, w0 + wl);
+        }
+    };
+    for (int wl = tid; wl < wpb; wl += SWF_BLK)
+        if (w0 + wl < W) topr[wl] = swap_record(src, W, n, n - 1, w0 + wl);
+    if (NB > 0) produce(0, 0, SWF_BLK);
+    if (NB > 1) produce(1, 0, SWF_BLK);
+    if (hop_nt > 0)
+        for (int k = tid; k < n; k += SWF_BLK) blk[k] = k / hop_nt;
+    __syncthreads();
+    const bool chainer = wave == 0 && lane < wpb && w < W;
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);                      // the recurrence is the critical path of the block
+    int crow = 0;                          // what the forward table says about the state carried at k+1 (its slot, or its position)
+    double Lc = 0.0, q1 = 0.0, q0 = 0.0;   // its likelihood, Lc / T[k+1], Lc / T[k]
+    if (chainer) {
+        const SwapPre top = topr[lane];
+        crow = top.row; Lc = top.L; q1 = -top.a; q0 = top.c;
+    }
+    // The ring holds three batches: while the recurrence works through batch b out of one register set it reads batch b + 1
+    // (made during batch b - 1) into the other, and the makers fill the slot of batch b + 2 (last read during batch b - 2).
+    struct Batch { SwapPre R[SW]; double T[SW]; };
+    auto fetch = [&](int b, Batch &B) {
+        const int k0 = n - 2 - b * SW;
+        const SwapPre *rb = ring + (size_t)(b % 3) * SW * wpb + lane;
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            const int kk = k0 - j > 0 ? k0 - j : 0;
+            B.R[j] = rb[(size_t)(k0 - j >= 0 ? j : 0) * wpb];
+            B.T[j] = src.ladder[kk > 0 ? kk - 1 : 0];                  // T[k-1] (uniform: a scalar load)
+        }
+    };
+    auto chain = [&](int b, const Batch &B) {
+        const int k0 = n - 2 - b * SW;
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            const int k = k0 - j;
+            if (k < 0) break;
+            const double spec = Lc / B.T[j];     // Lc / T[k-1]: needed if this pair accepts; does not wait for its decision
+            double la = B.R[j].a;                // -L[k] / T[k]
+            la += -q1;                           // -Lc / T[k+1]
+            la += q0;                            //  Lc / T[k]
+            la += B.R[j].b;                      //  L[k] / T[k+1]
+            const bool acc = (parity < 0 || (k & 1) == parity) && B.R[j].lu <= la;     // log u <= sum
+            fw[k + 1] = acc ? B.R[j].row : crow; // position k+1 is final: it keeps the carried state, or takes position k's
+            lf[k] = acc ? 1 : 0;
+            q1 = acc ? q0 : -B.R[j].a;
+            q0 = acc ? spec : B.R[j].c;
+            Lc = acc ? Lc : B.R[j].L;
+            crow = acc ? crow : B.R[j].row;
+        }
+    };
+    auto turn = [&](int b, Batch &cur, Batch &nxt) {                   // one batch: every wave passes here, one barrier
+        if (wave == 0) {
+            if (chainer) {
+                if (b + 1 < NB) fetch(b + 1, nxt);
+                chain(b, cur);
+            }
+        } else if (wave != 4 && b + 2 < NB) {                          // wave 4 shares the recurrence's SIMD: it sits the batches out
+            produce(b + 2, wave < 4 ? 64 : 128, SWF_BLK - 128);
+        }
+        __syncthreads();
+    };
+    Batch A, B;
+    if (chainer && NB > 0) fetch(0, A);
+    for (int b = 0; b < NB; b += 2) {
+        turn(b, A, B);
+        if (b + 1 < NB) turn(b + 1, B, A);
+    }
+    if (chainer) fw[0] = crow;
+    __syncthreads();
+    // write-out: a wave per walker, the lanes along the position (as swap_sweep_kernel<true>)
+    int32_t *g0 = fused ? slot_of : map, *g1 = fused ? temp_of : inv;
+    const int nw = W - w0 < wpb ? W - w0 : wpb;
+    bool far = false;
+    for (int wl = wave; wl < nw; wl += SWF_BLK / 64) {
+        const size_t row = (size_t)(w0 + wl) * n;
+        for (int k = lane; k < n; k += 64) {
+            const int f = sw_lds[(size_t)wl * ld + k];
+            g0[row + k] = f;
+            g1[row + f] = k;                                           // the inverse table: a scatter inside the walker's own row
+            if (hop_nt > 0) { const int hop = blk[f] - blk[k]; far = far || hop > 1 || hop < -1; }
+            if (k < n - 1 && k >= local0 && k < local0 + nlocal && sw_lds[(size_t)(wpb + wl) * ld + k])
+                atomicAdd((unsigned long long *)&nswap[row + k], 1ull);
+        }
+    }
+    if (hop_nt > 0 && __ballot(far) != 0 && lane == 0) atomicOr(hop_flag, 1);   // once per wave at most
+    if (amr.AM != nullptr) {                                           // the rows now at rank 0 into the AM ring (as swap_sweep_kernel<true>)
+        constexpr int NB6 = 6;
+        const int tot = nw * amr.d, ringrow = (int)(amr.iter % amr.cov_update);
+        for (int base = tid; base < tot; base += SWF_BLK * NB6) {
+            double v[NB6];
+            size_t dst[NB6];
+#pragma unroll
+            for (int u = 0; u < NB6; ++u) {
+                const int idx = base + SWF_BLK * u, ic = idx < tot ? idx : tot - 1;
+                const int wl = ic / amr.d, i = ic % amr.d;
+                const size_t r = (size_t)(w0 + wl) * n + (size_t)sw_lds[(size_t)wl * ld];
+                v[u] = amr.X[r * amr.d + i];
+                dst[u] = ((size_t)(w0 + wl) * amr.cov_update + (size_t)ringrow) * amr.d + (size_t)am_pos(i, amr.am_epl);
+            }
+#pragma unroll
+            for (int u = 0; u < NB6; ++u)
+                if (base + SWF_BLK * u < tot) amr.AM[dst[u]] = v[u];
+        }
+        if (amr.AMaux)
+            for (int wl = tid; wl < nw; wl += SWF_BLK) {
+                const size_t r = (size_t)(w0 + wl) * n + (size_t)sw_lds[(size_t)wl * ld];
+                const size_t arow = (size_t)(w0 + wl) * amr.cov_update + (size_t)ringrow;
+                amr.AMaux[arow * 2] = amr.lnL[r];
+                amr.AMaux[arow * 2 + 1] = amr.lp[r];
+            }
     }
 }
 
@@ -1460,6 +1614,39 @@ static int launch_swap_sweep(ptmi_engine *h, int W, int n, const SwapPre *pre, i
     return PTMI_OK;
 }
 
+// The sweep with its records made in the block (swap_fused_kernel) when its tables and the ring fit the LDS; *used says whether it
+// was launched (else the caller runs swap_prepare_kernel + swap_sweep_kernel).  PTMI_SWAP_FUSED=0: the two-kernel form (a
+// measurement / test switch, same results).
+static int launch_swap_fused(ptmi_engine *h, int W, int n, const SwapSrc &src, int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap,
+                             int local0, int nlocal, int parity, int32_t *inv, int hop_nt, bool *hop_done, const SwapAmRow *amr, bool *am_done,
+                             bool *used)
+{
+    *used = false;
+    if (hop_done) *hop_done = false;
+    if (am_done) *am_done = false;
+    const char *sw = getenv("PTMI_SWAP_FUSED");                     // read per call: the tests switch it
+    if (sw && atoi(sw) == 0) return PTMI_OK;
+    int wpb = 64, lg = 6;
+    while (wpb > 8 && swf_lds_bytes(wpb, n) > 160 * 1024) { wpb /= 2; --lg; }
+    const size_t lds = swf_lds_bytes(wpb, n);
+    if (lds > 160 * 1024) return PTMI_OK;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)swap_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
+    }
+    if (hop_nt > 0) {                                              // the multi-hop scan rides on the write-out
+        HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
+        if (hop_done) *hop_done = true;
+    }
+    const SwapAmRow none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0};
+    const bool with_am = amr != nullptr && slot_of != nullptr;
+    hipLaunchKernelGGL(swap_fused_kernel, dim3((unsigned)((W + wpb - 1) / wpb)), dim3(SWF_BLK), lds, h->stream, W, n, src, slot_of, temp_of, map,
+                       nswap, local0, nlocal, parity, inv, wpb, lg, hop_nt, h->d_hop, with_am ? *amr : none);
+    if (am_done) *am_done = with_am;
+    *used = true;
+    return PTMI_OK;
+}
+
 int ptmi_swap(ptmi_handle h, int64_t iter)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
@@ -1468,7 +1655,6 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
     if (!h->buf.nswap) return fail(PTMI_EINVAL, "nswap buffer missing");
     if (c.ntemps < 2) return PTMI_OK;
     const int W = c.nwalkers;
-    const long long tot = (long long)W * c.ntemps;
     if (c.swap_mode == PTMI_SWAP_ODDEVEN) {
         const int parity = swap_parity(c, iter);
         const long long np = (long long)W * ((c.ntemps - parity) / 2);
@@ -1479,13 +1665,20 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
         HIPCHK(hipGetLastError());
         return ptmi_swap_write_am(h, iter);
     }
-    hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps, h->d_ladder,
-                       (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, (SwapPre *)h->d_pre,
-                       (long long)iter, c.seed, c.walker0, 0);
+    const SwapSrc src = {h->d_ladder, (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, (long long)iter, c.seed,
+                         c.walker0, 0};
     // the sweep's write-out also stores the swap iteration's AM row (one kernel and one launch gap less per swap epoch)
     const SwapAmRow amr = {(const double *)h->buf.X, (const double *)h->buf.lnL, (const double *)h->buf.lp, h->buf.AM, h->buf.AMaux,
                            c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (long long)iter};
-    bool am_done = false;
+    bool am_done = false, used = false;
+    if (int rc = launch_swap_fused(h, W, c.ntemps, src, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1,
+                                   (int32_t *)nullptr, 0, nullptr, (c.temp0 == 0 && h->buf.AM) ? &amr : nullptr, &am_done, &used)) return rc;
+    if (used) {
+        HIPCHK(hipGetLastError());
+        return am_done ? PTMI_OK : ptmi_swap_write_am(h, iter);
+    }
+    hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)c.ntemps), dim3(256), 0, h->stream, W, c.ntemps, src,
+                       (SwapPre *)h->d_pre);
     if (int rc = launch_swap_sweep(h, W, c.ntemps, (const SwapPre *)h->d_pre, h->buf.slot_of, h->buf.temp_of,
                                    (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1, (int32_t *)nullptr, 0, nullptr,
                                    (c.temp0 == 0 && h->buf.AM) ? &amr : nullptr, &am_done)) return rc;
@@ -1525,11 +1718,18 @@ static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t 
     if (!h->buf.nswap) return fail(PTMI_EINVAL, "nswap buffer missing");
     const ptmi_config &c = h->cfg;
     const int W = c.nwalkers;
-    const long long tot = (long long)W * c.ntemps_global;
     if (int rc = ensure_xint(h)) return rc;
-    hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, W, c.ntemps_global,
-                       h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, (SwapPre *)h->d_pre,
-                       (long long)iter, c.seed, c.walker0, block_nt);
+    const SwapSrc src = {h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, (long long)iter, c.seed, c.walker0, block_nt};
+    const int parity = c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1;
+    bool used = false;
+    if (int rc = launch_swap_fused(h, W, c.ntemps_global, src, (int32_t *)nullptr, (int32_t *)nullptr, map, (u64 *)h->buf.nswap, c.temp0, c.ntemps,
+                                   parity, h->d_xint /* inv[W][ntemps_global] */, block_nt, &h->hop_from_sweep, nullptr, nullptr, &used)) return rc;
+    if (used) {
+        HIPCHK(hipGetLastError());
+        return PTMI_OK;
+    }
+    hipLaunchKernelGGL(swap_prepare_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)c.ntemps_global), dim3(256), 0, h->stream, W, c.ntemps_global,
+                       src, (SwapPre *)h->d_pre);
     if (int rc = launch_swap_sweep(h, W, c.ntemps_global, (const SwapPre *)h->d_pre, (int32_t *)nullptr,
                                    (int32_t *)nullptr, map, (u64 *)h->buf.nswap, c.temp0, c.ntemps,
                                    c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1, h->d_xint /* inv[W][ntemps_global] */,
@@ -1640,16 +1840,20 @@ __global__ void exchange_pack_kernel(int W, int nt, int d, const double *X, cons
     for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) dst[i] = X[r * d + i];
     if (threadIdx.x == 0) { dst[d] = lnL[r]; dst[d + 1] = lp[r]; }
 }
+// a block per walker looks through the source GPUs (at most two of them sent a row): a block per (walker, GPU) was 32 768
+// blocks at eight GPUs, nearly all of which found nothing
 __global__ void exchange_apply_kernel(int W, int nt, int d, double *X, double *lnL, double *lp, const int32_t *arr_slot,
-                                      const double *recv)
+                                      const double *recv, int nranks)
 {
-    const int w = (int)blockIdx.x, q = (int)blockIdx.y;
-    const int slot = arr_slot[(size_t)q * W + w];
-    if (slot < 0) return;
-    const size_t r = (size_t)w * nt + slot;
-    const double *src = recv + ((size_t)q * W + w) * (d + 2);
-    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) X[r * d + i] = src[i];
-    if (threadIdx.x == 0) { lnL[r] = src[d]; lp[r] = src[d + 1]; }
+    const int w = (int)blockIdx.x;
+    for (int q = 0; q < nranks; ++q) {
+        const int slot = arr_slot[(size_t)q * W + w];
+        if (slot < 0) continue;
+        const size_t r = (size_t)w * nt + slot;
+        const double *src = recv + ((size_t)q * W + w) * (d + 2);
+        for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) X[r * d + i] = src[i];
+        if (threadIdx.x == 0) { lnL[r] = src[d]; lp[r] = src[d + 1]; }
+    }
 }
 
 
@@ -1703,8 +1907,8 @@ int ptmi_exchange_apply(ptmi_handle h, const double *recv)
     const ptmi_config &c = h->cfg;
     const int W = c.nwalkers, nr = c.ntemps_global / c.ntemps;
     const int32_t *arr = h->d_xint + (size_t)W * c.ntemps_global + (size_t)W * c.ntemps;
-    hipLaunchKernelGGL(exchange_apply_kernel, dim3(W, nr), dim3(64), 0, h->stream, W, c.ntemps, c.ndim, h->buf.X, h->buf.lnL,
-                       h->buf.lp, arr, recv);
+    hipLaunchKernelGGL(exchange_apply_kernel, dim3(W), dim3(64), 0, h->stream, W, c.ntemps, c.ndim, h->buf.X, h->buf.lnL,
+                       h->buf.lp, arr, recv, nr);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -364,6 +364,25 @@ def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior, pers, mon
     assert_same(g.get("Ut"), o.Ut, "Ut")
 
 
+@pytest.mark.parametrize("fusedsweep", [1, 0])
+@pytest.mark.parametrize("nt,W", [(2, 70), (3, 5), (9, 131), (10, 64), (17, 33), (64, 100), (130, 65), (257, 40), (300, 9), (520, 37)])
+def test_swap_sweep_with_records_made_in_the_block(mods, nt, W, fusedsweep, monkeypatch):
+    """PTswap (PTMCMCSampler.py:631-697) by swap_fused_kernel -- the records of a batch of eight pairs made by the block's other
+    waves while wave 0 runs the hot -> cold recurrence on the previous batch -- and by the two-kernel form (PTMI_SWAP_FUSED=0:
+    swap_prepare_kernel + swap_sweep_kernel, which very long ladders keep): ladders whose pair count is and is not a multiple
+    of the batch, fewer pairs than one batch, walkers that do and do not fill the block (64 / 32 / 16 walkers per block as the
+    ladder grows), the swap iteration's AM row stored by the write-out.  Every table, counter and AM row against the oracle."""
+    orc, _lib, _ = mods
+    monkeypatch.setenv("PTMI_SWAP_FUSED", str(fusedsweep))
+    d = 3
+    g, o = _pair(mods, d, nt, W, weights=(20, 20, 0), cov_update=16, burn=1000, tskip=3, seed=17 * nt + W)
+    for n in (7, 12, 17):
+        g.run(n)
+        o.run(n)
+        _compare(g, o, "sweep nt=%d W=%d fused=%d " % (nt, W, fusedsweep))
+    assert o.nswap.sum() > 0 and g.swap_proposed == 12
+
+
 @pytest.mark.parametrize("d,nt,W", [(100, 16, 37), (100, 32, 70), (100, 48, 19), (64, 64, 9), (100, 64, 130)])
 def test_persistent_kernel_cold_first_walk(mods, d, nt, W):
     """The persistent SCAM kernel walks its units of 16 chains cold-first when a walker's ranks fill whole units (ntemps a
