@@ -239,7 +239,9 @@ int ptmi_exchange_status(ptmi_handle h, int32_t *violations);
 /* After ptmi_exchange_pack: 1 if some row of the sweep moves further than to a neighbouring block (possible only when the
  * carried state wins every pair of a whole block), else 0 -- the same answer on every GPU, computed from the global map.
  * With 0 only send[rank-1] and send[rank+1] hold rows: the caller exchanges those two segments with its neighbours
- * (RCCL send/recv over one xGMI link each way) and skips the all-to-all.  Synchronises the stream (4 bytes come back). */
+ * (RCCL send/recv over one xGMI link each way) and skips the all-to-all.  The four bytes set out for (pinned) host memory at
+ * the end of ptmi_exchange_pack; this call waits for THEM only (an event recorded behind the copy), not for the stream: work the
+ * caller queued behind the pack step -- the neighbour exchange, which every epoch needs -- runs meanwhile. */
 int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag);
 
 /* _updateRecursive (:769-794) for every walker at iteration `iter` (= the multiple of

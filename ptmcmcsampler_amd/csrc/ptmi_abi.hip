@@ -1439,6 +1439,7 @@ int ptmi_destroy(ptmi_handle h)
     if (!h) return PTMI_OK;
     (void)hipFree(h->d_ladder); (void)hipFree(h->d_temps); (void)hipFree(h->d_beta); (void)hipFree(h->d_loglpar); (void)hipFree(h->d_logppar);
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
+    if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
@@ -1709,6 +1710,9 @@ static int ensure_xint(ptmi_engine *h)
     HIPCHK(hipMemsetAsync(h->d_xint, 0, sizeof(int32_t) * xint_count(h->cfg), h->stream));
     HIPCHK(hipMalloc((void **)&h->d_hop, sizeof(int32_t)));
     HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipHostMalloc((void **)&h->h_hop, sizeof(int32_t), hipHostMallocDefault));
+    *h->h_hop = 0;
+    HIPCHK(hipEventCreateWithFlags(&h->hop_ev, hipEventDisableTiming));
     return PTMI_OK;
 }
 
@@ -1889,6 +1893,11 @@ int ptmi_exchange_pack(ptmi_handle h, const int32_t *map, double *send)
     }
     h->hop_from_sweep = false;
     HIPCHK(hipGetLastError());
+    // the flag sets out for the host now, with an event of its own: ptmi_exchange_multihop waits for these four bytes, not for
+    // whatever the caller has queued behind the pack step in the meantime (the neighbour exchange)
+    HIPCHK(hipMemcpyAsync(h->h_hop, h->d_hop, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->hop_ev, h->stream));
+    h->hop_pending = true;
     return PTMI_OK;
 }
 int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag)
@@ -1896,8 +1905,11 @@ int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag)
     if (!h || !flag) return fail(PTMI_EINVAL, "NULL argument");
     *flag = 0;
     if (!h->d_hop) return PTMI_OK;
-    HIPCHK(hipMemcpyAsync(flag, h->d_hop, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->hop_pending) {
+        HIPCHK(hipEventSynchronize(h->hop_ev));
+        h->hop_pending = false;
+    }
+    *flag = *h->h_hop;
     return PTMI_OK;
 }
 int ptmi_exchange_apply(ptmi_handle h, const double *recv)

@@ -104,6 +104,9 @@ struct ptmi_engine {
     void *d_pre;        // [ntg][W] records of the swap (log uniform, likelihood, own-likelihood quotients, row: swap_prepare_kernel)
     int32_t *d_hop;     // set when a row of the last sweep travels beyond a neighbouring block (by the sweep's write-out, else by ptmi_exchange_pack)
     bool hop_from_sweep;
+    int32_t *h_hop;     // pinned host copy of the flag, requested behind ptmi_exchange_pack; hop_ev marks its arrival
+    hipEvent_t hop_ev;
+    bool hop_pending;
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
     int32_t *d_gj_order, *d_gj_bucket;         // launch order of the chains ([nch]) and its counting-sort scratch ([3][GJ_BUCKETS])

@@ -139,7 +139,8 @@ class ShardedPTEngine(object):
         self.rows_moved = 0
         self.neighbour_swaps = 0                                                 # swap epochs served by the two neighbour links alone
         # device-side exchange (HIP engines): fixed [world][W][d+2] buffers; the plan, the packing and the apply step need no host
-        # round trip -- the ONE host synchronisation per swap epoch is the 4-byte multi-hop flag that picks the transport (swap())
+        # round trip -- the ONE host wait per swap epoch is for the 4-byte multi-hop flag (an event behind the pack step, not a stream
+        # synchronisation: the neighbour exchange is already queued when the host waits, swap())
         self.device_exchange = hasattr(L, "exchange_pack")
         if self.device_exchange:
             self._send = torch.zeros((self.world, self.W, self.d + 2), dtype=torch.float64, device=self.device)
@@ -175,8 +176,14 @@ class ShardedPTEngine(object):
             L.exchange_pack(self._map, self._send)                            # tables rewritten, leaving rows packed
             # A sweep moves a walker's rows between NEIGHBOURING blocks unless its carried state wins every pair of a
             # whole block: then (and only then) the all-to-all is needed; every rank reads the same flag off the map.
-            if hasattr(self.comm, "neighbour_exchange") and not L.exchange_multihop():
+            # The neighbour exchange is queued BEFORE the flag is read: every epoch needs it, and the four bytes (requested
+            # behind the pack step with their own event) arrive while it runs -- the host decides with the GPU still busy,
+            # and the launches that follow are queued before the stream runs dry.  In the rare multi-hop epoch the
+            # all-to-all then delivers every segment, the two edge ones again (same rows).
+            neighbour = hasattr(self.comm, "neighbour_exchange")
+            if neighbour:
                 self.comm.neighbour_exchange(self._send, self._recv)
+            if neighbour and not L.exchange_multihop():
                 self.neighbour_swaps += 1
             else:
                 self.comm.all_to_all(self._recv, self._send)                  # equal splits: send[q] -> rank q
