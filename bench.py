@@ -63,6 +63,9 @@ def parse():
                     help="evaluate the likelihood in a batched torch callback between ptmi_propose and ptmi_accept (one launch pair per "
                          "iteration) instead of inside the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat", type=float, default=0.2,
+                    help="seconds of unrelated f64 matrix products before the warmup steps, so that the timed steps run at the clocks "
+                         "of a long run (0 = from cold clocks)")
     ap.add_argument("--cpu-iters", type=int, default=100000, help="iterations per usable host core of the CPU baseline (10-30 s)")
     ap.add_argument("--ess-walkers", type=int, default=16, help="walkers whose T=1 chains the autocorrelation time is estimated from")
     ap.add_argument("--ess-burn", type=int, default=40000, help="the ESS window starts at this iteration at the earliest (adaptation settled)")
@@ -218,6 +221,18 @@ def main():
             torch.cuda.synchronize()
 
     it_warm, it_timed = a.warmup * TSKIP, a.steps * TSKIP
+    if a.preheat > 0:
+        # The part's clocks need tens of milliseconds of load to come up from idle; a bench step is ONE millisecond, so --warmup 5
+        # ends while they still ramp (measured: the first timed launches at 0.89 ms against 0.79 with the clocks up, 7 % of a
+        # 20-step wall).  Unrelated f64 work brings them up BEFORE the W warmup steps; the engine's state, the W warmup steps and
+        # the K timed steps are untouched.  --preheat 0 measures from cold clocks.
+        hm = torch.randn(2048, 2048, dtype=torch.float64, device="cuda")
+        t_h = time.perf_counter()
+        while time.perf_counter() - t_h < a.preheat:
+            for _ in range(8):
+                hm @ hm
+            torch.cuda.synchronize()
+        del hm
     eng.run(it_warm)
     fence()
     log("warmup done (%d iterations)" % it_warm)
@@ -324,7 +339,7 @@ def main():
         "metric": "MH updates/sec (whole node) + ESS/sec, 100-d Gaussian, 64 temps x 4096 walkers per GPU",
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic", "preheat_s": a.preheat,
         "config": {"workload": "BASELINE configs[%d]: %d-d %s logl%s, %d temps x %d walkers per GPU, %s cycle (pick per %s), "
                                "Tskip=100 (%s), covUpdate=1000, cov_mode=%s; one step = 100 MH iterations of every chain + the PT swap "
                                "(+ a covariance epoch every 10 steps)" % (
