@@ -269,6 +269,26 @@ class PTEngine(object):
             U, S = factorize(cov[np.ix_(g, g)] if self.ngr > 1 or len(g) != self.d else cov, self.per_walker)
             self.put_eig(U, S, w, gi)
 
+    def _eig_host_pooled(self):
+        """The pooled covariance's factorization on the host (factorize(), the same bits as _eig_host) with the GPU idle for as
+        short as possible: the matrix comes down into pinned memory, the eigenvector rows and eigenvalues go up from pinned
+        memory, one wait in all (the download's); the uploads are queued and the next launch behind them."""
+        torch = _torch()
+        d = self.d
+        if getattr(self, "_pin", None) is None:
+            self._pin = (torch.empty((d, d), dtype=torch.float64).pin_memory(), torch.empty((d, d), dtype=torch.float64).pin_memory(),
+                         torch.empty(d, dtype=torch.float64).pin_memory(), torch.cuda.Event())
+        cov_h, ut_h, s_h, ev = self._pin
+        with torch.cuda.stream(self.stream):
+            cov_h.copy_(self.t["cov"][0], non_blocking=True)
+            ev.record(self.stream)
+            ev.synchronize()
+            U, S = factorize(cov_h.numpy(), False)
+            np.copyto(ut_h.numpy(), U.T)
+            np.copyto(s_h.numpy(), S)
+            self.t["Ut"][0, 0].copy_(ut_h, non_blocking=True)
+            self.t["S"][0, 0].copy_(s_h, non_blocking=True)
+
     def _eig_hipsolver(self):
         """U, S of every covariance the engine holds by the ROCm library's symmetric eigensolver, on the stream (factorize()'s
         pooled rule: eigenvalues by decreasing size and in absolute value, eigenvectors as the rows of Ut)."""
@@ -365,11 +385,12 @@ class PTEngine(object):
             self._eig_hipsolver()
             self.eig_epochs += 1
             return
-        cov = self.get("cov")
-        if self.Wc == 1:
-            self._eig_host(0, cov[0])
+        if self.Wc == 1 and not self.per_walker and self.ngr == 1 and len(self.groups[0]) == self.d:
+            self._eig_host_pooled()
+        elif self.Wc == 1:
+            self._eig_host(0, self.get("cov")[0])
         else:
-            self._eig_host_all(cov)
+            self._eig_host_all(self.get("cov"))
         self.eig_epochs += 1
 
     def update_de(self):
