@@ -13,6 +13,7 @@ def main():
                      "from kernels group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows) or 1
     out.append("# kernel-trace summary of %s" % db.split("/")[-1])
+    out.append("# (a Cijk_* row of several hundred calls of about 0.25 ms = bench.py's --preheat matrix products: before the warmup steps, outside the timed region)")
     out.append("%-86s %7s %14s %14s %12s %12s %6s" % ("Name", "Calls", "TotalNs", "AvgNs", "MinNs", "MaxNs", "Pct"))
     for n, k, t, a, mn, mx in rows:
         out.append("%-86s %7d %14d %14.0f %12d %12d %6.2f" % (n[:86], k, t, a, mn, mx, 100.0 * t / tot))
