@@ -1,6 +1,6 @@
 """Builds libptmi.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-The per-chain kernel templates are compiled once per shape (ptmi_shape.hip with -DPTMI_G/-DPTMI_E/-DPTMI_L), all
+The per-chain kernel templates are compiled per shape, likelihood family and part (ptmi_shape.hip with -DPTMI_G/-DPTMI_E/-DPTMI_L/-DPTMI_PART), all
 translation units in parallel, then linked into one shared library."""
 import concurrent.futures
 import os
@@ -63,9 +63,15 @@ def build(force=False, verbose=False, jobs=None):
             # the iso / dense step kernels sit at the register limit of their occupancy: with LLVM's AMDGPU register-pressure
             # trackers the scheduler spills 20 instead of 96 bytes in the config-2 kernel (1.107 -> 1.072 ms per 100 steps,
             # dense 12.8 -> 12.5); the curved family (gradient jumps) measured 1.5 % slower with them and keeps the default
-            sched = ["-mllvm", "-amdgpu-use-amdgpu-trackers"] if fam != 2 else []
-            work.append((os.path.join(CSRC, "ptmi_shape.hip"), os.path.join(OBJ, "shape_%d_%d_%d.o" % (g, e, fam)),
-                         ["-DPTMI_G=%d" % g, "-DPTMI_E=%d" % e, "-DPTMI_L=%d" % fam] + sched))
+            # + the max-ILP scheduling strategy for the kernels of SCAM-only cycles of the same two families (part 0 of a shape:
+            # config-2 kernel 0.797 -> 0.782 ms per 100 steps, dense 5.81 -> 5.72); the kernels of cycles with AM / DE entries
+            # (part 1) measured 1-2 % slower with it and keep the default strategy.  max-memory-clause, metric bias 0, relaxed
+            # occupancy and no post-RA scheduling measured within 0.5 % of the default or worse.  PTMI_NO_ILP=1: an A/B build without it.
+            track = ["-mllvm", "-amdgpu-use-amdgpu-trackers"] if fam != 2 else []
+            ilp = [] if os.environ.get("PTMI_NO_ILP") else (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if fam != 2 else [])
+            defs = ["-DPTMI_G=%d" % g, "-DPTMI_E=%d" % e, "-DPTMI_L=%d" % fam]
+            work.append((os.path.join(CSRC, "ptmi_shape.hip"), os.path.join(OBJ, "shape_%d_%d_%d.o" % (g, e, fam)), defs + ["-DPTMI_PART=0"] + track + ilp))
+            work.append((os.path.join(CSRC, "ptmi_shape.hip"), os.path.join(OBJ, "shape_full_%d_%d_%d.o" % (g, e, fam)), defs + ["-DPTMI_PART=1"] + track))
     jobs = jobs or min(len(work), os.cpu_count() or 1)
     if verbose:
         print("compiling %d translation units with %d workers" % (len(work), jobs))

@@ -1635,8 +1635,3 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
     h->last_variant = (FULL ? PTMI_VAR_FULL : 0) | (c.ngroups > 1 ? PTMI_VAR_GROUPS : 0) | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
     return PTMI_OK;
 }
-template <int G, int EPL, int LOGL>
-static int launch_mh_l(ptmi_engine *h, KArgs &a, int grid, bool full)
-{
-    return full ? launch_mh_k<G, EPL, LOGL, true>(h, a, grid) : launch_mh_k<G, EPL, LOGL, false>(h, a, grid);
-}

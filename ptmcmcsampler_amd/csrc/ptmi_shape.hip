@@ -1,18 +1,30 @@
-// ptmi_shape.hip -- one kernel shape per translation unit: compile with -DPTMI_G=<lanes> -DPTMI_E=<slots>.
+// ptmi_shape.hip -- one kernel shape per translation unit: compile with -DPTMI_G=<lanes> -DPTMI_E=<slots> -DPTMI_L=<family>
+// -DPTMI_PART=<0|1>.  Part 1 holds the step kernels of cycles with AM / DE entries (FULL) and nothing else, part 0 everything
+// else of the shape: the two parts are built with different scheduler options (_build.py).
 #include "ptmi_mh.inc.h"
 #include "ptmi_gj.inc.h"
 
 #if !defined(PTMI_G) || !defined(PTMI_E) || !defined(PTMI_L)
 #error "compile with -DPTMI_G=<lanes per chain> -DPTMI_E=<register slots per lane> -DPTMI_L=<likelihood family>"
 #endif
+#ifndef PTMI_PART
+#error "compile with -DPTMI_PART=<0|1>"
+#endif
 #define PTMI_CAT_(a, b, c) ptmi_shape_##a##_##b##_##c
 #define PTMI_CAT(a, b, c) PTMI_CAT_(a, b, c)
+#define PTMI_CATF_(a, b, c) ptmi_shape_full_##a##_##b##_##c
+#define PTMI_CATF(a, b, c) PTMI_CATF_(a, b, c)
+
+#if PTMI_PART == 1
+int PTMI_CATF(PTMI_G, PTMI_E, PTMI_L)(ptmi_engine *h, KArgs &a, int grid) { return launch_mh_k<PTMI_G, PTMI_E, PTMI_L, true>(h, a, grid); }
+#else
+int PTMI_CATF(PTMI_G, PTMI_E, PTMI_L)(ptmi_engine *h, KArgs &a, int grid);
 
 int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid, bool full)
 {
     constexpr int G = PTMI_G, E = PTMI_E, L = PTMI_L;
     switch (op) {
-    case PTMI_OP_MH: return launch_mh_l<G, E, L>(h, a, grid, full);
+    case PTMI_OP_MH: return full ? PTMI_CATF(PTMI_G, PTMI_E, PTMI_L)(h, a, grid) : launch_mh_k<G, E, L, false>(h, a, grid);
     case PTMI_OP_EVAL: hipLaunchKernelGGL((eval_state_kernel<G, E, L>), dim3(grid), dim3(256), 0, h->stream, a); return PTMI_OK;
 #if PTMI_L == 0
     case PTMI_OP_PROPOSE:
@@ -63,3 +75,4 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
     }
     return fail(PTMI_EINVAL, "unknown shape op %d", op);
 }
+#endif
