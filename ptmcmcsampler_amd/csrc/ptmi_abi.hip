@@ -662,10 +662,18 @@ __global__ void pool_reduce_kernel(const double *part, int nslab, int d, double 
     if (idx >= (long long)d * ld) return;
     const int i = (int)(idx / ld), j = (int)(idx % ld);
     if (j < i) return;
-    // eight slabs' values requested at once (the sums stay in slab order)
+    // 32 slabs' values requested at once (the sums stay in slab order): ten thousand threads walk 512 partials each, the kernel is
+    // the latency of its loads
     const size_t st = (size_t)d * ld;
     double sum = 0.0;
     int s = 0;
+    for (; s + 32 <= nslab; s += 32) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = part[(size_t)(s + u) * st + idx];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) sum += v[u];
+    }
     for (; s + 8 <= nslab; s += 8) {
         double v[8];
 #pragma unroll
@@ -1964,7 +1972,7 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
             hipLaunchKernelGGL(pool_syrk_kernel<false>, dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
                                shift, (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
         const long long nel = (long long)d * (d + 1);
-        hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->d_pool_part, nslab, d,
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)((nel + 63) / 64)), dim3(64), 0, h->stream, (const double *)h->d_pool_part, nslab, d,
                            h->d_pool_T);
         const double nb = (double)W * (double)c.cov_update, nprev = (double)W * (double)(iter - c.cov_update);
         hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)(((long long)d * d + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->d_pool_T,
