@@ -1451,6 +1451,7 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
+    if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->side_go); (void)hipEventDestroy(h->side_done); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -1966,11 +1967,28 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
         const long long nrows = (long long)W * c.cov_update;
         const bool first = iter == c.cov_update;
         const double *shift = first ? (const double *)h->buf.AM : (const double *)h->buf.mu;     // the first epoch: walker 0's row 0
-        hipLaunchKernelGGL(pool_syrk_kernel<true>, dim3(nslab, ng), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d, shift,
-                           (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
-        if (ng > 1)
+        // Several macro tiles per side: the diagonal ones (nslab x ng blocks, half a round of the chip) go to a side stream and
+        // fill the last, partly empty round of the off-diagonal ones instead of a launch of their own behind them
+        // (1000-d, 512 walkers: 288 blocks beside 1152 with 512 resident at a time).
+        hipStream_t diag_stream = h->stream;
+        if (ng > 1) {
+            if (!h->side) {
+                HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->side_go, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(h->side_go, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->side, h->side_go, 0));
             hipLaunchKernelGGL(pool_syrk_kernel<false>, dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
                                shift, (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
+            diag_stream = h->side;
+        }
+        hipLaunchKernelGGL(pool_syrk_kernel<true>, dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
+                           (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
+        if (ng > 1) {
+            HIPCHK(hipEventRecord(h->side_done, h->side));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->side_done, 0));
+        }
         const long long nel = (long long)d * (d + 1);
         hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)((nel + 63) / 64)), dim3(64), 0, h->stream, (const double *)h->d_pool_part, nslab, d,
                            h->d_pool_T);

@@ -122,6 +122,8 @@ struct ptmi_engine {
     int de_on, de_head;
     int last_variant;   // PTMI_VAR_* flags of the most recent fused-MH launch (ptmi_last_mh_variant)
     hipEvent_t ev0, ev1;
+    hipStream_t side;            // pooled statistics at ndim > 111: the diagonal macro tiles run beside the off-diagonal ones
+    hipEvent_t side_go, side_done;
 };
 
 
