@@ -1638,7 +1638,7 @@ static int launch_swap_fused(ptmi_engine *h, int W, int n, const SwapSrc &src, i
     if (sw && atoi(sw) == 0) return PTMI_OK;
     // walkers per block: 16 puts the 4096 walkers of config 2 on every CU (64 per block ran on 64 CUs: 31 -> 24 us per swap epoch
     // at 64 ranks; 8 starve the producers: 38); long ladders are cut further by the LDS their tables need.  PTMI_SWF_WPB: a measurement switch
-    int wpb = 64, lg = 6, want = 16;
+    int wpb = 64, lg = 6, want = n <= 128 ? 16 : 32;               // 256 ranks: 94 us with 32 or 64, 104 with 16
     if (const char *wv = getenv("PTMI_SWF_WPB")) want = atoi(wv);
     while (wpb > 8 && wpb > want) { wpb /= 2; --lg; }
     while (wpb > 8 && swf_lds_bytes(wpb, n) > 160 * 1024) { wpb /= 2; --lg; }
