@@ -356,7 +356,10 @@ def main():
                      "traffic": None, "kernel": kernel, "avg_launch_ms": avg_launch_ms, "steps_per_launch": avg_steps,
                      "algorithmic_flops_per_update": flops_per_update, "algorithmic_bytes_per_update": bytes_per_update,
                      "algorithmic_hbm_gbs": hbm_view, "algorithmic_hbm_ratio": hbm_view / HBM_PEAK_GBS,
-                     "kernel_time_share_of_wall": kern_ms * 1e-3 / wall},
+                     "kernel_time_share_of_wall": kern_ms * 1e-3 / wall,
+                     # the timed launches in order: first and last (a ramp between them = clocks or adaptation still moving)
+                     "launch_ms_first": events[0][0].elapsed_time(events[0][1]) if events else None,
+                     "launch_ms_last": events[-1][0].elapsed_time(events[-1][1]) if events else None},
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
     # summary is per launch of 100 steps on one named workload
