@@ -1201,6 +1201,8 @@ static int set_step_args(const ptmi_engine *h, KArgs *a)
 {
     const ptmi_config &c = h->cfg;
     a->am_row0 = (int)(a->iter0 % c.cov_update);
+    static const bool am_small = getenv("PTMI_MEASURE_AM_SMALL") != nullptr;   // MEASUREMENT ONLY (results are wrong): every AM row of a walker into ONE cache-resident row
+    if (am_small) { a->cov_update = 1; a->am_row0 = 0; }
     a->swap_last = 0;
     if (c.tskip > 0 && c.ntemps_global > 1) {
         const long long last = a->iter0 + a->nsteps - 1;

@@ -1126,6 +1126,11 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         // wave of every block, are 15 % of the config-2 kernel (0.90 -> 0.77 ms without them, PTMI_MEASURE_NO_AM): the wave is its
         // block's straggler.  Sending the row through LDS and out as two coalesced stores of the whole wave was built twice -- stored
         // in the same step, and one step late so that no wait sits on the critical path -- and measured slower both times (1.00 ms).
+        // Round 3 (persistent blocks, cold-first walk): 0.783 ms with the stores, 0.751 with every row of a walker sent to ONE
+        // cache-resident row (PTMI_MEASURE_AM_SMALL), 0.697 without them.  Units of 16 rank-0 chains of 16 different walkers -- the
+        // same rows as 13 stores of a FULL wave in one unit of 64 instead of 13 four-lane stores in one unit of four -- measured
+        // 0.780 against 0.778: the cost is the bytes through the CU's store path (1.28 MB per CU and launch) and the scattered
+        // 64-byte writes behind it, not the issue slots of the instructions.
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
             double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
             am_store_row<G, EPL>(am, x, gl, d);
