@@ -119,6 +119,7 @@ class ColdSamples(object):
 
     def snap(self, it_done):
         if self.nw:
+            self.eng.am_expand(0, self.nw, it_hi=it_done)             # AM records -> rows for the walkers kept (a no-op with stored rows)
             self.snaps.append((it_done, self.eng.t["AM"][:self.nw].clone()))
 
     def series(self, first, last):
@@ -376,16 +377,26 @@ def main():
                                                + ", ".join(tr["source"]))
             out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_update * upd_per_launch
             break
-    if a.logl == "dense":
-        # config 3: the dense contraction bounds the kernel: 2d^2+3d flop per likelihood, +2d^2 per AM proposal
-        # the likelihood is summed over half of the symmetric precision matrix: d^2 + 3d flop executed per evaluation (SURVEY's
+    # cycles with AM entries pay 2 d^2 flop per AM proposal on the matrix cores ("+2d^2 per AM proposal"), whatever the
+    # likelihood: the share of AM picks is w_am / sum(w) over the entries that are in the cycle during the timed region (DE joins
+    # it after `burn` iterations)
+    w_on = [weights[0], weights[1], weights[2] if getattr(eng, "de_on", False) else 0]
+    f_am = (w_on[1] / float(sum(w_on))) if (len(weights) == 3 and sum(w_on) > 0 and a.mix != "nuts") else 0.0
+    if a.logl == "dense" or f_am > 0:
+        # config 3: the dense contraction bounds the kernel: 2d^2+3d flop per likelihood, +2d^2 per AM proposal.
+        # The likelihood is summed over half of the symmetric precision matrix: d^2 + 3d flop executed per evaluation (SURVEY's
         # 2d^2 + 3d prices the full product)
-        flops = d * d + 3 * d + (2 * d * d * weights[1] / float(sum(weights)) if weights[1] else 0.0)
+        base = (d * d + 3 * d) if a.logl == "dense" else flops_per_update
+        flops = base + 2 * d * d * f_am
         tfd = flops * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12
         out["roofline"].update({"bound": "mfma", "achieved": tfd, "frac": tfd / F64_PEAK_TFLOPS, "algorithmic_flops_per_update": flops,
-                                "flops_note": "executed flops: the quadratic form over half of the symmetric precision matrix (d^2 + 3d), "
-                                              "+ 2d^2 per AM proposal; the full-matrix count 2d^2 + 3d would read %.3f of peak" % (
-                                                  (2 * d * d + 3 * d + flops - d * d - 3 * d) * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS)})
+                                "am_pick_share": f_am,
+                                "flops_note": ("executed flops per update: %s + 2d^2 x the share of AM picks (%.3f)" % (
+                                    "the quadratic form over half of the symmetric precision matrix (d^2 + 3d)" if a.logl == "dense"
+                                    else "4d (proposal + isotropic likelihood)", f_am))})
+        if a.logl == "dense":
+            out["roofline"]["flops_note"] += "; the full-matrix count 2d^2 + 3d would read %.3f of peak" % (
+                (flops + d * d) * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS)
     if rank == 0:
         acc = eng.get("nacc").astype(np.float64)
         out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / max(1, eng.iter))        # over the whole run, ESS leg included

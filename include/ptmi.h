@@ -143,6 +143,14 @@ typedef struct ptmi_buffers {
     double *gj;         /* [W][T][8]   by RANK: the attributes of a rank's NUTSJump / HMCJump object (nutsjump.py:379-433):
                          *              epsilon, mu, Hbar, epsilonbar (starts at 1), NUTS calls, HMC calls, have-epsilon flag, leapfrogs taken so far
                          *              (needed with w_nuts + w_hmc > 0) */
+    void *AMrec;        /* [W][cov_update] 16-byte records beside the AM rows (optional; ptmi_am_records_ok): {double amp; uint64 meta},
+                         *              meta = direction k | accepted << 32 | KEY << 33.  With it the step kernels of SCAM-only cycles store
+                         *              the rank-0 chain's row (updateChains, :327-328) only as a KEY row -- first step of a launch, ring row 0,
+                         *              the swap's post-swap row -- and otherwise this record of the step (row = previous row + amp * Ut[k][:]
+                         *              if accepted): 16 bytes instead of 8 ndim.  ptmi_update_cov rebuilds the rows in LDS, bit for bit;
+                         *              other readers call ptmi_am_expand first.  The caller initialises every record to KEY (meta = 1 << 33)
+                         *              and marks rows it writes itself as KEY */
+    double *Ut_prev;    /* [d][d]      with AMrec: the table that was in force before the current one (ptmi_table_switched) */
 } ptmi_buffers;
 
 typedef struct ptmi_engine *ptmi_handle;
@@ -252,6 +260,17 @@ int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag);
  * separate step: on the host (LAPACK, as the reference) or ptmi_eig_jacobi. */
 int ptmi_update_cov(ptmi_handle h, int64_t iter);
 
+/* AM records (ptmi_buffers.AMrec; updateChains' buffer, :327-328).  ptmi_am_records_ok: 1 when the configuration's rank-0 rows can be
+ * kept as records -- SCAM-only cycle, one parameter group, pooled covariance, rank 0 on this GPU.  ptmi_am_expand rebuilds, in the AM
+ * buffer itself, the rows of iterations iter_lo .. iter_hi (at most one ring, inside the ring's current window) of walkers
+ * w0 .. w0 + nw - 1 from the KEY rows and the records, with the step kernel's arithmetic: what a record-free run would have
+ * stored.  ptmi_table_switched: the caller put a new table into Ut before iteration `iter` (and the previous one into Ut_prev) --
+ * rows of earlier iterations are rebuilt with Ut_prev; only needed when a table takes effect later than the iteration after its
+ * covariance epoch. */
+int ptmi_am_records_ok(const ptmi_config *cfg);
+int ptmi_am_expand(ptmi_handle h, int32_t w0, int32_t nw, int64_t iter_lo, int64_t iter_hi);
+int ptmi_table_switched(ptmi_handle h, int64_t iter);
+
 /* The eigendecomposition of _updateRecursive (:797-803, np.linalg.svd of the covariance) for every covariance the handle
  * holds (Wc matrices), on the device: Ut and S are overwritten from cov.  One-sided Jacobi, one block per matrix, both
  * tables in LDS (ndim <= 101, one parameter group); eigenvalues descending, every eigenvector (a row of Ut) with its
@@ -277,6 +296,11 @@ int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL /* dev [W][T] 
  * n inputs (op: 0 log, 1 exp, 2 cos2pi, 3 sqrt, 4 reciprocal-free divide a/b with b=in2). */
 int ptmi_selftest_math(int device, int op, const double *in, const double *in2, double *out, int64_t n);
 int ptmi_selftest_philox(int device, const uint32_t *ctr_key /* [n][6] */, uint32_t *out /* [n][4] */, int64_t n);
+/* Replay hook of the parity tests (tests/test_gpu_replay.py): the reference's RECORDED draws go into the production kernels in
+ * place of the Philox ones.  swap_uniforms (dev [W][ntemps_global - 1], index [w][k] = the uniform of pair (k, k+1), :679) feeds
+ * ptmi_swap / ptmi_swap_sweep*; draws (dev [W][T][4] 64-bit words per chain: P0 = cycle pick << 32 | scale-branch word, Q0, Q1 as
+ * DESIGN.md section 4 lays them out, and the bits of the SCAM normal, :873) feeds ptmi_propose.  NULL switches a hook off. */
+int ptmi_test_replay(ptmi_handle h, const double *swap_uniforms, const uint64_t *draws);
 
 /* plain device memory helpers, so that a C caller needs nothing but this library */
 int ptmi_malloc(void **p, size_t bytes);

@@ -68,6 +68,8 @@ def lib():
         L = C.CDLL(_SO)
         L.orc_log.restype = L.orc_exp.restype = L.orc_cos2pi.restype = C.c_double
         L.orc_log.argtypes = L.orc_exp.argtypes = L.orc_cos2pi.argtypes = [C.c_double]
+        L.orc_log_n.restype = None
+        L.orc_log_n.argtypes = [C.c_int64, _dp, _dp]
         L.orc_normal.restype = L.orc_normal_sin.restype = L.orc_sin2pi.restype = C.c_double
         L.orc_normal.argtypes = L.orc_normal_sin.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_unit_log.restype = C.c_double

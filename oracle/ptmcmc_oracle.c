@@ -109,6 +109,12 @@ ORC_API double orc_log(double x)
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+/* n logarithms at once (tests/test_swap_logspace.py walks 10^7 near-ties) */
+ORC_API void orc_log_n(int64_t n, const double *x, double *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = orc_log(x[i]);
+}
+
 ORC_API double orc_exp(double x)
 {
     if (x != x) return x;

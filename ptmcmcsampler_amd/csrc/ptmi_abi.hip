@@ -6,6 +6,8 @@
 #include <new>
 #include <vector>
 
+#include <type_traits>
+
 #include "ptmi_common.h"
 
 // ------------------------------------------------------------------ errors
@@ -51,6 +53,7 @@ struct SwapSrc {
     u64 seed;
     int walker0;
     int block_nt;                // > 0: lnL_pos is [n / block_nt][W][block_nt], as all-gathered
+    const double *u_over;        // TEST HOOK (ptmi_test_replay): the pair uniforms [W][n - 1] as recorded from the reference, or nullptr
 };
 __device__ __forceinline__ SwapPre swap_record(const SwapSrc &p, int W, int n, int k, int w)
 {
@@ -63,7 +66,7 @@ __device__ __forceinline__ SwapPre swap_record(const SwapSrc &p, int W, int n, i
         const u32 sid = (u32)((u64)(p.walker0 + w) * (u32)n + 0u);    // rank 0's stream (PT:679)
         u64 w0, w1;
         philox_words(p.seed, (u64)p.iter, sid, SLOT_SWAP + (u32)k, w0, w1);
-        u = det_log(w2uniform(w0));                                   // log of the [0,1) uniform; -inf for u = 0: always accepted
+        u = det_log(p.u_over ? p.u_over[(size_t)w * (n - 1) + k] : w2uniform(w0));   // log of the [0,1) uniform; -inf for u = 0: always accepted
         b = L / p.ladder[k + 1];
     }
     if (k > 0) c = L / p.ladder[k - 1];
@@ -97,7 +100,14 @@ __global__ void swap_prepare_kernel(int W, int n, SwapSrc src, SwapPre *pre)
 #define PTMI_SWEEP_BATCH 8
 #endif
 // the AM-buffer row of a swap iteration (PT:624-627, 327-328): the state that sits at rank 0 after the sweep
-struct SwapAmRow { const double *X, *lnL, *lp; double *AM, *AMaux; int d, cov_update, am_epl; long long iter; };
+struct SwapAmRow { const double *X, *lnL, *lp; double *AM, *AMaux; int d, cov_update, am_epl; long long iter; AmRec *AMrec; };
+// the post-swap rows are KEY rows of the AM records (ptmi_common.h AmRec)
+__device__ __forceinline__ void swap_am_key(const SwapAmRow &amr, int w0, int nw, int tid, int nthreads)
+{
+    if (amr.AMrec == nullptr) return;
+    const int ring = (int)(amr.iter % amr.cov_update);
+    for (int wl = tid; wl < nw; wl += nthreads) amr.AMrec[(size_t)(w0 + wl) * amr.cov_update + (size_t)ring] = AmRec{0.0, AMREC_KEY};
+}
 template <bool STG>
 __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n, const double *ladder, const SwapPre *pre,
                                   int32_t *slot_of, int32_t *temp_of, int32_t *map, u64 *nswap, int local0, int nlocal,
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n
                     amr.AMaux[arow * 2] = amr.lnL[r];
                     amr.AMaux[arow * 2 + 1] = amr.lp[r];
                 }
+            swap_am_key(amr, w0, nw, (int)threadIdx.x, 256);
         }
     }
 }
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(SWF_BLK) void swap_fused_kernel(int W, int n, SwapS
                 amr.AMaux[arow * 2] = amr.lnL[r];
                 amr.AMaux[arow * 2 + 1] = amr.lp[r];
             }
+        swap_am_key(amr, w0, nw, tid, SWF_BLK);
     }
 }
 
@@ -406,7 +418,7 @@ __global__ void swap_oddeven_kernel(int W, int n, const double *ladder, const do
 
 // AM-buffer row of a swap iteration: the state that now sits at rank 0 (PT:624-627, 327-328)
 __global__ void am_write_kernel(const double *X, const double *lnL, const double *lp, const int32_t *slot_of, double *AM,
-                                double *AMaux, int W, int nt, int d, int cov_update, long long iter, int am_epl)
+                                double *AMaux, int W, int nt, int d, int cov_update, long long iter, int am_epl, AmRec *AMrec)
 {
     const int w = (int)blockIdx.x;
     const size_t r = (size_t)w * nt + slot_of[(size_t)w * nt];
@@ -418,6 +430,7 @@ __global__ void am_write_kernel(const double *X, const double *lnL, const double
         ax[0] = lnL[r];
         ax[1] = lp[r];
     }
+    if (AMrec && threadIdx.x == 0) AMrec[(size_t)w * cov_update + (size_t)(iter % cov_update)] = AmRec{0.0, AMREC_KEY};
 }
 
 // ------------------------------------------------------------------ Welford
@@ -538,18 +551,30 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
 constexpr int PS_W = 112;       // columns of a macro tile
 // rows per staged chunk: 32 (8 k-steps x 7 tiles) on the diagonal, 16 (4 k-steps x 13 tiles) off it: some 55 matrix instructions
 // per wave cover a memory round trip, and two blocks share a CU (57 KB of LDS each)
-constexpr int ps_rc(bool diag) { return diag ? 32 : 16; }
+constexpr int ps_rc(bool diag, bool rec = false) { return (diag && !rec) ? 32 : 16; }
 typedef double ps_d4 __attribute__((ext_vector_type(4)));
 __host__ __device__ inline int pool_groups(int d) { return (d + 1 + PS_W - 1) / PS_W; }          // macro tiles per side (columns 0 .. d)
 // walkers per slab: up to 512 slabs when one macro tile covers the matrix, up to 32 beyond (a partial is d (d + 1) doubles);
 // part of the definition (summation order): oracle/oracle.py pool_slab is the same rule
 static inline int pool_slab(int nwalkers, int d) { const int target = d + 1 <= PS_W ? 512 : 32; const int s = (nwalkers + target - 1) / target; return s < 1 ? 1 : s; }
-template <bool DIAG>
+// REC: the buffer holds AM records (ptmi_common.h AmRec) -- KEY rows are read, the rows between them are rebuilt by the stagers
+// with the step kernels' own arithmetic (row = previous row + amp * Ut[k][:], one product and one sum per element), so the
+// statistics see bit for bit the rows a record-free run would have stored, without the 8 ndim bytes per row having been
+// written or read.  The recurrence runs down a column, so ONE thread stages all rows of a chunk for its column (threads
+// 0 .. 111: waves 0 and 1), and those two waves take 6 of the diagonal macro tile's 28 matrix tiles each instead of 7 (the
+// others 8): the chunk's staging (some 200 vector instructions) weighs what two tiles' matrix instructions do.
+struct PoolRec {
+    const AmRec *rec;            // [W][cov_update]
+    const double *Ut, *Utp;      // the table in force, and the one before it (rows 1 .. nprev of a ring were made with Utp)
+    int cu, nprev;
+};
+template <bool DIAG, bool REC>
 __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, long long nrows, int d, const double *shift,
                                                                      long long rows_per_slab, double *part, int am_epl,
-                                                                     int shift_epl /* row format of `shift` (an AM row at the first epoch) */)
+                                                                     int shift_epl /* row format of `shift` (an AM row at the first epoch) */,
+                                                                     PoolRec pr)
 {
-    constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG);
+    constexpr int NTW = DIAG ? (REC ? 8 : 7) : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG, REC);
     __shared__ double Dl[NA][2][PS_RC][PS_W];
     const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, g = lane >> 4;
@@ -567,15 +592,18 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
     int offa[NTW], offb[NTW];
     bool on[NTW];
     ps_d4 acc[NTW];
+    const int t0 = DIAG ? (REC ? (wave < 2 ? 6 * wave : 12 + 8 * (wave - 2)) : 7 * wave) : 0;
+    const int tcount = DIAG ? (REC ? (wave < 2 ? 6 : 8) : 7) : 0;
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
         int ti, tj;
         if (DIAG) {
-            int t = 7 * wave + n, row = 7;
+            int t = t0 + n, row = 7;
+            on[n] = n < tcount;
+            if (!on[n]) t = 0;
             ti = 0;
             while (t >= row) { t -= row; ++ti; --row; }
             tj = ti + t;
-            on[n] = true;
         } else {
             const int t = wave + 4 * n;
             on[n] = t < 49;
@@ -586,9 +614,10 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
         offb[n] = __builtin_amdgcn_readfirstlane(tj * 16);
         acc[n] = ps_d4{0.0, 0.0, 0.0, 0.0};
     }
-    // staging: threads 0..223 own one column of the macro tile(s) and every other row of a chunk
+    // staging: threads 0..223 own one column of the macro tile(s) and every other row of a chunk (REC: threads 0..111, every row)
     const int scol = (int)threadIdx.x % PS_W, srow = (int)threadIdx.x / PS_W;     // srow 0 / 1 (2: idle)
-    const bool stager = srow < 2;
+    const bool stager = REC ? srow == 0 : srow < 2;
+    constexpr int NV = REC ? PS_RC : PS_RC / 2;
     int gc[NA];
     double sh[NA];
 #pragma unroll
@@ -598,48 +627,137 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
     }
     // Loads are unconditional (row and column clamped into the slab: a branch per load made every one of them wait for its
     // own round trip, 2.6 ms per epoch); what a slot really holds is decided when it is staged.
-    double v[NA][PS_RC / 2];
-    int gcl[NA];
+    double v[NA][NV];
+    int gcl[NA], gcp[NA];
 #pragma unroll
-    for (int a2 = 0; a2 < NA; ++a2) gcl[a2] = am_pos(gc[a2] < d ? gc[a2] : d - 1, am_epl);      // where the column sits in a buffered row
+    for (int a2 = 0; a2 < NA; ++a2) {
+        gcp[a2] = gc[a2] < d ? gc[a2] : d - 1;                  // the column, clamped (parameter order: a row of Ut)
+        gcl[a2] = am_pos(gcp[a2], am_epl);                      // where the column sits in a buffered row
+    }
     long long vr0 = beg;
-    auto fetch = [&](long long r0) {
-        vr0 = r0;
+    double xc[NA];                                              // REC: the column's value in the row before the chunk
+    int vci = 0;                                                // REC: the chunk the fetched values belong to (its records are in Rl[vci & 1])
 #pragma unroll
-        for (int a2 = 0; a2 < NA; ++a2)
-#pragma unroll
-            for (int u = 0; u < PS_RC / 2; ++u) {
-                const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
-                v[a2][u] = rows[rc * d + gcl[a2]];
-            }
+    for (int a2 = 0; a2 < NA; ++a2) xc[a2] = 0.0;
+    // REC: the records of a chunk reach the stagers through LDS (Rl, two buffers), loaded TWO chunks ahead by the first PS_RC
+    // lanes of wave 2 (one 16-byte record each): the table row a stager needs is named by the record, and a stager that
+    // waited for the record itself before it could ask for the row would sit out a memory round trip in every chunk.  The
+    // loader lane also does everything that belongs to the ROW, not to a column: which table (ring row <= nprev: the one
+    // before), and the address of the source row -- the buffered row itself for a KEY row, else row k of the table.
+    struct __attribute__((aligned(16))) Prep { double amp; const double *base; unsigned flags, pad[3]; };
+    __shared__ Prep Rl[REC ? 2 : 1][REC ? PS_RC : 1];
+    const int ltid = (int)threadIdx.x - 128;
+    const bool loader = REC && ltid >= 0 && ltid < PS_RC;
+    AmRec lrec = AmRec{0.0, 0ull};
+    long long lrow = 0;
+    auto rec_load = [&](long long r0) {
+        if (loader) {
+            const long long r = r0 + ltid;
+            lrow = r < end ? r : end - 1;
+            lrec = pr.rec[lrow];
+        }
     };
-    auto stage = [&](int buf) {
-        if (stager) {
+    auto rec_put = [&](int ci) {
+        if (loader) {
+            // rows_per_slab is a whole number of rings, so the ring row is (row - beg) mod cu
+            const int rg = (int)((unsigned)(lrow - beg) % (unsigned)pr.cu);
+            const double *tab = (rg >= 1 && rg <= pr.nprev) ? pr.Utp : pr.Ut;
+            const unsigned fl = (unsigned)(lrec.meta >> 32);
+            const bool key = (fl & (unsigned)(AMREC_KEY >> 32)) != 0;
+            Prep q;
+            q.amp = lrec.amp;
+            q.base = key ? rows + lrow * d : tab + (size_t)(unsigned)lrec.meta * d;
+            q.flags = fl;
+            q.pad[0] = q.pad[1] = q.pad[2] = 0u;
+            Rl[ci & 1][ltid] = q;
+        }
+    };
+    auto fetch = [&](long long r0, int ci) {
+        vr0 = r0;
+        vci = ci;
+        if constexpr (REC) {
+#pragma unroll
+            for (int u = 0; u < PS_RC; ++u) {
+                const Prep &q = Rl[ci & 1][u];                                    // one address for the wave: broadcast reads
+                const double *base = q.base;
+                const bool key = (q.flags & (unsigned)(AMREC_KEY >> 32)) != 0;
+#pragma unroll
+                for (int a2 = 0; a2 < NA; ++a2) v[a2][u] = base[key ? gcl[a2] : gcp[a2]];
+            }
+        } else {
 #pragma unroll
             for (int a2 = 0; a2 < NA; ++a2)
 #pragma unroll
                 for (int u = 0; u < PS_RC / 2; ++u) {
-                    const bool live = vr0 + 2 * u + srow < end;
-                    const double x = gc[a2] < d ? v[a2][u] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
-                    Dl[a2][buf][2 * u + srow][scol] = live ? x : 0.0;
+                    const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
+                    v[a2][u] = rows[rc * d + gcl[a2]];
                 }
         }
     };
-    fetch(beg);
+    auto stage = [&](int buf) {
+        if (stager) {
+            if constexpr (REC) {
+#pragma unroll
+                for (int a2 = 0; a2 < NA; ++a2) {
+                    double x = xc[a2];
+#pragma unroll
+                    for (int u = 0; u < PS_RC; ++u) {
+                        const Prep &q = Rl[vci & 1][u];                 // again from LDS: 96 registers to keep them since the fetch
+                        const unsigned fl = q.flags;
+                        const double p = q.amp * v[a2][u];              // the step kernel's dq = amp * u_k ...
+                        const double moved = x + p;                     // ... and x + dq
+                        x = (fl & (unsigned)(AMREC_KEY >> 32)) ? v[a2][u] : ((fl & (unsigned)(AMREC_ACC >> 32)) ? moved : x);
+                        const bool live = vr0 + u < end;
+                        const double val = gc[a2] < d ? x - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
+                        Dl[a2][buf][u][scol] = live ? val : 0.0;
+                    }
+                    xc[a2] = x;
+                }
+            } else {
+#pragma unroll
+                for (int a2 = 0; a2 < NA; ++a2)
+#pragma unroll
+                    for (int u = 0; u < PS_RC / 2; ++u) {
+                        const bool live = vr0 + 2 * u + srow < end;
+                        const double x = gc[a2] < d ? v[a2][u] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
+                        Dl[a2][buf][2 * u + srow][scol] = live ? x : 0.0;
+                    }
+            }
+        }
+    };
+    if constexpr (REC) {
+        rec_load(beg);
+        rec_put(0);
+        rec_load(beg + PS_RC);
+        __syncthreads();
+    }
+    if (!REC || stager) fetch(beg, 0);
     stage(0);
+    if constexpr (REC) rec_put(1);
     __syncthreads();
-    int buf = 0;
-    for (long long r0 = beg; r0 < end; r0 += PS_RC) {
+    int buf = 0, ci = 0;
+    for (long long r0 = beg; r0 < end; r0 += PS_RC, ++ci) {
         const bool more = r0 + PS_RC < end;
-        if (more) fetch(r0 + PS_RC);
+        if (more && (!REC || stager)) fetch(r0 + PS_RC, ci + 1);
+        if constexpr (REC) rec_load(r0 + 2 * PS_RC);                   // clamped past the slab's end
         const double *Ab = &Dl[0][buf][0][0] + g * PS_W + c, *Bb = &Dl[NA - 1][buf][0][0] + g * PS_W + c;
+        auto mfma_chunk = [&](auto cnt) {
+            constexpr int CNT = decltype(cnt)::value;
 #pragma unroll
-        for (int k0 = 0; k0 < PS_RC; k0 += 4) {
+            for (int k0 = 0; k0 < PS_RC; k0 += 4) {
 #pragma unroll
-            for (int n = 0; n < NTW; ++n)
-                if (on[n]) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + offa[n]], Bb[k0 * PS_W + offb[n]], acc[n], 0, 0, 0);
+                for (int n = 0; n < CNT; ++n)
+                    if (DIAG || on[n]) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + offa[n]], Bb[k0 * PS_W + offb[n]], acc[n], 0, 0, 0);
+            }
+        };
+        if constexpr (DIAG && REC) {
+            if (wave < 2) mfma_chunk(std::integral_constant<int, 6>{});
+            else mfma_chunk(std::integral_constant<int, 8>{});
+        } else {
+            mfma_chunk(std::integral_constant<int, NTW>{});
         }
         if (more) stage(buf ^ 1);
+        if constexpr (REC) rec_put(ci + 2);                            // read at the top of the trip after next; last read at the top of this one
         __syncthreads();
         buf ^= 1;
     }
@@ -651,6 +769,35 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
         for (int r = 0; r < 4; ++r) {
             const int i = I * PS_W + offa[n] + g + 4 * r, j = J * PS_W + offb[n] + c;
             if (i < d && j <= d && i <= j) out[(size_t)i * (d + 1) + j] = acc[n][r];
+        }
+    }
+}
+
+// AM records -> rows: the rows of iterations it_lo .. it_hi of walkers w0 .. w0 + nw - 1, rebuilt in place in the AM buffer for the
+// readers that want rows (DE history, chain files, checkpoints of row readers, the ESS window).  Both iterations lie in the ring's
+// current window (base, base + cu]; the walk starts at the last KEY row at or before it_lo (the first step of every launch is one).
+// One block per walker, a thread per parameter, rows in time order; same arithmetic as the step kernels.
+__global__ __launch_bounds__(128) void am_expand_kernel(double *AM, const AmRec *rec, const double *Ut, const double *Utp, int d, int cu,
+                                                        int am_epl, int w0, long long it_lo, long long it_hi, long long switch_iter)
+{
+    const int w = w0 + (int)blockIdx.x;
+    const AmRec *rw = rec + (size_t)w * cu;
+    double *aw = AM + (size_t)w * cu * d;
+    // the KEY row to start from (uniform)
+    long long it0 = it_lo;
+    while (it0 > 0 && it0 > it_hi - cu + 1 && !(rw[it0 % cu].meta & AMREC_KEY)) --it0;
+    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) {
+        const int pos = am_pos(i, am_epl);
+        double x = aw[(size_t)(it0 % cu) * d + pos];
+        for (long long it = it0 + 1; it <= it_hi; ++it) {
+            const int ring = (int)(it % cu);
+            const AmRec q = rw[ring];
+            if (q.meta & AMREC_KEY) x = aw[(size_t)ring * d + pos];
+            else {
+                const double *tab = it >= switch_iter ? Ut : Utp;
+                if (q.meta & AMREC_ACC) x = x + q.amp * tab[(size_t)(unsigned)q.meta * d + i];
+                if (it >= it_lo) aw[(size_t)ring * d + pos] = x;
+            }
         }
     }
 }
@@ -1162,8 +1309,12 @@ static KArgs make_args(ptmi_engine *h)
     const ptmi_buffers &b = h->buf;
     a.X = b.X; a.lnL = b.lnL; a.lp = b.lp; a.temp_of = b.temp_of; a.slot_of = b.slot_of;
     a.Ut = b.Ut; a.S = b.S; a.DE = b.DE; a.AM = c.temp0 == 0 ? b.AM : nullptr; a.AMaux = c.temp0 == 0 ? b.AMaux : nullptr;
-    static const bool no_am = getenv("PTMI_MEASURE_NO_AM") != nullptr;   // MEASUREMENT ONLY (results are wrong): what the AM-row stores of the step kernels cost
+#ifdef PTMI_MEASURE      // measurement builds only (-DPTMI_MEASURE; results are wrong): what the AM-row stores of the step kernels cost
+    static const bool no_am = getenv("PTMI_MEASURE_NO_AM") != nullptr;
     if (no_am) a.AM = nullptr;
+#endif
+    a.AMrec = c.temp0 == 0 ? (AmRec *)b.AMrec : nullptr;
+    a.rp_draws = h->rp_draws;
     a.nacc = (u64 *)b.nacc; a.jstat = (u64 *)b.jstat;
     a.temps_mh = h->d_temps; a.beta = h->d_beta; a.logl_par = h->d_loglpar; a.logp_par = h->d_logppar;
     a.gsize = h->d_gsize; a.gmask = h->d_gmask; a.gcn = h->d_gcn; a.gdiv = h->d_gdiv; a.ngroups = c.ngroups > 1 ? c.ngroups : 1;
@@ -1201,8 +1352,10 @@ static int set_step_args(const ptmi_engine *h, KArgs *a)
 {
     const ptmi_config &c = h->cfg;
     a->am_row0 = (int)(a->iter0 % c.cov_update);
-    static const bool am_small = getenv("PTMI_MEASURE_AM_SMALL") != nullptr;   // MEASUREMENT ONLY (results are wrong): every AM row of a walker into ONE cache-resident row
+#ifdef PTMI_MEASURE      // measurement builds only (-DPTMI_MEASURE; results are wrong): every AM row of a walker into ONE cache-resident row
+    static const bool am_small = getenv("PTMI_MEASURE_AM_SMALL") != nullptr;
     if (am_small) { a->cov_update = 1; a->am_row0 = 0; }
+#endif
     a->swap_last = 0;
     if (c.tskip > 0 && c.ntemps_global > 1) {
         const long long last = a->iter0 + a->nsteps - 1;
@@ -1304,6 +1457,15 @@ static int upload(double **dst, const double *src, long long n)
     return PTMI_OK;
 }
 
+// AM records stand for rows only where every step of the rank-0 chain is a SCAM step along a row of ONE table that the readers can
+// look up again: SCAM-only cycle (no AM, DE, gradient or host-served entries), one parameter group, pooled covariance, rank 0 local
+int ptmi_am_records_ok(const ptmi_config *c)
+{
+    if (!c) return 0;
+    return c->w_scam > 0 && c->w_am == 0 && c->w_de == 0 && c->w_nuts == 0 && c->w_hmc == 0 && c->w_host == 0 && c->ngroups <= 1 &&
+           !c->cov_per_walker && c->temp0 == 0;
+}
+
 int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out)
 {
     if (!cfg || !buf || !out) return fail(PTMI_EINVAL, "NULL argument");
@@ -1346,6 +1508,10 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (!buf->X || !buf->lnL || !buf->lp || !buf->temp_of || !buf->slot_of || !buf->Ut || !buf->S || !buf->nacc || !buf->jstat)
         return fail(PTMI_EINVAL, "a required device buffer is NULL");
     if (c.w_de > 0 && !buf->DE) return fail(PTMI_EINVAL, "DE weight > 0 but no DE buffer");
+    if (buf->AMrec) {
+        if (!ptmi_am_records_ok(cfg)) return fail(PTMI_EINVAL, "AM records (ptmi_buffers.AMrec) serve SCAM-only cycles with one pooled table on the GPU that holds rank 0 (ptmi_am_records_ok)");
+        if (!buf->AM || !buf->Ut_prev) return fail(PTMI_EINVAL, "AM records need the AM and Ut_prev buffers");
+    }
     if ((unsigned long long)c.nwalkers * (unsigned)c.ntemps_global > 0xFFFFFFFFull) return fail(PTMI_EINVAL, "too many RNG streams");
     Shape s;
     if (!pick_shape(c.ndim, gj, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported (max 2048)", c.ndim);
@@ -1585,7 +1751,8 @@ int ptmi_swap_write_am(ptmi_handle h, int64_t iter)
     if (h->cfg.temp0 != 0 || !h->buf.AM) return PTMI_OK;
     hipLaunchKernelGGL(am_write_kernel, dim3(h->cfg.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.X,
                        (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)h->buf.slot_of, h->buf.AM,
-                       h->buf.AMaux, h->cfg.nwalkers, h->cfg.ntemps, h->cfg.ndim, h->cfg.cov_update, (long long)iter, am_row_epl(h->G, h->EPL));
+                       h->buf.AMaux, h->cfg.nwalkers, h->cfg.ntemps, h->cfg.ndim, h->cfg.cov_update, (long long)iter, am_row_epl(h->G, h->EPL),
+                       (AmRec *)h->buf.AMrec);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -1602,7 +1769,7 @@ static int launch_swap_sweep(ptmi_engine *h, int W, int n, const SwapPre *pre, i
 {
     if (hop_done) *hop_done = false;
     if (am_done) *am_done = false;
-    SwapAmRow none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0};
+    SwapAmRow none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, nullptr};
     int wpb = 64;                                                      // 2 tables of wpb x (n + 1) ints must fit the CU's LDS
     while (wpb > 8 && sizeof(int32_t) * (2 * (size_t)wpb * (size_t)(n + 1) + n) > 160 * 1024) wpb /= 2;
     const size_t lds = sizeof(int32_t) * (2 * (size_t)wpb * (size_t)(n + 1) + n);      // forward table, flags, block of a position
@@ -1654,7 +1821,7 @@ static int launch_swap_fused(ptmi_engine *h, int W, int n, const SwapSrc &src, i
         HIPCHK(hipMemsetAsync(h->d_hop, 0, sizeof(int32_t), h->stream));
         if (hop_done) *hop_done = true;
     }
-    const SwapAmRow none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0};
+    const SwapAmRow none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, nullptr};
     const bool with_am = amr != nullptr && slot_of != nullptr;
     hipLaunchKernelGGL(swap_fused_kernel, dim3((unsigned)((W + wpb - 1) / wpb)), dim3(SWF_BLK), lds, h->stream, W, n, src, slot_of, temp_of, map,
                        nswap, local0, nlocal, parity, inv, wpb, lg, hop_nt, h->d_hop, with_am ? *amr : none);
@@ -1682,10 +1849,10 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
         return ptmi_swap_write_am(h, iter);
     }
     const SwapSrc src = {h->d_ladder, (const double *)nullptr, (const double *)h->buf.lnL, (const int32_t *)h->buf.slot_of, (long long)iter, c.seed,
-                         c.walker0, 0};
+                         c.walker0, 0, h->rp_swap_u};
     // the sweep's write-out also stores the swap iteration's AM row (one kernel and one launch gap less per swap epoch)
     const SwapAmRow amr = {(const double *)h->buf.X, (const double *)h->buf.lnL, (const double *)h->buf.lp, h->buf.AM, h->buf.AMaux,
-                           c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (long long)iter};
+                           c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (long long)iter, (AmRec *)h->buf.AMrec};
     bool am_done = false, used = false;
     if (int rc = launch_swap_fused(h, W, c.ntemps, src, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1,
                                    (int32_t *)nullptr, 0, nullptr, (c.temp0 == 0 && h->buf.AM) ? &amr : nullptr, &am_done, &used)) return rc;
@@ -1738,7 +1905,7 @@ static int sweep_global(ptmi_handle h, int64_t iter, const double *lnL, int32_t 
     const ptmi_config &c = h->cfg;
     const int W = c.nwalkers;
     if (int rc = ensure_xint(h)) return rc;
-    const SwapSrc src = {h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, (long long)iter, c.seed, c.walker0, block_nt};
+    const SwapSrc src = {h->d_ladder, lnL, (const double *)nullptr, (const int32_t *)nullptr, (long long)iter, c.seed, c.walker0, block_nt, h->rp_swap_u};
     const int parity = c.swap_mode == PTMI_SWAP_ODDEVEN ? swap_parity(c, iter) : -1;
     bool used = false;
     if (int rc = launch_swap_fused(h, W, c.ntemps_global, src, (int32_t *)nullptr, (int32_t *)nullptr, map, (u64 *)h->buf.nswap, c.temp0, c.ntemps,
@@ -1973,6 +2140,14 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
         // fill the last, partly empty round of the off-diagonal ones instead of a launch of their own behind them
         // (1000-d, 512 walkers: 288 blocks beside 1152 with 512 resident at a time).
         hipStream_t diag_stream = h->stream;
+        // AM records: the stagers rebuild the rows between the KEY rows.  Rows 1 .. nprev of a ring were made with the table before
+        // the one in force (a table applied some iterations after its epoch, ptmi_table_switched)
+        const bool rec = h->buf.AMrec != nullptr;
+        const long long base = iter - c.cov_update, np = h->switch_iter - base - 1;
+        const PoolRec pr = {(const AmRec *)h->buf.AMrec, (const double *)h->buf.Ut, (const double *)h->buf.Ut_prev, c.cov_update,
+                            (int)(np < 0 ? 0 : (np > c.cov_update ? c.cov_update : np))};
+        const long long rps = (long long)SL * c.cov_update;
+        const int aepl = am_row_epl(h->G, h->EPL), sepl = first ? am_row_epl(h->G, h->EPL) : 0;
         if (ng > 1) {
             if (!h->side) {
                 HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -1981,12 +2156,16 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
             }
             HIPCHK(hipEventRecord(h->side_go, h->stream));
             HIPCHK(hipStreamWaitEvent(h->side, h->side_go, 0));
-            hipLaunchKernelGGL(pool_syrk_kernel<false>, dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
-                               shift, (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
+            if (rec) hipLaunchKernelGGL((pool_syrk_kernel<false, true>), dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
+                                        shift, rps, h->d_pool_part, aepl, sepl, pr);
+            else hipLaunchKernelGGL((pool_syrk_kernel<false, false>), dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
+                                    shift, rps, h->d_pool_part, aepl, sepl, pr);
             diag_stream = h->side;
         }
-        hipLaunchKernelGGL(pool_syrk_kernel<true>, dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
-                           (long long)SL * c.cov_update, h->d_pool_part, am_row_epl(h->G, h->EPL), first ? am_row_epl(h->G, h->EPL) : 0);
+        if (rec) hipLaunchKernelGGL((pool_syrk_kernel<true, true>), dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
+                                    rps, h->d_pool_part, aepl, sepl, pr);
+        else hipLaunchKernelGGL((pool_syrk_kernel<true, false>), dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
+                                rps, h->d_pool_part, aepl, sepl, pr);
         if (ng > 1) {
             HIPCHK(hipEventRecord(h->side_done, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->side_done, 0));
@@ -2020,12 +2199,45 @@ int ptmi_eig_jacobi(ptmi_handle h)
     return PTMI_OK;
 }
 
+int ptmi_am_expand(ptmi_handle h, int32_t w0, int32_t nw, int64_t iter_lo, int64_t iter_hi)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    const ptmi_config &c = h->cfg;
+    if (!h->buf.AMrec || !h->buf.AM) return PTMI_OK;                     // the buffer holds rows already
+    if (w0 < 0 || nw < 0 || w0 + nw > c.nwalkers) return fail(PTMI_EINVAL, "walkers [%d, %d) of %d", w0, w0 + nw, c.nwalkers);
+    if (iter_lo < 0 || iter_hi < iter_lo || iter_hi - iter_lo >= c.cov_update)
+        return fail(PTMI_EINVAL, "iterations %lld..%lld do not fit one ring of %d rows", (long long)iter_lo, (long long)iter_hi, c.cov_update);
+    if (nw == 0) return PTMI_OK;
+    hipLaunchKernelGGL(am_expand_kernel, dim3((unsigned)nw), dim3(128), 0, h->stream, h->buf.AM, (const AmRec *)h->buf.AMrec, (const double *)h->buf.Ut,
+                       (const double *)h->buf.Ut_prev, c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (int)w0, (long long)iter_lo, (long long)iter_hi,
+                       h->switch_iter);
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_table_switched(ptmi_handle h, int64_t iter)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    if (iter < 0) return fail(PTMI_EINVAL, "iter negative");
+    h->switch_iter = iter;
+    return PTMI_OK;
+}
+
+int ptmi_test_replay(ptmi_handle h, const double *swap_uniforms, const uint64_t *draws)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    h->rp_swap_u = swap_uniforms;
+    h->rp_draws = (const u64 *)draws;
+    return PTMI_OK;
+}
+
 int ptmi_update_de(ptmi_handle h)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
     const ptmi_config &c = h->cfg;
     if (!h->buf.DE) return PTMI_OK;
     if (!h->buf.AM) return fail(PTMI_EINVAL, "DE update needs the AM buffer on this GPU");
+    if (h->buf.AMrec) return fail(PTMI_EINVAL, "the DE history reads rows: call ptmi_am_expand first (AM records are for SCAM-only cycles)");
     const int wc = c.cov_per_walker ? c.nwalkers : 1;
     hipLaunchKernelGGL(de_update_kernel, dim3(c.cov_update, wc), dim3(64), 0, h->stream, h->buf.DE, (const double *)h->buf.AM,
                        c.ndim, c.de_size, c.cov_update, h->de_head, c.nwalkers, c.cov_per_walker ? 0 : 1,

@@ -31,6 +31,16 @@ __host__ __device__ inline int am_pos(int i, int epl)
 }
 constexpr int am_row_epl(int G, int EPL) { return (G == 4 && EPL == 25) ? EPL : 0; }      // = ptmi_shape_exact (declared below)
 
+// AM records (ptmi_buffers.AMrec, include/ptmi.h): beside every row of the AM buffer one 16-byte record.  A SCAM step moves the
+// rank-0 chain by amp * u_k or not at all, so (amp, k, accepted) -- 16 bytes -- says what the 8 ndim bytes of the row say, given
+// the row before it and the eigenvector table in force.  The step kernels of SCAM-only cycles then store the full row only as a
+// KEY row (first step of a launch, ring row 0; the swap's post-swap row is one too) and a record otherwise; readers rebuild the
+// rows in between with the kernel's own arithmetic (one product, one sum per element: bit-identical).
+// word 1 of a record: direction k in the low 32 bits, flags above.
+constexpr unsigned long long AMREC_ACC = 1ull << 32;      // the step was accepted: row = previous row + amp * Ut[k][:]
+constexpr unsigned long long AMREC_KEY = 1ull << 33;      // the AM buffer holds this row itself
+struct __attribute__((aligned(16))) AmRec { double amp; unsigned long long meta; };
+
 // ------------------------------------------------------------- kernel args
 struct KArgs {
     // state
@@ -38,6 +48,7 @@ struct KArgs {
     int32_t *temp_of, *slot_of;
     const double *Ut, *S, *DE;
     double *AM, *AMaux;
+    AmRec *AMrec;                // records beside the AM rows (SCAM-only cycles, one pooled table), or nullptr: every step stores its row
     u64 *nacc, *jstat;
     // small device tables owned by the engine
     const double *temps_mh, *beta, *logl_par, *logp_par;
@@ -74,6 +85,7 @@ struct KArgs {
     double *gj_scr, *gj_scal;    // scratch of the tree build: [slot][e][chain][lane], [level][scalar][chain]
     int gj_stack_off, gj_lds_levels;   // tree stack: offset (doubles) in the block's LDS and how many of the lowest heights live there
     const int32_t *gj_order;     // chain handled by each chain slot of the launch (chains of similar NUTS step size share a wave)
+    const u64 *rp_draws;         // TEST HOOK (ptmi_test_replay): propose_kernel takes P0, Q0, Q1 and the SCAM normal's bits of every chain from here
 };
 
 // gradient jumps (ptmi_gj.inc.h): per-rank state, Philox slots, layout of a chain's tree scratch
@@ -124,6 +136,9 @@ struct ptmi_engine {
     hipEvent_t ev0, ev1;
     hipStream_t side;            // pooled statistics at ndim > 111: the diagonal macro tiles run beside the off-diagonal ones
     hipEvent_t side_go, side_done;
+    long long switch_iter;       // AM records: rows of iterations >= switch_iter were made with buf.Ut, earlier ones with buf.Ut_prev (ptmi_table_switched)
+    const double *rp_swap_u;     // TEST HOOK (ptmi_test_replay): the swap's uniforms [W][ntemps_global - 1] instead of the Philox ones
+    const u64 *rp_draws;         // TEST HOOK: see KArgs
 };
 
 

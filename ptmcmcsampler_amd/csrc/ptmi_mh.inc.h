@@ -812,6 +812,24 @@ __device__ __forceinline__ void am_store_row(double *am, const double (&x)[EPL],
     }
 }
 
+// The rank-0 chain's row of one step (PT:327-328): the row itself, or -- with AM records (ptmi_common.h AmRec; SCAM-only cycles)
+// -- the 16-byte record of the step, the row itself only as a KEY row: first step of a launch and ring row 0.
+template <int G, int EPL>
+__device__ __forceinline__ void am_store_step(const KArgs &a, int w, int am_row, int k, const double (&x)[EPL], int gl, int d,
+                                              double amp, int kdir, bool accepted)
+{
+    const size_t r = (size_t)w * a.cov_update + (size_t)am_row;
+    if (a.AMrec != nullptr) {
+        const bool key = k == 0 || am_row == 0;
+        if (gl == 0) {
+            const unsigned long long meta = key ? AMREC_KEY : ((unsigned long long)(unsigned)kdir | (accepted ? AMREC_ACC : 0ull));
+            __builtin_nontemporal_store(ptmi_d2{amp, __longlong_as_double((long long)meta)}, reinterpret_cast<ptmi_d2 *>(a.AMrec + r));
+        }
+        if (!key) return;
+    }
+    am_store_row<G, EPL>(a.AM + r * d, x, gl, d);
+}
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; make consecutive
 // logical blocks (chains of one walker, sharing its Ut) land on one XCD's L2.
 __device__ __forceinline__ int logical_block()
@@ -1038,6 +1056,8 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         }
         double log_u;
         int jt = PTMI_J_SCAM;
+        double rec_amp = 0.0;          // AM records: the step's amplitude and direction (SCAM-only cycles)
+        int rec_k = 0;
         if constexpr (SCAMFAST) {
             ScamDraw sd;
             // sqrt(S_k): from the block's LDS copy where it has one, else from the chain's table (sqrt is correctly rounded: same bits)
@@ -1049,6 +1069,8 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
                 return det_sqrt(S[kk]);
             }, smem);
             log_u = sd.log_u;
+            rec_amp = sd.amp;
+            rec_k = sd.k;
             if constexpr (PAIRED) {
                 const double *row = smem + (size_t)sd.k * d;
                 const ptmi_d2 *rp = reinterpret_cast<const ptmi_d2 *>(row) + gl;
@@ -1108,7 +1130,8 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         // PT:615-622
         const double lnprob0 = beta * lnL + lp;
         const double diff = nlnprob - lnprob0 + 0.0;
-        if (diff > log_u) {
+        const bool accepted = diff > log_u;
+        if (accepted) {
             // x + dq again (bit-identical to q); keeping q alive instead would cost EPL more registers
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
@@ -1134,8 +1157,8 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         // 0.780 against 0.778: the cost is the bytes through the CU's store path (1.28 MB per CU and launch) and the scattered
         // 64-byte writes behind it, not the issue slots of the instructions.
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
-            double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
-            am_store_row<G, EPL>(am, x, gl, d);
+            if constexpr (SCAMFAST) am_store_step<G, EPL>(a, w, am_row, k, x, gl, d, rec_amp, rec_k, accepted);
+            else am_store_row<G, EPL>(a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d, x, gl, d);
             if (a.AMaux && gl == 0) {
                 double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
                 ax[0] = lnL;
@@ -1333,7 +1356,8 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         // PT:615-622
         const double lnprob0 = beta * lnL + lp;
         const double diff = nlnprob - lnprob0 + 0.0;
-        if (diff > log_u) {
+        const bool accepted = diff > log_u;
+        if (accepted) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 double inc = dq[e];
@@ -1346,8 +1370,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         }
         // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
-            double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
-            am_store_row<G, EPL>(am, x, gl, d);
+            am_store_step<G, EPL>(a, w, am_row, k, x, gl, d, sd.amp, sd.k, accepted);
             if (a.AMaux && gl == 0) {
                 double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
                 ax[0] = lnL;
@@ -1400,6 +1423,12 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     DrawBatch<false> batch;
     Draws dr;
     draws_for_step<false, true>(batch, dr, a, 0, sid, sid0, gl);
+    if (a.rp_draws != nullptr) {               // TEST HOOK (ptmi_test_replay): the proposal's draws as recorded from the reference
+        const u64 *r = a.rp_draws + (size_t)ch * 4;
+        dr.P0 = r[0]; dr.Q0 = r[1]; dr.Q1 = r[2];
+        dr.z = __longlong_as_double((long long)r[3]);
+        dr.pickw = (u32)(dr.P0 >> 32);
+    }
     const double log_u = dr.log_u, u_acc = w2uniform_open(batch.P1());
     const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, dr, Ut, false, S, DE, dq);
     if (live) {
@@ -1450,6 +1479,7 @@ __global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
     if (gl == 0) {
         const size_t r = (size_t)w * nt + t;
         if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 0] += 1;
+        if (am && a.AMrec) a.AMrec[(size_t)w * a.cov_update + (size_t)a.am_row0] = AmRec{0.0, AMREC_KEY};   // the split path stores rows
         if (am && a.AMaux) {
             double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)a.am_row0) * 2;
             ax[0] = acc ? nlnL : a.lnL[ch];

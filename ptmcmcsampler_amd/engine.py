@@ -92,7 +92,9 @@ class PTEngine(object):
     and iteration fixes the proposal type of all its temperature ranks (wave-uniform on the device, include/ptmi.h).
     ``nuts_maxdepth``: NUTS stops doubling at this tree height.  The reference doubles ``while s == 1`` with no cap
     (nutsjump.py:716-802); the default 24 (2^24 leapfrogs in one call, the ABI's limit) is out of reach of any run, i.e. the
-    reference's behaviour.  A lower value is an engine option (bounded cost per call).
+    reference's behaviour.  A lower value is an engine option (bounded cost per call).  Memory: the tree scratch holds
+    7 + 4 (maxdepth + 1) vectors of ndim doubles and 4 (maxdepth + 1) scalars per chain (107 vectors at 24, 51 at 10):
+    86 KB per chain at ndim = 100, i.e. 22 GB for 262 144 chains -- lower it for very large batches.
     ``eig_mode``: who factorizes the adapted covariance at a covariance epoch (PTMCMCSampler.py:797-803): ``"lapack"`` = the
     host, exactly as the reference (``np.linalg.svd`` per walker); ``"jacobi"`` = ``ptmi_eig_jacobi`` on the device, one
     block per walker, no host round trip (ndim <= 101, one parameter group; same subspaces, its own sign rule);
@@ -100,6 +102,11 @@ class PTEngine(object):
     tensor: no host round trip either; one parameter group) -- the choice for large ndim, where the host's LAPACK call is the
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
+    ``am_mode``: how the rank-0 chain's samples (updateChains' buffer, PTMCMCSampler.py:327-328) are kept between covariance
+    epochs.  ``"rows"``: every step stores its row.  ``"records"``: a SCAM step stores 16 bytes -- (amplitude, direction,
+    accepted) -- and full KEY rows only at the first step of a launch and at swaps; the pooled statistics rebuild the rows in
+    LDS and every other reader (``get("AM")``, ``am_expand``) gets them rebuilt in place, bit for bit what ``"rows"`` stores
+    (SCAM-only cycles with a pooled covariance; include/ptmi.h ``AMrec``).  ``"auto"`` = records where they apply.
     """
 
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
@@ -108,7 +115,7 @@ class PTEngine(object):
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
                  w_host=0, keep_lnl=False, groups=None, swap_mode="sweep",
                  grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
-                 eig_mode="lapack"):
+                 eig_mode="lapack", am_mode="auto"):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -138,6 +145,10 @@ class PTEngine(object):
         # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
         self.groups = [np.arange(self.d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
         self.ngr = len(self.groups)
+        # "whole": one group that IS the full parameter vector in order (a permutation of it needs put_eig's embedding)
+        self.whole = self.ngr == 1 and np.array_equal(self.groups[0], np.arange(self.d))
+        if eig_mode in ("jacobi", "hipsolver") and not self.whole:
+            raise ValueError("eig_mode=%r factorizes the full covariance: no parameter groups" % eig_mode)
         self.gsize = np.ascontiguousarray([len(g) for g in self.groups], dtype=np.int32)
         self.gmask = np.zeros((self.ngr, self.d))
         for gi, g in enumerate(self.groups):
@@ -171,6 +182,13 @@ class PTEngine(object):
             self.am_pos = np.where(e_ < 2 * (self.am_epl // 2), 8 * (e_ // 2) + 2 * ln_ + e_ % 2, 8 * (self.am_epl // 2) + ln_)   # where parameter i sits
             self.am_inv = np.argsort(self.am_pos)                                   # which parameter sits at position p
         self.owns_cold = self.temp0 == 0
+        if am_mode not in ("auto", "rows", "records"):
+            raise ValueError("am_mode must be 'auto', 'rows' or 'records'")
+        rec_ok = (self.weights[0] > 0 and self.weights[1] == 0 and self.weights[2] == 0 and not has_gj and int(w_host) == 0 and self.ngr == 1
+                  and not self.per_walker and self.owns_cold)            # = ptmi_am_records_ok
+        if am_mode == "records" and not rec_ok:
+            raise ValueError("am_mode='records' serves SCAM-only cycles with one parameter group and a pooled covariance")
+        self.am_records = rec_ok and am_mode != "rows"
         self.t = dict(
             X=z((W, nt, d)), lnL=z((W, nt)), lp=z((W, nt)),
             temp_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
@@ -184,7 +202,12 @@ class PTEngine(object):
             Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
             AMaux=z((W, self.cov_update, 2)) if (keep_lnl and self.owns_cold) else None,
             gj=z((W, nt, _lib.GJ_NSTATE)) if has_gj else None,
+            # AM records (include/ptmi.h): [..., 0] the amplitude's bits, [..., 1] the meta word; every record starts as KEY
+            AMrec=z((W, self.cov_update, 2), i64) if self.am_records else None,
+            Ut_prev=z((d, d)) if self.am_records else None,
         )
+        if self.am_records:
+            self.t["AMrec"][..., 1] = _lib.AMREC_KEY
         if has_gj:
             self.t["gj"][..., _lib.GJ_EPSBAR] = 1.0
         cov0 = np.asarray(cov0, dtype=np.float64)
@@ -217,6 +240,7 @@ class PTEngine(object):
         _lib.check(self.lib.ptmi_create(C.byref(cfg), C.byref(buf), C.byref(self.h)))
         self.de_on = False
         self.de_head = 0
+        self.switch_iter = 0
         self.iter = 0
         self.swap_proposed = 0
         self.eig_epochs = 0
@@ -239,6 +263,8 @@ class PTEngine(object):
     # ------------------------------------------------------------------ data access
     def get(self, name):
         """Device array -> numpy (counters as uint64; DE rows in parameter order whatever their device format)."""
+        if name == "AM":
+            self.am_expand()
         a = self.t[name].cpu().numpy()
         if name == "DE" and self.de_epl:
             lane, slot = np.arange(self.d) % 4, np.arange(self.d) // 4
@@ -252,6 +278,8 @@ class PTEngine(object):
         torch = _torch()
         if name == "AM":
             value = self.am_rows(np.asarray(value))                      # parameter order in, the buffer's row format on the device
+            if self.am_records:
+                self.t["AMrec"][..., 1] = _lib.AMREC_KEY                  # rows written from outside are KEY rows
         self.t[name].copy_(torch.from_numpy(np.ascontiguousarray(value)).to(self.t[name].dtype))
 
     def by_temp(self, name):
@@ -266,7 +294,7 @@ class PTEngine(object):
     def _eig_host(self, w, cov):
         """U, S of the jump covariance by LAPACK (see factorize)."""
         for gi, g in enumerate(self.groups):                          # per group, :139-145 and :797-803
-            U, S = factorize(cov[np.ix_(g, g)] if self.ngr > 1 or len(g) != self.d else cov, self.per_walker)
+            U, S = factorize(cov if self.whole else cov[np.ix_(g, g)], self.per_walker)
             self.put_eig(U, S, w, gi)
 
     def _eig_host_pooled(self):
@@ -293,12 +321,12 @@ class PTEngine(object):
         """U, S of every covariance the engine holds by the ROCm library's symmetric eigensolver, on the stream (factorize()'s
         pooled rule: eigenvalues by decreasing size and in absolute value, eigenvectors as the rows of Ut)."""
         torch = _torch()
-        if self.ngr != 1 or len(self.groups[0]) != self.d:
-            raise _lib.PtmiError("eig_mode='hipsolver' factorizes the full covariance (no parameter groups)")
         with torch.cuda.stream(self.stream):
             w, V = torch.linalg.eigh(self.t["cov"])                  # [Wc][d], [Wc][d][d] (columns)
-            self.t["Ut"][:, 0].copy_(V.flip(-1).transpose(-1, -2))
-            self.t["S"][:, 0].copy_(w.flip(-1).abs())
+            # by decreasing |eigenvalue| (a covariance's are >= 0 up to rounding: a slightly negative one must not jump the queue)
+            w, order = w.abs().sort(dim=-1, descending=True, stable=True)
+            self.t["Ut"][:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
+            self.t["S"][:, 0].copy_(w)
 
     def _eig_host_all(self, cov):
         """Per-walker mode: the W independent factorizations, one upload for all.  From 64 walkers on they run on a
@@ -307,8 +335,7 @@ class PTEngine(object):
         import os
         from . import _eigworker
         torch = _torch()
-        whole = self.ngr == 1 and len(self.groups[0]) == self.d
-        groups = None if whole else self.groups
+        groups = None if self.whole else self.groups
         nwork = int(os.environ.get("PTMI_EIG_WORKERS", min(64, _usable_cores())))
         if self.Wc < 64 or nwork <= 1:
             Ut, Sv = _eigworker.svd_chunk((cov, groups))
@@ -359,6 +386,15 @@ class PTEngine(object):
             return rows[..., self.am_pos]
         return rows[..., _torch().from_numpy(self.am_pos).to(rows.device)]
 
+    def am_expand(self, w0=0, nw=None, it_lo=None, it_hi=None):
+        """AM records -> rows, in place (``ptmi_am_expand``): the rows of iterations ``it_lo .. it_hi`` (default: everything the
+        ring holds, up to the current iteration) of walkers ``w0 .. w0 + nw - 1``.  A no-op with ``am_mode="rows"``."""
+        if not self.am_records:
+            return
+        it_hi = self.iter if it_hi is None else int(it_hi)
+        it_lo = max(0, it_hi - self.cov_update + 1) if it_lo is None else int(it_lo)
+        _lib.check(self.lib.ptmi_am_expand(self.h, int(w0), self.W - int(w0) if nw is None else int(nw), it_lo, it_hi))
+
     def _store_initial(self, i0=0):
         """updateChains(p0, lnlike0, lnprob0, i0), :491: row i0 % covUpdate of the AM ring holds the point."""
         torch = _torch()
@@ -367,6 +403,8 @@ class PTEngine(object):
             idx = self.t["slot_of"][:, 0].long()
             row = int(i0) % self.cov_update
             self.t["AM"][:, row, :] = self.am_rows(self.t["X"][ar, idx])
+            if self.am_records:
+                self.t["AMrec"][:, row, 1] = _lib.AMREC_KEY
             if self.t["AMaux"] is not None:
                 self.t["AMaux"][:, row, 0] = self.t["lnL"][ar, idx]
                 self.t["AMaux"][:, row, 1] = self.t["lp"][ar, idx]
@@ -377,6 +415,11 @@ class PTEngine(object):
         if not self.owns_cold:
             return
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
+        if self.am_records:
+            # AM records name a row of the table in force when they were written: the outgoing table stays at hand for the
+            # rows of the ring that are older than this epoch (ptmi_table_switched, include/ptmi.h)
+            self.t["Ut_prev"].copy_(self.t["Ut"][0, 0])
+            self._table_switched(it_done + 1)
         if self.eig_mode == "jacobi":
             _lib.check(self.lib.ptmi_eig_jacobi(self.h))              # stays on the stream: no host synchronisation
             self.eig_epochs += 1
@@ -385,13 +428,17 @@ class PTEngine(object):
             self._eig_hipsolver()
             self.eig_epochs += 1
             return
-        if self.Wc == 1 and not self.per_walker and self.ngr == 1 and len(self.groups[0]) == self.d:
+        if self.Wc == 1 and not self.per_walker and self.whole:
             self._eig_host_pooled()
         elif self.Wc == 1:
             self._eig_host(0, self.get("cov")[0])
         else:
             self._eig_host_all(self.get("cov"))
         self.eig_epochs += 1
+
+    def _table_switched(self, it):
+        self.switch_iter = int(it)
+        _lib.check(self.lib.ptmi_table_switched(self.h, int(it)))
 
     def update_de(self):
         if self.owns_cold and self.t["DE"] is not None:
@@ -413,7 +460,7 @@ class PTEngine(object):
         self.sync()
         st = {"t_" + k: v.cpu().numpy() for k, v in self.t.items() if v is not None and k not in ("Q", "qaux")}
         st.update(iter=self.iter, de_on=int(self.de_on), de_head=self.de_head, swap_proposed=self.swap_proposed,
-                  eig_epochs=self.eig_epochs)
+                  eig_epochs=self.eig_epochs, switch_iter=self.switch_iter)
         return st
 
     def restore(self, st):
@@ -423,6 +470,8 @@ class PTEngine(object):
                 v.copy_(torch.from_numpy(np.ascontiguousarray(st["t_" + k])).to(v.dtype))
         self.iter, self.swap_proposed = int(st["iter"]), int(st["swap_proposed"])
         self.eig_epochs = int(st["eig_epochs"])
+        if self.am_records:
+            self._table_switched(int(st["switch_iter"]) if "switch_iter" in st else 0)
         if self.t["DE"] is not None:
             self.set_de_head(int(st["de_head"]))
             if int(st["de_on"]):

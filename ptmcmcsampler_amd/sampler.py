@@ -105,7 +105,11 @@ class _PerRankJump(object):
         return j(x, iter, beta)
 
 
-_CKPT_FORMAT = 4      # ptmi_checkpoint.npz: 2 = DE rows in the piece-cyclic device format + run fingerprint; 3 = pooled mode keeps ONE (mu, M2); 4 = AM rows in the device's row format
+# ptmi_checkpoint.npz: 2 = DE rows in the piece-cyclic device format + run fingerprint; 3 = pooled mode keeps ONE (mu, M2);
+# 4 = AM rows in the device's row format; 5 = the fingerprint also covers ladder, Tskip, weights, engine modes and likelihood
+_CKPT_FORMAT = 5
+_CKPT_FORMAT_WHY = {2: "the DE history's row layout", 3: "the pooled statistics' state", 4: "the AM buffer's row layout",
+                    5: "what the run fingerprint covers"}
 
 
 class PTSampler(object):
@@ -408,9 +412,11 @@ class PTSampler(object):
                 for ii in range(self.ndim):
                     try:
                         taus.append(acor(self._chain[lo:hi, ii])[0])
-                    except AcorError:                                # "autocorrelation time too long": the reference's run would die
+                    except AcorError as err:                         # "autocorrelation time too long": the reference's run would die
                         taus = []                                    # here with acor's RuntimeError; this one keeps sampling and asks again
-                        break                                        # in 1000 iterations
+                        if self.verbose:                             # in 1000 iterations -- and says so
+                            print("neff check skipped at iteration {0}: {1} (parameter {2}, {3} rows)".format(end, err, ii, hi - lo))
+                        break
                 if len(taus) and np.isfinite(taus).any():
                     Neff = (end // self.thin) / max(1.0, np.nanmax(taus))
                     if int(Neff) >= self.neff:
@@ -442,21 +448,46 @@ class PTSampler(object):
         np.savez(tmp, **st)
         os.replace(tmp, self._ckpt)
 
+    _FP_NAMES = ("seed", "ndim", "ntemps", "nwalkers", "thin", "covUpdate", "burn", "DE row stride", "DE row format", "keep_walkers",
+                 "AM row format", "ladder", "Tskip", "jump weights", "engine modes", "likelihood / prior")
+
     def _fingerprint(self):
-        """What a checkpoint must agree on with the run that loads it."""
+        """What a checkpoint must agree on with the run that loads it: sizes and formats, and (as 63-bit digests) the ladder,
+        the jump weights, the engine modes and the likelihood / prior specification -- a resumed run that differs in any of
+        them would continue the old device state under a different sampler."""
+        import hashlib
         eng = self.engine
+
+        def digest(*parts):
+            h = hashlib.sha256()
+            for p in parts:
+                h.update(np.ascontiguousarray(p).tobytes() if isinstance(p, np.ndarray) else repr(p).encode())
+            return int.from_bytes(h.digest()[:8], "little") & 0x7FFFFFFFFFFFFFFF
+
+        def spec(s):        # a device specification ("dense", mu, P) by value; Python callbacks by name only
+            if s is None:
+                return ("callback",)
+            return tuple(np.asarray(v, dtype=np.float64) if not isinstance(v, str) else v for v in s)
+
+        groups = [np.asarray(g, dtype=np.int64) for g in self.groups]
         return np.asarray([self.seed & 0x7FFFFFFFFFFFFFFF, self.ndim, self.nchain, self.nwalkers, self.thin, self.covUpdate, self.burn,
-                           eng.de_ld, eng.de_epl, self.keep_walkers, eng.am_epl], dtype=np.int64)
+                           eng.de_ld, eng.de_epl, self.keep_walkers, eng.am_epl,
+                           digest(np.asarray(eng.ladder, dtype=np.float64), np.asarray(eng.temps_mh, dtype=np.float64)), self.Tskip,
+                           digest((self.SCAMweight, self.AMweight, self.DEweight) + tuple(self._grad_weights) + (len(self.host_jumps),)),
+                           digest((self.cov_mode, self.swap_mode, self.pick_mode, self.eig_mode, self.nuts_maxdepth, bool(self.split), bool(self.batched),
+                                   bool(eng.am_records)), *groups),
+                           digest(*(spec(self.logl_spec) + spec(self.logp_spec)))], dtype=np.int64)
 
     def _load_checkpoint(self):
         st = np.load(self._ckpt, allow_pickle=False)
         if "f_format" not in st.files or int(st["f_format"]) != _CKPT_FORMAT:
-            raise Exception("{0} was written in checkpoint format {1}; this build reads format {2} (the DE history's row layout "
-                            "changed): it cannot be resumed from".format(self._ckpt, int(st["f_format"]) if "f_format" in st.files else 1, _CKPT_FORMAT))
+            was = int(st["f_format"]) if "f_format" in st.files else 1
+            why = ", ".join(_CKPT_FORMAT_WHY[v] for v in range(max(was, 1) + 1, _CKPT_FORMAT + 1) if v in _CKPT_FORMAT_WHY)
+            raise Exception("{0} was written in checkpoint format {1}; this build reads format {2} (changed since: {3}): it cannot be "
+                            "resumed from".format(self._ckpt, was, _CKPT_FORMAT, why or "unknown"))
         fp = self._fingerprint()
         if not np.array_equal(st["f_fingerprint"], fp):
-            names = ("seed", "ndim", "ntemps", "nwalkers", "thin", "covUpdate", "burn", "DE row stride", "DE row format", "keep_walkers", "AM row format")
-            bad = [n for n, a, b in zip(names, st["f_fingerprint"], fp) if a != b]
+            bad = [n for n, a, b in zip(self._FP_NAMES, st["f_fingerprint"], fp) if a != b] or ["fingerprint length"]
             raise Exception("{0} belongs to a different run ({1} differ): refusing to resume from it".format(self._ckpt, ", ".join(bad)))
         self.engine.restore(st)
         n = min(self._chains.shape[1], st["f_chains"].shape[1])
@@ -519,6 +550,8 @@ class PTSampler(object):
 
         # iteration 0: the first row (:474-476, :491)
         eng.t["AM"][0, 0] = torch.from_numpy(eng.am_rows(X[0]).copy())
+        if eng.am_records:                                          # replayed rows are stored rows: KEY records (include/ptmi.h AMrec)
+            eng.t["AMrec"][0, :, 1] = _lib.AMREC_KEY
         eng.t["AMaux"][0, 0, 0], eng.t["AMaux"][0, 0, 1] = float(lnl[0]), float(lpr[0])
         self._chains[0, 0], self._lnlikes[0, 0], self._lnprobs[0, 0] = X[0], lnl[0], lnp[0]
         swapped_last = False
@@ -589,6 +622,7 @@ class PTSampler(object):
             return
         eng, kw = self.engine, self.keep_walkers
         rows = [i % eng.cov_update for i in iters]
+        eng.am_expand(0, kw, min(iters), max(iters))                # AM records -> rows for what is read here (a no-op with stored rows)
         X = eng.am_params(eng.t["AM"][:kw][:, rows].cpu().numpy())
         aux = eng.t["AMaux"][:kw][:, rows].cpu().numpy()
         beta0 = 1.0 / eng.temps_mh[0]

@@ -251,6 +251,46 @@ def test_full_size_dense_scam_through_pooled_covariance_epochs(mods):
     assert (js[..., 0, 0] == 300).all() and g.get("nswap").sum() > 0 and g.swap_proposed == 3
 
 
+def test_full_size_scam_persistent_kernel_on_adapted_tables(mods):
+    """BASELINE configs[1] at full size and AS BENCHMARKED -- mh_steps_kernel<4,25,iso,...,ULDS,512> (persistent blocks over one
+    LDS copy of the pooled eigenvector table, cold-first walk) -- on ADAPTED, dense tables: covUpdate = 100, 300 iterations = two
+    pooled covariance epochs and three swap epochs (with covUpdate = 1000 a short run only ever sees the start's unit vectors,
+    24 of a lane's 25 increments zero).  Pooled cov / Ut / S equal the oracle's on the same AM rows, and three walkers' chains
+    (first, middle, last) match the oracle bit for bit throughout (PTMCMCSampler.py:820-876, 605-622, 631-697, 769-803)."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    cov0 = np.eye(d) * 0.01
+    kw = dict(weights=(20, 0, 0), cov_update=100, burn=10000, tskip=100, seed=4321)
+    g = PTEngine(d, nt, W, cov0, cov_mode="pooled", **kw)
+    g.init_state(np.zeros(d))
+    sub = _Subset(orc, (0, 2047, 4095), d, nt, W, cov0, **kw)
+    for o in sub.subs:
+        o.init_state(np.zeros(d))
+    cu = kw["cov_update"]
+    for k in range(3):
+        if k > 0:
+            g.sync()
+            sub.epoch(g.get("AM"), k * cu)
+        g.run(cu)
+        for o in sub.subs:
+            o.run(cu)
+        flags, G, E = g.last_variant()
+        assert flags & _lib.VAR_PERSISTENT and flags & _lib.VAR_LDS_UT and not flags & _lib.VAR_FULL and (G, E) == (4, 25)
+        if k > 0:
+            assert_same(g.get("cov")[0], sub.subs[0].cov[0], "pooled cov after epoch %d" % k)
+            assert_same(g.get("Ut")[0], sub.subs[0].Ut[0], "Ut after epoch %d" % k)
+            assert_same(g.get("S")[0], sub.subs[0].S[0], "S after epoch %d" % k)
+            Ut = g.get("Ut")[0, 0]
+            assert (np.abs(Ut) > 1e-6).mean() > 0.9              # the adapted table is dense: every increment of a lane is live
+        _check_subset(g, sub, "scam segment %d" % k)
+    X, lnL = g.get("X"), g.get("lnL")
+    assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12, atol=1e-12)
+    so = g.get("slot_of")
+    assert (np.sort(so, axis=1) == np.arange(nt)).all()
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., 0, 0] == 300).all() and g.get("nswap").sum() > 0 and g.swap_proposed == 3
+
+
 def test_config4_slice_1000d_64_temps(mods):
     """BASELINE configs[3], one GPU's share: 1000-d isotropic Gaussian, 64 ranks x 512 walkers, default mix (64 lanes per
     chain); invariants on the batch and bit parity on two walkers, through a swap epoch."""
