@@ -54,6 +54,9 @@ def parse():
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
                          "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK; "
                          "_hipsolver: by the ROCm library's eigensolver on the stream (large ndim)")
+    ap.add_argument("--am-mode", default="auto", choices=["auto", "rows", "records"],
+                    help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): records = 16-byte step "
+                         "records between KEY rows where the cycle allows (SCAM-only, pooled), rows = every step stores its row")
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
@@ -188,7 +191,7 @@ def main():
         A = np.random.default_rng(0).standard_normal((d, d))
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
-              pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled",
+              pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled", am_mode=a.am_mode,
               eig_mode="jacobi" if a.cov_mode.endswith("_device") else ("hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack"))
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.prior == "box":

@@ -262,9 +262,10 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter);
 
 /* AM records (ptmi_buffers.AMrec; updateChains' buffer, :327-328).  ptmi_am_records_ok: 1 when the configuration's rank-0 rows can be
  * kept as records -- SCAM-only cycle, one parameter group, pooled covariance, rank 0 on this GPU.  ptmi_am_expand rebuilds, in the AM
- * buffer itself, the rows of iterations iter_lo .. iter_hi (at most one ring, inside the ring's current window) of walkers
- * w0 .. w0 + nw - 1 from the KEY rows and the records, with the step kernel's arithmetic: what a record-free run would have
- * stored.  ptmi_table_switched: the caller put a new table into Ut before iteration `iter` (and the previous one into Ut_prev) --
+ * buffer itself, the rows of iterations iter_lo .. iter_hi of walkers w0 .. w0 + nw - 1 from the KEY rows and the records, with the
+ * step kernel's arithmetic: what a record-free run would have stored.  Both iterations lie in the current covariance period
+ * [E, E + cov_update], E = the last multiple of cov_update below iter_hi (rows of an older period lose their KEY rows when the ring
+ * wraps; the statistics read a period when it is complete).  With AMrec a launch of ptmi_mh_steps may not cross a period.  ptmi_table_switched: the caller put a new table into Ut before iteration `iter` (and the previous one into Ut_prev) --
  * rows of earlier iterations are rebuilt with Ut_prev; only needed when a table takes effect later than the iteration after its
  * covariance epoch. */
 int ptmi_am_records_ok(const ptmi_config *cfg);

@@ -774,18 +774,21 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
 }
 
 // AM records -> rows: the rows of iterations it_lo .. it_hi of walkers w0 .. w0 + nw - 1, rebuilt in place in the AM buffer for the
-// readers that want rows (DE history, chain files, checkpoints of row readers, the ESS window).  Both iterations lie in the ring's
-// current window (base, base + cu]; the walk starts at the last KEY row at or before it_lo (the first step of every launch is one).
+// readers that want rows (chain files, the ESS window, tests).  Both iterations lie in the current covariance period [base, base + cu],
+// base = the last multiple of cov_update below it_hi: once the ring wraps, the KEY rows an older record hangs on are overwritten (the
+// statistics read a period when it is complete; nothing reads further back).  The walk starts at the last KEY row at or before it_lo
+// (the first step of every launch is one, and no launch crosses a period).
 // One block per walker, a thread per parameter, rows in time order; same arithmetic as the step kernels.
 __global__ __launch_bounds__(128) void am_expand_kernel(double *AM, const AmRec *rec, const double *Ut, const double *Utp, int d, int cu,
-                                                        int am_epl, int w0, long long it_lo, long long it_hi, long long switch_iter)
+                                                        int am_epl, int w0, long long it_lo, long long it_hi, long long switch_iter,
+                                                        long long base /* the covariance period's first row is iteration base (ring row 0) */)
 {
     const int w = w0 + (int)blockIdx.x;
     const AmRec *rw = rec + (size_t)w * cu;
     double *aw = AM + (size_t)w * cu * d;
     // the KEY row to start from (uniform)
     long long it0 = it_lo;
-    while (it0 > 0 && it0 > it_hi - cu + 1 && !(rw[it0 % cu].meta & AMREC_KEY)) --it0;
+    while (it0 > base && !(rw[it0 % cu].meta & AMREC_KEY)) --it0;
     for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) {
         const int pos = am_pos(i, am_epl);
         double x = aw[(size_t)(it0 % cu) * d + pos];
@@ -1356,6 +1359,9 @@ static int set_step_args(const ptmi_engine *h, KArgs *a)
     static const bool am_small = getenv("PTMI_MEASURE_AM_SMALL") != nullptr;
     if (am_small) { a->cov_update = 1; a->am_row0 = 0; }
 #endif
+    if (a->AMrec != nullptr && a->nsteps > 0 && (a->iter0 - 1) / c.cov_update != (a->iter0 + a->nsteps - 2) / c.cov_update && a->iter0 > 0)
+        return fail(PTMI_EINVAL, "with AM records a launch may not cross a multiple of cov_update (iterations %lld..%lld, cov_update=%d)",
+                    a->iter0, a->iter0 + a->nsteps - 1, c.cov_update);
     a->swap_last = 0;
     if (c.tskip > 0 && c.ntemps_global > 1) {
         const long long last = a->iter0 + a->nsteps - 1;
@@ -2205,12 +2211,14 @@ int ptmi_am_expand(ptmi_handle h, int32_t w0, int32_t nw, int64_t iter_lo, int64
     const ptmi_config &c = h->cfg;
     if (!h->buf.AMrec || !h->buf.AM) return PTMI_OK;                     // the buffer holds rows already
     if (w0 < 0 || nw < 0 || w0 + nw > c.nwalkers) return fail(PTMI_EINVAL, "walkers [%d, %d) of %d", w0, w0 + nw, c.nwalkers);
-    if (iter_lo < 0 || iter_hi < iter_lo || iter_hi - iter_lo >= c.cov_update)
-        return fail(PTMI_EINVAL, "iterations %lld..%lld do not fit one ring of %d rows", (long long)iter_lo, (long long)iter_hi, c.cov_update);
+    const long long base = iter_hi > 0 ? ((long long)(iter_hi - 1) / c.cov_update) * c.cov_update : 0;
+    if (iter_lo < base || iter_hi < iter_lo || iter_hi - iter_lo >= c.cov_update)
+        return fail(PTMI_EINVAL, "iterations %lld..%lld are not inside the covariance period that starts at %lld (AM records keep the rows of the "
+                                 "current period only)", (long long)iter_lo, (long long)iter_hi, base);
     if (nw == 0) return PTMI_OK;
     hipLaunchKernelGGL(am_expand_kernel, dim3((unsigned)nw), dim3(128), 0, h->stream, h->buf.AM, (const AmRec *)h->buf.AMrec, (const double *)h->buf.Ut,
                        (const double *)h->buf.Ut_prev, c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (int)w0, (long long)iter_lo, (long long)iter_hi,
-                       h->switch_iter);
+                       h->switch_iter, base);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

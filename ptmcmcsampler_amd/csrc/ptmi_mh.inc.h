@@ -1064,7 +1064,10 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
             // ULDS: the draw tables too come from the block's LDS when the host found room (a.tab_off >= 0).  Global reads share
             // the in-order vector-memory counter with the cold chain's AM-row stores: in the block's one cold wave every draw
             // pass waited for 25 stores to retire first
-            scam_draws_for_step<STR, ULDS ? 2 : 0>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
+            // PERS: the host always places the tables (launch_mh_k), so the read is an LDS read at COMPILE time: with the run-time
+            // choice (TM = 2) the two paths merged in an s_waitcnt vmcnt(0) -- every draw pass of a cold wave waited for its AM-row
+            // stores to retire, although it never took the global path
+            scam_draws_for_step<STR, PERS ? 1 : (ULDS ? 2 : 0)>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
                 if (ULDS && !ulds_box) return smem[d * d + kk];
                 return det_sqrt(S[kk]);
             }, smem);

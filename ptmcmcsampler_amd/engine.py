@@ -387,13 +387,20 @@ class PTEngine(object):
         return rows[..., _torch().from_numpy(self.am_pos).to(rows.device)]
 
     def am_expand(self, w0=0, nw=None, it_lo=None, it_hi=None):
-        """AM records -> rows, in place (``ptmi_am_expand``): the rows of iterations ``it_lo .. it_hi`` (default: everything the
-        ring holds, up to the current iteration) of walkers ``w0 .. w0 + nw - 1``.  A no-op with ``am_mode="rows"``."""
+        """AM records -> rows, in place (``ptmi_am_expand``): the rows of iterations ``it_lo .. it_hi`` of walkers
+        ``w0 .. w0 + nw - 1``; default: the current covariance period up to the current iteration (``am_period``) -- rows of an
+        older period are not kept in records mode.  A no-op with ``am_mode="rows"``."""
         if not self.am_records:
             return
         it_hi = self.iter if it_hi is None else int(it_hi)
-        it_lo = max(0, it_hi - self.cov_update + 1) if it_lo is None else int(it_lo)
+        it_lo = self.am_period(it_hi)[0] if it_lo is None else int(it_lo)
         _lib.check(self.lib.ptmi_am_expand(self.h, int(w0), self.W - int(w0) if nw is None else int(nw), it_lo, it_hi))
+
+    def am_period(self, it=None):
+        """(first, last) iteration of the covariance period the ring holds at iteration ``it``: [E, it], E = the last multiple of
+        covUpdate below ``it`` (row 0 of the ring until iteration E + covUpdate overwrites it)."""
+        it = self.iter if it is None else int(it)
+        return ((it - 1) // self.cov_update) * self.cov_update if it > 0 else 0, it
 
     def _store_initial(self, i0=0):
         """updateChains(p0, lnlike0, lnprob0, i0), :491: row i0 % covUpdate of the AM ring holds the point."""

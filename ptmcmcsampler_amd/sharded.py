@@ -153,6 +153,17 @@ class ShardedPTEngine(object):
     def am_params(self, rows):
         return self.local.am_params(rows) if hasattr(self.local, "am_params") else rows
 
+    @property
+    def am_records(self):
+        return bool(getattr(self.local, "am_records", False))
+
+    def am_expand(self, *args, **kw):
+        if hasattr(self.local, "am_expand"):
+            self.local.am_expand(*args, **kw)
+
+    def am_period(self, it=None):
+        return self.local.am_period(self.iter if it is None else it)
+
     def init_state(self, p0):
         p0 = np.asarray(p0, dtype=np.float64)
         if p0.ndim == 3:                                                      # [W][ntemps_global][d] -> my block
