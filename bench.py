@@ -54,9 +54,10 @@ def parse():
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
                          "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK; "
                          "_hipsolver: by the ROCm library's eigensolver on the stream (large ndim)")
-    ap.add_argument("--am-mode", default="auto", choices=["auto", "rows", "records"],
-                    help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): records = 16-byte step "
-                         "records between KEY rows where the cycle allows (SCAM-only, pooled), rows = every step stores its row")
+    ap.add_argument("--am-mode", default="auto", choices=["auto", "rows", "rle"],
+                    help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): rle = a step stores its "
+                         "row only when it was accepted, the pooled statistics weight every stored row by its run length; rows = every "
+                         "step stores its row")
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
@@ -122,7 +123,7 @@ class ColdSamples(object):
 
     def snap(self, it_done):
         if self.nw:
-            self.eng.am_expand(0, self.nw, it_hi=it_done)             # AM records -> rows for the walkers kept (a no-op with stored rows)
+            self.eng.am_expand(0, self.nw, it_hi=it_done)             # the repeats of rejected steps copied forward for the walkers kept (a no-op with stored rows)
             self.snaps.append((it_done, self.eng.t["AM"][:self.nw].clone()))
 
     def series(self, first, last):

@@ -143,14 +143,13 @@ typedef struct ptmi_buffers {
     double *gj;         /* [W][T][8]   by RANK: the attributes of a rank's NUTSJump / HMCJump object (nutsjump.py:379-433):
                          *              epsilon, mu, Hbar, epsilonbar (starts at 1), NUTS calls, HMC calls, have-epsilon flag, leapfrogs taken so far
                          *              (needed with w_nuts + w_hmc > 0) */
-    void *AMrec;        /* [W][cov_update] 16-byte records beside the AM rows (optional; ptmi_am_records_ok): {double amp; uint64 meta},
-                         *              meta = direction k | accepted << 32 | KEY << 33.  With it the step kernels of SCAM-only cycles store
-                         *              the rank-0 chain's row (updateChains, :327-328) only as a KEY row -- first step of a launch, ring row 0,
-                         *              the swap's post-swap row -- and otherwise this record of the step (row = previous row + amp * Ut[k][:]
-                         *              if accepted): 16 bytes instead of 8 ndim.  ptmi_update_cov rebuilds the rows in LDS, bit for bit;
-                         *              other readers call ptmi_am_expand first.  The caller initialises every record to KEY (meta = 1 << 33)
-                         *              and marks rows it writes itself as KEY */
-    double *Ut_prev;    /* [d][d]      with AMrec: the table that was in force before the current one (ptmi_table_switched) */
+    uint64_t *AMflag;   /* [W][cov_update] one flag word beside every AM row (optional; ptmi_am_flags_ok): bit 0 NEW = the step was accepted,
+                         *              bit 1 KEY = the row is stored whatever the step did (first step of a launch, ring rows 0 and 1, the swap's
+                         *              post-swap row, rows the caller writes).  With it the step kernels store the rank-0 chain's row
+                         *              (updateChains, :327-328) only when it is NEW or KEY -- a rejected proposal leaves the chain where it
+                         *              was, its row repeats the one before -- and ptmi_update_cov takes every stored row once, weighted by
+                         *              the length of its run.  Readers that want every row call ptmi_am_expand first.  The caller
+                         *              initialises every word to KEY (2) and marks rows it writes itself as KEY */
 } ptmi_buffers;
 
 typedef struct ptmi_engine *ptmi_handle;
@@ -256,21 +255,19 @@ int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag);
  * cov_update just completed): updates mu, M2 and cov.  With cov_per_walker == 0 ONE set
  * (mu[0], M2[0], cov[0]) is adapted from all walkers' buffered rows: shifted sums of outer products on the matrix
  * cores, slab by slab, combined with the running statistics by Chan's formula (the sample covariance of every
- * rank-0 sample so far; oracle: orc_pool_update).  The eigendecomposition (:797-803) is a
+ * rank-0 sample so far; oracle: orc_pool_update; with AMflag: over the stored rows, each scaled by the square root of its run
+ * length, oracle: orc_pool_update_rle).  The eigendecomposition (:797-803) is a
  * separate step: on the host (LAPACK, as the reference) or ptmi_eig_jacobi. */
 int ptmi_update_cov(ptmi_handle h, int64_t iter);
 
-/* AM records (ptmi_buffers.AMrec; updateChains' buffer, :327-328).  ptmi_am_records_ok: 1 when the configuration's rank-0 rows can be
- * kept as records -- SCAM-only cycle, one parameter group, pooled covariance, rank 0 on this GPU.  ptmi_am_expand rebuilds, in the AM
- * buffer itself, the rows of iterations iter_lo .. iter_hi of walkers w0 .. w0 + nw - 1 from the KEY rows and the records, with the
- * step kernel's arithmetic: what a record-free run would have stored.  Both iterations lie in the current covariance period
- * [E, E + cov_update], E = the last multiple of cov_update below iter_hi (rows of an older period lose their KEY rows when the ring
- * wraps; the statistics read a period when it is complete).  With AMrec a launch of ptmi_mh_steps may not cross a period.  ptmi_table_switched: the caller put a new table into Ut before iteration `iter` (and the previous one into Ut_prev) --
- * rows of earlier iterations are rebuilt with Ut_prev; only needed when a table takes effect later than the iteration after its
- * covariance epoch. */
-int ptmi_am_records_ok(const ptmi_config *cfg);
+/* AM row flags (ptmi_buffers.AMflag; updateChains' buffer, :327-328).  ptmi_am_flags_ok: 1 when the configuration can keep them --
+ * pooled covariance, rank 0 on this GPU (the per-walker recurrence of :778-794 takes every row in turn).  ptmi_am_expand copies, in
+ * the AM buffer itself, every row that was not stored from the row before it, for iterations iter_lo .. iter_hi of walkers
+ * w0 .. w0 + nw - 1: what a flag-free run would have stored.  Both iterations lie in the current covariance period
+ * [E, E + cov_update], E = the last multiple of cov_update below iter_hi (once the ring wraps, the stored row an older repeat hangs on
+ * is overwritten; the statistics read a period when it is complete).  With AMflag a launch of ptmi_mh_steps may not cross a period. */
+int ptmi_am_flags_ok(const ptmi_config *cfg);
 int ptmi_am_expand(ptmi_handle h, int32_t w0, int32_t nw, int64_t iter_lo, int64_t iter_hi);
-int ptmi_table_switched(ptmi_handle h, int64_t iter);
 
 /* The eigendecomposition of _updateRecursive (:797-803, np.linalg.svd of the covariance) for every covariance the handle
  * holds (Wc matrices), on the device: Ut and S are overwritten from cov.  One-sided Jacobi, one block per matrix, both

@@ -43,7 +43,7 @@ class Cfg(C.Structure):
 
 class State(C.Structure):
     _fields_ = [("X", _dp), ("lnL", _dp), ("lp", _dp), ("temp_of", _ip), ("slot_of", _ip), ("Ut", _dp), ("S", _dp),
-                ("DE", _dp), ("AM", _dp), ("nacc", _up), ("jstat", _up), ("gj", _dp)]
+                ("DE", _dp), ("AM", _dp), ("nacc", _up), ("jstat", _up), ("gj", _dp), ("AMflag", _up)]
 
 
 class Replay(C.Structure):
@@ -95,6 +95,8 @@ def lib():
         L.orc_welford2.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_int]
         L.orc_pool_update.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _dp, _dp, _dp]
         L.orc_pool_update.restype = None
+        L.orc_pool_update_rle.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _up, _dp, _dp, _dp]
+        L.orc_pool_update_rle.restype = None
         L.orc_de_update.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.orc_de_update_pooled.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.orc_eval_state.argtypes = [C.POINTER(Cfg), C.POINTER(State)]
@@ -186,6 +188,18 @@ def pool_update(AM, mu, M2, it, slab=None):
     cov = np.empty((d, d))
     AMc = np.ascontiguousarray(AM)
     lib().orc_pool_update(d, W, mem, it, pool_slab(W, d) if slab is None else slab, _p(AMc), _p(mu), _p(M2), _p(cov))
+    return cov
+
+
+def pool_update_rle(AM, flag, mu, M2, it, slab=None):
+    """Pooled-covariance epoch over run-length-compacted rows (orc_pool_update_rle; the engine's am_mode "rle"): flag [W][mem]
+    uint64, bit 0 NEW, bit 1 KEY; every stored row once, weighted by its run length."""
+    W, mem, d = AM.shape
+    cov = np.empty((d, d))
+    AMc = np.ascontiguousarray(AM)
+    fl = np.ascontiguousarray(flag, dtype=np.uint64)
+    assert fl.shape == (W, mem) and (fl[:, 0] & 3).all(), "ring row 0 of every walker is a stored row"
+    lib().orc_pool_update_rle(d, W, mem, it, pool_slab(W, d) if slab is None else slab, _p(AMc), _p(fl, _up), _p(mu), _p(M2), _p(cov))
     return cov
 
 
@@ -289,8 +303,12 @@ class OracleEngine(object):
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep",
                  grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
-                 eig_mode="lapack"):
+                 eig_mode="lapack", am_mode="auto"):
         assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi")
+        assert am_mode in ("auto", "rows", "rle")
+        # the engine's am_mode: "rle" (pooled covariance on the block that holds rank 0) weights the pooled statistics by run lengths
+        self.am_rle = am_mode != "rows" and cov_mode == "pooled" and temp0 == 0
+        assert self.am_rle or am_mode != "rle"
         self.eig_mode = eig_mode
         self.pick_mode = pick_mode
         self.swap_mode = swap_mode
@@ -330,6 +348,7 @@ class OracleEngine(object):
         self.M2 = np.zeros((self.Wc, d, d))
         self.DE = np.zeros((self.Wc, burn, d))
         self.AM = np.zeros((W, cov_update, d))
+        self.AMflag = np.full((W, cov_update), 2, dtype=np.uint64)      # every row starts as a KEY row
         self.nacc = np.zeros((W, nt), dtype=np.uint64)
         self.jstat = np.zeros((W, nt, J_NTYPES, 2), dtype=np.uint64)
         # gradient jumps (PTMCMCSampler.py:225-258): whitening from the INITIAL covariance, never adapted (nutsjump.py:45)
@@ -360,7 +379,7 @@ class OracleEngine(object):
     def _state(self):
         return State(_p(self.X), _p(self.lnL), _p(self.lp), _p(self.temp_of, _ip), _p(self.slot_of, _ip), _p(self.Ut),
                      _p(self.S), _p(self.DE), _p(self.AM) if self.temp0 == 0 else None, _p(self.nacc, _up),
-                     _p(self.jstat, _up), _p(self.gj))
+                     _p(self.jstat, _up), _p(self.gj), _p(self.AMflag, _up) if (self.temp0 == 0 and self.am_rle) else None)
 
     def _svd(self, w):
         # LAPACK results depend on the BLAS thread count in the last bits, so the checker uses the product's rule:
@@ -401,6 +420,7 @@ class OracleEngine(object):
         lib().orc_eval_state(C.byref(self.cfg), C.byref(self._state()))
         if self.temp0 == 0:
             self.AM[:, 0, :] = self.X[np.arange(self.W), self.slot_of[:, 0]]   # updateChains(p0, ..., 0), :491
+            self.AMflag[:, 0] = 2
 
     def by_temp(self, a):
         """Reorder a per-slot array [W][nt][...] into temperature order."""
@@ -417,6 +437,8 @@ class OracleEngine(object):
                 if self.per_walker:
                     for w in range(self.W):
                         self.cov[w] = welford(self.AM[w], self.mu[w], self.M2[w], it - 1)
+                elif self.am_rle:
+                    self.cov[0] = pool_update_rle(self.AM, self.AMflag, self.mu[0], self.M2[0], it - 1)
                 else:
                     self.cov[0] = pool_update(self.AM, self.mu[0], self.M2[0], it - 1)
                 for w in range(self.Wc):

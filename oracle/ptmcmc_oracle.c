@@ -346,6 +346,9 @@ typedef struct {
     uint64_t *nacc;     /* [W][ntemps]      by RANK */
     uint64_t *jstat;    /* [W][ntemps][J_NTYPES][2]  (proposed, accepted) by RANK */
     double *gj;         /* [W][ntemps][GJ_NSTATE]    gradient-jump state by RANK (NULL without gradient jumps) */
+    uint64_t *AMflag;   /* [W][cov_update]  the engine's AM row flags (include/ptmi.h AMflag), or NULL: bit 0 NEW = the step was
+                         * accepted, bit 1 KEY = first step of a launch, ring rows 0 and 1, the swap's row.  The oracle stores every
+                         * row whatever the flags say; they only weight the pooled statistics (orc_pool_update_rle) */
 } orc_state;
 
 typedef struct {
@@ -764,7 +767,7 @@ ORC_API int orc_gradjump(const orc_cfg *c, int kind, const double *x, int64_t it
 /* ------------------------------------------------------------ MH steps */
 /* One Metropolis-Hastings update of one chain: PT:601-622 with _jump PT:1048-1067,
  * SCAM PT:820-876, AM PT:879-933, DE PT:936-985. */
-static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, orc_replay *rp, double *buf)
+static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, orc_replay *rp, double *buf, int k /* step of the launch */)
 {
     const int d = c->ndim, nt = c->ntemps;
     const size_t ch = (size_t)w * nt + s;
@@ -889,7 +892,8 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
     /* native schedule: the accept uniform is the (0,1] one of word P[1], its log by orc_unit_log */
     const double log_u = r ? orc_log(rp_next(r, K_UNI, 0)) : orc_unit_log(P[1]);
     const double diff = newlnprob - lnprob0 + qxy;                  /* qxy = 0 for SCAM / AM / DE */
-    if (diff > log_u) {
+    const int accepted = diff > log_u;
+    if (accepted) {
         memcpy(x, q, sizeof(double) * d);
         st->lnL[ch] = newlnL; st->lp[ch] = lp;
         st->nacc[(size_t)w * nt + t] += 1;
@@ -900,8 +904,12 @@ static void mh_one(const orc_cfg *c, orc_state *st, int w, int s, int64_t it, or
      * (the reference stores the post-swap state, PT:624-627; orc_swap then writes it) */
     if (c->temp0 + t == 0 && st->AM) {
         const int swap_follows = c->tskip > 0 && c->ntemps_global > 1 && it % c->tskip == 0;
-        if (!swap_follows)
-            memcpy(st->AM + ((size_t)w * c->cov_update + (size_t)(it % c->cov_update)) * d, x, sizeof(double) * d);
+        if (!swap_follows) {
+            const int64_t ring = it % c->cov_update;
+            memcpy(st->AM + ((size_t)w * c->cov_update + (size_t)ring) * d, x, sizeof(double) * d);
+            if (st->AMflag)       /* the step kernels' rule (am_store_step): KEY = first step of a launch, ring rows 0 and 1 */
+                st->AMflag[(size_t)w * c->cov_update + (size_t)ring] = ((k == 0 || ring <= 1) ? 2u : 0u) | (accepted ? 1u : 0u);
+        }
     }
 }
 
@@ -910,7 +918,7 @@ ORC_API int orc_mh_steps(const orc_cfg *c, orc_state *st, int64_t iter0, int nst
     double *buf = (double *)malloc(sizeof(double) * 4 * (size_t)c->ndim);
     for (int k = 0; k < nsteps; ++k)
         for (int w = 0; w < c->nwalkers; ++w)
-            for (int s = 0; s < c->ntemps; ++s) mh_one(c, st, w, s, iter0 + k, rp, buf);
+            for (int s = 0; s < c->ntemps; ++s) mh_one(c, st, w, s, iter0 + k, rp, buf, k);
     free(buf);
     int64_t err = 0;
     if (rp) for (int t = 0; t < c->ntemps; ++t) err |= rp[t].err;
@@ -985,9 +993,11 @@ ORC_API void orc_swap_apply(const orc_cfg *c, orc_state *st, const int32_t *map,
         int32_t *so = st->slot_of + (size_t)w * nt, *to = st->temp_of + (size_t)w * nt;
         for (int j = 0; j < nt; ++j) ns[j] = so[map[(size_t)w * nt + j]];
         for (int j = 0; j < nt; ++j) { so[j] = ns[j]; to[ns[j]] = j; }
-        if (st->AM && c->temp0 == 0)
+        if (st->AM && c->temp0 == 0) {
             memcpy(st->AM + ((size_t)w * c->cov_update + (size_t)(iter % c->cov_update)) * d,
                    st->X + ((size_t)w * nt + so[0]) * d, sizeof(double) * d);
+            if (st->AMflag) st->AMflag[(size_t)w * c->cov_update + (size_t)(iter % c->cov_update)] = 2u;   /* the swap's row is a KEY row */
+        }
     }
     free(ns);
 }
@@ -1077,6 +1087,57 @@ ORC_API void orc_pool_update(int d, int nwalkers, int mem, int64_t iter, int sla
         }
     for (int i = 0; i < d; ++i) mu[i] = first ? c[i] + t[i] / nb : mu[i] + (t[i] / nb) * g;
     free(c); free(dx); free(T); free(Ts); free(t); free(ts);
+}
+
+/* The same over run-length-compacted rows (the engine's am_mode "rle", include/ptmi.h AMflag).  A rejected proposal leaves the rank-0
+ * chain where it was, so its row repeats the row before it; the flags say which rows are STORED rows (NEW or KEY).  Within a slab every
+ * stored row r enters ONCE, scaled by s = sqrt(n_r), n_r = the length of its run (to the next stored row, or to the slab's end; ring row
+ * 0 of every walker is a KEY row, so a run never leaves its walker's ring): a = s dx, T_ij += a_i a_j, t_i += a_i s -- the sums of
+ * n_r dx dx^T and n_r dx, i.e. the same statistics as orc_pool_update with every repeat collapsed into one weighted row (s * s is n_r
+ * up to one rounding).  Everything else as above. */
+ORC_API void orc_pool_update_rle(int d, int nwalkers, int mem, int64_t iter, int slab, const double *AM, const uint64_t *flag, double *mu,
+                                 double *M2, double *cov)
+{
+    const int first = iter == mem;
+    const double nb = (double)nwalkers * (double)mem, nprev = (double)nwalkers * (double)(iter - mem);
+    double *c = (double *)malloc(sizeof(double) * (size_t)d), *a = (double *)malloc(sizeof(double) * (size_t)d);
+    double *T = (double *)calloc((size_t)d * d, sizeof(double)), *Ts = (double *)malloc(sizeof(double) * (size_t)d * d);
+    double *t = (double *)calloc((size_t)d, sizeof(double)), *ts = (double *)malloc(sizeof(double) * (size_t)d);
+    for (int i = 0; i < d; ++i) c[i] = first ? AM[i] : mu[i];
+    for (int w0 = 0; w0 < nwalkers; w0 += slab) {
+        const int w1 = w0 + slab < nwalkers ? w0 + slab : nwalkers;
+        const size_t beg = (size_t)w0 * mem, end = (size_t)w1 * mem;
+        memset(Ts, 0, sizeof(double) * (size_t)d * d);
+        memset(ts, 0, sizeof(double) * (size_t)d);
+        for (size_t r = beg; r < end; ++r) {
+            if (!(flag[r] & 3u)) continue;
+            size_t nx = r + 1;
+            while (nx < end && !(flag[nx] & 3u)) ++nx;
+            const double s = sqrt((double)(nx - r));
+            const double *x = AM + r * d;
+            for (int i = 0; i < d; ++i) a[i] = (x[i] - c[i]) * s;
+            for (int i = 0; i < d; ++i) {
+                ts[i] = fma(a[i], s, ts[i]);
+                for (int j = i; j < d; ++j) Ts[(size_t)i * d + j] = fma(a[i], a[j], Ts[(size_t)i * d + j]);
+            }
+        }
+        for (int i = 0; i < d; ++i) {
+            t[i] += ts[i];
+            for (int j = i; j < d; ++j) T[(size_t)i * d + j] += Ts[(size_t)i * d + j];
+        }
+    }
+    const double f = nprev * nb / (nprev + nb), g = nb / (nprev + nb), den = nprev + nb - 1.0;
+    for (int i = 0; i < d; ++i)
+        for (int j = i; j < d; ++j) {
+            const double M2b = T[(size_t)i * d + j] - (t[i] * t[j]) / nb;
+            double m;
+            if (first) m = M2b;
+            else m = (M2[(size_t)i * d + j] + M2b) + ((t[i] / nb) * (t[j] / nb)) * f;
+            M2[(size_t)i * d + j] = M2[(size_t)j * d + i] = m;
+            cov[(size_t)i * d + j] = cov[(size_t)j * d + i] = m / den;
+        }
+    for (int i = 0; i < d; ++i) mu[i] = first ? c[i] + t[i] / nb : mu[i] + (t[i] / nb) * g;
+    free(c); free(a); free(T); free(Ts); free(t); free(ts);
 }
 
 /* ----------------------------------------------------------- DE buffer */

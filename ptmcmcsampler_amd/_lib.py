@@ -33,8 +33,8 @@ SWAP_MODES = {"sweep": 0, "oddeven": 1}
 PICK_MODES = {"chain": 0, "walker": 1}        # PTMI_PICK_CHAIN, PTMI_PICK_WALKER      # PTMI_SWAP_SWEEP, PTMI_SWAP_ODDEVEN
 
 BUFFER_FIELDS = ("X", "lnL", "lp", "temp_of", "slot_of", "Ut", "S", "DE", "AM", "nacc", "jstat", "nswap",
-                 "mu", "M2", "cov", "Q", "qaux", "AMaux", "gj", "AMrec", "Ut_prev")
-AMREC_ACC, AMREC_KEY = 1 << 32, 1 << 33        # meta word of an AM record (include/ptmi.h ptmi_buffers.AMrec)
+                 "mu", "M2", "cov", "Q", "qaux", "AMaux", "gj", "AMflag")
+AMROW_NEW, AMROW_KEY = 1, 2                    # flag word of an AM row (include/ptmi.h ptmi_buffers.AMflag)
 
 
 class Buffers(C.Structure):
@@ -47,7 +47,7 @@ SYMBOLS = (
     "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_last_mh_variant", "ptmi_swap", "ptmi_swap_gather_lnl",
     "ptmi_swap_sweep", "ptmi_swap_sweep_blocks", "ptmi_exchange_pack", "ptmi_exchange_apply", "ptmi_exchange_status", "ptmi_exchange_multihop",
     "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_eig_jacobi", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept",
-    "ptmi_am_records_ok", "ptmi_am_expand", "ptmi_table_switched", "ptmi_test_replay",
+    "ptmi_am_flags_ok", "ptmi_am_expand", "ptmi_test_replay",
     "ptmi_selftest_math", "ptmi_selftest_philox", "ptmi_malloc", "ptmi_free", "ptmi_memcpy_h2d", "ptmi_memcpy_d2h",
     "ptmi_memset", "ptmi_timer_start", "ptmi_timer_stop_ms",
 )
@@ -101,9 +101,8 @@ def load():
     L.ptmi_exchange_status.argtypes = [H, C.POINTER(C.c_int32)]
     L.ptmi_exchange_multihop.argtypes = [H, C.POINTER(C.c_int32)]
     L.ptmi_update_cov.argtypes = [H, C.c_int64]
-    L.ptmi_am_records_ok.argtypes = [C.POINTER(Config)]
+    L.ptmi_am_flags_ok.argtypes = [C.POINTER(Config)]
     L.ptmi_am_expand.argtypes = [H, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
-    L.ptmi_table_switched.argtypes = [H, C.c_int64]
     L.ptmi_test_replay.argtypes = [H, C.c_void_p, C.c_void_p]
     L.ptmi_propose.argtypes = [H, C.c_int64]
     L.ptmi_accept.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p]

@@ -100,13 +100,13 @@ __global__ void swap_prepare_kernel(int W, int n, SwapSrc src, SwapPre *pre)
 #define PTMI_SWEEP_BATCH 8
 #endif
 // the AM-buffer row of a swap iteration (PT:624-627, 327-328): the state that sits at rank 0 after the sweep
-struct SwapAmRow { const double *X, *lnL, *lp; double *AM, *AMaux; int d, cov_update, am_epl; long long iter; AmRec *AMrec; };
-// the post-swap rows are KEY rows of the AM records (ptmi_common.h AmRec)
+struct SwapAmRow { const double *X, *lnL, *lp; double *AM, *AMaux; int d, cov_update, am_epl; long long iter; AmFlag *AMflag; };
+// the post-swap rows are KEY rows (AM row flags, ptmi_common.h)
 __device__ __forceinline__ void swap_am_key(const SwapAmRow &amr, int w0, int nw, int tid, int nthreads)
 {
-    if (amr.AMrec == nullptr) return;
+    if (amr.AMflag == nullptr) return;
     const int ring = (int)(amr.iter % amr.cov_update);
-    for (int wl = tid; wl < nw; wl += nthreads) amr.AMrec[(size_t)(w0 + wl) * amr.cov_update + (size_t)ring] = AmRec{0.0, AMREC_KEY};
+    for (int wl = tid; wl < nw; wl += nthreads) amr.AMflag[(size_t)(w0 + wl) * amr.cov_update + (size_t)ring] = AMROW_KEY;
 }
 template <bool STG>
 __global__ __launch_bounds__(STG ? 256 : 64) void swap_sweep_kernel(int W, int n, const double *ladder, const SwapPre *pre,
@@ -418,7 +418,7 @@ __global__ void swap_oddeven_kernel(int W, int n, const double *ladder, const do
 
 // AM-buffer row of a swap iteration: the state that now sits at rank 0 (PT:624-627, 327-328)
 __global__ void am_write_kernel(const double *X, const double *lnL, const double *lp, const int32_t *slot_of, double *AM,
-                                double *AMaux, int W, int nt, int d, int cov_update, long long iter, int am_epl, AmRec *AMrec)
+                                double *AMaux, int W, int nt, int d, int cov_update, long long iter, int am_epl, AmFlag *AMflag)
 {
     const int w = (int)blockIdx.x;
     const size_t r = (size_t)w * nt + slot_of[(size_t)w * nt];
@@ -430,7 +430,7 @@ __global__ void am_write_kernel(const double *X, const double *lnL, const double
         ax[0] = lnL[r];
         ax[1] = lp[r];
     }
-    if (AMrec && threadIdx.x == 0) AMrec[(size_t)w * cov_update + (size_t)(iter % cov_update)] = AmRec{0.0, AMREC_KEY};
+    if (AMflag && threadIdx.x == 0) AMflag[(size_t)w * cov_update + (size_t)(iter % cov_update)] = AMROW_KEY;
 }
 
 // ------------------------------------------------------------------ Welford
@@ -551,30 +551,26 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
 constexpr int PS_W = 112;       // columns of a macro tile
 // rows per staged chunk: 32 (8 k-steps x 7 tiles) on the diagonal, 16 (4 k-steps x 13 tiles) off it: some 55 matrix instructions
 // per wave cover a memory round trip, and two blocks share a CU (57 KB of LDS each)
-constexpr int ps_rc(bool diag, bool rec = false) { return (diag && !rec) ? 32 : 16; }
+constexpr int ps_rc(bool diag) { return diag ? 32 : 16; }
 typedef double ps_d4 __attribute__((ext_vector_type(4)));
 __host__ __device__ inline int pool_groups(int d) { return (d + 1 + PS_W - 1) / PS_W; }          // macro tiles per side (columns 0 .. d)
 // walkers per slab: up to 512 slabs when one macro tile covers the matrix, up to 32 beyond (a partial is d (d + 1) doubles);
 // part of the definition (summation order): oracle/oracle.py pool_slab is the same rule
 static inline int pool_slab(int nwalkers, int d) { const int target = d + 1 <= PS_W ? 512 : 32; const int s = (nwalkers + target - 1) / target; return s < 1 ? 1 : s; }
-// REC: the buffer holds AM records (ptmi_common.h AmRec) -- KEY rows are read, the rows between them are rebuilt by the stagers
-// with the step kernels' own arithmetic (row = previous row + amp * Ut[k][:], one product and one sum per element), so the
-// statistics see bit for bit the rows a record-free run would have stored, without the 8 ndim bytes per row having been
-// written or read.  The recurrence runs down a column, so ONE thread stages all rows of a chunk for its column (threads
-// 0 .. 111: waves 0 and 1), and those two waves take 6 of the diagonal macro tile's 28 matrix tiles each instead of 7 (the
-// others 8): the chunk's staging (some 200 vector instructions) weighs what two tiles' matrix instructions do.
-struct PoolRec {
-    const AmRec *rec;            // [W][cov_update]
-    const double *Ut, *Utp;      // the table in force, and the one before it (rows 1 .. nprev of a ring were made with Utp)
-    int cu, nprev;
-};
-template <bool DIAG, bool REC>
+// RLE (AM row flags, ptmi_common.h): a slab's matrix is not its rows but its STORED rows, each scaled by the square root of the
+// length of its run (pool_rle_kernel lists them: src = the row, wgt = sqrt(run length)): sum over runs of n dx dx^T as
+// (sqrt(n) dx) (sqrt(n) dx)^T, column d of the staged matrix holding sqrt(n) so that the column sums come out as sum n dx.
+// The oracle defines the same sums (orc_pool_update_rle): 43 % fewer rows to read, stage and multiply at the stationary
+// acceptance of a SCAM cycle.  A stager needs the list entry before it can ask for the row: the entries of chunk i + 2 are
+// requested while the rows of chunk i + 1 are in flight and chunk i is multiplied.
+struct PoolRle { const int32_t *src; const double *wgt; const int32_t *cnt; };
+template <bool DIAG, bool RLE>
 __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, long long nrows, int d, const double *shift,
                                                                      long long rows_per_slab, double *part, int am_epl,
                                                                      int shift_epl /* row format of `shift` (an AM row at the first epoch) */,
-                                                                     PoolRec pr)
+                                                                     PoolRle rl)
 {
-    constexpr int NTW = DIAG ? (REC ? 8 : 7) : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG, REC);
+    constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG);
     __shared__ double Dl[NA][2][PS_RC][PS_W];
     const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, g = lane >> 4;
@@ -587,23 +583,21 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
         J = I + 1 + p;
     }
     const long long beg = (long long)blockIdx.x * rows_per_slab;
-    const long long end = beg + rows_per_slab < nrows ? beg + rows_per_slab : nrows;
+    // RLE: the loop runs over the slab's LIST (entries beg .. beg + count - 1 of src / wgt), not over its rows
+    const long long end = RLE ? beg + rl.cnt[blockIdx.x] : (beg + rows_per_slab < nrows ? beg + rows_per_slab : nrows);
     // tiles of this wave: offsets of their A (rows of the output) and B (columns) fragments inside the macro tile
     int offa[NTW], offb[NTW];
     bool on[NTW];
     ps_d4 acc[NTW];
-    const int t0 = DIAG ? (REC ? (wave < 2 ? 6 * wave : 12 + 8 * (wave - 2)) : 7 * wave) : 0;
-    const int tcount = DIAG ? (REC ? (wave < 2 ? 6 : 8) : 7) : 0;
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
         int ti, tj;
         if (DIAG) {
-            int t = t0 + n, row = 7;
-            on[n] = n < tcount;
-            if (!on[n]) t = 0;
+            int t = 7 * wave + n, row = 7;
             ti = 0;
             while (t >= row) { t -= row; ++ti; --row; }
             tj = ti + t;
+            on[n] = true;
         } else {
             const int t = wave + 4 * n;
             on[n] = t < 49;
@@ -614,10 +608,9 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
         offb[n] = __builtin_amdgcn_readfirstlane(tj * 16);
         acc[n] = ps_d4{0.0, 0.0, 0.0, 0.0};
     }
-    // staging: threads 0..223 own one column of the macro tile(s) and every other row of a chunk (REC: threads 0..111, every row)
+    // staging: threads 0..223 own one column of the macro tile(s) and every other row of a chunk
     const int scol = (int)threadIdx.x % PS_W, srow = (int)threadIdx.x / PS_W;     // srow 0 / 1 (2: idle)
-    const bool stager = REC ? srow == 0 : srow < 2;
-    constexpr int NV = REC ? PS_RC : PS_RC / 2;
+    const bool stager = srow < 2;
     int gc[NA];
     double sh[NA];
 #pragma unroll
@@ -627,137 +620,66 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
     }
     // Loads are unconditional (row and column clamped into the slab: a branch per load made every one of them wait for its
     // own round trip, 2.6 ms per epoch); what a slot really holds is decided when it is staged.
-    double v[NA][NV];
-    int gcl[NA], gcp[NA];
+    double v[NA][PS_RC / 2];
+    double wg[RLE ? PS_RC / 2 : 1];              // RLE: sqrt(run length) of the rows in v
+    int nsrc[RLE ? PS_RC / 2 : 1];               // RLE: the rows of the chunk after the one in v
+    int gcl[NA];
 #pragma unroll
-    for (int a2 = 0; a2 < NA; ++a2) {
-        gcp[a2] = gc[a2] < d ? gc[a2] : d - 1;                  // the column, clamped (parameter order: a row of Ut)
-        gcl[a2] = am_pos(gcp[a2], am_epl);                      // where the column sits in a buffered row
-    }
+    for (int a2 = 0; a2 < NA; ++a2) gcl[a2] = am_pos(gc[a2] < d ? gc[a2] : d - 1, am_epl);      // where the column sits in a buffered row
     long long vr0 = beg;
-    double xc[NA];                                              // REC: the column's value in the row before the chunk
-    int vci = 0;                                                // REC: the chunk the fetched values belong to (its records are in Rl[vci & 1])
+    auto list = [&](long long r0) {              // RLE: request the list entries of the chunk that starts at entry r0
+        if constexpr (RLE) {
 #pragma unroll
-    for (int a2 = 0; a2 < NA; ++a2) xc[a2] = 0.0;
-    // REC: the records of a chunk reach the stagers through LDS (Rl, two buffers), loaded TWO chunks ahead by the first PS_RC
-    // lanes of wave 2 (one 16-byte record each): the table row a stager needs is named by the record, and a stager that
-    // waited for the record itself before it could ask for the row would sit out a memory round trip in every chunk.  The
-    // loader lane also does everything that belongs to the ROW, not to a column: which table (ring row <= nprev: the one
-    // before), and the address of the source row -- the buffered row itself for a KEY row, else row k of the table.
-    struct __attribute__((aligned(16))) Prep { double amp; const double *base; unsigned flags, pad[3]; };
-    __shared__ Prep Rl[REC ? 2 : 1][REC ? PS_RC : 1];
-    const int ltid = (int)threadIdx.x - 128;
-    const bool loader = REC && ltid >= 0 && ltid < PS_RC;
-    AmRec lrec = AmRec{0.0, 0ull};
-    long long lrow = 0;
-    auto rec_load = [&](long long r0) {
-        if (loader) {
-            const long long r = r0 + ltid;
-            lrow = r < end ? r : end - 1;
-            lrec = pr.rec[lrow];
-        }
-    };
-    auto rec_put = [&](int ci) {
-        if (loader) {
-            // rows_per_slab is a whole number of rings, so the ring row is (row - beg) mod cu
-            const int rg = (int)((unsigned)(lrow - beg) % (unsigned)pr.cu);
-            const double *tab = (rg >= 1 && rg <= pr.nprev) ? pr.Utp : pr.Ut;
-            const unsigned fl = (unsigned)(lrec.meta >> 32);
-            const bool key = (fl & (unsigned)(AMREC_KEY >> 32)) != 0;
-            Prep q;
-            q.amp = lrec.amp;
-            q.base = key ? rows + lrow * d : tab + (size_t)(unsigned)lrec.meta * d;
-            q.flags = fl;
-            q.pad[0] = q.pad[1] = q.pad[2] = 0u;
-            Rl[ci & 1][ltid] = q;
-        }
-    };
-    auto fetch = [&](long long r0, int ci) {
-        vr0 = r0;
-        vci = ci;
-        if constexpr (REC) {
-#pragma unroll
-            for (int u = 0; u < PS_RC; ++u) {
-                const Prep &q = Rl[ci & 1][u];                                    // one address for the wave: broadcast reads
-                const double *base = q.base;
-                const bool key = (q.flags & (unsigned)(AMREC_KEY >> 32)) != 0;
-#pragma unroll
-                for (int a2 = 0; a2 < NA; ++a2) v[a2][u] = base[key ? gcl[a2] : gcp[a2]];
+            for (int u = 0; u < PS_RC / 2; ++u) {
+                const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
+                nsrc[u] = rl.src[rc];
             }
-        } else {
+        }
+    };
+    auto fetch = [&](long long r0) {
+        vr0 = r0;
 #pragma unroll
-            for (int a2 = 0; a2 < NA; ++a2)
+        for (int u = 0; u < PS_RC / 2; ++u) {
+            const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
+            const long long row = RLE ? (long long)nsrc[u] : rc;
+            if constexpr (RLE) wg[u] = rl.wgt[rc];
 #pragma unroll
-                for (int u = 0; u < PS_RC / 2; ++u) {
-                    const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
-                    v[a2][u] = rows[rc * d + gcl[a2]];
-                }
+            for (int a2 = 0; a2 < NA; ++a2) v[a2][u] = rows[row * d + gcl[a2]];
         }
     };
     auto stage = [&](int buf) {
         if (stager) {
-            if constexpr (REC) {
 #pragma unroll
-                for (int a2 = 0; a2 < NA; ++a2) {
-                    double x = xc[a2];
+            for (int a2 = 0; a2 < NA; ++a2)
 #pragma unroll
-                    for (int u = 0; u < PS_RC; ++u) {
-                        const Prep &q = Rl[vci & 1][u];                 // again from LDS: 96 registers to keep them since the fetch
-                        const unsigned fl = q.flags;
-                        const double p = q.amp * v[a2][u];              // the step kernel's dq = amp * u_k ...
-                        const double moved = x + p;                     // ... and x + dq
-                        x = (fl & (unsigned)(AMREC_KEY >> 32)) ? v[a2][u] : ((fl & (unsigned)(AMREC_ACC >> 32)) ? moved : x);
-                        const bool live = vr0 + u < end;
-                        const double val = gc[a2] < d ? x - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
-                        Dl[a2][buf][u][scol] = live ? val : 0.0;
-                    }
-                    xc[a2] = x;
+                for (int u = 0; u < PS_RC / 2; ++u) {
+                    const bool live = vr0 + 2 * u + srow < end;
+                    double x = gc[a2] < d ? v[a2][u] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
+                    if constexpr (RLE) x = x * wg[u];
+                    Dl[a2][buf][2 * u + srow][scol] = live ? x : 0.0;
                 }
-            } else {
-#pragma unroll
-                for (int a2 = 0; a2 < NA; ++a2)
-#pragma unroll
-                    for (int u = 0; u < PS_RC / 2; ++u) {
-                        const bool live = vr0 + 2 * u + srow < end;
-                        const double x = gc[a2] < d ? v[a2][u] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
-                        Dl[a2][buf][2 * u + srow][scol] = live ? x : 0.0;
-                    }
-            }
         }
     };
-    if constexpr (REC) {
-        rec_load(beg);
-        rec_put(0);
-        rec_load(beg + PS_RC);
-        __syncthreads();
-    }
-    if (!REC || stager) fetch(beg, 0);
+    list(beg);
+    fetch(beg);
+    list(beg + PS_RC);
     stage(0);
-    if constexpr (REC) rec_put(1);
     __syncthreads();
-    int buf = 0, ci = 0;
-    for (long long r0 = beg; r0 < end; r0 += PS_RC, ++ci) {
+    int buf = 0;
+    for (long long r0 = beg; r0 < end; r0 += PS_RC) {
         const bool more = r0 + PS_RC < end;
-        if (more && (!REC || stager)) fetch(r0 + PS_RC, ci + 1);
-        if constexpr (REC) rec_load(r0 + 2 * PS_RC);                   // clamped past the slab's end
+        if (more) {
+            fetch(r0 + PS_RC);
+            list(r0 + 2 * PS_RC);
+        }
         const double *Ab = &Dl[0][buf][0][0] + g * PS_W + c, *Bb = &Dl[NA - 1][buf][0][0] + g * PS_W + c;
-        auto mfma_chunk = [&](auto cnt) {
-            constexpr int CNT = decltype(cnt)::value;
 #pragma unroll
-            for (int k0 = 0; k0 < PS_RC; k0 += 4) {
+        for (int k0 = 0; k0 < PS_RC; k0 += 4) {
 #pragma unroll
-                for (int n = 0; n < CNT; ++n)
-                    if (DIAG || on[n]) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + offa[n]], Bb[k0 * PS_W + offb[n]], acc[n], 0, 0, 0);
-            }
-        };
-        if constexpr (DIAG && REC) {
-            if (wave < 2) mfma_chunk(std::integral_constant<int, 6>{});
-            else mfma_chunk(std::integral_constant<int, 8>{});
-        } else {
-            mfma_chunk(std::integral_constant<int, NTW>{});
+            for (int n = 0; n < NTW; ++n)
+                if (on[n]) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + offa[n]], Bb[k0 * PS_W + offb[n]], acc[n], 0, 0, 0);
         }
         if (more) stage(buf ^ 1);
-        if constexpr (REC) rec_put(ci + 2);                            // read at the top of the trip after next; last read at the top of this one
         __syncthreads();
         buf ^= 1;
     }
@@ -773,34 +695,58 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
     }
 }
 
-// AM records -> rows: the rows of iterations it_lo .. it_hi of walkers w0 .. w0 + nw - 1, rebuilt in place in the AM buffer for the
-// readers that want rows (chain files, the ESS window, tests).  Both iterations lie in the current covariance period [base, base + cu],
-// base = the last multiple of cov_update below it_hi: once the ring wraps, the KEY rows an older record hangs on are overwritten (the
-// statistics read a period when it is complete; nothing reads further back).  The walk starts at the last KEY row at or before it_lo
-// (the first step of every launch is one, and no launch crosses a period).
-// One block per walker, a thread per parameter, rows in time order; same arithmetic as the step kernels.
-__global__ __launch_bounds__(128) void am_expand_kernel(double *AM, const AmRec *rec, const double *Ut, const double *Utp, int d, int cu,
-                                                        int am_epl, int w0, long long it_lo, long long it_hi, long long switch_iter,
-                                                        long long base /* the covariance period's first row is iteration base (ring row 0) */)
+// The list of a slab's stored rows (AM row flags) and the square roots of their run lengths: entry j of slab s (at beg + j) is the
+// j-th row of the slab whose flag word says NEW or KEY; its run ends where the next stored row begins (ring row 0 of every walker is
+// a KEY row, so a run never crosses into another walker's ring) or at the slab's end.  One block per slab, rows in order.
+__global__ __launch_bounds__(256) void pool_rle_kernel(const AmFlag *flag, long long nrows, long long rows_per_slab, int32_t *src, double *wgt,
+                                                       int32_t *cnt)
+{
+    __shared__ int wsum[4], base_s;
+    const long long beg = (long long)blockIdx.x * rows_per_slab;
+    const long long end = beg + rows_per_slab < nrows ? beg + rows_per_slab : nrows;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (long long r0 = beg; r0 < end; r0 += 256) {
+        const long long r = r0 + threadIdx.x;
+        const bool em = r < end && (flag[r] & (AMROW_NEW | AMROW_KEY)) != 0;
+        const unsigned long long m = __ballot(em);
+        if (lane == 0) wsum[wave] = (int)__popcll(m);
+        __syncthreads();
+        int off = base_s + (int)__popcll(m & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wave; ++k) off += wsum[k];
+        if (em) src[beg + off] = (int32_t)r;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    const int n = base_s;
+    if (threadIdx.x == 0) cnt[blockIdx.x] = n;
+    for (int j = (int)threadIdx.x; j < n; j += 256) {
+        const long long here = src[beg + j], next = j + 1 < n ? (long long)src[beg + j + 1] : end;
+        wgt[beg + j] = det_sqrt((double)(next - here));
+    }
+}
+
+// AM row flags -> every row: rows that were not stored (rejected steps) are copied forward from the row before them, in place,
+// for the readers that want every row (DE history, chain files, the ESS window, tests): iterations it_lo .. it_hi of walkers
+// w0 .. w0 + nw - 1.  Both iterations lie in the current covariance period [base, base + cu], base = the last multiple of cov_update
+// below it_hi (ring row 0): once the ring wraps, the stored row an older repeat hangs on is overwritten (the statistics read a period
+// when it is complete; nothing reads further back).  One block per walker, a thread per parameter, rows in time order.
+__global__ __launch_bounds__(128) void am_expand_kernel(double *AM, const AmFlag *flag, int d, int cu, int w0, long long it_lo, long long it_hi,
+                                                        long long base)
 {
     const int w = w0 + (int)blockIdx.x;
-    const AmRec *rw = rec + (size_t)w * cu;
+    const AmFlag *fw = flag + (size_t)w * cu;
     double *aw = AM + (size_t)w * cu * d;
-    // the KEY row to start from (uniform)
-    long long it0 = it_lo;
-    while (it0 > base && !(rw[it0 % cu].meta & AMREC_KEY)) --it0;
-    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) {
-        const int pos = am_pos(i, am_epl);
-        double x = aw[(size_t)(it0 % cu) * d + pos];
+    long long it0 = it_lo;                                   // the stored row to start from (uniform)
+    while (it0 > base && !(fw[it0 % cu] & (AMROW_NEW | AMROW_KEY))) --it0;
+    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) {       // element i of the buffer's row format, whatever it is
+        double x = aw[(size_t)(it0 % cu) * d + i];
         for (long long it = it0 + 1; it <= it_hi; ++it) {
             const int ring = (int)(it % cu);
-            const AmRec q = rw[ring];
-            if (q.meta & AMREC_KEY) x = aw[(size_t)ring * d + pos];
-            else {
-                const double *tab = it >= switch_iter ? Ut : Utp;
-                if (q.meta & AMREC_ACC) x = x + q.amp * tab[(size_t)(unsigned)q.meta * d + i];
-                if (it >= it_lo) aw[(size_t)ring * d + pos] = x;
-            }
+            if (fw[ring] & (AMROW_NEW | AMROW_KEY)) x = aw[(size_t)ring * d + i];
+            else if (it >= it_lo) aw[(size_t)ring * d + i] = x;
         }
     }
 }
@@ -1316,7 +1262,7 @@ static KArgs make_args(ptmi_engine *h)
     static const bool no_am = getenv("PTMI_MEASURE_NO_AM") != nullptr;
     if (no_am) a.AM = nullptr;
 #endif
-    a.AMrec = c.temp0 == 0 ? (AmRec *)b.AMrec : nullptr;
+    a.AMflag = c.temp0 == 0 ? (AmFlag *)b.AMflag : nullptr;
     a.rp_draws = h->rp_draws;
     a.nacc = (u64 *)b.nacc; a.jstat = (u64 *)b.jstat;
     a.temps_mh = h->d_temps; a.beta = h->d_beta; a.logl_par = h->d_loglpar; a.logp_par = h->d_logppar;
@@ -1359,8 +1305,8 @@ static int set_step_args(const ptmi_engine *h, KArgs *a)
     static const bool am_small = getenv("PTMI_MEASURE_AM_SMALL") != nullptr;
     if (am_small) { a->cov_update = 1; a->am_row0 = 0; }
 #endif
-    if (a->AMrec != nullptr && a->nsteps > 0 && (a->iter0 - 1) / c.cov_update != (a->iter0 + a->nsteps - 2) / c.cov_update && a->iter0 > 0)
-        return fail(PTMI_EINVAL, "with AM records a launch may not cross a multiple of cov_update (iterations %lld..%lld, cov_update=%d)",
+    if (a->AMflag != nullptr && a->nsteps > 0 && (a->iter0 - 1) / c.cov_update != (a->iter0 + a->nsteps - 2) / c.cov_update && a->iter0 > 0)
+        return fail(PTMI_EINVAL, "with AM row flags a launch may not cross a multiple of cov_update (iterations %lld..%lld, cov_update=%d)",
                     a->iter0, a->iter0 + a->nsteps - 1, c.cov_update);
     a->swap_last = 0;
     if (c.tskip > 0 && c.ntemps_global > 1) {
@@ -1463,13 +1409,12 @@ static int upload(double **dst, const double *src, long long n)
     return PTMI_OK;
 }
 
-// AM records stand for rows only where every step of the rank-0 chain is a SCAM step along a row of ONE table that the readers can
-// look up again: SCAM-only cycle (no AM, DE, gradient or host-served entries), one parameter group, pooled covariance, rank 0 local
-int ptmi_am_records_ok(const ptmi_config *c)
+// AM row flags serve the pooled covariance (the per-walker recurrence of PT:778-794 takes every row in turn) on the GPU that holds
+// rank 0
+int ptmi_am_flags_ok(const ptmi_config *c)
 {
     if (!c) return 0;
-    return c->w_scam > 0 && c->w_am == 0 && c->w_de == 0 && c->w_nuts == 0 && c->w_hmc == 0 && c->w_host == 0 && c->ngroups <= 1 &&
-           !c->cov_per_walker && c->temp0 == 0;
+    return !c->cov_per_walker && c->temp0 == 0;
 }
 
 int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *out)
@@ -1514,9 +1459,10 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     if (!buf->X || !buf->lnL || !buf->lp || !buf->temp_of || !buf->slot_of || !buf->Ut || !buf->S || !buf->nacc || !buf->jstat)
         return fail(PTMI_EINVAL, "a required device buffer is NULL");
     if (c.w_de > 0 && !buf->DE) return fail(PTMI_EINVAL, "DE weight > 0 but no DE buffer");
-    if (buf->AMrec) {
-        if (!ptmi_am_records_ok(cfg)) return fail(PTMI_EINVAL, "AM records (ptmi_buffers.AMrec) serve SCAM-only cycles with one pooled table on the GPU that holds rank 0 (ptmi_am_records_ok)");
-        if (!buf->AM || !buf->Ut_prev) return fail(PTMI_EINVAL, "AM records need the AM and Ut_prev buffers");
+    if (buf->AMflag) {
+        if (!ptmi_am_flags_ok(cfg)) return fail(PTMI_EINVAL, "AM row flags (ptmi_buffers.AMflag) serve the pooled covariance on the GPU that holds rank 0 (ptmi_am_flags_ok)");
+        if (!buf->AM) return fail(PTMI_EINVAL, "AM row flags need the AM buffer");
+        if ((long long)c.nwalkers * c.cov_update > 0x7FFFFFFFLL) return fail(PTMI_EINVAL, "AM row flags index rows with 32 bits: nwalkers * cov_update too large");
     }
     if ((unsigned long long)c.nwalkers * (unsigned)c.ntemps_global > 0xFFFFFFFFull) return fail(PTMI_EINVAL, "too many RNG streams");
     Shape s;
@@ -1593,6 +1539,12 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         const int SL = pool_slab(c.nwalkers, c.ndim), nslab = (c.nwalkers + SL - 1) / SL;
         e = hipMalloc((void **)&h->d_pool_part, sizeof(double) * (size_t)nslab * c.ndim * (c.ndim + 1));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_pool_T, sizeof(double) * (size_t)c.ndim * (c.ndim + 1));
+        if (buf->AMflag) {                                                // the slabs' lists of stored rows (pool_rle_kernel)
+            const size_t nrows = (size_t)c.nwalkers * c.cov_update;
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_rle_src, sizeof(int32_t) * nrows);
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_rle_wgt, sizeof(double) * nrows);
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_rle_cnt, sizeof(int32_t) * (size_t)nslab);
+        }
     }
     // AM increments ahead of the launch (am_gemm_kernel): the 16- and 64-lane shapes with one pooled table, ndim <= 1024
     if (e == hipSuccess && !gj && c.w_am > 0 && !c.cov_per_walker && c.ngroups <= 1 && s.G > 4 && c.ndim <= 1024 && c.w_host == 0 &&
@@ -1623,6 +1575,7 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
+    (void)hipFree(h->d_rle_src); (void)hipFree(h->d_rle_wgt); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->side_go); (void)hipEventDestroy(h->side_done); }
@@ -1758,7 +1711,7 @@ int ptmi_swap_write_am(ptmi_handle h, int64_t iter)
     hipLaunchKernelGGL(am_write_kernel, dim3(h->cfg.nwalkers), dim3(64), 0, h->stream, (const double *)h->buf.X,
                        (const double *)h->buf.lnL, (const double *)h->buf.lp, (const int32_t *)h->buf.slot_of, h->buf.AM,
                        h->buf.AMaux, h->cfg.nwalkers, h->cfg.ntemps, h->cfg.ndim, h->cfg.cov_update, (long long)iter, am_row_epl(h->G, h->EPL),
-                       (AmRec *)h->buf.AMrec);
+                       (AmFlag *)h->buf.AMflag);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -1858,7 +1811,7 @@ int ptmi_swap(ptmi_handle h, int64_t iter)
                          c.walker0, 0, h->rp_swap_u};
     // the sweep's write-out also stores the swap iteration's AM row (one kernel and one launch gap less per swap epoch)
     const SwapAmRow amr = {(const double *)h->buf.X, (const double *)h->buf.lnL, (const double *)h->buf.lp, h->buf.AM, h->buf.AMaux,
-                           c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (long long)iter, (AmRec *)h->buf.AMrec};
+                           c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (long long)iter, (AmFlag *)h->buf.AMflag};
     bool am_done = false, used = false;
     if (int rc = launch_swap_fused(h, W, c.ntemps, src, h->buf.slot_of, h->buf.temp_of, (int32_t *)nullptr, (u64 *)h->buf.nswap, 0, c.ntemps, -1,
                                    (int32_t *)nullptr, 0, nullptr, (c.temp0 == 0 && h->buf.AM) ? &amr : nullptr, &am_done, &used)) return rc;
@@ -2146,14 +2099,13 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
         // fill the last, partly empty round of the off-diagonal ones instead of a launch of their own behind them
         // (1000-d, 512 walkers: 288 blocks beside 1152 with 512 resident at a time).
         hipStream_t diag_stream = h->stream;
-        // AM records: the stagers rebuild the rows between the KEY rows.  Rows 1 .. nprev of a ring were made with the table before
-        // the one in force (a table applied some iterations after its epoch, ptmi_table_switched)
-        const bool rec = h->buf.AMrec != nullptr;
-        const long long base = iter - c.cov_update, np = h->switch_iter - base - 1;
-        const PoolRec pr = {(const AmRec *)h->buf.AMrec, (const double *)h->buf.Ut, (const double *)h->buf.Ut_prev, c.cov_update,
-                            (int)(np < 0 ? 0 : (np > c.cov_update ? c.cov_update : np))};
+        // AM row flags: the slabs' lists of stored rows and run lengths first, then the sums over them
+        const bool rle = h->buf.AMflag != nullptr;
+        const PoolRle pr = {h->d_rle_src, h->d_rle_wgt, h->d_rle_cnt};
         const long long rps = (long long)SL * c.cov_update;
         const int aepl = am_row_epl(h->G, h->EPL), sepl = first ? am_row_epl(h->G, h->EPL) : 0;
+        if (rle) hipLaunchKernelGGL(pool_rle_kernel, dim3(nslab), dim3(256), 0, h->stream, (const AmFlag *)h->buf.AMflag, nrows, rps, h->d_rle_src,
+                                    h->d_rle_wgt, h->d_rle_cnt);
         if (ng > 1) {
             if (!h->side) {
                 HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -2162,13 +2114,13 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
             }
             HIPCHK(hipEventRecord(h->side_go, h->stream));
             HIPCHK(hipStreamWaitEvent(h->side, h->side_go, 0));
-            if (rec) hipLaunchKernelGGL((pool_syrk_kernel<false, true>), dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
+            if (rle) hipLaunchKernelGGL((pool_syrk_kernel<false, true>), dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
                                         shift, rps, h->d_pool_part, aepl, sepl, pr);
             else hipLaunchKernelGGL((pool_syrk_kernel<false, false>), dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
                                     shift, rps, h->d_pool_part, aepl, sepl, pr);
             diag_stream = h->side;
         }
-        if (rec) hipLaunchKernelGGL((pool_syrk_kernel<true, true>), dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
+        if (rle) hipLaunchKernelGGL((pool_syrk_kernel<true, true>), dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
                                     rps, h->d_pool_part, aepl, sepl, pr);
         else hipLaunchKernelGGL((pool_syrk_kernel<true, false>), dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
                                 rps, h->d_pool_part, aepl, sepl, pr);
@@ -2209,25 +2161,16 @@ int ptmi_am_expand(ptmi_handle h, int32_t w0, int32_t nw, int64_t iter_lo, int64
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
     const ptmi_config &c = h->cfg;
-    if (!h->buf.AMrec || !h->buf.AM) return PTMI_OK;                     // the buffer holds rows already
+    if (!h->buf.AMflag || !h->buf.AM) return PTMI_OK;                    // every row is stored already
     if (w0 < 0 || nw < 0 || w0 + nw > c.nwalkers) return fail(PTMI_EINVAL, "walkers [%d, %d) of %d", w0, w0 + nw, c.nwalkers);
     const long long base = iter_hi > 0 ? ((long long)(iter_hi - 1) / c.cov_update) * c.cov_update : 0;
     if (iter_lo < base || iter_hi < iter_lo || iter_hi - iter_lo >= c.cov_update)
-        return fail(PTMI_EINVAL, "iterations %lld..%lld are not inside the covariance period that starts at %lld (AM records keep the rows of the "
-                                 "current period only)", (long long)iter_lo, (long long)iter_hi, base);
+        return fail(PTMI_EINVAL, "iterations %lld..%lld are not inside the covariance period that starts at %lld (with AM row flags the ring keeps "
+                                 "the rows of the current period only)", (long long)iter_lo, (long long)iter_hi, base);
     if (nw == 0) return PTMI_OK;
-    hipLaunchKernelGGL(am_expand_kernel, dim3((unsigned)nw), dim3(128), 0, h->stream, h->buf.AM, (const AmRec *)h->buf.AMrec, (const double *)h->buf.Ut,
-                       (const double *)h->buf.Ut_prev, c.ndim, c.cov_update, am_row_epl(h->G, h->EPL), (int)w0, (long long)iter_lo, (long long)iter_hi,
-                       h->switch_iter, base);
+    hipLaunchKernelGGL(am_expand_kernel, dim3((unsigned)nw), dim3(128), 0, h->stream, h->buf.AM, (const AmFlag *)h->buf.AMflag, c.ndim, c.cov_update,
+                       (int)w0, (long long)iter_lo, (long long)iter_hi, base);
     HIPCHK(hipGetLastError());
-    return PTMI_OK;
-}
-
-int ptmi_table_switched(ptmi_handle h, int64_t iter)
-{
-    if (!h) return fail(PTMI_EINVAL, "NULL handle");
-    if (iter < 0) return fail(PTMI_EINVAL, "iter negative");
-    h->switch_iter = iter;
     return PTMI_OK;
 }
 
@@ -2245,7 +2188,6 @@ int ptmi_update_de(ptmi_handle h)
     const ptmi_config &c = h->cfg;
     if (!h->buf.DE) return PTMI_OK;
     if (!h->buf.AM) return fail(PTMI_EINVAL, "DE update needs the AM buffer on this GPU");
-    if (h->buf.AMrec) return fail(PTMI_EINVAL, "the DE history reads rows: call ptmi_am_expand first (AM records are for SCAM-only cycles)");
     const int wc = c.cov_per_walker ? c.nwalkers : 1;
     hipLaunchKernelGGL(de_update_kernel, dim3(c.cov_update, wc), dim3(64), 0, h->stream, h->buf.DE, (const double *)h->buf.AM,
                        c.ndim, c.de_size, c.cov_update, h->de_head, c.nwalkers, c.cov_per_walker ? 0 : 1,

@@ -31,15 +31,14 @@ __host__ __device__ inline int am_pos(int i, int epl)
 }
 constexpr int am_row_epl(int G, int EPL) { return (G == 4 && EPL == 25) ? EPL : 0; }      // = ptmi_shape_exact (declared below)
 
-// AM records (ptmi_buffers.AMrec, include/ptmi.h): beside every row of the AM buffer one 16-byte record.  A SCAM step moves the
-// rank-0 chain by amp * u_k or not at all, so (amp, k, accepted) -- 16 bytes -- says what the 8 ndim bytes of the row say, given
-// the row before it and the eigenvector table in force.  The step kernels of SCAM-only cycles then store the full row only as a
-// KEY row (first step of a launch, ring row 0; the swap's post-swap row is one too) and a record otherwise; readers rebuild the
-// rows in between with the kernel's own arithmetic (one product, one sum per element: bit-identical).
-// word 1 of a record: direction k in the low 32 bits, flags above.
-constexpr unsigned long long AMREC_ACC = 1ull << 32;      // the step was accepted: row = previous row + amp * Ut[k][:]
-constexpr unsigned long long AMREC_KEY = 1ull << 33;      // the AM buffer holds this row itself
-struct __attribute__((aligned(16))) AmRec { double amp; unsigned long long meta; };
+// AM row flags (ptmi_buffers.AMflag, include/ptmi.h): one 8-byte word beside every row of the AM buffer.  A rejected proposal
+// leaves the rank-0 chain where it was -- its row repeats the row before it (43 % of the rows at the stationary acceptance of a
+// SCAM cycle).  With the flags the step kernels store a row only when it is NEW (the step was accepted) or a KEY row (first step of
+// a launch, ring rows 0 and 1, the swap's post-swap row), and the pooled statistics take every stored row once, weighted by the
+// length of its run (orc_pool_update_rle).  Readers that want every row call ptmi_am_expand (copy-forward) first.
+constexpr unsigned long long AMROW_NEW = 1ull;      // the step was accepted: the row differs from its predecessor and is stored
+constexpr unsigned long long AMROW_KEY = 2ull;      // the row is stored whatever the step did
+typedef unsigned long long AmFlag;
 
 // ------------------------------------------------------------- kernel args
 struct KArgs {
@@ -48,7 +47,7 @@ struct KArgs {
     int32_t *temp_of, *slot_of;
     const double *Ut, *S, *DE;
     double *AM, *AMaux;
-    AmRec *AMrec;                // records beside the AM rows (SCAM-only cycles, one pooled table), or nullptr: every step stores its row
+    AmFlag *AMflag;              // flags beside the AM rows (pooled covariance), or nullptr: every step stores its row
     u64 *nacc, *jstat;
     // small device tables owned by the engine
     const double *temps_mh, *beta, *logl_par, *logp_par;
@@ -136,7 +135,9 @@ struct ptmi_engine {
     hipEvent_t ev0, ev1;
     hipStream_t side;            // pooled statistics at ndim > 111: the diagonal macro tiles run beside the off-diagonal ones
     hipEvent_t side_go, side_done;
-    long long switch_iter;       // AM records: rows of iterations >= switch_iter were made with buf.Ut, earlier ones with buf.Ut_prev (ptmi_table_switched)
+    int32_t *d_rle_src;          // pooled statistics over run-length-compacted rows: the stored rows of each slab [nrows] ...
+    double *d_rle_wgt;           // ... the square roots of their run lengths [nrows] ...
+    int32_t *d_rle_cnt;          // ... and how many each slab has [nslab]
     const double *rp_swap_u;     // TEST HOOK (ptmi_test_replay): the swap's uniforms [W][ntemps_global - 1] instead of the Philox ones
     const u64 *rp_draws;         // TEST HOOK: see KArgs
 };

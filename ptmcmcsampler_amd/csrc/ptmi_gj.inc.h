@@ -1065,7 +1065,8 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? 2 : 1) void mh_ste
         // PT:615-622
         const double lnprob0 = beta * lnL + lp;
         const double diff = nlnprob - lnprob0 + qxy;
-        if (diff > log_u) {
+        const bool accepted = diff > log_u;
+        if (accepted) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) x[e] = q[e];
             lnL = nlnL;
@@ -1074,13 +1075,20 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? 2 : 1) void mh_ste
 #pragma unroll
             for (int j = 0; j < PTMI_J_NTYPES; ++j) ja[j] += (jt == j);
         }
-        // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
+        // PT:327-328 (the post-swap row of a swap iteration is written by the swap); with AM row flags (ptmi_common.h) only a new
+        // or a KEY row is stored (am_store_step's rule)
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
             double *am = a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d;
+            bool store = true;
+            if (a.AMflag != nullptr) {
+                const bool key = k == 0 || am_row <= 1;
+                if (gl == 0) a.AMflag[(size_t)w * a.cov_update + (size_t)am_row] = (key ? AMROW_KEY : 0ull) | (accepted ? AMROW_NEW : 0ull);
+                store = key || accepted;
+            }
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int i = gl + G * e;
-                if (i < d) am[i] = x[e];
+                if (store && i < d) am[i] = x[e];
             }
             if (a.AMaux && gl == 0) {
                 double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;

@@ -812,20 +812,16 @@ __device__ __forceinline__ void am_store_row(double *am, const double (&x)[EPL],
     }
 }
 
-// The rank-0 chain's row of one step (PT:327-328): the row itself, or -- with AM records (ptmi_common.h AmRec; SCAM-only cycles)
-// -- the 16-byte record of the step, the row itself only as a KEY row: first step of a launch and ring row 0.
+// The rank-0 chain's row of one step (PT:327-328).  With AM row flags (ptmi_common.h) the row is stored only when the step
+// changed it or when it is a KEY row -- first step of a launch, ring rows 0 and 1 -- and its flag word says which.
 template <int G, int EPL>
-__device__ __forceinline__ void am_store_step(const KArgs &a, int w, int am_row, int k, const double (&x)[EPL], int gl, int d,
-                                              double amp, int kdir, bool accepted)
+__device__ __forceinline__ void am_store_step(const KArgs &a, int w, int am_row, int k, const double (&x)[EPL], int gl, int d, bool accepted)
 {
     const size_t r = (size_t)w * a.cov_update + (size_t)am_row;
-    if (a.AMrec != nullptr) {
-        const bool key = k == 0 || am_row == 0;
-        if (gl == 0) {
-            const unsigned long long meta = key ? AMREC_KEY : ((unsigned long long)(unsigned)kdir | (accepted ? AMREC_ACC : 0ull));
-            __builtin_nontemporal_store(ptmi_d2{amp, __longlong_as_double((long long)meta)}, reinterpret_cast<ptmi_d2 *>(a.AMrec + r));
-        }
-        if (!key) return;
+    if (a.AMflag != nullptr) {
+        const bool key = k == 0 || am_row <= 1;
+        if (gl == 0) __builtin_nontemporal_store((key ? AMROW_KEY : 0ull) | (accepted ? AMROW_NEW : 0ull), a.AMflag + r);
+        if (!(key || accepted)) return;
     }
     am_store_row<G, EPL>(a.AM + r * d, x, gl, d);
 }
@@ -1056,8 +1052,6 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         }
         double log_u;
         int jt = PTMI_J_SCAM;
-        double rec_amp = 0.0;          // AM records: the step's amplitude and direction (SCAM-only cycles)
-        int rec_k = 0;
         if constexpr (SCAMFAST) {
             ScamDraw sd;
             // sqrt(S_k): from the block's LDS copy where it has one, else from the chain's table (sqrt is correctly rounded: same bits)
@@ -1072,8 +1066,6 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
                 return det_sqrt(S[kk]);
             }, smem);
             log_u = sd.log_u;
-            rec_amp = sd.amp;
-            rec_k = sd.k;
             if constexpr (PAIRED) {
                 const double *row = smem + (size_t)sd.k * d;
                 const ptmi_d2 *rp = reinterpret_cast<const ptmi_d2 *>(row) + gl;
@@ -1160,8 +1152,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         // 0.780 against 0.778: the cost is the bytes through the CU's store path (1.28 MB per CU and launch) and the scattered
         // 64-byte writes behind it, not the issue slots of the instructions.
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
-            if constexpr (SCAMFAST) am_store_step<G, EPL>(a, w, am_row, k, x, gl, d, rec_amp, rec_k, accepted);
-            else am_store_row<G, EPL>(a.AM + ((size_t)w * a.cov_update + (size_t)am_row) * d, x, gl, d);
+            am_store_step<G, EPL>(a, w, am_row, k, x, gl, d, accepted);
             if (a.AMaux && gl == 0) {
                 double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
                 ax[0] = lnL;
@@ -1373,7 +1364,7 @@ __global__ __launch_bounds__(BLK, BLK / 256) void mh_dense_scam_kernel(const KAr
         }
         // PT:327-328 (the post-swap row of a swap iteration is written by the swap)
         if (cold && !(a.swap_last && k == a.nsteps - 1)) {
-            am_store_step<G, EPL>(a, w, am_row, k, x, gl, d, sd.amp, sd.k, accepted);
+            am_store_step<G, EPL>(a, w, am_row, k, x, gl, d, accepted);
             if (a.AMaux && gl == 0) {
                 double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
                 ax[0] = lnL;
@@ -1482,7 +1473,7 @@ __global__ __launch_bounds__(256) void accept_kernel(const KArgs a)
     if (gl == 0) {
         const size_t r = (size_t)w * nt + t;
         if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 0] += 1;
-        if (am && a.AMrec) a.AMrec[(size_t)w * a.cov_update + (size_t)a.am_row0] = AmRec{0.0, AMREC_KEY};   // the split path stores rows
+        if (am && a.AMflag) a.AMflag[(size_t)w * a.cov_update + (size_t)a.am_row0] = AMROW_KEY | (acc ? AMROW_NEW : 0ull);   // the split path stores every row
         if (am && a.AMaux) {
             double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)a.am_row0) * 2;
             ax[0] = acc ? nlnL : a.lnL[ch];

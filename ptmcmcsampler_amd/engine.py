@@ -103,10 +103,12 @@ class PTEngine(object):
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
     ``am_mode``: how the rank-0 chain's samples (updateChains' buffer, PTMCMCSampler.py:327-328) are kept between covariance
-    epochs.  ``"rows"``: every step stores its row.  ``"records"``: a SCAM step stores 16 bytes -- (amplitude, direction,
-    accepted) -- and full KEY rows only at the first step of a launch and at swaps; the pooled statistics rebuild the rows in
-    LDS and every other reader (``get("AM")``, ``am_expand``) gets them rebuilt in place, bit for bit what ``"rows"`` stores
-    (SCAM-only cycles with a pooled covariance; include/ptmi.h ``AMrec``).  ``"auto"`` = records where they apply.
+    epochs.  ``"rows"``: every step stores its row.  ``"rle"`` (pooled covariance): a rejected proposal leaves the chain where it
+    was, so a step stores its row only when it was accepted (or is a KEY row: first step of a launch, ring rows 0 and 1, the
+    swap's row) plus a flag word, and the pooled statistics take every stored row once, weighted by its run length (include/ptmi.h
+    ``AMflag``; oracle: ``orc_pool_update_rle`` -- the same sample covariance, summed in another order).  Readers that want
+    every row (``get("AM")``, the DE history, chain files) get the repeats copied forward first (``am_expand``).
+    ``"auto"`` = ``"rle"`` where it applies.
     """
 
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
@@ -182,13 +184,12 @@ class PTEngine(object):
             self.am_pos = np.where(e_ < 2 * (self.am_epl // 2), 8 * (e_ // 2) + 2 * ln_ + e_ % 2, 8 * (self.am_epl // 2) + ln_)   # where parameter i sits
             self.am_inv = np.argsort(self.am_pos)                                   # which parameter sits at position p
         self.owns_cold = self.temp0 == 0
-        if am_mode not in ("auto", "rows", "records"):
-            raise ValueError("am_mode must be 'auto', 'rows' or 'records'")
-        rec_ok = (self.weights[0] > 0 and self.weights[1] == 0 and self.weights[2] == 0 and not has_gj and int(w_host) == 0 and self.ngr == 1
-                  and not self.per_walker and self.owns_cold)            # = ptmi_am_records_ok
-        if am_mode == "records" and not rec_ok:
-            raise ValueError("am_mode='records' serves SCAM-only cycles with one parameter group and a pooled covariance")
-        self.am_records = rec_ok and am_mode != "rows"
+        if am_mode not in ("auto", "rows", "rle"):
+            raise ValueError("am_mode must be 'auto', 'rows' or 'rle'")
+        rle_ok = not self.per_walker and self.owns_cold                  # = ptmi_am_flags_ok
+        if am_mode == "rle" and not rle_ok:
+            raise ValueError("am_mode='rle' serves the pooled covariance (cov_mode='pooled')")
+        self.am_rle = rle_ok and am_mode != "rows"
         self.t = dict(
             X=z((W, nt, d)), lnL=z((W, nt)), lp=z((W, nt)),
             temp_of=torch.arange(nt, dtype=i32, device=self.device).repeat(W, 1).contiguous(),
@@ -202,12 +203,10 @@ class PTEngine(object):
             Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
             AMaux=z((W, self.cov_update, 2)) if (keep_lnl and self.owns_cold) else None,
             gj=z((W, nt, _lib.GJ_NSTATE)) if has_gj else None,
-            # AM records (include/ptmi.h): [..., 0] the amplitude's bits, [..., 1] the meta word; every record starts as KEY
-            AMrec=z((W, self.cov_update, 2), i64) if self.am_records else None,
-            Ut_prev=z((d, d)) if self.am_records else None,
+            AMflag=z((W, self.cov_update), i64) if self.am_rle else None,     # AM row flags (include/ptmi.h): every row starts as KEY
         )
-        if self.am_records:
-            self.t["AMrec"][..., 1] = _lib.AMREC_KEY
+        if self.am_rle:
+            self.t["AMflag"].fill_(_lib.AMROW_KEY)
         if has_gj:
             self.t["gj"][..., _lib.GJ_EPSBAR] = 1.0
         cov0 = np.asarray(cov0, dtype=np.float64)
@@ -240,7 +239,6 @@ class PTEngine(object):
         _lib.check(self.lib.ptmi_create(C.byref(cfg), C.byref(buf), C.byref(self.h)))
         self.de_on = False
         self.de_head = 0
-        self.switch_iter = 0
         self.iter = 0
         self.swap_proposed = 0
         self.eig_epochs = 0
@@ -272,14 +270,14 @@ class PTEngine(object):
             return np.ascontiguousarray(a[..., pos])
         if name == "AM" and self.am_pos is not None:
             return np.ascontiguousarray(a[..., self.am_pos])              # parameter order whatever the device format
-        return a.view(np.uint64) if name in ("nacc", "jstat", "nswap") else a
+        return a.view(np.uint64) if name in ("nacc", "jstat", "nswap", "AMflag") else a
 
     def put(self, name, value):
         torch = _torch()
         if name == "AM":
             value = self.am_rows(np.asarray(value))                      # parameter order in, the buffer's row format on the device
-            if self.am_records:
-                self.t["AMrec"][..., 1] = _lib.AMREC_KEY                  # rows written from outside are KEY rows
+            if self.am_rle:
+                self.t["AMflag"].fill_(_lib.AMROW_KEY)                    # rows written from outside are KEY rows
         self.t[name].copy_(torch.from_numpy(np.ascontiguousarray(value)).to(self.t[name].dtype))
 
     def by_temp(self, name):
@@ -387,10 +385,11 @@ class PTEngine(object):
         return rows[..., _torch().from_numpy(self.am_pos).to(rows.device)]
 
     def am_expand(self, w0=0, nw=None, it_lo=None, it_hi=None):
-        """AM records -> rows, in place (``ptmi_am_expand``): the rows of iterations ``it_lo .. it_hi`` of walkers
-        ``w0 .. w0 + nw - 1``; default: the current covariance period up to the current iteration (``am_period``) -- rows of an
-        older period are not kept in records mode.  A no-op with ``am_mode="rows"``."""
-        if not self.am_records:
+        """Every row of the AM ring, in place (``ptmi_am_expand``): the rows of rejected steps, which ``am_mode="rle"`` does not
+        store, are copied forward from the row before them, for iterations ``it_lo .. it_hi`` of walkers ``w0 .. w0 + nw - 1``;
+        default: the current covariance period up to the current iteration (``am_period``) -- once the ring wraps, the repeats of
+        an older period have lost the row they hang on.  A no-op with ``am_mode="rows"``."""
+        if not self.am_rle:
             return
         it_hi = self.iter if it_hi is None else int(it_hi)
         it_lo = self.am_period(it_hi)[0] if it_lo is None else int(it_lo)
@@ -398,9 +397,10 @@ class PTEngine(object):
 
     def am_period(self, it=None):
         """(first, last) iteration of the covariance period the ring holds at iteration ``it``: [E, it], E = the last multiple of
-        covUpdate below ``it`` (row 0 of the ring until iteration E + covUpdate overwrites it)."""
+        covUpdate below ``it`` (row 0 of the ring, until iteration E + covUpdate overwrites it)."""
         it = self.iter if it is None else int(it)
-        return ((it - 1) // self.cov_update) * self.cov_update if it > 0 else 0, it
+        E = ((it - 1) // self.cov_update) * self.cov_update if it > 0 else 0
+        return E + (1 if it - E >= self.cov_update else 0), it
 
     def _store_initial(self, i0=0):
         """updateChains(p0, lnlike0, lnprob0, i0), :491: row i0 % covUpdate of the AM ring holds the point."""
@@ -410,8 +410,8 @@ class PTEngine(object):
             idx = self.t["slot_of"][:, 0].long()
             row = int(i0) % self.cov_update
             self.t["AM"][:, row, :] = self.am_rows(self.t["X"][ar, idx])
-            if self.am_records:
-                self.t["AMrec"][:, row, 1] = _lib.AMREC_KEY
+            if self.am_rle:
+                self.t["AMflag"][:, row] = _lib.AMROW_KEY
             if self.t["AMaux"] is not None:
                 self.t["AMaux"][:, row, 0] = self.t["lnL"][ar, idx]
                 self.t["AMaux"][:, row, 1] = self.t["lp"][ar, idx]
@@ -422,11 +422,6 @@ class PTEngine(object):
         if not self.owns_cold:
             return
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
-        if self.am_records:
-            # AM records name a row of the table in force when they were written: the outgoing table stays at hand for the
-            # rows of the ring that are older than this epoch (ptmi_table_switched, include/ptmi.h)
-            self.t["Ut_prev"].copy_(self.t["Ut"][0, 0])
-            self._table_switched(it_done + 1)
         if self.eig_mode == "jacobi":
             _lib.check(self.lib.ptmi_eig_jacobi(self.h))              # stays on the stream: no host synchronisation
             self.eig_epochs += 1
@@ -443,12 +438,10 @@ class PTEngine(object):
             self._eig_host_all(self.get("cov"))
         self.eig_epochs += 1
 
-    def _table_switched(self, it):
-        self.switch_iter = int(it)
-        _lib.check(self.lib.ptmi_table_switched(self.h, int(it)))
-
-    def update_de(self):
+    def update_de(self, it_done=None):
         if self.owns_cold and self.t["DE"] is not None:
+            if it_done is not None:
+                self.am_expand(it_hi=it_done)                          # the DE history takes every row of the ring (a no-op with stored rows)
             _lib.check(self.lib.ptmi_update_de(self.h))
             self.de_head = (self.de_head + min(self.cov_update, self.burn)) % self.burn
 
@@ -467,7 +460,7 @@ class PTEngine(object):
         self.sync()
         st = {"t_" + k: v.cpu().numpy() for k, v in self.t.items() if v is not None and k not in ("Q", "qaux")}
         st.update(iter=self.iter, de_on=int(self.de_on), de_head=self.de_head, swap_proposed=self.swap_proposed,
-                  eig_epochs=self.eig_epochs, switch_iter=self.switch_iter)
+                  eig_epochs=self.eig_epochs)
         return st
 
     def restore(self, st):
@@ -477,8 +470,6 @@ class PTEngine(object):
                 v.copy_(torch.from_numpy(np.ascontiguousarray(st["t_" + k])).to(v.dtype))
         self.iter, self.swap_proposed = int(st["iter"]), int(st["swap_proposed"])
         self.eig_epochs = int(st["eig_epochs"])
-        if self.am_records:
-            self._table_switched(int(st["switch_iter"]) if "switch_iter" in st else 0)
         if self.t["DE"] is not None:
             self.set_de_head(int(st["de_head"]))
             if int(st["de_on"]):
@@ -520,7 +511,7 @@ class PTEngine(object):
         if (it - 1) % cu == 0 and it - 1 != 0:
             self.update_cov(it - 1)
         if (it - 1) % burn == 0 and it - 1 != 0:
-            self.update_de()                                          # :563-571
+            self.update_de(it - 1)                                    # :563-571
         if it - 1 == burn and self.weights[2] > 0 and self.t["DE"] is not None:
             self.set_de_active(True)                                  # :574-585
 

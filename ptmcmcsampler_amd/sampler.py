@@ -475,7 +475,7 @@ class PTSampler(object):
                            digest(np.asarray(eng.ladder, dtype=np.float64), np.asarray(eng.temps_mh, dtype=np.float64)), self.Tskip,
                            digest((self.SCAMweight, self.AMweight, self.DEweight) + tuple(self._grad_weights) + (len(self.host_jumps),)),
                            digest((self.cov_mode, self.swap_mode, self.pick_mode, self.eig_mode, self.nuts_maxdepth, bool(self.split), bool(self.batched),
-                                   bool(eng.am_records)), *groups),
+                                   bool(eng.am_rle)), *groups),
                            digest(*(spec(self.logl_spec) + spec(self.logp_spec)))], dtype=np.int64)
 
     def _load_checkpoint(self):
@@ -550,8 +550,8 @@ class PTSampler(object):
 
         # iteration 0: the first row (:474-476, :491)
         eng.t["AM"][0, 0] = torch.from_numpy(eng.am_rows(X[0]).copy())
-        if eng.am_records:                                          # replayed rows are stored rows: KEY records (include/ptmi.h AMrec)
-            eng.t["AMrec"][0, :, 1] = _lib.AMREC_KEY
+        if eng.am_rle:                                              # replayed rows are stored rows: KEY (include/ptmi.h AMflag)
+            eng.t["AMflag"].fill_(_lib.AMROW_KEY)
         eng.t["AMaux"][0, 0, 0], eng.t["AMaux"][0, 0, 1] = float(lnl[0]), float(lpr[0])
         self._chains[0, 0], self._lnlikes[0, 0], self._lnprobs[0, 0] = X[0], lnl[0], lnp[0]
         swapped_last = False
@@ -622,7 +622,7 @@ class PTSampler(object):
             return
         eng, kw = self.engine, self.keep_walkers
         rows = [i % eng.cov_update for i in iters]
-        eng.am_expand(0, kw, min(iters), max(iters))                # AM records -> rows for what is read here (a no-op with stored rows)
+        eng.am_expand(0, kw, min(iters), max(iters))                # repeats copied forward for what is read here (a no-op with stored rows)
         X = eng.am_params(eng.t["AM"][:kw][:, rows].cpu().numpy())
         aux = eng.t["AMaux"][:kw][:, rows].cpu().numpy()
         beta0 = 1.0 / eng.temps_mh[0]

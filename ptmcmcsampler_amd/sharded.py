@@ -154,8 +154,8 @@ class ShardedPTEngine(object):
         return self.local.am_params(rows) if hasattr(self.local, "am_params") else rows
 
     @property
-    def am_records(self):
-        return bool(getattr(self.local, "am_records", False))
+    def am_rle(self):
+        return bool(getattr(self.local, "am_rle", False))
 
     def am_expand(self, *args, **kw):
         if hasattr(self.local, "am_expand"):
@@ -236,14 +236,17 @@ class ShardedPTEngine(object):
         for name in ("Ut", "S"):
             self.comm.broadcast(L.t[name])
 
-    def update_de(self):
+    def update_de(self, it_done=None):
         torch, L = _torch(), self.local
         if L.t.get("DE") is None:
             return
         size, mem = self.burn, min(self.cov_update, self.burn)
         idx = (self.de_head + torch.arange(mem, device=self.device)) % size
         if self.owns_cold:
-            L.update_de()
+            if it_done is not None and getattr(L, "am_rle", False):
+                L.update_de(it_done)                                  # every row of the ring first (PTEngine.am_expand)
+            else:
+                L.update_de()
             rows = L.t["DE"][:, idx].contiguous()
         else:
             rows = torch.empty((L.t["DE"].shape[0], mem, L.t["DE"].shape[2]), dtype=torch.float64, device=self.device)
@@ -258,7 +261,7 @@ class ShardedPTEngine(object):
         if (it - 1) % cu == 0 and it - 1 != 0:
             self.update_cov(it - 1)
         if (it - 1) % burn == 0 and it - 1 != 0:
-            self.update_de()
+            self.update_de(it - 1)
         if it - 1 == burn and self.weights[2] > 0 and self.local.t.get("DE") is not None:
             self.local.set_de_active(True)
 

@@ -67,12 +67,15 @@ class OracleLocal(object):
         o = self.o
         if self.owns_cold:
             o.AM[np.arange(o.W), it % o.cov_update] = o.X[np.arange(o.W), o.slot_of[:, 0]]
+            o.AMflag[:, it % o.cov_update] = 2                     # the swap's row is a KEY row (AM row flags)
 
     def update_cov(self, it_done):
         o = self.o
         if o.per_walker:
             for w in range(o.W):
                 o.cov[w] = orc.welford(o.AM[w], o.mu[w], o.M2[w], it_done)
+        elif o.am_rle:
+            o.cov[0] = orc.pool_update_rle(o.AM, o.AMflag, o.mu[0], o.M2[0], it_done)
         else:
             o.cov[0] = orc.pool_update(o.AM, o.mu[0], o.M2[0], it_done)
         for w in range(o.Wc):

@@ -35,19 +35,19 @@ def test_struct_layouts_match_the_header(lib):
     import subprocess
     import tempfile
     assert C.sizeof(lib.Config) == 26 * 4 + 2 * 8 + 8 + 8 + 2 * 8 + 4 * 8 + 3 * 8   # 26 int32, 2 doubles, seed, stream, pointers/lengths
-    assert C.sizeof(lib.Buffers) == 21 * 8
+    assert C.sizeof(lib.Buffers) == 20 * 8
     # the C compiler's view of include/ptmi.h
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "l.c")
-        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "ptmi.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", '
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "ptmi.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", '
                              'sizeof(ptmi_config), offsetof(ptmi_config, swap_mode), offsetof(ptmi_config, seed), '
                              'offsetof(ptmi_config, group_mask), sizeof(ptmi_buffers), offsetof(ptmi_buffers, AMaux), '
-                             'offsetof(ptmi_config, hmc_eps), offsetof(ptmi_config, gj_tab), offsetof(ptmi_buffers, gj), offsetof(ptmi_buffers, AMrec), offsetof(ptmi_buffers, Ut_prev));return 0;}\n')
+                             'offsetof(ptmi_config, hmc_eps), offsetof(ptmi_config, gj_tab), offsetof(ptmi_buffers, gj), offsetof(ptmi_buffers, AMflag));return 0;}\n')
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(td, "l")])
         got = [int(v) for v in subprocess.check_output([os.path.join(td, "l")]).split()]
     assert got == [C.sizeof(lib.Config), lib.Config.swap_mode.offset, lib.Config.seed.offset, lib.Config.group_mask.offset,
                    C.sizeof(lib.Buffers), lib.Buffers.AMaux.offset, lib.Config.hmc_eps.offset, lib.Config.gj_tab.offset,
-                   lib.Buffers.gj.offset, lib.Buffers.AMrec.offset, lib.Buffers.Ut_prev.offset]
+                   lib.Buffers.gj.offset, lib.Buffers.AMflag.offset]
     dims = (2, 32, 33, 100, 104, 105, 112, 113, 256, 416, 417, 512, 513, 640, 641, 1024, 1025, 2048)
     assert [lib.lanes_for(d) for d in dims] == [lib.load().ptmi_lanes_for(d) for d in dims]
     assert [lib.lanes_for(d, grad=True) for d in dims] == [lib.load().ptmi_lanes_for_grad(d) for d in dims]

@@ -1,0 +1,140 @@
+"""AM row flags (include/ptmi.h ``ptmi_buffers.AMflag``, ``PTEngine(am_mode="rle")``): a rejected proposal leaves the rank-0 chain
+where it was, so the step kernels store its row (updateChains' buffer, PTMCMCSampler.py:327-328) only when the step was accepted
+or the row is a KEY row, and the pooled statistics take every stored row once, weighted by its run length
+(``orc_pool_update_rle``).  Everything a reader sees -- every row of the ring (``ptmi_am_expand``), the pooled covariance, the
+chains -- equals the oracle bit for bit; and the weighted sums are the plain ones up to rounding.
+
+Run on the GPU box: ``python -m pytest tests -m gpu``.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare, _pair, assert_same, mods  # noqa: F401  (mods is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense(d, seed=0):
+    A = np.random.default_rng(seed).standard_normal((d, d))
+    return ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
+
+
+CASES = [
+    # d, nt, W, cov_update, tskip, weights, extra
+    (100, 64, 3, 40, 20, (20, 0, 0), {}),                       # the persistent kernel of the exact shape, swaps, epochs
+    (100, 5, 9, 25, 7, (20, 0, 0), {}),                         # a ring shorter than a chunk, a swap period that does not divide it
+    (100, 1, 6, 30, 0, (20, 0, 0), {}),                         # one temperature: no swap ever writes a KEY row
+    (100, 64, 2, 50, 25, (20, 0, 0), {"logl": "dense"}),        # mh_dense_scam_kernel
+    (100, 8, 4, 33, 11, (20, 0, 0), {"box": True}),             # box prior: many rejected proposals, long runs
+    (100, 64, 2, 40, 20, (20, 20, 20), {"burn": 80}),           # the staged default-mix kernel, DE history filled from expanded rows
+    (37, 6, 5, 20, 10, (20, 20, 0), {}),                        # a 4-lane shape with padding slots, AM in the cycle
+    (7, 3, 4, 16, 4, (20, 0, 0), {}),
+    (130, 4, 3, 24, 8, (20, 0, 0), {}),                         # 16 lanes per chain, two macro tiles in the statistics
+    (500, 2, 2, 16, 8, (20, 0, 20), {"burn": 32}),              # 64 lanes per chain, DE
+    (20, 4, 5, 30, 10, (10, 0, 10), {"nuts": True}),            # the gradient-jump kernel
+]
+
+
+@pytest.mark.parametrize("d,nt,W,cu,tskip,weights,extra", CASES)
+def test_rle_engine_matches_the_oracle(mods, d, nt, W, cu, tskip, weights, extra):
+    orc, _lib, PTEngine = mods
+    kw = dict(weights=weights, cov_update=cu, burn=extra.get("burn", 1000), tskip=tskip, seed=31, cov_mode="pooled", cov0=np.eye(d) * 0.01)
+    if extra.get("logl") == "dense":
+        kw["logl"] = _dense(d)
+    if extra.get("box"):
+        rs = np.random.RandomState(4)
+        kw["logp"] = ("box", -0.25 - rs.rand(d) * 0.1, 0.2 + rs.rand(d) * 0.1)
+        kw["p0"] = rs.uniform(-0.05, 0.05, (W, nt, d))
+    if extra.get("nuts"):
+        kw.update(logl=("curved",), logp=("box", -10 * np.ones(d), 10 * np.ones(d)), cov0=np.eye(d), grad_weights=(10, 5),
+                  p0=np.tile(np.array([-0.1, -0.5] * (d // 2)), (W, nt, 1)))
+    g, o = _pair(mods, d, nt, W, am_mode="rle", **kw)
+    assert g.am_rle and o.am_rle
+    total = 0
+    for n in (cu + 3, 1, 2 * cu - 5, 17, cu):                   # launches of odd lengths, epochs inside
+        g.run(n)
+        o.run(n)
+        total += n
+        _compare(g, o, "rle d=%d it=%d " % (d, total))          # get("AM") copies the repeats of the current period forward
+        lo, hi = g.am_period()
+        rows = np.arange(lo, hi + 1) % cu
+        assert_same(g.get("AMflag")[:, rows] & 3, o.AMflag[:, rows] & 3, "flags d=%d it=%d" % (d, total))
+        assert_same(g.get("cov"), o.cov, "cov d=%d it=%d" % (d, total))
+        assert_same(g.get("Ut"), o.Ut, "Ut")
+    fl = g.get("AMflag")
+    assert 0 < ((fl & 3) == 0).mean()                           # some rows were not stored
+    if kw["burn"] < total:
+        assert_same(np.roll(g.get("DE")[0], -g.de_head, axis=0), o.DE[0], "DE history")
+    if extra.get("box"):
+        assert ((fl & 3) == 0).mean() > 0.3
+
+
+def test_rows_mode_still_matches_its_oracle_and_rle_within_rounding(mods):
+    """am_mode="rows" keeps the plain sums (orc_pool_update); the weighted sums of am_mode="rle" are the same statistics up to
+    rounding: covariances agree to 1e-12 relative after the first epoch (the runs then part at the level of the last bits)."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu = 100, 8, 6, 60
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=20, seed=9, cov_mode="pooled", cov0=np.eye(d) * 0.01)
+    r, ro = _pair(mods, d, nt, W, am_mode="rows", **kw)
+    g, go = _pair(mods, d, nt, W, am_mode="rle", **kw)
+    assert not r.am_rle and r.t["AMflag"] is None and not ro.am_rle
+    r.run(cu + 1)
+    ro.run(cu + 1)
+    g.run(cu + 1)
+    _compare(r, ro, "rows ")
+    assert_same(r.get("cov"), ro.cov, "rows cov")
+    a, b = r.get("cov")[0], g.get("cov")[0]
+    assert not np.array_equal(a, b) and np.abs(a - b).max() < 1e-12 * np.abs(a).max()
+    r.run(3 * cu)
+    ro.run(3 * cu)
+    _compare(r, ro, "rows later ")
+
+
+def test_expand_of_a_range_leaves_the_other_rows_alone(mods):
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu = 100, 4, 6, 50
+    rs = np.random.RandomState(4)
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=10, seed=5, cov_mode="pooled", cov0=np.eye(d) * 0.01,
+              logp=("box", -0.25 - rs.rand(d) * 0.1, 0.2 + rs.rand(d) * 0.1), p0=rs.uniform(-0.05, 0.05, (W, nt, d)))
+    g, o = _pair(mods, d, nt, W, am_mode="rle", **kw)
+    g.run(130)
+    o.run(130)
+    g.sync()
+    before = g.am_params(g.t["AM"].cpu().numpy())               # stored rows valid, the repeats stale
+    g.am_expand(2, 3, 111, 125)                                 # walkers 2..4, iterations 111..125
+    after = g.am_params(g.t["AM"].cpu().numpy())
+    rows = np.arange(111, 126) % cu
+    assert_same(after[2:5][:, rows], o.AM[2:5][:, rows], "expanded range")
+    mask = np.ones(after.shape[:2], bool)
+    mask[2:5, rows] = False
+    assert_same(after[mask], before[mask], "rows outside the range")
+    assert not np.array_equal(before[2:5][:, rows], o.AM[2:5][:, rows])      # they did need filling
+    with pytest.raises(_lib.PtmiError):
+        g.am_expand(0, 1, 90, 125)                              # reaches into the period before: refused
+
+
+def test_rle_is_refused_for_per_walker_covariances(mods):
+    orc, _lib, PTEngine = mods
+    with pytest.raises(ValueError):
+        PTEngine(10, 2, 2, np.eye(10), weights=(20, 0, 0), cov_mode="per_walker", am_mode="rle")
+    g = PTEngine(10, 2, 2, np.eye(10), weights=(20, 20, 20), cov_mode="per_walker")      # auto: rows
+    assert not g.am_rle and g.t["AMflag"] is None
+
+
+def test_checkpoint_of_an_rle_run_continues_bit_identically(mods):
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 8, 5
+    kw = dict(weights=(20, 0, 0), cov_update=40, burn=1000, tskip=10, seed=77, cov_mode="pooled")
+    a = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    a.init_state(np.zeros(d))
+    a.run(95)
+    st = a.checkpoint()
+    a.run(130)
+    b = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    b.init_state(np.zeros(d))
+    b.restore(st)
+    b.run(130)
+    for name in ("X", "lnL", "cov", "Ut", "S"):
+        assert_same(a.get(name), b.get(name), name)
+    lo, hi = a.am_period()
+    rows = np.arange(lo, hi + 1) % 40
+    assert_same(a.get("AM")[:, rows], b.get("AM")[:, rows], "AM")

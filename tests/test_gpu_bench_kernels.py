@@ -138,11 +138,15 @@ class _Subset(object):
         self.mu, self.M2 = np.zeros(d), np.zeros((d, d))
         self.DE = np.zeros((self.burn, d))
 
-    def epoch(self, AM, it_done):
-        """PTMCMCSampler.py:545-585 for iteration it_done + 1, from all walkers' AM rows."""
+    def epoch(self, AM, it_done, flags=None):
+        """PTMCMCSampler.py:545-585 for iteration it_done + 1, from all walkers' AM rows (flags: the device's AM row flags of an
+        engine in am_mode "rle": the statistics then weight every stored row by its run length)."""
         orc, d, W = self.orc, self.d, self.W
         if it_done % self.cu == 0:
-            cov_o = orc.pool_update(AM, self.mu, self.M2, it_done)
+            if flags is not None:
+                cov_o = orc.pool_update_rle(AM, flags, self.mu, self.M2, it_done)
+            else:
+                cov_o = orc.pool_update(AM, self.mu, self.M2, it_done)
             for o in self.subs:
                 o.cov[0] = cov_o
                 o._svd(0)
@@ -187,7 +191,7 @@ def test_full_size_default_mix_with_covariance_and_de_epochs(mods):
     for k in range(4):
         if k > 0:
             g.sync()
-            sub.epoch(g.get("AM"), k * cu)
+            sub.epoch(g.get("AM"), k * cu, g.get("AMflag") if g.am_rle else None)
         g.run(cu)                                   # starts with the device's own epoch
         for o in sub.subs:
             o.run(cu)
@@ -230,7 +234,7 @@ def test_full_size_dense_scam_through_pooled_covariance_epochs(mods):
     for k in range(3):
         if k > 0:
             g.sync()
-            sub.epoch(g.get("AM"), k * cu)
+            sub.epoch(g.get("AM"), k * cu, g.get("AMflag") if g.am_rle else None)
         g.run(cu)
         for o in sub.subs:
             o.run(cu)
@@ -270,7 +274,7 @@ def test_full_size_scam_persistent_kernel_on_adapted_tables(mods):
     for k in range(3):
         if k > 0:
             g.sync()
-            sub.epoch(g.get("AM"), k * cu)
+            sub.epoch(g.get("AM"), k * cu, g.get("AMflag") if g.am_rle else None)
         g.run(cu)
         for o in sub.subs:
             o.run(cu)

@@ -145,8 +145,8 @@ def _compare(g, o, what=""):
     for name in ("X", "lnL", "lp", "temp_of", "slot_of", "nacc", "jstat"):
         assert_same(g.get(name), getattr(o, name), what + name)
     assert_same(g.get("nswap"), o.nswap, what + "nswap")
-    if g.owns_cold and getattr(g, "am_records", False):
-        lo, hi = g.am_period()                                   # AM records keep the rows of the current covariance period
+    if g.owns_cold and getattr(g, "am_rle", False):
+        lo, hi = g.am_period()                                   # am_mode "rle": the ring keeps the rows of the current covariance period
         rows = np.arange(lo, hi + 1) % g.cov_update
         assert_same(g.get("AM")[:, rows], o.AM[:, rows], what + "AM (current period)")
     elif g.owns_cold:
