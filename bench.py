@@ -54,6 +54,9 @@ def parse():
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
                          "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK; "
                          "_hipsolver: by the ROCm library's eigensolver on the stream (large ndim)")
+    ap.add_argument("--eig-lag", type=int, default=1, choices=[0, 1],
+                    help="pooled covariance factorized by the host: 1 = the eigenvectors of a covariance epoch take effect one launch late, the "
+                         "host factorizing while that launch runs (PTEngine eig_lag); 0 = at once, the GPU idle meanwhile (the reference's order)")
     ap.add_argument("--am-mode", default="auto", choices=["auto", "rows", "rle"],
                     help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): rle = a step stores its "
                          "row only when it was accepted, the pooled statistics weight every stored row by its run length; rows = every "
@@ -194,6 +197,8 @@ def main():
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
               pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled", am_mode=a.am_mode,
               eig_mode="jacobi" if a.cov_mode.endswith("_device") else ("hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack"))
+    eig_lag = a.eig_lag if (kw["cov_mode"] == "pooled" and kw["eig_mode"] == "lapack" and (world == 1 and not a.sharded or a.partition == "walkers")) else 0
+    kw.update(eig_lag=eig_lag)
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.prior == "box":
         kw.update(logp=("box", np.full(d, -10.0), np.full(d, 10.0)))
@@ -346,11 +351,12 @@ def main():
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "preheat_s": a.preheat,
         "config": {"workload": "BASELINE configs[%d]: %d-d %s logl%s, %d temps x %d walkers per GPU, %s cycle (pick per %s), "
-                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s; one step = 100 MH iterations of every chain + the PT swap "
-                               "(+ a covariance epoch every 10 steps)" % (
+                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s, am_mode=%s, eig_lag=%d; one step = 100 MH iterations of every chain + "
+                               "the PT swap (+ a covariance epoch every 10 steps)" % (
                                    {"iso": 3 if d >= 1000 else 1, "dense": 2, "curved": 4}[a.logl], d,
                                    {"iso": "isotropic Gaussian", "dense": "dense Gaussian", "curved": "curved-likelihood"}[a.logl],
-                                   " + box prior" if a.prior == "box" else "", nt, W, a.mix, a.pick, a.swap_mode, a.cov_mode),
+                                   " + box prior" if a.prior == "box" else "", nt, W, a.mix, a.pick, a.swap_mode, a.cov_mode,
+                                   "rle" if getattr(eng, "am_rle", False) else "rows", eig_lag),
                    "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "iterations_per_step": TSKIP,
                    "parallelism": ("temperature blocks x%d" if a.partition == "temps" else "walker blocks x%d") % world},
         "iterations_timed": it_timed, "swap_epochs_timed": it_timed // TSKIP if nt * world > 1 else 0, "cov_epochs_timed": n_cov[0],

@@ -303,7 +303,11 @@ class OracleEngine(object):
                  cov_mode="per_walker", hot_chain=False, lanes=None, Tmin=1, Tmax=None,
                  ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep",
                  grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
-                 eig_mode="lapack", am_mode="auto"):
+                 eig_mode="lapack", am_mode="auto", eig_lag=0):
+        assert eig_lag in (0, 1)
+        # the engine's eig_lag: the factorization of a covariance epoch takes effect one segment late (pooled covariance, host LAPACK)
+        self.eig_lag = int(eig_lag) if (cov_mode == "pooled" and eig_mode == "lapack" and groups is None) else 0
+        self._eig_pending = False
         assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi")
         assert am_mode in ("auto", "rows", "rle")
         # the engine's am_mode: "rle" (pooled covariance on the block that holds rank 0) weights the pooled statistics by run lengths
@@ -441,8 +445,11 @@ class OracleEngine(object):
                     self.cov[0] = pool_update_rle(self.AM, self.AMflag, self.mu[0], self.M2[0], it - 1)
                 else:
                     self.cov[0] = pool_update(self.AM, self.mu[0], self.M2[0], it - 1)
-                for w in range(self.Wc):
-                    self._svd(w)
+                if self.eig_lag:
+                    self._eig_pending = True
+                else:
+                    for w in range(self.Wc):
+                        self._svd(w)
             if (it - 1) % burn == 0 and it - 1 != 0:
                 if self.per_walker:
                     for w in range(self.W):
@@ -499,6 +506,10 @@ class OracleEngine(object):
             assert err == 0, "replay error %d at iter %d" % (err, it)
             if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
                 self.swap(end, C.byref(rp_arr[0]) if rp_arr is not None else None)
+            if self._eig_pending:                              # eig_lag = 1: the table of the epoch takes effect from the next segment on
+                for w in range(self.Wc):
+                    self._svd(w)
+                self._eig_pending = False
             if record:
                 rec["X"].append(self.by_temp(self.X).copy())
                 rec["lnL"].append(self.by_temp(self.lnL).copy())

@@ -102,6 +102,11 @@ class PTEngine(object):
     tensor: no host round trip either; one parameter group) -- the choice for large ndim, where the host's LAPACK call is the
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
+    ``eig_lag`` (0 or 1; pooled covariance factorized by the host): with 1 the eigenvectors of a covariance epoch take effect one
+    launch late -- ``run`` queues the launch that follows the epoch (and its swap) with the table in force, the host factorizes
+    the new covariance MEANWHILE, and the launch after that uses the result.  The reference applies them at once
+    (PTMCMCSampler.py:560); the pooled covariance is an engine mode anyway, and the adaptation only ever sees the table 1 / 10 of a
+    period later.  Same statistics, same factorization, no GPU idle time at the epoch (oracle: ``OracleEngine(eig_lag=1)``).
     ``am_mode``: how the rank-0 chain's samples (updateChains' buffer, PTMCMCSampler.py:327-328) are kept between covariance
     epochs.  ``"rows"``: every step stores its row.  ``"rle"`` (pooled covariance): a rejected proposal leaves the chain where it
     was, so a step stores its row only when it was accepted (or is a KEY row: first step of a launch, ring rows 0 and 1, the
@@ -117,7 +122,7 @@ class PTEngine(object):
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
                  w_host=0, keep_lnl=False, groups=None, swap_mode="sweep",
                  grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
-                 eig_mode="lapack", am_mode="auto"):
+                 eig_mode="lapack", am_mode="auto", eig_lag=0):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -143,6 +148,9 @@ class PTEngine(object):
         if eig_mode not in ("lapack", "jacobi", "hipsolver"):
             raise ValueError("eig_mode must be 'lapack', 'jacobi' or 'hipsolver'")
         self.eig_mode = eig_mode
+        if eig_lag not in (0, 1):
+            raise ValueError("eig_lag must be 0 or 1")
+        self.eig_lag, self._eig_pending = int(eig_lag), False
         self.Wc = self.W if self.per_walker else 1
         # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
         self.groups = [np.arange(self.d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
@@ -299,6 +307,11 @@ class PTEngine(object):
         """The pooled covariance's factorization on the host (factorize(), the same bits as _eig_host) with the GPU idle for as
         short as possible: the matrix comes down into pinned memory, the eigenvector rows and eigenvalues go up from pinned
         memory, one wait in all (the download's); the uploads are queued and the next launch behind them."""
+        self._eig_begin()
+        self._eig_end()
+
+    def _eig_begin(self):
+        """First half of _eig_host_pooled: the covariance sets out for pinned host memory behind the statistics kernels."""
         torch = _torch()
         d = self.d
         if getattr(self, "_pin", None) is None:
@@ -308,12 +321,22 @@ class PTEngine(object):
         with torch.cuda.stream(self.stream):
             cov_h.copy_(self.t["cov"][0], non_blocking=True)
             ev.record(self.stream)
+        self._eig_pending = True
+
+    def _eig_end(self):
+        """Second half: wait for the covariance (NOT for the stream: with eig_lag = 1 a launch is running meanwhile), factorize,
+        queue the uploads; whatever is launched next reads the new table."""
+        torch = _torch()
+        cov_h, ut_h, s_h, ev = self._pin
+        with torch.cuda.stream(self.stream):
             ev.synchronize()
             U, S = factorize(cov_h.numpy(), False)
             np.copyto(ut_h.numpy(), U.T)
             np.copyto(s_h.numpy(), S)
             self.t["Ut"][0, 0].copy_(ut_h, non_blocking=True)
             self.t["S"][0, 0].copy_(s_h, non_blocking=True)
+        self._eig_pending = False
+        self.eig_epochs += 1
 
     def _eig_hipsolver(self):
         """U, S of every covariance the engine holds by the ROCm library's symmetric eigensolver, on the stream (factorize()'s
@@ -431,7 +454,11 @@ class PTEngine(object):
             self.eig_epochs += 1
             return
         if self.Wc == 1 and not self.per_walker and self.whole:
-            self._eig_host_pooled()
+            if self.eig_lag:
+                self._eig_begin()                                     # run() finishes it behind the next launch
+            else:
+                self._eig_host_pooled()
+            return
         elif self.Wc == 1:
             self._eig_host(0, self.get("cov")[0])
         else:
@@ -550,6 +577,8 @@ class PTEngine(object):
             self.mh_steps(it, end - it + 1)
             if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
                 self.swap(end)
+            if self._eig_pending:
+                self._eig_end()                                       # eig_lag = 1: the host factorized while that launch ran
             it = end + 1
         self.iter = last
 

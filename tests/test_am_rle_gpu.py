@@ -64,8 +64,6 @@ def test_rle_engine_matches_the_oracle(mods, d, nt, W, cu, tskip, weights, extra
     assert 0 < ((fl & 3) == 0).mean()                           # some rows were not stored
     if kw["burn"] < total:
         assert_same(np.roll(g.get("DE")[0], -g.de_head, axis=0), o.DE[0], "DE history")
-    if extra.get("box"):
-        assert ((fl & 3) == 0).mean() > 0.3
 
 
 def test_rows_mode_still_matches_its_oracle_and_rle_within_rounding(mods):
@@ -138,3 +136,32 @@ def test_checkpoint_of_an_rle_run_continues_bit_identically(mods):
     lo, hi = a.am_period()
     rows = np.arange(lo, hi + 1) % 40
     assert_same(a.get("AM")[:, rows], b.get("AM")[:, rows], "AM")
+
+
+@pytest.mark.parametrize("am_mode,weights", [("rle", (20, 0, 0)), ("rows", (20, 0, 0)), ("rle", (20, 20, 20))])
+def test_eig_lag_applies_the_table_one_launch_late(mods, am_mode, weights):
+    """eig_lag = 1 (pooled covariance, host factorization): the launch that follows a covariance epoch still runs with the table in
+    force, the host factorizes meanwhile, the launch after that uses the result.  HIP == oracle (OracleEngine(eig_lag=1)) bit for bit;
+    against eig_lag = 0 the chains are the same up to the end of the epoch's first launch and differ afterwards."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu, tskip = 100, 8, 5, 40, 10
+    kw = dict(weights=weights, cov_update=cu, burn=80, tskip=tskip, seed=13, cov_mode="pooled", cov0=np.eye(d) * 0.01, am_mode=am_mode)
+    g, o = _pair(mods, d, nt, W, eig_lag=1, **kw)
+    z, _ = _pair(mods, d, nt, W, eig_lag=0, **kw)
+    assert g.eig_lag == 1 and o.eig_lag == 1
+    for n in (cu, tskip, 3, cu - 3, 2 * cu + 7, 33):
+        before = g.get("Ut").copy()
+        g.run(n)
+        o.run(n)
+        z.run(n)
+        _compare(g, o, "lag it=%d " % g.iter)
+        assert_same(g.get("Ut"), o.Ut, "Ut it=%d" % g.iter)
+        assert_same(g.get("cov"), o.cov, "cov it=%d" % g.iter)
+        if g.iter == cu:
+            assert np.array_equal(g.get("X"), z.get("X"))                # nothing adapted yet
+        if g.iter == cu + tskip:
+            assert not np.array_equal(before, g.get("Ut"))               # the table changed during this run ...
+            assert np.array_equal(g.get("Ut"), z.get("Ut"))              # ... into the same table (same rows, same statistics) ...
+            assert not np.array_equal(g.get("X"), z.get("X"))            # ... but this launch still ran with the old one
+    assert not np.array_equal(g.get("X"), z.get("X"))
+    assert g.eig_epochs == z.eig_epochs
