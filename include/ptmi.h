@@ -297,7 +297,8 @@ int ptmi_selftest_philox(int device, const uint32_t *ctr_key /* [n][6] */, uint3
 /* Replay hook of the parity tests (tests/test_gpu_replay.py): the reference's RECORDED draws go into the production kernels in
  * place of the Philox ones.  swap_uniforms (dev [W][ntemps_global - 1], index [w][k] = the uniform of pair (k, k+1), :679) feeds
  * ptmi_swap / ptmi_swap_sweep*; draws (dev [W][T][4] 64-bit words per chain: P0 = cycle pick << 32 | scale-branch word, Q0, Q1 as
- * DESIGN.md section 4 lays them out, and the bits of the SCAM normal, :873) feeds ptmi_propose.  NULL switches a hook off. */
+ * DESIGN.md section 4 lays them out, and the bits of a double: the SCAM normal, :873, or DE's scale uniform, :976) feeds ptmi_propose.
+ * NULL switches a hook off. */
 int ptmi_test_replay(ptmi_handle h, const double *swap_uniforms, const uint64_t *draws);
 
 /* plain device memory helpers, so that a C caller needs nothing but this library */

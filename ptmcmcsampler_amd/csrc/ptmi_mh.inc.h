@@ -620,7 +620,8 @@ template <int G, int EPL, bool FULL, bool STR, bool GRP, bool GJ = false>
 __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, const Draws &dr,
                                        const double *Ut, bool ut_padded, const double *S, const double *DE,
                                        double (&dq)[EPL], bool s_sqrt = false, bool am_here = true, const double *tsm = nullptr,
-                                       long long *am_next = nullptr /* where the chain's next precomputed AM increment is (a.am_inc) */)
+                                       long long *am_next = nullptr /* where the chain's next precomputed AM increment is (a.am_inc) */,
+                                       const double *de_u = nullptr /* TEST HOOK (propose_kernel): DE's scale uniform as a double */)
 {
     // s_sqrt: S holds sqrt(eigenvalue) already (the block's LDS copy; sqrt is correctly rounded, so the bits are the same)
     auto root_s = [&](int k) { const double v = S[k]; return s_sqrt ? v : det_sqrt(v); };
@@ -680,7 +681,7 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         const u32 nn = (mm + 1u + h2index((u32)dr.Q0, Bn - 1u)) % Bn;
         double scale;
         if (plo > T50) scale = 1.0;
-        else scale = w2uniform(dr.Q1) * 2.4 / a.gdiv[g] * cc.de_mul;  // PT:976
+        else scale = (de_u ? *de_u : w2uniform(dr.Q1)) * 2.4 / a.gdiv[g] * cc.de_mul;  // PT:976
         const double *rm = DE + (size_t)((mm + (u32)a.de_head) % Bn) * a.de_ld;
         const double *rn = DE + (size_t)((nn + (u32)a.de_head) % Bn) * a.de_ld;
         // G == 4: rows are stored in 16-byte pieces dealt to the four lanes in turn (ptmi_de_row_stride: piece 4 e2 + lane
@@ -1417,14 +1418,17 @@ __global__ __launch_bounds__(256) void propose_kernel(const KArgs a)
     DrawBatch<false> batch;
     Draws dr;
     draws_for_step<false, true>(batch, dr, a, 0, sid, sid0, gl);
+    double rp_val = 0.0;
     if (a.rp_draws != nullptr) {               // TEST HOOK (ptmi_test_replay): the proposal's draws as recorded from the reference
         const u64 *r = a.rp_draws + (size_t)ch * 4;
         dr.P0 = r[0]; dr.Q0 = r[1]; dr.Q1 = r[2];
-        dr.z = __longlong_as_double((long long)r[3]);
+        rp_val = __longlong_as_double((long long)r[3]);    // the SCAM normal (PT:873), or DE's scale uniform (PT:976)
+        dr.z = rp_val;
         dr.pickw = (u32)(dr.P0 >> 32);
     }
     const double log_u = dr.log_u, u_acc = w2uniform_open(batch.P1());
-    const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, dr, Ut, false, S, DE, dq);
+    const int jt = propose<G, EPL, true, false, GRP>(a, a.iter0, sid, gl, cc, dr, Ut, false, S, DE, dq, false, true, nullptr, nullptr,
+                                                     a.rp_draws != nullptr ? &rp_val : nullptr);
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {

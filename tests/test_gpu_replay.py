@@ -37,7 +37,7 @@ def test_swap_sweep_on_the_references_uniforms(mods, fused, monkeypatch):
         e = PTEngine(2, n, 1, np.eye(2), ladder=ladder, weights=(20, 0, 0), tskip=1, cov_mode="pooled")
         e.init_state(np.zeros(2))
         e.put("lnL", lnL[None])                                     # slot s holds rank s at the start
-        u_k = np.ascontiguousarray(u[::-1], dtype=np.float64)        # drawn hottest pair first (k = n - 2 ... 0): index by k
+        u_k = np.array(u[::-1], dtype=np.float64)        # drawn hottest pair first (k = n - 2 ... 0): index by k
         ud = torch.from_numpy(u_k).to(e.device)
         _lib.check(e.lib.ptmi_test_replay(e.h, C.c_void_p(ud.data_ptr()), None))
         e.swap(1)
