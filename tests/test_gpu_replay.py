@@ -96,13 +96,9 @@ def test_scam_and_de_proposals_on_the_references_draws(mods):
                 assert mm != nn and all(v == mm for v in ints[1:-1])
                 prob = unis[0]
                 plo = 0xFFFFFFFF if prob > 0.5 else 0
-                q1 = 0
-                if prob <= 0.5:
-                    rr = unis[1]
-                    q1 = int(rr * 2.0 ** 53) << 11
-                    assert (q1 >> 11) * 2.0 ** -53 == rr
+                rr = unis[1] if prob <= 0.5 else 0.0                 # PT:976: the scale uniform, handed over as a double
                 off = (nn - mm - 1) % Bn
-                words[w, 0] = [(pick << 32) | plo, (_word(mm, Bn) << 32) | _word(off, Bn - 1), q1, 0]
+                words[w, 0] = [(pick << 32) | plo, (_word(mm, Bn) << 32) | _word(off, Bn - 1), 0, np.float64(rr).view(np.uint64)]
         wd = torch.from_numpy(words.view(np.int64)).to(e.device)
         _lib.check(e.lib.ptmi_test_replay(e.h, None, C.c_void_p(wd.data_ptr())))
         _lib.check(e.lib.ptmi_propose(e.h, 1))
