@@ -210,8 +210,9 @@ enum { PTMI_VAR_STAGED = 1,    /* strided lane layout, tables in LDS, products o
        PTMI_VAR_LDS_DRAWT = 256, /* the tables of the draws (log slices, base angles) are in LDS */
        PTMI_VAR_DENSE_SCAM = 512, /* mh_dense_scam_kernel: dense likelihood + SCAM-only cycle, P and Ut unpadded in LDS, 512-thread
                                   * blocks (two waves per SIMD over one copy of the tables) -- what bench.py --logl dense times */
-       PTMI_VAR_PERSISTENT = 1024 /* SCAM-only cycle, one eigenvector table for the launch (pooled covariance): persistent blocks, one
-                                   * per CU over one LDS copy of the table, each wave walking over units of 16 chains -- what bench.py times */ };
+       PTMI_VAR_PERSISTENT = 1024, /* SCAM-only cycle, one eigenvector table for the launch (pooled covariance): persistent blocks, one
+                                    * per CU over one LDS copy of the table, each wave walking over units of 16 chains -- what bench.py times */
+       PTMI_VAR_PC = 2048      /* cycles with AM entries, per-chain picks: stepper and AM-producer waves paired per SIMD (mh_pc_kernel) */ };
 int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant);
 
 /* PTswap (:631-697) for iteration `iter` when the whole ladder is on this GPU. */

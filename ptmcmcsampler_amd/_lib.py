@@ -28,7 +28,7 @@ class Config(C.Structure):
         ("group_size", C.POINTER(C.c_int32)), ("group_mask", _dp), ("gj_tab", _dp)]
 
 
-VAR_STAGED, VAR_FULL, VAR_LDS_UT, VAR_GROUPS, VAR_GRADJUMP, VAR_UNIFORM, VAR_AMQ, VAR_LDS_BOX, VAR_LDS_DRAWT, VAR_DENSE_SCAM, VAR_PERSISTENT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024   # ptmi_last_mh_variant
+VAR_STAGED, VAR_FULL, VAR_LDS_UT, VAR_GROUPS, VAR_GRADJUMP, VAR_UNIFORM, VAR_AMQ, VAR_LDS_BOX, VAR_LDS_DRAWT, VAR_DENSE_SCAM, VAR_PERSISTENT, VAR_PC = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048   # ptmi_last_mh_variant
 SWAP_MODES = {"sweep": 0, "oddeven": 1}
 PICK_MODES = {"chain": 0, "walker": 1}        # PTMI_PICK_CHAIN, PTMI_PICK_WALKER      # PTMI_SWAP_SWEEP, PTMI_SWAP_ODDEVEN
 

@@ -1184,6 +1184,233 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
     }       // units of a persistent block (one trip otherwise)
 }
 
+// Cycles with AM entries, per-chain picks (the reference's _jump), 4-lane shapes, one table for the block: the staged full
+// kernel as a PRODUCER / CONSUMER pair per SIMD.  mh_steps_kernel<..., FULL, STAGE> runs the AM queue and the steps in ONE wave
+// per SIMD (395 registers): every latency of the step -- the DE gather's memory round trip above all -- and every dependency of
+// the matrix pass is exposed.  Here a block is eight waves over the same LDS tables: waves 0-3 step their 16 chains each
+// (state, proposal bodies, likelihood, accept: under 256 registers without the accumulators and the table operands), waves
+// 4-7 -- wave 4 + j on the SIMD of wave j -- compute the AM increments of wave j's chains: they list the AM picks of the
+// launch themselves (the picks depend on the streams alone), run the matrix pass for 16 events at a time
+// (am_mfma_product: the arithmetic of an increment is unchanged) and hand the increments over through the ring of 16 slots
+// in LDS that the queue of mh_steps_kernel uses.  Two words in LDS per pair order them: `produced` (events whose increments
+// are in the ring; written by the producer behind its ring writes) and `consumed` (events the stepper has read; written by
+// the stepper behind its ring reads): the producer computes a pass ahead and waits for `consumed` before it overwrites slots,
+// the stepper waits for `produced` at an AM step, and publishes partial progress inside a step (else a step that straddles
+// two passes would wait for a pass that waits for it).  Events are numbered (step, chain) ascending by both sides.
+// Matrix and vector instructions of a SIMD still exclude each other: what the split buys is that either wave's waits are the
+// other's issue slots.
+template <int EPL, int LOGL, int PRI>
+__global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
+{
+    constexpr int G = 4, CPB = 64;
+    constexpr bool STR = true;
+    constexpr int LD = mfma_ld(EPL), AMQ_LD = 4 * EPL + 2;
+    static_assert(LOGL != PTMI_LOGL_DENSE, "the dense likelihood's table does not leave room for the ring");
+    const int d = a.d, nt = a.nt;
+    const long long nch = (long long)a.W * nt;
+    const int lane = (int)(threadIdx.x & 63), wave8 = (int)(threadIdx.x >> 6);
+    const int pair = wave8 & 3;
+    const bool producer = wave8 >= 4;
+    const int c16 = lane & 15, gl = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tab_n = 4 * ((d + 3) / 4) * LD;
+#define PTMI_PC_UL (smem)
+#define PTMI_PC_SQ (smem + (size_t)tab_n)
+#define PTMI_PC_RING(slot) (smem + a.amq_off + ((size_t)pair * 16 + (size_t)(slot)) * AMQ_LD)
+#define PTMI_PC_CD (smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)pair * 128)
+#define PTMI_PC_IDX ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + pair * 128)
+#define PTMI_PC_FLG ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + 4 * 128 + pair * 2)
+    // ---- the block's tables
+    size_t w0 = 0;
+    if (a.per_walker) {
+        const long long ch0 = (long long)logical_block() * CPB;
+        w0 = (size_t)((ch0 < nch ? ch0 : nch - 1) / nt);
+    }
+    {
+        const double *UtBlk = a.Ut + w0 * d * d, *Sb = a.S + w0 * d;
+        draw_table_fill(smem, a.tab_off, 512);
+        for (int i = (int)threadIdx.x; i < d; i += 512) PTMI_PC_SQ[i] = det_sqrt(Sb[i]);
+        for (int i = (int)threadIdx.x; i < tab_n; i += 512) {
+            const int r = i / LD, c = i % LD;
+            PTMI_PC_UL[i] = (r < d && c < d) ? UtBlk[(size_t)r * d + c] : 0.0;
+        }
+        box_table_fill<G, EPL>(a, smem, 512);
+        if (threadIdx.x < 8) ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + 4 * 128)[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    // ---- the chain of this lane (the producer's lanes mirror their stepper's)
+    long long ch = (long long)logical_block() * CPB + pair * 16 + c16;
+    const bool live = ch < nch;
+    if (!live) ch = nch - 1;
+    const int w = (int)(ch / nt);
+    const int t = a.temp_of[ch];
+    const int tg = a.temp0 + t;
+    const double beta = a.beta[t];
+    const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
+    const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
+    const u32 sid = sid0 + (u32)tg;
+    int *const flg = PTMI_PC_FLG;
+    if (producer) {
+        __builtin_amdgcn_s_setprio(1);                   // the matrix passes are the longer half of the pair's work
+        const int w_de = a.de_on ? a.w_de : 0;
+        const u32 L = (u32)(a.w_host + a.w_scam + a.w_am + w_de);
+        int known = 0, q_done = 0, kb = 0;
+        int *const idx = PTMI_PC_IDX;
+        double *const cdl = PTMI_PC_CD;
+        for (;;) {
+            // list the AM picks of further blocks of four steps: lane (c16, gl) evaluates chain c16 at step kb + gl (as propose())
+            while (known - q_done < 16 && kb < a.nsteps) {
+                bool ev = false;
+                double cdv = 0.0;
+                if (kb + gl < a.nsteps) {
+                    u64 p0, p1;
+                    philox_words(a.seed, (u64)(a.iter0 + kb + gl), sid, 0u, p0, p1);
+                    const int ind = (int)h2index((u32)(p0 >> 32), L) - a.w_host;
+                    ev = live && ind >= a.w_scam && ind < a.w_scam + a.w_am;
+                    constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
+                    const u32 plo = (u32)p0;
+                    cdv = a.gcn[0] * cc.sc(plo > T97 ? 0 : (plo > T90 ? 1 : 2));               // PT:928
+                }
+                const u64 mask = __ballot(ev);
+                const int rank = known + (int)__popcll(mask & ((1ull << lane) - 1ull));
+                if (ev) {
+                    idx[rank & 127] = c16 | ((kb + gl) << 4);
+                    cdl[rank & 127] = cdv;
+                }
+                known += (int)__popcll(mask);
+                kb += 4;
+            }
+            if (known == q_done) break;                      // every AM pick of the launch is served
+            asm volatile("" ::: "memory");                   // LDS serves a wave in order; this orders the compiler
+            const int hi = known < q_done + 16 ? known : q_done + 16;
+            const int r = q_done + c16;
+            const bool valid = r < hi;
+            const int entry = idx[(valid ? r : q_done) & 127];
+            const double cd_ev = cdl[(valid ? r : q_done) & 127];
+            const int owner = entry & 15;
+            const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
+            const long long it_ev = a.iter0 + (entry >> 4);
+            MfmaAcc<EPL> acc;
+            am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_PC_UL, true, LD, PTMI_PC_SQ, true, acc, smem);
+            // the slots of ranks q_done .. hi - 1 held ranks 16 below: wait until the stepper has read those
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&flg[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < hi - 16)
+                __builtin_amdgcn_s_sleep(2);
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) PTMI_PC_RING(r & 15)[gl * EPL + e] = acc.at(e);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&flg[0], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            q_done = hi;
+        }
+        return;
+    }
+    // ---- the stepper
+    const double *DE = a.DE ? a.DE + (a.per_walker ? (size_t)w : 0) * (size_t)a.de_size * a.de_ld : nullptr;
+    double *xrow = a.X + (size_t)ch * d;
+    DrawBatch<STR> batch;
+    double x[EPL], dq[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(x[e], xrow, e);
+    double lnL = a.lnL[ch], lp = a.lp[ch];
+    u32 nacc = 0, jp[PTMI_J_FUSED] = {0, 0, 0}, ja[PTMI_J_FUSED] = {0, 0, 0};
+    const bool cold = live && tg == 0 && a.AM != nullptr;
+    int am_row = a.am_row0;
+    int base = 0;                                            // AM events of this wave's chains before the current step
+    for (int k = 0; k < a.nsteps; ++k) {
+        const long long it = a.iter0 + k;
+        Draws dr;
+        draws_for_step<STR, true, 1>(batch, dr, a, k, sid, sid0, gl, smem);
+        const double log_u = dr.log_u;
+        const int jt = propose<G, EPL, true, STR, false>(a, it, sid, gl, cc, dr, PTMI_PC_UL, true, PTMI_PC_SQ, DE, dq, true, false, smem);
+        {
+            const bool is_am = live && jt == PTMI_J_AM;
+            const u32 m16 = (u32)(__ballot(is_am) & 0xFFFFull);           // the chains' first lanes
+            if (m16) {                                                    // wave-uniform
+                const int my = base + (int)__popc(m16 & ((1u << c16) - 1u));
+                const int need = base + (int)__popc(m16);
+                int got = base;
+                bool pending = is_am;
+                while (got < need) {
+                    const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flg[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const int avail = p < need ? p : need;
+                    if (avail > got) {
+                        if (pending && my < avail) {
+#pragma unroll
+                            for (int e = 0; e < EPL; ++e) dq[e] = PTMI_PC_RING(my & 15)[gl * EPL + e];
+                            pending = false;
+                        }
+                        // the values are in registers before the slots are given back
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        got = avail;
+                        if (lane == 0) __hip_atomic_store(&flg[1], got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                base = need;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PTMI_J_FUSED; ++j) jp[j] += (jt == j);
+        // PT:605-612
+        double nlp, nlnL = 0.0, nlnprob;
+        {
+            double q[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
+            if constexpr (PRI == PTMI_LOGP_FLAT) nlp = 0.0;
+            else nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
+            nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, nullptr);
+            nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
+        }
+        // PT:615-622
+        const double lnprob0 = beta * lnL + lp;
+        const double diff = nlnprob - lnprob0 + 0.0;
+        const bool accepted = diff > log_u;
+        if (accepted) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                double inc = dq[e];
+                asm volatile("" : "+v"(inc));
+                x[e] = x[e] + inc;
+            }
+            lnL = nlnL;
+            lp = nlp;
+            nacc += 1;
+#pragma unroll
+            for (int j = 0; j < PTMI_J_FUSED; ++j) ja[j] += (jt == j);
+        }
+        if (cold && !(a.swap_last && k == a.nsteps - 1)) {          // PT:327-328
+            am_store_step<G, EPL>(a, w, am_row, k, x, gl, d, accepted);
+            if (a.AMaux && gl == 0) {
+                double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row) * 2;
+                ax[0] = lnL;
+                ax[1] = lp;
+            }
+        }
+        am_row = am_row + 1 == a.cov_update ? 0 : am_row + 1;
+    }
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = gl + G * e;
+            if (e < safe_slots(G, EPL) || i < d) xrow[i] = x[e];
+        }
+        if (gl == 0) {
+            a.lnL[ch] = lnL;
+            a.lp[ch] = lp;
+            const size_t r = (size_t)w * nt + t;
+            a.nacc[r] += nacc;
+#pragma unroll
+            for (int j = 0; j < PTMI_J_FUSED; ++j) {
+                a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 0] += jp[j];
+                a.jstat[(r * PTMI_J_NTYPES + j) * 2 + 1] += ja[j];
+            }
+        }
+    }
+}
+
 // Dense Gaussian likelihood, SCAM-only cycle, one eigenvector table for the whole block (pooled covariance, or the ranks of
 // one walker filling the block): BASELINE configs[2] as bench.py --logl dense runs it.  Everything a step reads sits in
 // LDS -- the precision matrix and the eigenvector table UNPADDED side by side, the mean and sqrt(eigenvalues) behind them
@@ -1584,6 +1811,32 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             if (FULL && sizeof(double) * even(lds / sizeof(double)) + DRAWT <= 160 * 1024) {
                 a.tab_off = (int)even(lds / sizeof(double));
                 lds = sizeof(double) * (size_t)a.tab_off + DRAWT;
+            }
+            // per-chain picks with AM in the cycle: the producer / consumer form (mh_pc_kernel) when its lists fit beside the ring;
+            // PTMI_NO_PC=1 keeps the one-wave kernel (a measurement / test switch, same results)
+            if constexpr (FULL && LOGL != PTMI_LOGL_DENSE) {
+                static const bool no_pc = getenv("PTMI_NO_PC") != nullptr;
+                const size_t lists = sizeof(double) * 4 * 128 + sizeof(int) * 8;         // cd of the listed events, the pairs' two counters
+                if (a.amq_on && a.lds_u && a.tab_off >= 0 && !no_pc && lds + lists <= 160 * 1024 &&
+                    (c.logp_kind == PTMI_LOGP_FLAT || (c.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0))) {
+                    // the lists sit directly behind the ring: everything placed behind the queue moves up by their size
+                    const int shift = (int)(lists / sizeof(double));
+                    if (a.box_off >= 0) a.box_off += shift;
+                    a.tab_off += shift;
+                    const size_t ldp = lds + lists;
+                    auto launch_pc = [&](auto kp) -> int {
+                        if (ldp > 64 * 1024) {
+                            hipError_t e = hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldp);
+                            if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", ldp, hipGetErrorString(e));
+                        }
+                        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), ldp, h->stream, a);
+                        h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_FULL | PTMI_VAR_LDS_UT | PTMI_VAR_AMQ | PTMI_VAR_PC |
+                                          (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | PTMI_VAR_LDS_DRAWT;
+                        return PTMI_OK;
+                    };
+                    if (c.logp_kind == PTMI_LOGP_BOX) return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_BOX>);
+                    return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_FLAT>);
+                }
             }
             auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, true, false>;
             if (lds > 64 * 1024) {
