@@ -1199,7 +1199,16 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
 // two passes would wait for a pass that waits for it).  Events are numbered (step, chain) ascending by both sides.
 // Matrix and vector instructions of a SIMD still exclude each other: what the split buys is that either wave's waits are the
 // other's issue slots.
-template <int EPL, int LOGL, int PRI>
+#ifndef PTMI_PC_PRIO
+#define PTMI_PC_PRIO 0       // wave priority of the producers (measured: 1 and 3 cost 9 % against 0) ...
+#endif
+#ifndef PTMI_PC_SPRIO
+#define PTMI_PC_SPRIO 1      // ... and of the steppers (1 or 3: 0.8 % better than 0)
+#endif
+#ifndef PTMI_PC_SLEEP
+#define PTMI_PC_SLEEP 2
+#endif
+template <int EPL, int LOGL, int PRI, bool PERS>
 __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
 {
     constexpr int G = 4, CPB = 64;
@@ -1222,7 +1231,7 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
 #define PTMI_PC_FLG ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + 4 * 128 + pair * 2)
     // ---- the block's tables
     size_t w0 = 0;
-    if (a.per_walker) {
+    if (!PERS && a.per_walker) {
         const long long ch0 = (long long)logical_block() * CPB;
         w0 = (size_t)((ch0 < nch ? ch0 : nch - 1) / nt);
     }
@@ -1238,8 +1247,84 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
         if (threadIdx.x < 8) ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + 4 * 128)[threadIdx.x] = 0;
         __syncthreads();
     }
-    // ---- the chain of this lane (the producer's lanes mirror their stepper's)
-    long long ch = (long long)logical_block() * CPB + pair * 16 + c16;
+    // ---- units of 16 chains.  A block serves four units at a time (one per pair); with ONE table for the launch (pooled
+    // covariance: PERS) the blocks are persistent -- one per CU, the tables staged once -- and every pair walks over its own
+    // units without waiting for the block's other pairs (the AM picks of a unit vary by a few percent: a block of four ended
+    // with its slowest pair).  The event numbers and the two counters run on from unit to unit.
+    const long long nunits = (nch + 15) / 16;
+    const long long ustride = PERS ? (long long)gridDim.x * 4 : nunits;
+    int *const flg = PTMI_PC_FLG;
+    if (producer) {
+        if (PTMI_PC_PRIO) __builtin_amdgcn_s_setprio(PTMI_PC_PRIO);
+        const int w_de = a.de_on ? a.w_de : 0;
+        const u32 L = (u32)(a.w_host + a.w_scam + a.w_am + w_de);
+        int known = 0, q_done = 0;
+        int *const idx = PTMI_PC_IDX;
+        double *const cdl = PTMI_PC_CD;
+        for (long long unit = (long long)(PERS ? blockIdx.x : logical_block()) * 4 + pair; unit < nunits; unit += ustride) {
+            // the chain of this lane: the producer's lanes mirror their stepper's
+            long long ch = unit * 16 + c16;
+            const bool live = ch < nch;
+            if (!live) ch = nch - 1;
+            const int w = (int)(ch / nt);
+            const int t = a.temp_of[ch];
+            const ChainConst cc = chain_const(a.temps_mh[t], a.beta[t], d);
+            const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg) + (u32)(a.temp0 + t);
+            int kb = 0;
+            for (;;) {
+                // list the AM picks of further blocks of four steps: lane (c16, gl) evaluates chain c16 at step kb + gl (as propose())
+                while (known - q_done < 16 && kb < a.nsteps) {
+                    bool ev = false;
+                    double cdv = 0.0;
+                    if (kb + gl < a.nsteps) {
+                        u64 p0, p1;
+                        philox_words(a.seed, (u64)(a.iter0 + kb + gl), sid, 0u, p0, p1);
+                        const int ind = (int)h2index((u32)(p0 >> 32), L) - a.w_host;
+                        ev = live && ind >= a.w_scam && ind < a.w_scam + a.w_am;
+                        constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
+                        const u32 plo = (u32)p0;
+                        cdv = a.gcn[0] * cc.sc(plo > T97 ? 0 : (plo > T90 ? 1 : 2));               // PT:928
+                    }
+                    const u64 mask = __ballot(ev);
+                    const int rank = known + (int)__popcll(mask & ((1ull << lane) - 1ull));
+                    if (ev) {
+                        idx[rank & 127] = c16 | ((kb + gl) << 4);
+                        cdl[rank & 127] = cdv;
+                    }
+                    known += (int)__popcll(mask);
+                    kb += 4;
+                }
+                if (known == q_done) break;                  // every AM pick of the unit is served (a pass does not straddle units)
+                asm volatile("" ::: "memory");               // LDS serves a wave in order; this orders the compiler
+                const int hi = known < q_done + 16 ? known : q_done + 16;
+                const int r = q_done + c16;
+                const bool valid = r < hi;
+                const int entry = idx[(valid ? r : q_done) & 127];
+                const double cd_ev = cdl[(valid ? r : q_done) & 127];
+                const int owner = entry & 15;
+                const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
+                const long long it_ev = a.iter0 + (entry >> 4);
+                MfmaAcc<EPL> acc;
+                am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_PC_UL, true, LD, PTMI_PC_SQ, true, acc, smem);
+                // the slots of ranks q_done .. hi - 1 held ranks 16 below: wait until the stepper has read those
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&flg[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < hi - 16)
+                    __builtin_amdgcn_s_sleep(PTMI_PC_SLEEP);
+                if (valid) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) PTMI_PC_RING(r & 15)[gl * EPL + e] = acc.at(e);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&flg[0], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                q_done = hi;
+            }
+        }
+        return;
+    }
+    // ---- the stepper
+    if (PTMI_PC_SPRIO) __builtin_amdgcn_s_setprio(PTMI_PC_SPRIO);
+    int base = 0;                                            // AM events of this wave's chains before the current step
+    for (long long unit = (long long)(PERS ? blockIdx.x : logical_block()) * 4 + pair; unit < nunits; unit += ustride) {
+    long long ch = unit * 16 + c16;
     const bool live = ch < nch;
     if (!live) ch = nch - 1;
     const int w = (int)(ch / nt);
@@ -1249,63 +1334,6 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
     const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
     const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
     const u32 sid = sid0 + (u32)tg;
-    int *const flg = PTMI_PC_FLG;
-    if (producer) {
-        __builtin_amdgcn_s_setprio(1);                   // the matrix passes are the longer half of the pair's work
-        const int w_de = a.de_on ? a.w_de : 0;
-        const u32 L = (u32)(a.w_host + a.w_scam + a.w_am + w_de);
-        int known = 0, q_done = 0, kb = 0;
-        int *const idx = PTMI_PC_IDX;
-        double *const cdl = PTMI_PC_CD;
-        for (;;) {
-            // list the AM picks of further blocks of four steps: lane (c16, gl) evaluates chain c16 at step kb + gl (as propose())
-            while (known - q_done < 16 && kb < a.nsteps) {
-                bool ev = false;
-                double cdv = 0.0;
-                if (kb + gl < a.nsteps) {
-                    u64 p0, p1;
-                    philox_words(a.seed, (u64)(a.iter0 + kb + gl), sid, 0u, p0, p1);
-                    const int ind = (int)h2index((u32)(p0 >> 32), L) - a.w_host;
-                    ev = live && ind >= a.w_scam && ind < a.w_scam + a.w_am;
-                    constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
-                    const u32 plo = (u32)p0;
-                    cdv = a.gcn[0] * cc.sc(plo > T97 ? 0 : (plo > T90 ? 1 : 2));               // PT:928
-                }
-                const u64 mask = __ballot(ev);
-                const int rank = known + (int)__popcll(mask & ((1ull << lane) - 1ull));
-                if (ev) {
-                    idx[rank & 127] = c16 | ((kb + gl) << 4);
-                    cdl[rank & 127] = cdv;
-                }
-                known += (int)__popcll(mask);
-                kb += 4;
-            }
-            if (known == q_done) break;                      // every AM pick of the launch is served
-            asm volatile("" ::: "memory");                   // LDS serves a wave in order; this orders the compiler
-            const int hi = known < q_done + 16 ? known : q_done + 16;
-            const int r = q_done + c16;
-            const bool valid = r < hi;
-            const int entry = idx[(valid ? r : q_done) & 127];
-            const double cd_ev = cdl[(valid ? r : q_done) & 127];
-            const int owner = entry & 15;
-            const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
-            const long long it_ev = a.iter0 + (entry >> 4);
-            MfmaAcc<EPL> acc;
-            am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_PC_UL, true, LD, PTMI_PC_SQ, true, acc, smem);
-            // the slots of ranks q_done .. hi - 1 held ranks 16 below: wait until the stepper has read those
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&flg[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < hi - 16)
-                __builtin_amdgcn_s_sleep(2);
-            if (valid) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) PTMI_PC_RING(r & 15)[gl * EPL + e] = acc.at(e);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(&flg[0], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            q_done = hi;
-        }
-        return;
-    }
-    // ---- the stepper
     const double *DE = a.DE ? a.DE + (a.per_walker ? (size_t)w : 0) * (size_t)a.de_size * a.de_ld : nullptr;
     double *xrow = a.X + (size_t)ch * d;
     DrawBatch<STR> batch;
@@ -1316,7 +1344,6 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
     u32 nacc = 0, jp[PTMI_J_FUSED] = {0, 0, 0}, ja[PTMI_J_FUSED] = {0, 0, 0};
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
-    int base = 0;                                            // AM events of this wave's chains before the current step
     for (int k = 0; k < a.nsteps; ++k) {
         const long long it = a.iter0 + k;
         Draws dr;
@@ -1345,7 +1372,7 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
                         got = avail;
                         if (lane == 0) __hip_atomic_store(&flg[1], got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(PTMI_PC_SLEEP);
                     }
                 }
                 base = need;
@@ -1409,6 +1436,7 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
             }
         }
     }
+    }       // units
 }
 
 // Dense Gaussian likelihood, SCAM-only cycle, one eigenvector table for the whole block (pooled covariance, or the ranks of
@@ -1824,18 +1852,28 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                     if (a.box_off >= 0) a.box_off += shift;
                     a.tab_off += shift;
                     const size_t ldp = lds + lists;
+                    // ONE table for the launch (pooled covariance): persistent blocks, one per CU (PTMI_PC_PERS=0: a block per 64 chains)
+                    static int ncu = 0;
+                    if (!ncu && (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || ncu < 1)) ncu = 256;
+                    const char *pe = getenv("PTMI_PC_PERS");
+                    const bool pers = !c.cov_per_walker && !(pe && atoi(pe) == 0);
+                    const int gridp = pers ? (grid < ncu ? grid : ncu) : grid;
                     auto launch_pc = [&](auto kp) -> int {
                         if (ldp > 64 * 1024) {
                             hipError_t e = hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldp);
                             if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", ldp, hipGetErrorString(e));
                         }
-                        hipLaunchKernelGGL(kp, dim3(grid), dim3(512), ldp, h->stream, a);
+                        hipLaunchKernelGGL(kp, dim3(gridp), dim3(512), ldp, h->stream, a);
                         h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_FULL | PTMI_VAR_LDS_UT | PTMI_VAR_AMQ | PTMI_VAR_PC |
-                                          (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | PTMI_VAR_LDS_DRAWT;
+                                          (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | PTMI_VAR_LDS_DRAWT | (pers ? PTMI_VAR_PERSISTENT : 0);
                         return PTMI_OK;
                     };
-                    if (c.logp_kind == PTMI_LOGP_BOX) return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_BOX>);
-                    return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_FLAT>);
+                    if (pers) {
+                        if (c.logp_kind == PTMI_LOGP_BOX) return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_BOX, true>);
+                        return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_FLAT, true>);
+                    }
+                    if (c.logp_kind == PTMI_LOGP_BOX) return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_BOX, false>);
+                    return launch_pc(mh_pc_kernel<EPL, LOGL, PTMI_LOGP_FLAT, false>);
                 }
             }
             auto kern = mh_steps_kernel<G, EPL, LOGL, FULL, true, false>;
