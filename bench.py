@@ -197,7 +197,7 @@ def main():
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
               pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled", am_mode=a.am_mode,
               eig_mode="jacobi" if a.cov_mode.endswith("_device") else ("hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack"))
-    eig_lag = a.eig_lag if (kw["cov_mode"] == "pooled" and kw["eig_mode"] == "lapack" and (world == 1 and not a.sharded or a.partition == "walkers")) else 0
+    eig_lag = a.eig_lag if (kw["cov_mode"] == "pooled" and kw["eig_mode"] == "lapack") else 0
     kw.update(eig_lag=eig_lag)
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.prior == "box":
@@ -374,7 +374,7 @@ def main():
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
     # summary is per launch of 100 steps on one named workload
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):

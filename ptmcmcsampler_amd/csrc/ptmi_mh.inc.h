@@ -1269,7 +1269,8 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
             const int w = (int)(ch / nt);
             const int t = a.temp_of[ch];
             const ChainConst cc = chain_const(a.temps_mh[t], a.beta[t], d);
-            const u32 sid = (u32)((u64)(a.walker0 + w) * (u32)a.ntg) + (u32)(a.temp0 + t);
+            const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
+            const u32 sid = sid0 + (u32)(a.temp0 + t);
             int kb = 0;
             for (;;) {
                 // list the AM picks of further blocks of four steps: lane (c16, gl) evaluates chain c16 at step kb + gl (as propose())
@@ -1279,7 +1280,13 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
                     if (kb + gl < a.nsteps) {
                         u64 p0, p1;
                         philox_words(a.seed, (u64)(a.iter0 + kb + gl), sid, 0u, p0, p1);
-                        const int ind = (int)h2index((u32)(p0 >> 32), L) - a.w_host;
+                        u32 pickw = (u32)(p0 >> 32);
+                        if (a.pick_walker) {                 // pick_mode WALKER: the word of the walker's rank 0 picks the type for all its ranks
+                            u64 q0, q1;
+                            philox_words(a.seed, (u64)(a.iter0 + kb + gl), sid0, 0u, q0, q1);
+                            pickw = (u32)(q0 >> 32);
+                        }
+                        const int ind = (int)h2index(pickw, L) - a.w_host;
                         ev = live && ind >= a.w_scam && ind < a.w_scam + a.w_am;
                         constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
                         const u32 plo = (u32)p0;
@@ -1840,12 +1847,12 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 a.tab_off = (int)even(lds / sizeof(double));
                 lds = sizeof(double) * (size_t)a.tab_off + DRAWT;
             }
-            // per-chain picks with AM in the cycle: the producer / consumer form (mh_pc_kernel) when its lists fit beside the ring;
+            // AM in the cycle: the producer / consumer form (mh_pc_kernel) when its lists fit beside the ring;
             // PTMI_NO_PC=1 keeps the one-wave kernel (a measurement / test switch, same results)
             if constexpr (FULL && LOGL != PTMI_LOGL_DENSE) {
-                static const bool no_pc = getenv("PTMI_NO_PC") != nullptr;
+                const bool no_pc = getenv("PTMI_NO_PC") != nullptr;                      // read per launch: the tests switch it
                 const size_t lists = sizeof(double) * 4 * 128 + sizeof(int) * 8;         // cd of the listed events, the pairs' two counters
-                if (a.amq_on && a.lds_u && a.tab_off >= 0 && !no_pc && lds + lists <= 160 * 1024 &&
+                if (c.w_am > 0 && a.lds_u && a.tab_off >= 0 && !no_pc && lds + lists <= 160 * 1024 &&
                     (c.logp_kind == PTMI_LOGP_FLAT || (c.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0))) {
                     // the lists sit directly behind the ring: everything placed behind the queue moves up by their size
                     const int shift = (int)(lists / sizeof(double));
@@ -1864,7 +1871,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                             if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", ldp, hipGetErrorString(e));
                         }
                         hipLaunchKernelGGL(kp, dim3(gridp), dim3(512), ldp, h->stream, a);
-                        h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_FULL | PTMI_VAR_LDS_UT | PTMI_VAR_AMQ | PTMI_VAR_PC |
+                        h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_FULL | PTMI_VAR_LDS_UT | PTMI_VAR_PC |
                                           (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | PTMI_VAR_LDS_DRAWT | (pers ? PTMI_VAR_PERSISTENT : 0);
                         return PTMI_OK;
                     };

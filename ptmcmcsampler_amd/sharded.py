@@ -133,6 +133,12 @@ class ShardedPTEngine(object):
         self.stream = getattr(L, "stream", None)
         self.iter, self.swap_proposed = 0, 0
         self.de_head = 0
+        # eig_lag = 1 (PTEngine): the owner of rank 0 factorizes the pooled covariance while every GPU runs the launch that follows
+        # the epoch; the table is broadcast behind that launch's swap.  Without it seven GPUs wait at the broadcast for GPU 0's
+        # statistics and factorization.  The same decision on every rank (from the configuration alone).
+        self.eig_lag = int(kw.get("eig_lag", 0)) if (kw.get("cov_mode", "per_walker") == "pooled" and kw.get("eig_mode", "lapack") == "lapack"
+                                                     and kw.get("groups") is None) else 0
+        self._bcast_pending = False
         self._lnl_loc = torch.zeros((self.W, self.nt), dtype=torch.float64, device=self.device)
         self._map = torch.zeros((self.W, self.ntg), dtype=torch.int32, device=self.device)
         self._parts = torch.empty((self.world * self.W, self.nt), dtype=torch.float64, device=self.device)
@@ -231,8 +237,15 @@ class ShardedPTEngine(object):
         L = self.local
         if self.owns_cold:
             L.update_cov(it_done)
+        if self.eig_lag:
+            self._bcast_pending = True                                    # run() finishes the epoch behind the next launch
+            return
+        self._bcast_table()
+
+    def _bcast_table(self):
         # the other blocks only ever read the factorization: the covariance itself stays where it is adapted
         # (pooled: 80 KB of eigenvectors per epoch at ndim = 100; per walker: a third less than with cov)
+        L = self.local
         for name in ("Ut", "S"):
             self.comm.broadcast(L.t[name])
 
@@ -276,6 +289,11 @@ class ShardedPTEngine(object):
             self.mh_steps(it, end - it + 1)
             if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
                 self.swap(end)
+            if self._bcast_pending:                                       # eig_lag = 1: the owner factorized while that launch ran
+                if self.owns_cold and getattr(self.local, "_eig_pending", False):
+                    self.local._eig_end()
+                self._bcast_table()
+                self._bcast_pending = False
             it = end + 1
         self.iter = last
         self.local.iter = last

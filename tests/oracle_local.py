@@ -25,6 +25,12 @@ class OracleLocal(object):
         self.t = dict(X=al(o.X), lnL=al(o.lnL), lp=al(o.lp), temp_of=al(o.temp_of), slot_of=al(o.slot_of),
                       Ut=al(o.Ut), S=al(o.S), cov=al(o.cov), DE=al(self.ring), AM=al(o.AM) if self.owns_cold else None)
         self.iter = 0
+        self._eig_pending = False
+
+    def _eig_end(self):
+        for w in range(self.o.Wc):
+            self.o._svd(w)
+        self._eig_pending = False
 
     def get(self, name):
         if name in ("nacc", "jstat", "nswap", "mu", "M2"):
@@ -78,6 +84,9 @@ class OracleLocal(object):
             o.cov[0] = orc.pool_update_rle(o.AM, o.AMflag, o.mu[0], o.M2[0], it_done)
         else:
             o.cov[0] = orc.pool_update(o.AM, o.mu[0], o.M2[0], it_done)
+        if o.eig_lag:
+            self._eig_pending = True                                # ShardedPTEngine.run finishes the epoch behind the next launch
+            return
         for w in range(o.Wc):
             o._svd(w)
 

@@ -59,16 +59,24 @@ def test_dense_with_am_runs_on_the_matrix_cores_and_matches(mods, cov_mode, nt, 
     assert o.jstat[..., 1, 1].sum() > 0                        # AM proposals were accepted
 
 
-def test_iso_default_mix_pooled_runs_staged(mods):
-    """The default-mix kernel of bench.py --mix default (iso likelihood: the eigenvector table in LDS)."""
+@pytest.mark.parametrize("pc", [True, False])
+def test_iso_default_mix_pooled_runs_staged(mods, pc, monkeypatch):
+    """The default-mix kernels of bench.py --mix default (iso likelihood: the eigenvector table in LDS): mh_pc_kernel (stepper and
+    AM-producer waves paired per SIMD, persistent blocks: what the bench times) and, with PTMI_NO_PC=1, the one-wave kernel with
+    its AM queue."""
     orc, _lib, _ = mods
+    if not pc:
+        monkeypatch.setenv("PTMI_NO_PC", "1")
     g, o = _pair(mods, 100, 64, 3, cov0=np.eye(100) * 0.01, weights=(20, 20, 20), cov_update=40, burn=80, tskip=20,
                  seed=3, cov_mode="pooled")
     g.run(170)
     o.run(170)
     flags, G, E = g.last_variant()
     assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and flags & _lib.VAR_LDS_UT
-    assert flags & _lib.VAR_AMQ                                # per-chain picks, a third of them AM: increments through the queue
+    if pc:
+        assert flags & _lib.VAR_PC and flags & _lib.VAR_PERSISTENT
+    else:
+        assert flags & _lib.VAR_AMQ and not flags & _lib.VAR_PC    # per-chain picks, a third of them AM: increments through the queue
     assert flags & _lib.VAR_LDS_DRAWT                          # the draws' tables sit behind the queue in LDS
     _compare(g, o, "mix ")
     assert o.jstat[..., 2, 0].sum() > 0
@@ -76,11 +84,12 @@ def test_iso_default_mix_pooled_runs_staged(mods):
 
 @pytest.mark.parametrize("weights,nt,W,n,queued", [((20, 20, 0), 64, 2, 131, True), ((30, 5, 0), 5, 7, 97, True), ((5, 1, 20), 3, 5, 150, True),
                                                    ((0, 20, 0), 4, 4, 60, False), ((1, 30, 0), 4, 4, 60, False)])
-def test_am_queue_matches_in_place_am(mods, weights, nt, W, n, queued):
-    """The AM queue of the staged full kernel (increments computed 16 events at a time, four to seven steps ahead, through a
-    ring in LDS) against the oracle's AM (PTMCMCSampler.py:879-933): launches of odd lengths, sparse and dense AM picks, a
-    wave with dead lanes, DE switching on in between; AM-heavy cycles stay in place."""
+def test_am_queue_matches_in_place_am(mods, weights, nt, W, n, queued, monkeypatch):
+    """The AM queue of the one-wave staged full kernel (PTMI_NO_PC=1; increments computed 16 events at a time, four to seven steps
+    ahead, through a ring in LDS) against the oracle's AM (PTMCMCSampler.py:879-933): launches of odd lengths, sparse and dense AM
+    picks, a wave with dead lanes, DE switching on in between; AM-heavy cycles stay in place."""
     orc, _lib, _ = mods
+    monkeypatch.setenv("PTMI_NO_PC", "1")
     d = 100
     g, o = _pair(mods, d, nt, W, cov0=np.eye(d) * 0.01, weights=weights, cov_update=20, burn=40, tskip=7, seed=17, cov_mode="pooled")
     for m in (n, 3, 1, 46):                                    # the queue restarts with every launch, whatever its length
@@ -89,6 +98,28 @@ def test_am_queue_matches_in_place_am(mods, weights, nt, W, n, queued):
     flags, G, E = g.last_variant()
     assert flags & _lib.VAR_STAGED and flags & _lib.VAR_FULL and bool(flags & _lib.VAR_AMQ) == queued
     _compare(g, o, "am queue %r " % (weights,))
+    assert o.jstat[..., 1, 0].sum() > 0
+
+
+@pytest.mark.parametrize("weights,nt,W,n,cov_mode,pick", [((20, 20, 0), 64, 2, 131, "pooled", "chain"), ((30, 5, 0), 5, 7, 97, "pooled", "chain"),
+                                                          ((5, 1, 20), 3, 5, 150, "pooled", "chain"), ((0, 20, 0), 4, 4, 60, "pooled", "chain"),
+                                                          ((1, 30, 0), 4, 4, 60, "pooled", "chain"), ((20, 20, 20), 64, 3, 120, "per_walker", "chain"),
+                                                          ((20, 20, 20), 64, 2, 120, "pooled", "walker"), ((20, 20, 20), 7, 11, 90, "pooled", "walker")])
+def test_producer_consumer_kernel_matches_the_oracle(mods, weights, nt, W, n, cov_mode, pick):
+    """mh_pc_kernel (stepper + AM-producer wave pairs, the ring handed over through two LDS counters) against the oracle's AM
+    (PTMCMCSampler.py:879-933): launches of odd lengths (the event numbers restart with every launch, passes do not straddle
+    units), sparse and AM-only cycles, waves with dead lanes, DE switching on in between, a block per walker (per-walker tables: not
+    persistent), one pick per walker."""
+    orc, _lib, _ = mods
+    d = 100
+    g, o = _pair(mods, d, nt, W, cov0=np.eye(d) * 0.01, weights=weights, cov_update=20, burn=40, tskip=7, seed=17, cov_mode=cov_mode,
+                 pick_mode=pick)
+    for m in (n, 3, 1, 46):
+        g.run(m)
+        o.run(m)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_PC and flags & _lib.VAR_FULL and bool(flags & _lib.VAR_PERSISTENT) == (cov_mode == "pooled")
+    _compare(g, o, "pc %r %s %s " % (weights, cov_mode, pick))
     assert o.jstat[..., 1, 0].sum() > 0
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes, one JSON line per workload, into gpurun_out/sweep_<tag>/ (copy the merged file to
 # profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r03'
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sweep_$TAG
 mkdir -p $OUT

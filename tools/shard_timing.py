@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ptmcmcsampler_amd.engine import PTEngine
 
 d, nt, W = 100, 64, 4096
+results = {}
 for N in [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8]:
     ntg = nt * N
     e = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=1000, burn=10000, tskip=100, seed=1, cov_mode="pooled",
@@ -45,5 +46,19 @@ for N in [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8]:
     ms = timed(epoch)
     mh = timed(lambda it: e.mh_steps(it + 1, 99))
     print("N=%d (ladder of %d): swap epoch %.3f ms on the device, 100 MH steps %.3f ms -> %.1f %% of the MH time" % (N, ntg, ms, mh, 100 * ms / mh), flush=True)
+    # the owner's covariance epoch (pooled statistics over the stored rows), once per covUpdate / Tskip swap epochs
+    e.run(1000 - e.iter if e.iter < 1000 else 0)
+    from ptmcmcsampler_amd import _lib
+    cov = timed(lambda it: _lib.check(e.lib.ptmi_update_cov(e.h, 1000)), 3)
+    results[N] = {"swap_epoch_device_ms": ms, "mh_100_steps_ms": mh, "cov_epoch_stats_ms": cov}
     del e
     torch.cuda.empty_cache()
+import json
+out = {"workload": "ndim=%d, %d ranks per GPU, %d walkers, SCAM cycle, pooled covariance (am_mode rle), Tskip=100, covUpdate=1000" % (d, nt, W),
+       "what": "device time per swap epoch as block 0 of an N x 64-rank ladder sees it (gather, sweep of the whole ladder, pack, apply, AM row), "
+               "100 MH steps of its 64 x 4096 chains, the owner's pooled statistics per covariance epoch; one MI355X, tools/shard_timing.py",
+       "by_ngpus": {str(k): v for k, v in results.items()}}
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "shard_timing.json")
+os.makedirs(os.path.dirname(path), exist_ok=True)
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path)
