@@ -47,7 +47,8 @@ for N in [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8]:
     mh = timed(lambda it: e.mh_steps(it + 1, 99))
     print("N=%d (ladder of %d): swap epoch %.3f ms on the device, 100 MH steps %.3f ms -> %.1f %% of the MH time" % (N, ntg, ms, mh, 100 * ms / mh), flush=True)
     # the owner's covariance epoch (pooled statistics over the stored rows), once per covUpdate / Tskip swap epochs
-    e.run(1000 - e.iter if e.iter < 1000 else 0)
+    for seg in range(10):                                    # a full ring of rows and flags (no swaps: block 0 alone cannot run them)
+        e.mh_steps(100 * seg + 1, 100)
     from ptmcmcsampler_amd import _lib
     cov = timed(lambda it: _lib.check(e.lib.ptmi_update_cov(e.h, 1000)), 3)
     results[N] = {"swap_epoch_device_ms": ms, "mh_100_steps_ms": mh, "cov_epoch_stats_ms": cov}
