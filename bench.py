@@ -54,9 +54,11 @@ def parse():
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
                          "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK; "
                          "_hipsolver: by the ROCm library's eigensolver on the stream (large ndim)")
-    ap.add_argument("--eig-lag", type=int, default=1, choices=[0, 1],
-                    help="pooled covariance factorized by the host: 1 = the eigenvectors of a covariance epoch take effect one launch late, the "
-                         "host factorizing while that launch runs (PTEngine eig_lag); 0 = at once, the GPU idle meanwhile (the reference's order)")
+    ap.add_argument("--eig-lag", type=int, default=-1,
+                    help="pooled covariance: the eigenvectors of a covariance epoch take effect this many launches late, the factorization "
+                         "running meanwhile (PTEngine eig_lag: the host's LAPACK beside the GPU, or the ROCm library on a side stream); "
+                         "0 = at once, the GPU idle / the stream blocked meanwhile (the reference's order); default: 1 with the host's LAPACK, "
+                         "9 with the library (ndim >= 512)")
     ap.add_argument("--am-mode", default="auto", choices=["auto", "rows", "rle"],
                     help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): rle = a step stores its "
                          "row only when it was accepted, the pooled statistics weight every stored row by its run length; rows = every "
@@ -197,7 +199,11 @@ def main():
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
               pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled", am_mode=a.am_mode,
               eig_mode="jacobi" if a.cov_mode.endswith("_device") else ("hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack"))
-    eig_lag = a.eig_lag if (kw["cov_mode"] == "pooled" and kw["eig_mode"] == "lapack") else 0
+    eig_lag = 0
+    if kw["cov_mode"] == "pooled" and kw["eig_mode"] in ("lapack", "hipsolver"):
+        eig_lag = a.eig_lag if a.eig_lag >= 0 else (1 if kw["eig_mode"] == "lapack" else 9)
+        if kw["eig_mode"] == "hipsolver" and not (world == 1 and not a.sharded or a.partition == "walkers"):
+            eig_lag = 0                      # the sharded engine broadcasts the table of the host path only
     kw.update(eig_lag=eig_lag)
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.prior == "box":

@@ -304,10 +304,10 @@ class OracleEngine(object):
                  ntemps_global=None, temp0=0, walker0=0, groups=None, swap_mode="sweep",
                  grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
                  eig_mode="lapack", am_mode="auto", eig_lag=0):
-        assert eig_lag in (0, 1)
-        # the engine's eig_lag: the factorization of a covariance epoch takes effect one segment late (pooled covariance, host LAPACK)
+        assert eig_lag >= 0
+        # the engine's eig_lag: the factorization of a covariance epoch takes effect eig_lag segments late (pooled covariance, host LAPACK)
         self.eig_lag = int(eig_lag) if (cov_mode == "pooled" and eig_mode == "lapack" and groups is None) else 0
-        self._eig_pending = False
+        self._eig_pending, self._eig_wait = False, 0
         assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi")
         assert am_mode in ("auto", "rows", "rle")
         # the engine's am_mode: "rle" (pooled covariance on the block that holds rank 0) weights the pooled statistics by run lengths
@@ -438,6 +438,7 @@ class OracleEngine(object):
         cu, burn = self.cov_update, self.burn
         if self.temp0 == 0:
             if (it - 1) % cu == 0 and it - 1 != 0:
+                self._eig_finish()                             # a factorization still pending from the epoch before
                 if self.per_walker:
                     for w in range(self.W):
                         self.cov[w] = welford(self.AM[w], self.mu[w], self.M2[w], it - 1)
@@ -446,7 +447,7 @@ class OracleEngine(object):
                 else:
                     self.cov[0] = pool_update(self.AM, self.mu[0], self.M2[0], it - 1)
                 if self.eig_lag:
-                    self._eig_pending = True
+                    self._eig_pending, self._eig_wait = True, self.eig_lag
                 else:
                     for w in range(self.Wc):
                         self._svd(w)
@@ -458,6 +459,12 @@ class OracleEngine(object):
                     lib().orc_de_update_pooled(self.d, burn, cu, self.W, _p(self.DE), _p(self.AM))
         if it - 1 == burn:
             self.cfg.de_on = 1
+
+    def _eig_finish(self):
+        if self._eig_pending:
+            for w in range(self.Wc):
+                self._svd(w)
+        self._eig_pending, self._eig_wait = False, 0
 
     def _next_event(self, it, niter):
         """Last iteration of the segment that starts at ``it`` (no epoch inside, swap only at its end)."""
@@ -506,10 +513,10 @@ class OracleEngine(object):
             assert err == 0, "replay error %d at iter %d" % (err, it)
             if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
                 self.swap(end, C.byref(rp_arr[0]) if rp_arr is not None else None)
-            if self._eig_pending:                              # eig_lag = 1: the table of the epoch takes effect from the next segment on
-                for w in range(self.Wc):
-                    self._svd(w)
-                self._eig_pending = False
+            if self._eig_pending:                              # eig_lag segments after the epoch its table takes effect
+                self._eig_wait -= 1
+                if self._eig_wait <= 0:
+                    self._eig_finish()
             if record:
                 rec["X"].append(self.by_temp(self.X).copy())
                 rec["lnL"].append(self.by_temp(self.lnL).copy())

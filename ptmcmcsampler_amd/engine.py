@@ -102,11 +102,14 @@ class PTEngine(object):
     tensor: no host round trip either; one parameter group) -- the choice for large ndim, where the host's LAPACK call is the
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
-    ``eig_lag`` (0 or 1; pooled covariance factorized by the host): with 1 the eigenvectors of a covariance epoch take effect one
-    launch late -- ``run`` queues the launch that follows the epoch (and its swap) with the table in force, the host factorizes
-    the new covariance MEANWHILE, and the launch after that uses the result.  The reference applies them at once
-    (PTMCMCSampler.py:560); the pooled covariance is an engine mode anyway, and the adaptation only ever sees the table 1 / 10 of a
-    period later.  Same statistics, same factorization, no GPU idle time at the epoch (oracle: ``OracleEngine(eig_lag=1)``).
+    ``eig_lag`` (L >= 0 launches; pooled covariance): the eigenvectors of a covariance epoch take effect L launches late --
+    ``run`` queues the L launches that follow the epoch (and their swaps) with the table in force, the factorization runs
+    MEANWHILE, and the launch after them uses the result (a new epoch finishes a pending one first).  The reference applies the
+    table at once (PTMCMCSampler.py:560); the pooled covariance is an engine mode anyway, and with L = 1 the adaptation sees its
+    table a tenth of a period late.  ``eig_mode="lapack"``: the host factorizes while the GPU samples (L = 1 hides it at
+    ndim = 100); ``eig_mode="hipsolver"``: the library's kernels run on a side stream BESIDE the launches (22 ms at ndim = 1000
+    beside 2.6 ms launches: L = 9).  Same statistics, same factorization, no GPU idle time at the epoch (oracle:
+    ``OracleEngine(eig_lag=L)``).
     ``am_mode``: how the rank-0 chain's samples (updateChains' buffer, PTMCMCSampler.py:327-328) are kept between covariance
     epochs.  ``"rows"``: every step stores its row.  ``"rle"`` (pooled covariance): a rejected proposal leaves the chain where it
     was, so a step stores its row only when it was accepted (or is a KEY row: first step of a launch, ring rows 0 and 1, the
@@ -148,9 +151,9 @@ class PTEngine(object):
         if eig_mode not in ("lapack", "jacobi", "hipsolver"):
             raise ValueError("eig_mode must be 'lapack', 'jacobi' or 'hipsolver'")
         self.eig_mode = eig_mode
-        if eig_lag not in (0, 1):
-            raise ValueError("eig_lag must be 0 or 1")
-        self.eig_lag, self._eig_pending = int(eig_lag), False
+        if int(eig_lag) < 0:
+            raise ValueError("eig_lag must be >= 0 launches")
+        self.eig_lag, self._eig_pending, self._eig_wait = int(eig_lag), False, 0
         self.Wc = self.W if self.per_walker else 1
         # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
         self.groups = [np.arange(self.d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
@@ -338,6 +341,43 @@ class PTEngine(object):
         self._eig_pending = False
         self.eig_epochs += 1
 
+    def _eig_begin_side(self):
+        """eig_mode "hipsolver" with eig_lag > 0: the library's eigensolver on a SIDE stream, behind the statistics kernels and
+        beside the launches that follow (its thousands of small kernels fill what the step kernel leaves free); the result waits in
+        staging tensors until _eig_end_side."""
+        torch = _torch()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._side_go, self._side_done = torch.cuda.Event(), torch.cuda.Event()
+            self._ut_next, self._s_next = torch.empty_like(self.t["Ut"]), torch.empty_like(self.t["S"])
+        self._side_go.record(self.stream)
+        self._side.wait_event(self._side_go)
+        with torch.cuda.stream(self._side):
+            w, V = torch.linalg.eigh(self.t["cov"])
+            w, order = w.abs().sort(dim=-1, descending=True, stable=True)
+            self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
+            self._s_next[:, 0].copy_(w)
+            self._side_done.record(self._side)
+        self._eig_pending = True
+
+    def _eig_end_side(self):
+        torch = _torch()
+        self.stream.wait_event(self._side_done)
+        with torch.cuda.stream(self.stream):
+            self.t["Ut"].copy_(self._ut_next)
+            self.t["S"].copy_(self._s_next)
+        self._eig_pending = False
+        self.eig_epochs += 1
+
+    def _eig_finish(self):
+        """The pending factorization of the last covariance epoch takes effect (eig_lag launches after it, or at the next epoch)."""
+        if self._eig_pending:
+            if self.eig_mode == "hipsolver":
+                self._eig_end_side()
+            else:
+                self._eig_end()
+        self._eig_wait = 0
+
     def _eig_hipsolver(self):
         """U, S of every covariance the engine holds by the ROCm library's symmetric eigensolver, on the stream (factorize()'s
         pooled rule: eigenvalues by decreasing size and in absolute value, eigenvectors as the rows of Ut)."""
@@ -444,18 +484,24 @@ class PTEngine(object):
         """Covariance epoch after iteration ``it_done`` (:545-560): device Welford, host SVD."""
         if not self.owns_cold:
             return
+        self._eig_finish()                                            # a factorization still pending from the epoch before
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
         if self.eig_mode == "jacobi":
             _lib.check(self.lib.ptmi_eig_jacobi(self.h))              # stays on the stream: no host synchronisation
             self.eig_epochs += 1
             return
         if self.eig_mode == "hipsolver":
+            if self.eig_lag and not self.per_walker:
+                self._eig_begin_side()                                # run() puts it into force eig_lag launches later
+                self._eig_wait = self.eig_lag
+                return
             self._eig_hipsolver()
             self.eig_epochs += 1
             return
         if self.Wc == 1 and not self.per_walker and self.whole:
             if self.eig_lag:
-                self._eig_begin()                                     # run() finishes it behind the next launch
+                self._eig_begin()                                     # run() finishes it behind the eig_lag-th launch from here
+                self._eig_wait = self.eig_lag
             else:
                 self._eig_host_pooled()
             return
@@ -577,8 +623,10 @@ class PTEngine(object):
             self.mh_steps(it, end - it + 1)
             if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
                 self.swap(end)
-            if self._eig_pending:
-                self._eig_end()                                       # eig_lag = 1: the host factorized while that launch ran
+            if self._eig_pending:                                     # eig_lag launches after the epoch its table takes effect
+                self._eig_wait -= 1
+                if self._eig_wait <= 0:
+                    self._eig_finish()
             it = end + 1
         self.iter = last
 

@@ -138,7 +138,7 @@ class ShardedPTEngine(object):
         # statistics and factorization.  The same decision on every rank (from the configuration alone).
         self.eig_lag = int(kw.get("eig_lag", 0)) if (kw.get("cov_mode", "per_walker") == "pooled" and kw.get("eig_mode", "lapack") == "lapack"
                                                      and kw.get("groups") is None) else 0
-        self._bcast_pending = False
+        self._bcast_pending, self._bcast_wait = False, 0
         self._lnl_loc = torch.zeros((self.W, self.nt), dtype=torch.float64, device=self.device)
         self._map = torch.zeros((self.W, self.ntg), dtype=torch.int32, device=self.device)
         self._parts = torch.empty((self.world * self.W, self.nt), dtype=torch.float64, device=self.device)
@@ -235,12 +235,20 @@ class ShardedPTEngine(object):
     # ---- covariance / DE epochs (PTMCMCSampler.py:545-576) ----------------------------------
     def update_cov(self, it_done):
         L = self.local
+        if self._bcast_pending:
+            self._finish_table()                                          # still pending from the epoch before
         if self.owns_cold:
             L.update_cov(it_done)
         if self.eig_lag:
-            self._bcast_pending = True                                    # run() finishes the epoch behind the next launch
+            self._bcast_pending, self._bcast_wait = True, self.eig_lag    # run() finishes the epoch eig_lag launches later
             return
         self._bcast_table()
+
+    def _finish_table(self):
+        if self.owns_cold and getattr(self.local, "_eig_pending", False):
+            self.local._eig_finish() if hasattr(self.local, "_eig_finish") else self.local._eig_end()
+        self._bcast_table()
+        self._bcast_pending, self._bcast_wait = False, 0
 
     def _bcast_table(self):
         # the other blocks only ever read the factorization: the covariance itself stays where it is adapted
@@ -289,11 +297,10 @@ class ShardedPTEngine(object):
             self.mh_steps(it, end - it + 1)
             if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
                 self.swap(end)
-            if self._bcast_pending:                                       # eig_lag = 1: the owner factorized while that launch ran
-                if self.owns_cold and getattr(self.local, "_eig_pending", False):
-                    self.local._eig_end()
-                self._bcast_table()
-                self._bcast_pending = False
+            if self._bcast_pending:                                       # the owner factorized while those launches ran
+                self._bcast_wait -= 1
+                if self._bcast_wait <= 0:
+                    self._finish_table()
             it = end + 1
         self.iter = last
         self.local.iter = last

@@ -27,9 +27,10 @@ class OracleLocal(object):
         self.iter = 0
         self._eig_pending = False
 
-    def _eig_end(self):
-        for w in range(self.o.Wc):
-            self.o._svd(w)
+    def _eig_finish(self):
+        if self._eig_pending:
+            for w in range(self.o.Wc):
+                self.o._svd(w)
         self._eig_pending = False
 
     def get(self, name):

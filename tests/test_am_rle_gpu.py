@@ -165,3 +165,19 @@ def test_eig_lag_applies_the_table_one_launch_late(mods, am_mode, weights):
             assert not np.array_equal(g.get("X"), z.get("X"))            # ... but this launch still ran with the old one
     assert not np.array_equal(g.get("X"), z.get("X"))
     assert g.eig_epochs == z.eig_epochs
+
+
+@pytest.mark.parametrize("lag", [2, 3, 4, 7])
+def test_eig_lag_of_several_launches(mods, lag):
+    """eig_lag = L launches (four launches per covariance period here): the table of an epoch takes effect L launches later, at the
+    latest at the next epoch (L >= 4: its statistics are then taken before it is in force).  HIP == OracleEngine(eig_lag=L)."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu, tskip = 100, 8, 5, 40, 10
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=tskip, seed=21, cov_mode="pooled", cov0=np.eye(d) * 0.01)
+    g, o = _pair(mods, d, nt, W, eig_lag=lag, **kw)
+    for n in (cu + tskip, 7, 3 * cu - 7, 2 * cu):
+        g.run(n)
+        o.run(n)
+        _compare(g, o, "lag %d it=%d " % (lag, g.iter))
+        assert_same(g.get("Ut"), o.Ut, "Ut it=%d" % g.iter)
+    assert g.eig_epochs >= 5
