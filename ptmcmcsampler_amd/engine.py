@@ -352,16 +352,26 @@ class PTEngine(object):
             self._ut_next, self._s_next = torch.empty_like(self.t["Ut"]), torch.empty_like(self.t["S"])
         self._side_go.record(self.stream)
         self._side.wait_event(self._side_go)
-        with torch.cuda.stream(self._side):
-            w, V = torch.linalg.eigh(self.t["cov"])
-            w, order = w.abs().sort(dim=-1, descending=True, stable=True)
-            self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
-            self._s_next[:, 0].copy_(w)
-            self._side_done.record(self._side)
+
+        def work():
+            # on a thread of its own: the library's driver waits on the host for its status word, which would keep this
+            # thread from queueing the launches the factorization is meant to run beside
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(self._side):
+                w, V = torch.linalg.eigh(self.t["cov"])
+                w, order = w.abs().sort(dim=-1, descending=True, stable=True)
+                self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
+                self._s_next[:, 0].copy_(w)
+                self._side_done.record(self._side)
+
+        import threading
+        self._side_thread = threading.Thread(target=work, daemon=True)
+        self._side_thread.start()
         self._eig_pending = True
 
     def _eig_end_side(self):
         torch = _torch()
+        self._side_thread.join()
         self.stream.wait_event(self._side_done)
         with torch.cuda.stream(self.stream):
             self.t["Ut"].copy_(self._ut_next)
