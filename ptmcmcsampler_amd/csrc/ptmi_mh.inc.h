@@ -1214,7 +1214,9 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
     constexpr int G = 4, CPB = 64;
     constexpr bool STR = true;
     constexpr int LD = mfma_ld(EPL), AMQ_LD = 4 * EPL + 2;
-    static_assert(LOGL != PTMI_LOGL_DENSE, "the dense likelihood's table does not leave room for the ring");
+    // dense likelihood: its half table takes the eigenvector table's place in LDS (both do not fit beside the ring); the
+    // eigenvectors are then read from global memory (L2) by the producers' matrix passes and the steppers' SCAM steps
+    constexpr bool DENSE = LOGL == PTMI_LOGL_DENSE;
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
     const int lane = (int)(threadIdx.x & 63), wave8 = (int)(threadIdx.x >> 6);
@@ -1223,7 +1225,7 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
     const int c16 = lane & 15, gl = lane >> 4;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tab_n = 4 * ((d + 3) / 4) * LD;
-#define PTMI_PC_UL (smem)
+#define PTMI_PC_UL (smem)                         // the eigenvector table (iso / curved) or the dense likelihood's half table
 #define PTMI_PC_SQ (smem + (size_t)tab_n)
 #define PTMI_PC_RING(slot) (smem + a.amq_off + ((size_t)pair * 16 + (size_t)(slot)) * AMQ_LD)
 #define PTMI_PC_CD (smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)pair * 128)
@@ -1237,11 +1239,12 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
     }
     {
         const double *UtBlk = a.Ut + w0 * d * d, *Sb = a.S + w0 * d;
+        const double *src = DENSE ? a.logl_par + d + (size_t)d * d /* the half table Tl */ : UtBlk;
         draw_table_fill(smem, a.tab_off, 512);
         for (int i = (int)threadIdx.x; i < d; i += 512) PTMI_PC_SQ[i] = det_sqrt(Sb[i]);
         for (int i = (int)threadIdx.x; i < tab_n; i += 512) {
             const int r = i / LD, c = i % LD;
-            PTMI_PC_UL[i] = (r < d && c < d) ? UtBlk[(size_t)r * d + c] : 0.0;
+            PTMI_PC_UL[i] = (r < d && c < d) ? src[(size_t)r * d + c] : 0.0;
         }
         box_table_fill<G, EPL>(a, smem, 512);
         if (threadIdx.x < 8) ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + 4 * 128)[threadIdx.x] = 0;
@@ -1254,6 +1257,7 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
     const long long nunits = (nch + 15) / 16;
     const long long ustride = PERS ? (long long)gridDim.x * 4 : nunits;
     int *const flg = PTMI_PC_FLG;
+    const double *const UtG = a.Ut + w0 * d * d;             // DENSE: the block's eigenvector table in global memory
     if (producer) {
         if (PTMI_PC_PRIO) __builtin_amdgcn_s_setprio(PTMI_PC_PRIO);
         const int w_de = a.de_on ? a.w_de : 0;
@@ -1312,7 +1316,8 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
                 const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
                 const long long it_ev = a.iter0 + (entry >> 4);
                 MfmaAcc<EPL> acc;
-                am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_PC_UL, true, LD, PTMI_PC_SQ, true, acc, smem);
+                if constexpr (DENSE) am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, UtG, false, d, PTMI_PC_SQ, true, acc, smem);
+                else am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_PC_UL, true, LD, PTMI_PC_SQ, true, acc, smem);
                 // the slots of ranks q_done .. hi - 1 held ranks 16 below: wait until the stepper has read those
                 while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&flg[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < hi - 16)
                     __builtin_amdgcn_s_sleep(PTMI_PC_SLEEP);
@@ -1356,7 +1361,9 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
         Draws dr;
         draws_for_step<STR, true, 1>(batch, dr, a, k, sid, sid0, gl, smem);
         const double log_u = dr.log_u;
-        const int jt = propose<G, EPL, true, STR, false>(a, it, sid, gl, cc, dr, PTMI_PC_UL, true, PTMI_PC_SQ, DE, dq, true, false, smem);
+        int jt;
+        if constexpr (DENSE) jt = propose<G, EPL, true, STR, false>(a, it, sid, gl, cc, dr, UtG, false, PTMI_PC_SQ, DE, dq, true, false, smem);
+        else jt = propose<G, EPL, true, STR, false>(a, it, sid, gl, cc, dr, PTMI_PC_UL, true, PTMI_PC_SQ, DE, dq, true, false, smem);
         {
             const bool is_am = live && jt == PTMI_J_AM;
             const u32 m16 = (u32)(__ballot(is_am) & 0xFFFFull);           // the chains' first lanes
@@ -1395,7 +1402,7 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
             for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
             if constexpr (PRI == PTMI_LOGP_FLAT) nlp = 0.0;
             else nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
-            nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, nullptr);
+            nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, DENSE ? PTMI_PC_UL : nullptr);
             nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
         }
         // PT:615-622
@@ -1849,10 +1856,12 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             }
             // AM in the cycle: the producer / consumer form (mh_pc_kernel) when its lists fit beside the ring;
             // PTMI_NO_PC=1 keeps the one-wave kernel (a measurement / test switch, same results)
-            if constexpr (FULL && LOGL != PTMI_LOGL_DENSE) {
+            if constexpr (FULL) {
                 const bool no_pc = getenv("PTMI_NO_PC") != nullptr;                      // read per launch: the tests switch it
                 const size_t lists = sizeof(double) * 4 * 128 + sizeof(int) * 8;         // cd of the listed events, the pairs' two counters
-                if (c.w_am > 0 && a.lds_u && a.tab_off >= 0 && !no_pc && lds + lists <= 160 * 1024 &&
+                // iso / curved: the eigenvector table in LDS; dense: the likelihood's table there, the eigenvectors read from global memory
+                const bool tables_ok = LOGL == PTMI_LOGL_DENSE ? !a.lds_u : a.lds_u != 0;
+                if (c.w_am > 0 && tables_ok && a.tab_off >= 0 && !no_pc && lds + lists <= 160 * 1024 &&
                     (c.logp_kind == PTMI_LOGP_FLAT || (c.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0))) {
                     // the lists sit directly behind the ring: everything placed behind the queue moves up by their size
                     const int shift = (int)(lists / sizeof(double));
@@ -1871,7 +1880,7 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                             if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", ldp, hipGetErrorString(e));
                         }
                         hipLaunchKernelGGL(kp, dim3(gridp), dim3(512), ldp, h->stream, a);
-                        h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_FULL | PTMI_VAR_LDS_UT | PTMI_VAR_PC |
+                        h->last_variant = PTMI_VAR_STAGED | PTMI_VAR_FULL | (a.lds_u ? PTMI_VAR_LDS_UT : 0) | PTMI_VAR_PC |
                                           (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | PTMI_VAR_LDS_DRAWT | (pers ? PTMI_VAR_PERSISTENT : 0);
                         return PTMI_OK;
                     };
