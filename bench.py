@@ -393,6 +393,20 @@ def main():
                                                + ", ".join(tr["source"]))
             out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_update * upd_per_launch
             break
+    # What the launch MUST move, counted live from this run's own state (not a counter): every chain's row, lnL and lp in and out,
+    # and the rank-0 rows and flag words it stored (am_mode rle: only the accepted steps' rows -- the stored share is read off the
+    # AM flags of the ring as it stands after the run).  The PMC figure above is a committed profile of the same workload; a
+    # kernel change that adds traffic moves one of the two, and their ratio says so.
+    if not a.callback and a.mix != "nuts" and getattr(eng, "owns_cold", False) and hasattr(eng, "t"):
+        stored = 1.0
+        if getattr(eng, "am_rle", False):
+            fl = eng.t["AMflag"]
+            stored = float(((fl & 3) != 0).double().mean().item())
+        per_launch_model = 2.0 * nt * W * (8 * d + 16) + W * avg_steps * (stored * 8 * d + (8 if getattr(eng, "am_rle", False) else 0))
+        out["roofline"]["traffic_model_bytes"] = per_launch_model
+        out["roofline"]["am_rows_stored_share"] = stored
+        if out["roofline"].get("traffic"):
+            out["roofline"]["traffic_over_model"] = out["roofline"]["traffic"] / per_launch_model
     # cycles with AM entries pay 2 d^2 flop per AM proposal on the matrix cores ("+2d^2 per AM proposal"), whatever the
     # likelihood: the share of AM picks is w_am / sum(w) over the entries that are in the cycle during the timed region (DE joins
     # it after `burn` iterations)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes for the bench kernels; run on the GPU box through gpurun from the repo root:
-#   gpurun --timeout 1800 -- 'bash tools/gpu_profile.sh r03'
+#   gpurun --timeout 1800 -- 'bash tools/gpu_profile.sh r04'
 # Writes text summaries under gpurun_out/prof_<tag>/ ; copy them to profiles/<tag>_*.txt (tracked).
 # One bench "step" = 100 MH iterations + the PT swap (bench.py).  Counter passes never combine with --stats or trace domains.
 set -u
@@ -33,8 +33,9 @@ run dense_sq --pmc $MF -- --logl dense --steps 20 --warmup 5
 run densemix_stats --stats -- --logl dense --mix default --pick walker --steps 20 --warmup 105
 # default SCAM/AM/DE mix with DE active (burn = 10000 iterations = 100 steps): per chain pick and per walker pick
 run mix_stats --stats -- --mix default --steps 20 --warmup 105
+run mix_sq --pmc $MF -- --mix default --steps 10 --warmup 105
+run mix_sq2 --pmc $SQ -- --mix default --steps 10 --warmup 105
 run mixw_stats --stats -- --mix default --pick walker --steps 20 --warmup 105
-run mixw_sq --pmc $MF -- --mix default --pick walker --steps 10 --warmup 105
 # per-walker covariance: device Jacobi eigensolver
 run pwd_stats --stats -- --cov-mode per_walker_device --steps 20 --warmup 5
 # config 5 shape on one GPU (curved likelihood, SCAM / DE / NUTS) and config 4's share of one GPU (1000-d, 64 x 512 chains)

@@ -23,7 +23,7 @@ _, write_kb = counter(pw, "WRITE_SIZE")
 out = {
     "round": int(tag[1:]),
     "kernel": kern,
-    "workload": "ndim=100 ntemps=64 nwalkers=4096 mix=scam logl=iso",
+    "workload": "ndim=100 ntemps=64 nwalkers=4096 mix=scam logl=iso (am_mode rle: the rank-0 rows of accepted steps only)",
     "steps_per_launch": 100,
     "pick": "chain",
     "FETCH_SIZE_KB_per_dispatch": fetch_kb,
