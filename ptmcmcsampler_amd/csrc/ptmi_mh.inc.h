@@ -110,6 +110,38 @@ __device__ __forceinline__ void mfma_tab_vec(const double *T, int ld, int d, con
         }
     }
 }
+// The same product for the padded half table (PADDED, LOWER) with the vector operand FORMED where it is used (vec(e): e.g. the
+// residual (x + dq) - mu of a proposal): a caller that holds x and dq does not keep a third row-sized array alive across the product.
+template <int EPL, class VF>
+__device__ __forceinline__ void mfma_half_tab_vecf(const double *T, int ld, int d, VF vec, MfmaAcc<EPL> &acc)
+{
+    constexpr int NT = MfmaAcc<EPL>::NT;
+    const int c = (int)(threadIdx.x & 15), g = (int)((threadIdx.x & 63) >> 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc.t[t] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
+    double cur[NT], nxt[NT];
+    auto fetch = [&](int e, double (&dst)[NT]) {
+        const double *row = T + (size_t)(4 * e + g) * ld + c;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (16 * t <= 4 * e + 3) dst[t] = row[16 * t];
+    };
+    fetch(0, cur);
+    constexpr bool EXACT = safe_slots(4, EPL) == EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        if (EXACT || 4 * e < d) {                          // wave-uniform
+            if (e + 1 < EPL && (EXACT || 4 * (e + 1) < d)) fetch(e + 1, nxt);
+            const double ve = vec(e);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (16 * t <= 4 * e + 3) acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t], ve, acc.t[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 constexpr int mfma_ld(int EPL) { return 16 * ((4 * EPL + 15) / 16); }
 
 // ----------------------------------------------------------- log-likelihoods
@@ -491,13 +523,21 @@ __device__ __forceinline__ void scam_draws_for_step(ScamBatch<STR> &b, ScamDraw 
 // of an asm statement: the chain through C needs no wait state, the first vector read of the result does (mfma_acc_settle).
 // GUARD: an operand may have been written by the vector pipe just before (the weight ahead of the first product of a
 // k-step; a table value selected against its bounds): two wait states inside the statement.
-template <bool GUARD>
+// ACCV: the accumulators in ordinary vector registers ("+v": gfx950 takes either file as C / D).  mh_pc_kernel asks for it: a
+// kernel that pins accumulation registers is given HALF its budget as such (128 + 128 at two waves per SIMD), and its stepper
+// waves, which hold three rows and use no accumulator, then shuttle their state through the other half.
+template <bool GUARD, bool ACCV = false>
 __device__ __forceinline__ void mfma_f64_acc(ptmi_d4 &acc, double ta, double w)
 {
-    if (GUARD) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(ta), "v"(w));
-    else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(ta), "v"(w));
+    if constexpr (ACCV) {
+        if (GUARD) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(ta), "v"(w));
+        else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(ta), "v"(w));
+    } else {
+        if (GUARD) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(ta), "v"(w));
+        else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(ta), "v"(w));
+    }
 }
-template <int NT>
+template <int NT, bool ACCV = false>
 __device__ __forceinline__ void mfma_acc_begin(ptmi_d4 (&t)[NT])
 {
 #pragma unroll
@@ -505,15 +545,21 @@ __device__ __forceinline__ void mfma_acc_begin(ptmi_d4 (&t)[NT])
     // the "+a" pins are where the zeros are materialised (v_accvgpr_write); the wait states between such a write and a
     // matrix instruction that reads the register as C go BEHIND them (volatile statements keep their order)
 #pragma unroll
-    for (int i = 0; i < NT; ++i) asm volatile("" : "+a"(t[i]));
+    for (int i = 0; i < NT; ++i) {
+        if constexpr (ACCV) asm volatile("" : "+v"(t[i]));
+        else asm volatile("" : "+a"(t[i]));
+    }
     asm volatile("s_nop 7");
 }
-template <int NT>
+template <int NT, bool ACCV = false>
 __device__ __forceinline__ void mfma_acc_settle(ptmi_d4 (&t)[NT])
 {
     asm volatile("s_nop 15\n\ts_nop 15");              // 16-pass matrix instruction -> vector read of its result (18 states needed)
 #pragma unroll
-    for (int i = 0; i < NT; ++i) asm volatile("" : "+a"(t[i]));   // every read of the result is behind the wait
+    for (int i = 0; i < NT; ++i) {                      // every read of the result is behind the wait
+        if constexpr (ACCV) asm volatile("" : "+v"(t[i]));
+        else asm volatile("" : "+a"(t[i]));
+    }
 }
 
 // The AM increment U (cd sqrt(S) z) (PT:879-933) of the 16 chains in the columns of the wave, on the matrix cores (strided
@@ -524,7 +570,7 @@ __device__ __forceinline__ void mfma_acc_settle(ptmi_d4 (&t)[NT])
 // instructions and only fewer instructions help: table-driven draws (ptmi_device.h unit_log / unit_sincos) and no
 // accumulator traffic.  The accumulation order (k ascending) is that of mfma_tab_vec.
 // active / sid / it / cd are the column's: the chain's own (propose) or those of a queued AM event (mh_steps_kernel).
-template <int EPL>
+template <int EPL, bool ACCV = false>
 __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32 sid, long long it, double cd, int ng,
                                                 const double *Ut, bool ut_padded, int uld, const double *S, bool s_sqrt, MfmaAcc<EPL> &acc,
                                                 const double *tsm = nullptr)
@@ -563,12 +609,12 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
     // the NT products of one k-step; the LDS copy's values come straight from the read, the global table's through a select
     auto kstep = [&](const double (&tt)[NT], double w) {
         if (ut_padded) {
-            mfma_f64_acc<true>(acc.t[0], tt[0], w);
+            mfma_f64_acc<true, ACCV>(acc.t[0], tt[0], w);
 #pragma unroll
-            for (int t = 1; t < NT; ++t) mfma_f64_acc<false>(acc.t[t], tt[t], w);
+            for (int t = 1; t < NT; ++t) mfma_f64_acc<false, ACCV>(acc.t[t], tt[t], w);
         } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mfma_f64_acc<true>(acc.t[t], tt[t], w);
+            for (int t = 0; t < NT; ++t) mfma_f64_acc<true, ACCV>(acc.t[t], tt[t], w);
         }
     };
     // -DPTMI_AM_PROFILE: shader-clock counts of the pieces, printed by the first wave (13 pairs at d = 100; measured:
@@ -580,7 +626,7 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
 #else
 #define PTMI_STAMP(i)
 #endif
-    mfma_acc_begin<NT>(acc.t);
+    mfma_acc_begin<NT, ACCV>(acc.t);
 #pragma unroll 1
     for (int e = 0; e < esteps; e += 2) {
         double ta[NT], tb[NT], wa, wb;
@@ -601,12 +647,12 @@ __device__ __forceinline__ void am_mfma_product(const KArgs &a, bool active, u32
         PTMI_STAMP(3)
     }
 #ifdef PTMI_AM_PROFILE
-    mfma_acc_settle<NT>(acc.t);
+    mfma_acc_settle<NT, ACCV>(acc.t);
     PTMI_STAMP(4)
     if (blockIdx.x == 0 && threadIdx.x == 0 && it % 64 == 0)
         printf("am profile it %lld: philox+rows %llu  f64 %llu  mfmaA %llu  mfmaB %llu  settle %llu cycles (13 pairs)\n", it, tp[0], tp[1], tp[2], tp[3], tp[4]);
 #endif
-    mfma_acc_settle<NT>(acc.t);
+    mfma_acc_settle<NT, ACCV>(acc.t);
 }
 
 // One proposal for the caller's chain (PT:1048-1067, 820-985) from the iteration's draws: writes the increment dq
@@ -1205,6 +1251,9 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
 #ifndef PTMI_PC_SPRIO
 #define PTMI_PC_SPRIO 1      // ... and of the steppers (1 or 3: 0.8 % better than 0)
 #endif
+#ifndef PTMI_PC_ACCV
+#define PTMI_PC_ACCV 1       // the producers' accumulators in ordinary vector registers (mfma_f64_acc)
+#endif
 #ifndef PTMI_PC_SLEEP
 #define PTMI_PC_SLEEP 2
 #endif
@@ -1231,6 +1280,7 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
 #define PTMI_PC_CD (smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)pair * 128)
 #define PTMI_PC_IDX ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + pair * 128)
 #define PTMI_PC_FLG ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + 4 * 128 + pair * 2)
+#define PTMI_PC_MU (smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128 + 260)      // DENSE: the mean, 4 EPL doubles behind the counters
     // ---- the block's tables
     size_t w0 = 0;
     if (!PERS && a.per_walker) {
@@ -1248,6 +1298,8 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
         }
         box_table_fill<G, EPL>(a, smem, 512);
         if (threadIdx.x < 8) ((int *)(smem + a.amq_off + (size_t)4 * 16 * AMQ_LD + (size_t)4 * 128) + 4 * 128)[threadIdx.x] = 0;
+        if constexpr (DENSE)
+            for (int i = (int)threadIdx.x; i < 4 * EPL; i += 512) PTMI_PC_MU[i] = i < d ? a.logl_par[i] : 0.0;
         __syncthreads();
     }
     // ---- units of 16 chains.  A block serves four units at a time (one per pair); with ONE table for the launch (pooled
@@ -1316,8 +1368,8 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
                 const u32 sid_ev = (u32)__shfl((int)sid, owner, 64);
                 const long long it_ev = a.iter0 + (entry >> 4);
                 MfmaAcc<EPL> acc;
-                if constexpr (DENSE) am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, UtG, false, d, PTMI_PC_SQ, true, acc, smem);
-                else am_mfma_product<EPL>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_PC_UL, true, LD, PTMI_PC_SQ, true, acc, smem);
+                if constexpr (DENSE) am_mfma_product<EPL, PTMI_PC_ACCV != 0>(a, valid, sid_ev, it_ev, cd_ev, d, UtG, false, d, PTMI_PC_SQ, true, acc, smem);
+                else am_mfma_product<EPL, PTMI_PC_ACCV != 0>(a, valid, sid_ev, it_ev, cd_ev, d, PTMI_PC_UL, true, LD, PTMI_PC_SQ, true, acc, smem);
                 // the slots of ranks q_done .. hi - 1 held ranks 16 below: wait until the stepper has read those
                 while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&flg[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < hi - 16)
                     __builtin_amdgcn_s_sleep(PTMI_PC_SLEEP);
@@ -1396,13 +1448,30 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
         for (int j = 0; j < PTMI_J_FUSED; ++j) jp[j] += (jt == j);
         // PT:605-612
         double nlp, nlnL = 0.0, nlnprob;
-        {
+        if constexpr (DENSE) {
+            // -1/2 r^T P r over the half table (eval_logl), the residual r = (x + dq) - mu formed where it is used: nothing of row
+            // size lives beside x, dq and the accumulators
+            if constexpr (PRI == PTMI_LOGP_FLAT) nlp = 0.0;
+            else nlp = eval_logp_q<G, EPL, STR>(a, smem, gl, [&](int e) { return x[e] + dq[e]; });
+            auto rf = [&](int e) {
+                const int i = gl + G * e;
+                const double qe = x[e] + dq[e];
+                return i < d ? qe - PTMI_PC_MU[i] : 0.0;
+            };
+            MfmaAcc<EPL> pacc;
+            mfma_half_tab_vecf<EPL>(PTMI_PC_UL, LD, d, rf, pacc);
+            double pq = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) pq = __builtin_fma(rf(e), pacc.at(e), pq);
+            nlnL = -grp_sum<G, STR>(pq);
+            nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
+        } else {
             double q[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
             if constexpr (PRI == PTMI_LOGP_FLAT) nlp = 0.0;
             else nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
-            nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, DENSE ? PTMI_PC_UL : nullptr);
+            nlnL = eval_logl<G, EPL, LOGL, STR>(a, q, gl, nullptr);
             nlnprob = nlp == -__builtin_inf() ? -__builtin_inf() : beta * nlnL + nlp;
         }
         // PT:615-622
@@ -1858,7 +1927,8 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             // PTMI_NO_PC=1 keeps the one-wave kernel (a measurement / test switch, same results)
             if constexpr (FULL) {
                 const bool no_pc = getenv("PTMI_NO_PC") != nullptr;                      // read per launch: the tests switch it
-                const size_t lists = sizeof(double) * 4 * 128 + sizeof(int) * 8;         // cd of the listed events, the pairs' two counters
+                // cd of the listed events, the pairs' two counters; dense: the likelihood's mean behind them
+                const size_t lists = sizeof(double) * 4 * 128 + sizeof(int) * 8 + (LOGL == PTMI_LOGL_DENSE ? sizeof(double) * 4 * EPL : 0);
                 // iso / curved: the eigenvector table in LDS; dense: the likelihood's table there, the eigenvectors read from global memory
                 const bool tables_ok = LOGL == PTMI_LOGL_DENSE ? !a.lds_u : a.lds_u != 0;
                 if (c.w_am > 0 && tables_ok && a.tab_off >= 0 && !no_pc && lds + lists <= 160 * 1024 &&
