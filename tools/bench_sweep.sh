@@ -1,6 +1,6 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes, one JSON line per workload, into gpurun_out/sweep_<tag>/ (copy the merged file to
-# profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r03'
+# profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r04'
 TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sweep_$TAG
@@ -13,6 +13,8 @@ b mix_chain --no-cpu-baseline --mix default --steps 100 --warmup 110
 b mix_walker --no-cpu-baseline --mix default --pick walker --steps 100 --warmup 110
 b dense --no-cpu-baseline --logl dense --steps 50 --warmup 20 --ess-window 0   # config 3, SCAM cycle
 b dense_mix_walker --no-cpu-baseline --logl dense --mix default --pick walker --steps 30 --warmup 110 --ess-window 0
+b dense_mix_chain --no-cpu-baseline --logl dense --mix default --steps 30 --warmup 110 --ess-window 0
+b scam_rows_nolag --no-cpu-baseline --am-mode rows --eig-lag 0 --ess-window 0        # config 2 as round 3 ran it: every row stored, table applied at once
 b per_walker_lapack --no-cpu-baseline --cov-mode per_walker --steps 20 --warmup 10 --ess-window 0
 b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10 --ess-window 0
 b callback --no-cpu-baseline --callback --steps 10 --warmup 2 --ess-window 0
