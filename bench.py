@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
     ap.add_argument("--prior", default="flat", choices=["flat", "box"],
                     help="flat: the headline workload; box: uniform on [-10, 10]^d, the usual lnpriorfn of a reference run")
-    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "pooled_hipsolver", "per_walker", "per_walker_device"],
+    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "pooled_hipsolver", "per_walker", "per_walker_device", "per_walker_jacobi"],
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
-                         "_device: the covariance epochs are factorized by the device Jacobi eigensolver instead of host LAPACK; "
+                         "_device: the covariance epochs are factorized on the device (tridiagonal QL kernel) instead of host LAPACK, "
+                         "_jacobi: by the device Jacobi kernel; "
                          "_hipsolver: by the ROCm library's eigensolver on the stream (large ndim)")
     ap.add_argument("--eig-lag", type=int, default=-1,
                     help="pooled covariance: the eigenvectors of a covariance epoch take effect this many launches late, the factorization "
@@ -198,7 +199,8 @@ def main():
         logl = ("dense", np.zeros(d), np.linalg.inv(A @ A.T / d + np.eye(d)))
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
               pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled", am_mode=a.am_mode,
-              eig_mode="jacobi" if a.cov_mode.endswith("_device") else ("hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack"))
+              eig_mode="ql" if a.cov_mode.endswith("_device") else ("jacobi" if a.cov_mode.endswith("_jacobi") else (
+                  "hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack")))
     eig_lag = 0
     if kw["cov_mode"] == "pooled" and kw["eig_mode"] in ("lapack", "hipsolver"):
         eig_lag = a.eig_lag if a.eig_lag >= 0 else (1 if kw["eig_mode"] == "lapack" else 9)

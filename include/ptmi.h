@@ -276,6 +276,11 @@ int ptmi_am_expand(ptmi_handle h, int32_t w0, int32_t nw, int64_t iter_lo, int64
  * largest component positive.  Same subspaces as LAPACK, but not its column signs: a run adapted this way is not a
  * bit-replica of one adapted through the host.  Asynchronous on the handle's stream. */
 int ptmi_eig_jacobi(ptmi_handle h);
+/* The same by Householder tridiagonalization + implicit QL iterations (oracle: orc_eig_ql; ndim <= 128): one block of two waves per
+ * matrix, two per CU at ndim = 100.  The choice for thousands of per-walker covariances: a 100 x 100 matrix takes a quarter of the
+ * Jacobi kernel's time on the nearly degenerate spectra an isotropic target adapts to.  Eigenvalues in absolute value, descending;
+ * sign rule as ptmi_eig_jacobi.  Asynchronous on the handle's stream. */
+int ptmi_eig_ql(ptmi_handle h);
 
 /* _updateDEbuffer (:806-817): drop the oldest cov_update rows of each DE history and
  * append the AM buffer (pooled mode: row r comes from walker r mod W). */

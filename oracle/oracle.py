@@ -107,6 +107,7 @@ def lib():
         L.orc_logl.restype = C.c_double
         L.orc_logl.argtypes = [C.POINTER(Cfg), _dp]
         L.orc_eig_jacobi.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int]
+        L.orc_eig_ql.argtypes = [C.c_int, _dp, _dp, _dp]
         assert L.orc_sizeof_cfg() == C.sizeof(Cfg)
         _lib = L
     return _lib
@@ -163,6 +164,16 @@ def eig_jacobi(cov, max_sweeps=JACOBI_MAX_SWEEPS):
     d = len(cov)
     Ut, S = np.zeros((d, d)), np.zeros(d)
     n = lib().orc_eig_jacobi(d, _p(cov), _p(Ut), _p(S), max_sweeps)
+    return Ut, S, n
+
+
+def eig_ql(cov):
+    """(Ut, S, iterations) by the engine's tridiagonal QL definition (orc_eig_ql): eigenvectors as ROWS of Ut, |eigenvalues| descending."""
+    cov = np.ascontiguousarray(cov, dtype=np.float64)
+    d = len(cov)
+    Ut, S = np.zeros((d, d)), np.zeros(d)
+    n = lib().orc_eig_ql(d, _p(cov), _p(Ut), _p(S))
+    assert n >= 0, "QL did not converge"
     return Ut, S, n
 
 
@@ -308,7 +319,7 @@ class OracleEngine(object):
         # the engine's eig_lag: the factorization of a covariance epoch takes effect eig_lag segments late (pooled covariance, host LAPACK)
         self.eig_lag = int(eig_lag) if (cov_mode == "pooled" and eig_mode == "lapack" and groups is None) else 0
         self._eig_pending, self._eig_wait = False, 0
-        assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi")
+        assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi", "ql")
         assert am_mode in ("auto", "rows", "rle")
         # the engine's am_mode: "rle" (pooled covariance on the block that holds rank 0) weights the pooled statistics by run lengths
         self.am_rle = am_mode != "rows" and cov_mode == "pooled" and temp0 == 0
@@ -395,8 +406,8 @@ class OracleEngine(object):
         except ImportError:
             import contextlib
             threadpool_limits = lambda limits: contextlib.nullcontext()   # noqa: E731
-        if self.eig_mode == "jacobi" and getattr(self, "_initial_done", False):
-            Ut, S, _ = eig_jacobi(self.cov[w])           # the engine's device eigensolver (covariance epochs only)
+        if self.eig_mode in ("jacobi", "ql") and getattr(self, "_initial_done", False):
+            Ut, S, _ = eig_jacobi(self.cov[w]) if self.eig_mode == "jacobi" else eig_ql(self.cov[w])   # the engine's device eigensolvers (covariance epochs only)
             self.Ut[w, 0], self.S[w, 0] = Ut, S
             return
         for gi, g in enumerate(self.groups):               # per group, PTMCMCSampler.py:139-145, 797-803

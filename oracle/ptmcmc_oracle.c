@@ -1258,4 +1258,134 @@ ORC_API int orc_eig_jacobi(int d, const double *cov, double *Ut, double *S, int 
     return sweep;
 }
 
+/* ---------------------------------------------- tridiagonal QL eigensolver */
+/* The engine's eig_mode "ql" (ptmi_eig_ql, csrc/ptmi_abi.hip eig_ql_kernel): the eigendecomposition of a symmetric matrix by
+ * Householder tridiagonalization with the transformations accumulated, then implicit QL iterations with shifts on the tridiagonal
+ * matrix (the classical tred2 / tql2 pair of the EISPACK literature, restated without the row scaling: covariances are of moderate
+ * size) -- a few passes of O(n) dependent scalar work per eigenvalue, where the Jacobi sweeps of eig_mode "jacobi" take nine sweeps
+ * of n^2 / 2 rotations on the nearly degenerate spectra an isotropic target adapts to.  Every sum is a k-ascending chain of one
+ * product and one sum (no fma), every quotient a correctly rounded division, the only other function sqrt: the kernel does the same
+ * operations in the same order, so both give the same bits.  Output as orc_eig_jacobi: eigenvalues in absolute value, descending
+ * (ties by ascending column), eigenvectors as ROWS of Ut, each with its largest-magnitude component (first of equals) made
+ * positive.  Returns the number of QL iterations (negative: an eigenvalue did not converge within ORC_QL_MAXIT). */
+#define ORC_QL_MAXIT 60
+ORC_API int orc_eig_ql(int n, const double *cov, double *Ut, double *S)
+{
+    double *z = (double *)malloc(sizeof(double) * ((size_t)n * n + 2 * (size_t)n)), *d = z + (size_t)n * n, *e = d + n;
+    memcpy(z, cov, sizeof(double) * (size_t)n * n);
+#define Z(i, j) z[(size_t)(i) * n + (j)]
+    /* Householder reduction of the lower triangle, rows n-1 .. 1; row i of z keeps the vector u, column i keeps u / h */
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0;
+        if (l > 0)
+            for (int k = 0; k <= l; ++k) h = h + Z(i, k) * Z(i, k);
+        if (l == 0 || h == 0.0) {
+            e[i] = Z(i, l);
+            d[i] = 0.0;
+            continue;
+        }
+        const double f0 = Z(i, l);
+        const double g0 = f0 >= 0.0 ? -sqrt(h) : sqrt(h);
+        e[i] = g0;
+        h = h - f0 * g0;
+        Z(i, l) = f0 - g0;
+        for (int j = 0; j <= l; ++j) {
+            Z(j, i) = Z(i, j) / h;
+            double g = 0.0;
+            for (int k = 0; k <= j; ++k) g = g + Z(j, k) * Z(i, k);
+            for (int k = j + 1; k <= l; ++k) g = g + Z(k, j) * Z(i, k);
+            e[j] = g / h;
+        }
+        double f = 0.0;
+        for (int j = 0; j <= l; ++j) f = f + e[j] * Z(i, j);
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) e[j] = e[j] - hh * Z(i, j);
+        for (int j = 0; j <= l; ++j)
+            for (int k = 0; k <= j; ++k) Z(j, k) = Z(j, k) - (Z(i, j) * e[k] + e[j] * Z(i, k));
+        d[i] = h;
+    }
+    d[0] = 0.0;
+    e[0] = 0.0;
+    /* accumulation of the transformations (column j of the leading block only needs its own product g) */
+    for (int i = 0; i < n; ++i) {
+        const int l = i - 1;
+        if (d[i] != 0.0) {
+            for (int j = 0; j <= l; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= l; ++k) g = g + Z(i, k) * Z(k, j);
+                for (int k = 0; k <= l; ++k) Z(k, j) = Z(k, j) - g * Z(k, i);
+            }
+        }
+        d[i] = Z(i, i);
+        Z(i, i) = 1.0;
+        for (int j = 0; j <= l; ++j) { Z(j, i) = 0.0; Z(i, j) = 0.0; }
+    }
+    /* implicit QL on (d, e); the rotations go into the columns of z */
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    int iters = 0, failed = 0;
+    for (int l = 0; l < n; ++l) {
+        const double t0 = fabs(d[l]) + fabs(e[l]);
+        if (tst1 < t0) tst1 = t0;
+        int m = l;
+        while (m < n - 1 && tst1 + fabs(e[m]) != tst1) ++m;       /* e[n-1] = 0 ends the search at the latest */
+        if (m > l) {
+            int it = 0;
+            do {
+                if (++it > ORC_QL_MAXIT) { failed = 1; break; }
+                ++iters;
+                const double g = d[l];
+                const double p0 = (d[l + 1] - g) / (2.0 * e[l]);
+                const double r0 = sqrt(p0 * p0 + 1.0);
+                const double pr = p0 + (p0 >= 0.0 ? r0 : -r0);
+                d[l] = e[l] / pr;
+                d[l + 1] = e[l] * pr;
+                const double dl1 = d[l + 1];
+                const double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] = d[i] - h;
+                f = f + h;
+                double p = d[m], c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    const double gg = c * e[i], hh = c * p;
+                    const double r = sqrt(p * p + e[i] * e[i]);
+                    const double ri = 1.0 / r;                       /* ONE division on the rotations' dependent chain */
+                    e[i + 1] = s * r;
+                    s = e[i] * ri;
+                    c = p * ri;
+                    p = c * d[i] - s * gg;
+                    d[i + 1] = hh + s * (c * gg + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        const double zk = Z(k, i + 1);
+                        Z(k, i + 1) = s * Z(k, i) + c * zk;
+                        Z(k, i) = c * Z(k, i) - s * zk;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (tst1 + fabs(e[l]) != tst1);
+        }
+        d[l] = d[l] + f;
+        e[l] = 0.0;
+    }
+    /* order and signs as orc_eig_jacobi */
+    for (int k = 0; k < n; ++k) {
+        const double mine = fabs(d[k]);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (fabs(d[j]) > mine) || (fabs(d[j]) == mine && j < k);
+        int im = 0;
+        for (int i = 1; i < n; ++i) if (fabs(Z(i, k)) > fabs(Z(im, k))) im = i;
+        const double sg = Z(im, k) < 0.0 ? -1.0 : 1.0;
+        for (int i = 0; i < n; ++i) Ut[(size_t)rank * n + i] = sg * Z(i, k);
+        S[rank] = mine;
+    }
+#undef Z
+    free(z);
+    return failed ? -iters - 1 : iters;
+}
+
 ORC_API int orc_sizeof_cfg(void) { return (int)sizeof(orc_cfg); }

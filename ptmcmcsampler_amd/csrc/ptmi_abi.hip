@@ -1138,6 +1138,183 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
     }
 }
 
+// ----------------------------------------------------------- tridiagonal QL eigensolver (eig_mode "ql")
+// The eigendecomposition of PT:797-803 by Householder tridiagonalization with the transformations accumulated, then implicit QL
+// iterations on the tridiagonal matrix (oracle: orc_eig_ql -- the kernel does the oracle's operations in the oracle's order, sums as
+// k-ascending chains of one product and one sum, so both give the same bits).  eig_jacobi_kernel needs nine sweeps of n^2 / 2
+// rotations, each moving two rows of W and two of V through LDS (4.4 ms per 100 x 100 matrix, one matrix per CU), on the nearly
+// degenerate spectra an isotropic target adapts to; here the O(n^3) work is two passes over the matrix and the rest is a chain of
+// some 7500 plane rotations whose scalars depend on each other (one sqrt and one division each) while the columns they turn do not.
+// One block of two waves per matrix, two blocks per CU at ndim = 100 (the matrix, the subdiagonal and one work row: 81.6 KB):
+//  * reduction, row i = n-1 .. 1: every thread forms the row's scalars itself (broadcast reads: no barrier for them); thread j owns
+//    row j of the products p = A u / h and of the rank-two update;
+//  * accumulation, row i = 0 .. n-1: thread j owns column j of the leading block (its product and its update need nothing else);
+//  * QL: ONE wave (64 lanes, rows k and k + 64 of the eigenvector matrix each) runs the scalar recurrence in every lane and turns
+//    its rows; nothing is synchronised inside this phase.
+constexpr int QL_THREADS = 128;
+constexpr int QL_MAXIT = 60;
+__global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, double *Ut, double *S, int n, int ut_stride, int s_stride, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) double qsm[];
+    double *z = qsm, *e = qsm + (size_t)n * n, *pq = e + n;      // pq: the products p / h, then q; after the accumulation: the diagonal d
+    const int t = (int)threadIdx.x;
+    const double *A = cov + (size_t)blockIdx.x * n * n;
+#define QZ(i, j) z[(i) * n + (j)]
+    for (int i = t; i < n * n; i += QL_THREADS) z[i] = A[i];
+    unsigned long long hmask[2] = {0ull, 0ull};                   // rows whose reflector exists (the oracle's d[i] != 0), n <= 128
+    __syncthreads();
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0;
+        if (l > 0)
+            for (int k = 0; k <= l; ++k) { const double v = QZ(i, k); h = h + v * v; }
+        if (l == 0 || h == 0.0) {                                 // uniform
+            if (t == 0) e[i] = QZ(i, l);
+            __syncthreads();
+            continue;
+        }
+        const double f0 = QZ(i, l);
+        const double g0 = f0 >= 0.0 ? -det_sqrt(h) : det_sqrt(h);
+        h = h - f0 * g0;
+        __syncthreads();                                          // every thread has read Z(i, l)
+        if (t == 0) { e[i] = g0; QZ(i, l) = f0 - g0; }
+        __syncthreads();
+        for (int j = t; j <= l; j += QL_THREADS) {
+            QZ(j, i) = QZ(i, j) / h;
+            double g = 0.0;
+            for (int k = 0; k <= j; ++k) g = g + QZ(j, k) * QZ(i, k);
+            for (int k = j + 1; k <= l; ++k) g = g + QZ(k, j) * QZ(i, k);
+            pq[j] = g / h;
+        }
+        __syncthreads();
+        double f = 0.0;
+        for (int j = 0; j <= l; ++j) f = f + pq[j] * QZ(i, j);
+        const double hh = f / (h + h);
+        __syncthreads();                                          // every thread has its f
+        for (int j = t; j <= l; j += QL_THREADS) pq[j] = pq[j] - hh * QZ(i, j);
+        __syncthreads();
+        for (int j = t; j <= l; j += QL_THREADS) {
+            const double uj = QZ(i, j), qj = pq[j];
+            for (int k = 0; k <= j; ++k) QZ(j, k) = QZ(j, k) - (uj * pq[k] + qj * QZ(i, k));
+        }
+        hmask[i >> 6] |= 1ull << (i & 63);
+        __syncthreads();
+    }
+    if (t == 0) e[0] = 0.0;
+    // accumulation of the transformations
+    for (int i = 0; i < n; ++i) {
+        const int l = i - 1;
+        if ((hmask[i >> 6] >> (i & 63)) & 1ull) {
+            for (int j = t; j <= l; j += QL_THREADS) {
+                double g = 0.0;
+                for (int k = 0; k <= l; ++k) g = g + QZ(i, k) * QZ(k, j);
+                for (int k = 0; k <= l; ++k) QZ(k, j) = QZ(k, j) - g * QZ(k, i);
+            }
+        }
+        __syncthreads();
+        if (t == 0) { pq[i] = QZ(i, i); QZ(i, i) = 1.0; }
+        for (int j = t; j <= l; j += QL_THREADS) { QZ(j, i) = 0.0; QZ(i, j) = 0.0; }
+        __syncthreads();
+    }
+    double *d = pq;
+    int iters = 0, failed = 0;
+    if (t < 64) {
+        // ---- implicit QL: one wave, no barrier; lane `t` turns rows t and t + 64
+        const int k0 = t, k1 = t + 64;
+        const bool r0 = k0 < n, r1 = k1 < n;
+        // e[i - 1] = e[i]: lanes in ascending order of i, a chunk of 64 at a time (a chunk's reads come before its writes)
+        for (int i0 = 1; i0 < n; i0 += 64) {
+            const int i = i0 + t;
+            const double v = i < n ? e[i] : 0.0;
+            asm volatile("" ::: "memory");
+            if (i < n) e[i - 1] = v;
+            asm volatile("" ::: "memory");
+        }
+        if (t == 0) e[n - 1] = 0.0;
+        asm volatile("" ::: "memory");
+        double f = 0.0, tst1 = 0.0;
+        for (int l = 0; l < n && !failed; ++l) {
+            const double t0 = __builtin_fabs(d[l]) + __builtin_fabs(e[l]);
+            if (tst1 < t0) tst1 = t0;
+            int m = l;
+            while (m < n - 1 && tst1 + __builtin_fabs(e[m]) != tst1) ++m;
+            if (m > l) {
+                int it = 0;
+                double el;
+                do {
+                    if (++it > QL_MAXIT) { failed = 1; break; }
+                    ++iters;
+                    const double g = d[l], e_l = e[l];
+                    const double p0 = (d[l + 1] - g) / (2.0 * e_l);
+                    const double rr0 = det_sqrt(p0 * p0 + 1.0);
+                    const double pr = p0 + (p0 >= 0.0 ? rr0 : -rr0);
+                    const double dl = e_l / pr, dl1 = e_l * pr;
+                    const double h = g - dl;
+                    const double el1 = e[l + 1];
+                    double p = d[m];
+                    asm volatile("" ::: "memory");
+                    if (t == 0) { d[l] = dl; d[l + 1] = dl1; }
+                    for (int i = l + 2 + t; i < n; i += 64) d[i] = d[i] - h;
+                    asm volatile("" ::: "memory");
+                    f = f + h;
+                    if (m == l + 1) p = dl1; else if (m >= l + 2) p = p - h;     // d[m] as the updates above leave it
+                    double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+                    double en = e[m - 1], dn = d[m - 1];             // the next rotation's inputs are asked for a rotation ahead
+                    for (int i = m - 1; i >= l; --i) {
+                        c3 = c2; c2 = c; s2 = s;
+                        const double ei = en, di = dn;
+                        if (i > l) { en = e[i - 1]; dn = d[i - 1]; }
+                        const double gg = c * ei, hh = c * p;
+                        const double r = det_sqrt(p * p + ei * ei);
+                        const double ri = 1.0 / r;
+                        const double e1 = s * r;
+                        s = ei * ri;
+                        c = p * ri;
+                        p = c * di - s * gg;
+                        const double d1 = hh + s * (c * gg + s * di);
+                        if (t == 0) { e[i + 1] = e1; d[i + 1] = d1; }
+                        if (r0) {
+                            const double za = QZ(k0, i), zb = QZ(k0, i + 1);
+                            QZ(k0, i + 1) = s * za + c * zb;
+                            QZ(k0, i) = c * za - s * zb;
+                        }
+                        if (r1) {
+                            const double za = QZ(k1, i), zb = QZ(k1, i + 1);
+                            QZ(k1, i + 1) = s * za + c * zb;
+                            QZ(k1, i) = c * za - s * zb;
+                        }
+                    }
+                    p = -s * s2 * c3 * el1 * e_l / dl1;
+                    el = s * p;
+                    asm volatile("" ::: "memory");
+                    if (t == 0) { e[l] = el; d[l] = c * p; }
+                    asm volatile("" ::: "memory");
+                } while (tst1 + __builtin_fabs(el) != tst1);
+            }
+            asm volatile("" ::: "memory");
+            if (t == 0) { d[l] = d[l] + f; e[l] = 0.0; }
+            asm volatile("" ::: "memory");
+        }
+        if (t == 0 && status) {
+            if (failed) atomicOr(status, 1);
+        }
+    }
+    __syncthreads();
+    // order and signs as eig_jacobi_kernel / orc_eig_ql
+    double *Uo = Ut + (size_t)blockIdx.x * ut_stride, *So = S + (size_t)blockIdx.x * s_stride;
+    for (int k = t; k < n; k += QL_THREADS) {
+        const double mine = __builtin_fabs(d[k]);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const double o = __builtin_fabs(d[j]); rank += (o > mine) || (o == mine && j < k); }
+        int im = 0;
+        for (int i = 1; i < n; ++i) if (__builtin_fabs(QZ(i, k)) > __builtin_fabs(QZ(im, k))) im = i;
+        const double sg = QZ(im, k) < 0.0 ? -1.0 : 1.0;
+        for (int i = 0; i < n; ++i) Uo[(size_t)rank * n + i] = sg * QZ(i, k);
+        So[rank] = mine;
+    }
+#undef QZ
+}
+
 // ------------------------------------------------ launch order of the gradient-jump kernel
 // Counting sort of the chains by the NUTS step size of their rank (half-octave classes, smallest first = longest
 // trees first; a rank that has no step size yet is in class 0: its first call searches for one), then dealt across the
@@ -2153,6 +2330,23 @@ int ptmi_eig_jacobi(ptmi_handle h)
     const int nmat = c.cov_per_walker ? c.nwalkers : 1;
     hipLaunchKernelGGL(eig_jacobi_kernel, dim3(nmat), dim3(JAC_THREADS), lds, h->stream, (const double *)h->buf.cov, h->buf.Ut, h->buf.S,
                        d, d * d, d);
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_eig_ql(ptmi_handle h)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    const ptmi_config &c = h->cfg;
+    if (!h->buf.cov || !h->buf.Ut || !h->buf.S) return fail(PTMI_EINVAL, "cov / Ut / S buffers missing");
+    if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "the device eigensolver factorizes the full covariance (no parameter groups)");
+    const int d = c.ndim;
+    const size_t lds = sizeof(double) * ((size_t)d * d + 2 * (size_t)d);
+    if (lds > 160 * 1024 || d > 128) return fail(PTMI_EUNSUPPORTED, "the QL eigensolver keeps the %d x %d matrix in LDS: ndim <= 128", d, d);
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eig_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nmat = c.cov_per_walker ? c.nwalkers : 1;
+    hipLaunchKernelGGL(eig_ql_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, (const double *)h->buf.cov, h->buf.Ut, h->buf.S, d, d * d, d,
+                       (int32_t *)nullptr);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -97,7 +97,9 @@ class PTEngine(object):
     86 KB per chain at ndim = 100, i.e. 22 GB for 262 144 chains -- lower it for very large batches.
     ``eig_mode``: who factorizes the adapted covariance at a covariance epoch (PTMCMCSampler.py:797-803): ``"lapack"`` = the
     host, exactly as the reference (``np.linalg.svd`` per walker); ``"jacobi"`` = ``ptmi_eig_jacobi`` on the device, one
-    block per walker, no host round trip (ndim <= 101, one parameter group; same subspaces, its own sign rule);
+    block per walker, no host round trip (ndim <= 101, one parameter group; same subspaces, its own sign rule); ``"ql"`` =
+    ``ptmi_eig_ql``, Householder tridiagonalization + implicit QL on the device (ndim <= 128; a quarter of the Jacobi kernel's time
+    on nearly degenerate spectra, two matrices per CU: the choice for thousands of per-walker covariances);
     ``"hipsolver"`` = the ROCm library's symmetric eigensolver on the engine's stream (``torch.linalg.eigh`` on the device
     tensor: no host round trip either; one parameter group) -- the choice for large ndim, where the host's LAPACK call is the
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
@@ -148,8 +150,8 @@ class PTEngine(object):
         if pick_mode not in _lib.PICK_MODES:
             raise ValueError("pick_mode must be 'chain' or 'walker'")
         self.pick_mode = pick_mode
-        if eig_mode not in ("lapack", "jacobi", "hipsolver"):
-            raise ValueError("eig_mode must be 'lapack', 'jacobi' or 'hipsolver'")
+        if eig_mode not in ("lapack", "jacobi", "ql", "hipsolver"):
+            raise ValueError("eig_mode must be 'lapack', 'jacobi', 'ql' or 'hipsolver'")
         self.eig_mode = eig_mode
         if int(eig_lag) < 0:
             raise ValueError("eig_lag must be >= 0 launches")
@@ -160,7 +162,7 @@ class PTEngine(object):
         self.ngr = len(self.groups)
         # "whole": one group that IS the full parameter vector in order (a permutation of it needs put_eig's embedding)
         self.whole = self.ngr == 1 and np.array_equal(self.groups[0], np.arange(self.d))
-        if eig_mode in ("jacobi", "hipsolver") and not self.whole:
+        if eig_mode in ("jacobi", "ql", "hipsolver") and not self.whole:
             raise ValueError("eig_mode=%r factorizes the full covariance: no parameter groups" % eig_mode)
         self.gsize = np.ascontiguousarray([len(g) for g in self.groups], dtype=np.int32)
         self.gmask = np.zeros((self.ngr, self.d))
@@ -496,8 +498,8 @@ class PTEngine(object):
             return
         self._eig_finish()                                            # a factorization still pending from the epoch before
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
-        if self.eig_mode == "jacobi":
-            _lib.check(self.lib.ptmi_eig_jacobi(self.h))              # stays on the stream: no host synchronisation
+        if self.eig_mode in ("jacobi", "ql"):                         # stays on the stream: no host synchronisation
+            _lib.check(self.lib.ptmi_eig_jacobi(self.h) if self.eig_mode == "jacobi" else self.lib.ptmi_eig_ql(self.h))
             self.eig_epochs += 1
             return
         if self.eig_mode == "hipsolver":

@@ -68,12 +68,71 @@ def test_device_jacobi_is_bit_identical_to_the_oracle(d):
         assert np.array_equal(S[w].view(np.uint64), oS.view(np.uint64)), (d, w)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 33, 99, 100, 101, 128])
+def test_oracle_ql_factorizes_like_lapack(d):
+    """orc_eig_ql (Householder tridiagonalization + implicit QL; the engine's eig_mode "ql") against LAPACK."""
+    rs = np.random.RandomState(d)
+    cov = _spd(d, rs) * 10.0 ** rs.uniform(-6, 3)
+    Ut, S, iters = orc.eig_ql(cov)
+    scale = np.abs(cov).max()
+    assert np.abs(Ut.T @ np.diag(S) @ Ut - cov).max() <= 1e-12 * scale
+    assert np.abs(Ut @ Ut.T - np.eye(d)).max() <= 1e-12
+    assert (np.diff(S) <= 0).all() and (S >= 0).all()
+    w = np.linalg.svd(cov, compute_uv=False)
+    assert np.abs(S - w).max() <= 1e-12 * w.max()
+    big = np.abs(Ut).argmax(axis=1)
+    assert (Ut[np.arange(d), big] > 0).all()
+    U, _, _ = np.linalg.svd(cov)
+    assert np.abs(np.abs(np.einsum("ki,ik->k", Ut, U)) - 1).max() <= 1e-8
+    # a nearly degenerate spectrum (the cumulative covariance of an isotropic target): where the Jacobi sweeps are slow
+    X = rs.randn(4000, d)
+    C = np.cov(X.T) if d > 1 else np.array([[1.0]])
+    Ut, S, iters = orc.eig_ql(C)
+    assert np.abs(Ut.T @ np.diag(S) @ Ut - C).max() <= 1e-12 * np.abs(C).max() and iters <= 3 * d + 3
+
+
+def test_oracle_ql_degenerate_inputs():
+    Ut, S, n = orc.eig_ql(np.eye(6) * 0.01)
+    assert n == 0 and np.array_equal(np.abs(Ut), np.eye(6)) and np.array_equal(S, np.full(6, 0.01))
+    Ut, S, n = orc.eig_ql(np.zeros((4, 4)))
+    assert not S.any() and np.abs(Ut @ Ut.T - np.eye(4)).max() == 0
+    rs = np.random.RandomState(1)
+    cov = _spd(7, rs)
+    cov[:, 2] = 0
+    cov[2, :] = 0
+    Ut, S, _ = orc.eig_ql(cov)
+    assert S[-1] <= 1e-15 and abs(abs(Ut[-1, 2]) - 1) < 1e-12
+    assert np.abs(Ut.T @ np.diag(S) @ Ut - cov).max() <= 1e-13
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("cov_mode,d,nt,W", [("per_walker", 100, 4, 6), ("per_walker", 12, 64, 3), ("pooled", 100, 3, 40)])
-def test_sampling_with_device_eigensolver_matches_oracle(cov_mode, d, nt, W):
-    """A whole run adapted through ptmi_eig_jacobi: every array equals the oracle's run adapted through orc_eig_jacobi."""
+@pytest.mark.parametrize("d", [1, 2, 7, 50, 99, 100, 101, 128])
+def test_device_ql_is_bit_identical_to_the_oracle(d):
+    from ptmcmcsampler_amd import _lib
     from ptmcmcsampler_amd.engine import PTEngine
-    kw = dict(weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=5, cov_mode=cov_mode, eig_mode="jacobi")
+    rs = np.random.RandomState(200 + d)
+    W = 6
+    g = PTEngine(d, 1, W, np.eye(d), weights=(1, 0, 0), cov_update=4, burn=4, tskip=0, eig_mode="ql")
+    X = rs.randn(3000, d)
+    covs = np.stack([_spd(d, rs) * 10.0 ** rs.uniform(-4, 2) for _ in range(W - 3)] +
+                    [np.cov(X.T).reshape(d, d), np.eye(d) * 0.01, np.zeros((d, d))])
+    g.put("cov", covs)
+    _lib.check(g.lib.ptmi_eig_ql(g.h))
+    g.sync()
+    Ut, S = g.get("Ut")[:, 0], g.get("S")[:, 0]
+    for w in range(W):
+        oUt, oS, _ = orc.eig_ql(covs[w])
+        assert np.array_equal(Ut[w].view(np.uint64), oUt.view(np.uint64)), (d, w)
+        assert np.array_equal(S[w].view(np.uint64), oS.view(np.uint64)), (d, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cov_mode,d,nt,W,eig", [("per_walker", 100, 4, 6, "jacobi"), ("per_walker", 12, 64, 3, "jacobi"), ("pooled", 100, 3, 40, "jacobi"),
+                                                 ("per_walker", 100, 4, 6, "ql"), ("per_walker", 12, 64, 3, "ql"), ("pooled", 100, 3, 40, "ql")])
+def test_sampling_with_device_eigensolver_matches_oracle(cov_mode, d, nt, W, eig):
+    """A whole run adapted through ptmi_eig_jacobi / ptmi_eig_ql: every array equals the oracle's run adapted through orc_eig_jacobi / orc_eig_ql."""
+    from ptmcmcsampler_amd.engine import PTEngine
+    kw = dict(weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=5, cov_mode=cov_mode, eig_mode=eig)
     rs = np.random.RandomState(3)
     cov0, p0 = _spd(d, rs) * 0.01, rs.randn(W, nt, d) * 0.3
     g, o = PTEngine(d, nt, W, cov0, **kw), orc.OracleEngine(d, nt, W, cov0, **kw)
@@ -81,7 +140,7 @@ def test_sampling_with_device_eigensolver_matches_oracle(cov_mode, d, nt, W):
         e.init_state(p0)
         e.run(170)
     g.sync()
-    for name in ("X", "lnL", "slot_of", "nacc", "jstat", "nswap", "AM", "cov", "Ut", "S"):
+    for name in ("X", "lnL", "slot_of", "nacc", "jstat", "nswap", "cov", "Ut", "S") + (("AM",) if cov_mode == "per_walker" else ()):
         a, b = g.get(name), getattr(o, name)
         assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), name
     assert g.eig_epochs == 4 and o.jstat[..., 1, 1].sum() > 0
