@@ -1263,12 +1263,20 @@ ORC_API int orc_eig_jacobi(int d, const double *cov, double *Ut, double *S, int 
  * Householder tridiagonalization with the transformations accumulated, then implicit QL iterations with shifts on the tridiagonal
  * matrix (the classical tred2 / tql2 pair of the EISPACK literature, restated without the row scaling: covariances are of moderate
  * size) -- a few passes of O(n) dependent scalar work per eigenvalue, where the Jacobi sweeps of eig_mode "jacobi" take nine sweeps
- * of n^2 / 2 rotations on the nearly degenerate spectra an isotropic target adapts to.  Every sum is a k-ascending chain of one
- * product and one sum (no fma), every quotient a correctly rounded division, the only other function sqrt: the kernel does the same
+ * of n^2 / 2 rotations on the nearly degenerate spectra an isotropic target adapts to.  Every dot product is eight interleaved fma chains (QL_DOT8), every other sum one product and one
+ * sum, every quotient a correctly rounded division, the only other function sqrt: the kernel does the same
  * operations in the same order, so both give the same bits.  Output as orc_eig_jacobi: eigenvalues in absolute value, descending
  * (ties by ascending column), eigenvectors as ROWS of Ut, each with its largest-magnitude component (first of equals) made
  * positive.  Returns the number of QL iterations (negative: an eigenvalue did not converge within ORC_QL_MAXIT). */
 #define ORC_QL_MAXIT 60
+/* the dot products of the reduction and accumulation phases: eight interleaved fma chains (term k into chain k mod 8), combined as
+ * ((s0 + s4) + (s2 + s6)) + ((s1 + s5) + (s3 + s7)) -- a thread of the kernel runs the eight chains side by side */
+#define QL_DOT8(n_, term_a, term_b, out)                                                                  \
+    do {                                                                                                  \
+        double s8_[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};                                         \
+        for (int k = 0; k < (n_); ++k) s8_[k & 7] = fma((term_a), (term_b), s8_[k & 7]);                  \
+        (out) = ((s8_[0] + s8_[4]) + (s8_[2] + s8_[6])) + ((s8_[1] + s8_[5]) + (s8_[3] + s8_[7]));        \
+    } while (0)
 ORC_API int orc_eig_ql(int n, const double *cov, double *Ut, double *S)
 {
     double *z = (double *)malloc(sizeof(double) * ((size_t)n * n + 2 * (size_t)n)), *d = z + (size_t)n * n, *e = d + n;
@@ -1278,8 +1286,7 @@ ORC_API int orc_eig_ql(int n, const double *cov, double *Ut, double *S)
     for (int i = n - 1; i >= 1; --i) {
         const int l = i - 1;
         double h = 0.0;
-        if (l > 0)
-            for (int k = 0; k <= l; ++k) h = h + Z(i, k) * Z(i, k);
+        if (l > 0) QL_DOT8(l + 1, Z(i, k), Z(i, k), h);
         if (l == 0 || h == 0.0) {
             e[i] = Z(i, l);
             d[i] = 0.0;
@@ -1292,13 +1299,12 @@ ORC_API int orc_eig_ql(int n, const double *cov, double *Ut, double *S)
         Z(i, l) = f0 - g0;
         for (int j = 0; j <= l; ++j) {
             Z(j, i) = Z(i, j) / h;
-            double g = 0.0;
-            for (int k = 0; k <= j; ++k) g = g + Z(j, k) * Z(i, k);
-            for (int k = j + 1; k <= l; ++k) g = g + Z(k, j) * Z(i, k);
+            double g;
+            QL_DOT8(l + 1, (k <= j ? Z(j, k) : Z(k, j)), Z(i, k), g);
             e[j] = g / h;
         }
-        double f = 0.0;
-        for (int j = 0; j <= l; ++j) f = f + e[j] * Z(i, j);
+        double f;
+        QL_DOT8(l + 1, e[k], Z(i, k), f);
         const double hh = f / (h + h);
         for (int j = 0; j <= l; ++j) e[j] = e[j] - hh * Z(i, j);
         for (int j = 0; j <= l; ++j)
@@ -1312,8 +1318,8 @@ ORC_API int orc_eig_ql(int n, const double *cov, double *Ut, double *S)
         const int l = i - 1;
         if (d[i] != 0.0) {
             for (int j = 0; j <= l; ++j) {
-                double g = 0.0;
-                for (int k = 0; k <= l; ++k) g = g + Z(i, k) * Z(k, j);
+                double g;
+                QL_DOT8(l + 1, Z(i, k), Z(k, j), g);
                 for (int k = 0; k <= l; ++k) Z(k, j) = Z(k, j) - g * Z(k, i);
             }
         }

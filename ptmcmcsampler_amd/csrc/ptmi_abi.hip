@@ -1140,8 +1140,8 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
 
 // ----------------------------------------------------------- tridiagonal QL eigensolver (eig_mode "ql")
 // The eigendecomposition of PT:797-803 by Householder tridiagonalization with the transformations accumulated, then implicit QL
-// iterations on the tridiagonal matrix (oracle: orc_eig_ql -- the kernel does the oracle's operations in the oracle's order, sums as
-// k-ascending chains of one product and one sum, so both give the same bits).  eig_jacobi_kernel needs nine sweeps of n^2 / 2
+// iterations on the tridiagonal matrix (oracle: orc_eig_ql -- the kernel does the oracle's operations in the oracle's order, dot products
+// as eight interleaved fma chains, so both give the same bits).  eig_jacobi_kernel needs nine sweeps of n^2 / 2
 // rotations, each moving two rows of W and two of V through LDS (4.4 ms per 100 x 100 matrix, one matrix per CU), on the nearly
 // degenerate spectra an isotropic target adapts to; here the O(n^3) work is two passes over the matrix and the rest is a chain of
 // some 7500 plane rotations whose scalars depend on each other (one sqrt and one division each) while the columns they turn do not.
@@ -1153,21 +1153,51 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
 //    its rows; nothing is synchronised inside this phase.
 constexpr int QL_THREADS = 128;
 constexpr int QL_MAXIT = 60;
+// the oracle's QL_DOT8: eight interleaved fma chains, term k into chain k mod 8 (a dependent f64 operation costs a lone wave some 20
+// cycles: one chain of 100 terms is 2000 cycles, eight side by side 300)
+template <class FA, class FB>
+__device__ __forceinline__ double ql_dot8(int cnt, FA fa, FB fb)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+    int k = 0;
+    for (; k + 8 <= cnt; k += 8) {
+        s0 = __builtin_fma(fa(k), fb(k), s0);
+        s1 = __builtin_fma(fa(k + 1), fb(k + 1), s1);
+        s2 = __builtin_fma(fa(k + 2), fb(k + 2), s2);
+        s3 = __builtin_fma(fa(k + 3), fb(k + 3), s3);
+        s4 = __builtin_fma(fa(k + 4), fb(k + 4), s4);
+        s5 = __builtin_fma(fa(k + 5), fb(k + 5), s5);
+        s6 = __builtin_fma(fa(k + 6), fb(k + 6), s6);
+        s7 = __builtin_fma(fa(k + 7), fb(k + 7), s7);
+    }
+    if (k < cnt) s0 = __builtin_fma(fa(k), fb(k), s0);
+    if (k + 1 < cnt) s1 = __builtin_fma(fa(k + 1), fb(k + 1), s1);
+    if (k + 2 < cnt) s2 = __builtin_fma(fa(k + 2), fb(k + 2), s2);
+    if (k + 3 < cnt) s3 = __builtin_fma(fa(k + 3), fb(k + 3), s3);
+    if (k + 4 < cnt) s4 = __builtin_fma(fa(k + 4), fb(k + 4), s4);
+    if (k + 5 < cnt) s5 = __builtin_fma(fa(k + 5), fb(k + 5), s5);
+    if (k + 6 < cnt) s6 = __builtin_fma(fa(k + 6), fb(k + 6), s6);
+    return ((s0 + s4) + (s2 + s6)) + ((s1 + s5) + (s3 + s7));
+}
+// (Measured and dropped: the matrix in a global scratch with 3 n doubles of LDS per block, sixteen blocks per CU and all 4096 matrices
+// resident at once -- every broadcast read became an L2 round trip: 84 ms per epoch against 41.)
 __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, double *Ut, double *S, int n, int ut_stride, int s_stride, int32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) double qsm[];
-    double *z = qsm, *e = qsm + (size_t)n * n, *pq = e + n;      // pq: the products p / h, then q; after the accumulation: the diagonal d
+    double *z = qsm, *e = qsm + (((size_t)n * n + 1) & ~(size_t)1), *pq = e + n;     // pq: the products p / h, then q; after the accumulation: the diagonal d
     const int t = (int)threadIdx.x;
     const double *A = cov + (size_t)blockIdx.x * n * n;
 #define QZ(i, j) z[(i) * n + (j)]
     for (int i = t; i < n * n; i += QL_THREADS) z[i] = A[i];
+#ifdef PTMI_QL_PROFILE
+    unsigned long long qt0 = __builtin_readcyclecounter(), qt1, qt2, qt3;
+#endif
     unsigned long long hmask[2] = {0ull, 0ull};                   // rows whose reflector exists (the oracle's d[i] != 0), n <= 128
     __syncthreads();
     for (int i = n - 1; i >= 1; --i) {
         const int l = i - 1;
         double h = 0.0;
-        if (l > 0)
-            for (int k = 0; k <= l; ++k) { const double v = QZ(i, k); h = h + v * v; }
+        if (l > 0) h = ql_dot8(l + 1, [&](int k) { return QZ(i, k); }, [&](int k) { return QZ(i, k); });
         if (l == 0 || h == 0.0) {                                 // uniform
             if (t == 0) e[i] = QZ(i, l);
             __syncthreads();
@@ -1181,14 +1211,11 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
         __syncthreads();
         for (int j = t; j <= l; j += QL_THREADS) {
             QZ(j, i) = QZ(i, j) / h;
-            double g = 0.0;
-            for (int k = 0; k <= j; ++k) g = g + QZ(j, k) * QZ(i, k);
-            for (int k = j + 1; k <= l; ++k) g = g + QZ(k, j) * QZ(i, k);
+            const double g = ql_dot8(l + 1, [&](int k) { return k <= j ? QZ(j, k) : QZ(k, j); }, [&](int k) { return QZ(i, k); });
             pq[j] = g / h;
         }
         __syncthreads();
-        double f = 0.0;
-        for (int j = 0; j <= l; ++j) f = f + pq[j] * QZ(i, j);
+        const double f = ql_dot8(l + 1, [&](int k) { return pq[k]; }, [&](int k) { return QZ(i, k); });
         const double hh = f / (h + h);
         __syncthreads();                                          // every thread has its f
         for (int j = t; j <= l; j += QL_THREADS) pq[j] = pq[j] - hh * QZ(i, j);
@@ -1201,13 +1228,15 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
         __syncthreads();
     }
     if (t == 0) e[0] = 0.0;
+#ifdef PTMI_QL_PROFILE
+    qt1 = __builtin_readcyclecounter();
+#endif
     // accumulation of the transformations
     for (int i = 0; i < n; ++i) {
         const int l = i - 1;
         if ((hmask[i >> 6] >> (i & 63)) & 1ull) {
             for (int j = t; j <= l; j += QL_THREADS) {
-                double g = 0.0;
-                for (int k = 0; k <= l; ++k) g = g + QZ(i, k) * QZ(k, j);
+                const double g = ql_dot8(l + 1, [&](int k) { return QZ(i, k); }, [&](int k) { return QZ(k, j); });
                 for (int k = 0; k <= l; ++k) QZ(k, j) = QZ(k, j) - g * QZ(k, i);
             }
         }
@@ -1216,54 +1245,67 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
         for (int j = t; j <= l; j += QL_THREADS) { QZ(j, i) = 0.0; QZ(i, j) = 0.0; }
         __syncthreads();
     }
-    double *d = pq;
+    // ---- implicit QL: one wave, no barrier; lane `t` turns rows t and t + 64.  The diagonal and the subdiagonal are re-laid as
+    // pairs {d[i], e[i]} over the 2 n doubles of e and pq (one 16-byte read and one 16-byte write per rotation); of the two
+    // columns a rotation turns, the lower one is the next rotation's upper one and stays in a register.
+    typedef double ql_d2 __attribute__((ext_vector_type(2)));
+    ql_d2 *de = reinterpret_cast<ql_d2 *>(e);
     int iters = 0, failed = 0;
+#ifdef PTMI_QL_PROFILE
+    qt2 = __builtin_readcyclecounter();
+#endif
     if (t < 64) {
-        // ---- implicit QL: one wave, no barrier; lane `t` turns rows t and t + 64
         const int k0 = t, k1 = t + 64;
         const bool r0 = k0 < n, r1 = k1 < n;
-        // e[i - 1] = e[i]: lanes in ascending order of i, a chunk of 64 at a time (a chunk's reads come before its writes)
-        for (int i0 = 1; i0 < n; i0 += 64) {
-            const int i = i0 + t;
-            const double v = i < n ? e[i] : 0.0;
+        {
+            // e[i - 1] = e[i], e[n - 1] = 0, then the pairs: every lane reads its entries before any lane writes
+            const int ia = t, ib = t + 64;
+            const double da = ia < n ? pq[ia] : 0.0, db = ib < n ? pq[ib] : 0.0;
+            const double ea = ia + 1 < n ? e[ia + 1] : 0.0, eb = ib + 1 < n ? e[ib + 1] : 0.0;
             asm volatile("" ::: "memory");
-            if (i < n) e[i - 1] = v;
+            if (ia < n) de[ia] = ql_d2{da, ea};
+            if (ib < n) de[ib] = ql_d2{db, eb};
             asm volatile("" ::: "memory");
         }
-        if (t == 0) e[n - 1] = 0.0;
-        asm volatile("" ::: "memory");
+#define QD(i) de[i].x
+#define QE(i) de[i].y
         double f = 0.0, tst1 = 0.0;
         for (int l = 0; l < n && !failed; ++l) {
-            const double t0 = __builtin_fabs(d[l]) + __builtin_fabs(e[l]);
+            const ql_d2 del = de[l];
+            const double t0 = __builtin_fabs(del.x) + __builtin_fabs(del.y);
             if (tst1 < t0) tst1 = t0;
             int m = l;
-            while (m < n - 1 && tst1 + __builtin_fabs(e[m]) != tst1) ++m;
+            while (m < n - 1 && tst1 + __builtin_fabs(QE(m)) != tst1) ++m;
+            double dlf = del.x;                                  // d[l] as the iterations leave it
             if (m > l) {
                 int it = 0;
                 double el;
                 do {
                     if (++it > QL_MAXIT) { failed = 1; break; }
                     ++iters;
-                    const double g = d[l], e_l = e[l];
-                    const double p0 = (d[l + 1] - g) / (2.0 * e_l);
+                    const ql_d2 pl = de[l], pl1 = de[l + 1];
+                    const double g = pl.x, e_l = pl.y;
+                    const double p0 = (pl1.x - g) / (2.0 * e_l);
                     const double rr0 = det_sqrt(p0 * p0 + 1.0);
                     const double pr = p0 + (p0 >= 0.0 ? rr0 : -rr0);
                     const double dl = e_l / pr, dl1 = e_l * pr;
                     const double h = g - dl;
-                    const double el1 = e[l + 1];
-                    double p = d[m];
+                    const double el1 = pl1.y;
+                    double p = QD(m);
                     asm volatile("" ::: "memory");
-                    if (t == 0) { d[l] = dl; d[l + 1] = dl1; }
-                    for (int i = l + 2 + t; i < n; i += 64) d[i] = d[i] - h;
+                    if (t == 0) { QD(l) = dl; QD(l + 1) = dl1; }
+                    for (int i = l + 2 + t; i < n; i += 64) QD(i) = QD(i) - h;
                     asm volatile("" ::: "memory");
                     f = f + h;
                     if (m == l + 1) p = dl1; else if (m >= l + 2) p = p - h;     // d[m] as the updates above leave it
                     double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
-                    double en = e[m - 1], dn = d[m - 1];             // the next rotation's inputs are asked for a rotation ahead
+                    ql_d2 nx = de[m - 1];                            // the next rotation's inputs are asked for a rotation ahead
+                    double zb0 = r0 ? z[k0 * n + m] : 0.0, zb1 = r1 ? z[k1 * n + m] : 0.0;     // column i + 1 of the lane's rows, carried
                     for (int i = m - 1; i >= l; --i) {
                         c3 = c2; c2 = c; s2 = s;
-                        const double ei = en, di = dn;
-                        if (i > l) { en = e[i - 1]; dn = d[i - 1]; }
+                        const double di = nx.x, ei = nx.y;
+                        if (i > l) nx = de[i - 1];
+                        const double za0 = r0 ? z[k0 * n + i] : 0.0, za1 = r1 ? z[k1 * n + i] : 0.0;
                         const double gg = c * ei, hh = c * p;
                         const double r = det_sqrt(p * p + ei * ei);
                         const double ri = 1.0 / r;
@@ -1272,27 +1314,24 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
                         c = p * ri;
                         p = c * di - s * gg;
                         const double d1 = hh + s * (c * gg + s * di);
-                        if (t == 0) { e[i + 1] = e1; d[i + 1] = d1; }
-                        if (r0) {
-                            const double za = QZ(k0, i), zb = QZ(k0, i + 1);
-                            QZ(k0, i + 1) = s * za + c * zb;
-                            QZ(k0, i) = c * za - s * zb;
-                        }
-                        if (r1) {
-                            const double za = QZ(k1, i), zb = QZ(k1, i + 1);
-                            QZ(k1, i + 1) = s * za + c * zb;
-                            QZ(k1, i) = c * za - s * zb;
-                        }
+                        if (t == 0) de[i + 1] = ql_d2{d1, e1};
+                        if (r0) z[k0 * n + i + 1] = s * za0 + c * zb0;
+                        if (r1) z[k1 * n + i + 1] = s * za1 + c * zb1;
+                        zb0 = c * za0 - s * zb0;
+                        zb1 = c * za1 - s * zb1;
                     }
+                    if (r0) z[k0 * n + l] = zb0;
+                    if (r1) z[k1 * n + l] = zb1;
                     p = -s * s2 * c3 * el1 * e_l / dl1;
                     el = s * p;
+                    dlf = c * p;
                     asm volatile("" ::: "memory");
-                    if (t == 0) { e[l] = el; d[l] = c * p; }
+                    if (t == 0) de[l] = ql_d2{dlf, el};
                     asm volatile("" ::: "memory");
                 } while (tst1 + __builtin_fabs(el) != tst1);
             }
             asm volatile("" ::: "memory");
-            if (t == 0) { d[l] = d[l] + f; e[l] = 0.0; }
+            if (t == 0) de[l] = ql_d2{dlf + f, 0.0};
             asm volatile("" ::: "memory");
         }
         if (t == 0 && status) {
@@ -1300,12 +1339,16 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
         }
     }
     __syncthreads();
+#ifdef PTMI_QL_PROFILE
+    qt3 = __builtin_readcyclecounter();
+    if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 3000)) printf("ql block %d: reduce %llu accumulate %llu ql %llu cycles, %d iterations\n", (int)blockIdx.x, qt1 - qt0, qt2 - qt1, qt3 - qt2, iters);
+#endif
     // order and signs as eig_jacobi_kernel / orc_eig_ql
     double *Uo = Ut + (size_t)blockIdx.x * ut_stride, *So = S + (size_t)blockIdx.x * s_stride;
     for (int k = t; k < n; k += QL_THREADS) {
-        const double mine = __builtin_fabs(d[k]);
+        const double mine = __builtin_fabs(QD(k));
         int rank = 0;
-        for (int j = 0; j < n; ++j) { const double o = __builtin_fabs(d[j]); rank += (o > mine) || (o == mine && j < k); }
+        for (int j = 0; j < n; ++j) { const double o = __builtin_fabs(QD(j)); rank += (o > mine) || (o == mine && j < k); }
         int im = 0;
         for (int i = 1; i < n; ++i) if (__builtin_fabs(QZ(i, k)) > __builtin_fabs(QZ(im, k))) im = i;
         const double sg = QZ(im, k) < 0.0 ? -1.0 : 1.0;
@@ -1313,6 +1356,8 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
         So[rank] = mine;
     }
 #undef QZ
+#undef QD
+#undef QE
 }
 
 // ------------------------------------------------ launch order of the gradient-jump kernel
@@ -2341,7 +2386,7 @@ int ptmi_eig_ql(ptmi_handle h)
     if (!h->buf.cov || !h->buf.Ut || !h->buf.S) return fail(PTMI_EINVAL, "cov / Ut / S buffers missing");
     if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "the device eigensolver factorizes the full covariance (no parameter groups)");
     const int d = c.ndim;
-    const size_t lds = sizeof(double) * ((size_t)d * d + 2 * (size_t)d);
+    const size_t lds = sizeof(double) * ((((size_t)d * d + 1) & ~(size_t)1) + 2 * (size_t)d);
     if (lds > 160 * 1024 || d > 128) return fail(PTMI_EUNSUPPORTED, "the QL eigensolver keeps the %d x %d matrix in LDS: ndim <= 128", d, d);
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eig_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nmat = c.cov_per_walker ? c.nwalkers : 1;
