@@ -1360,6 +1360,243 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
 #undef QE
 }
 
+// ---- the same in three kernels, for MANY matrices (per-walker covariances).  The QL phase is a chain of dependent scalar
+// operations (some 45 of them per rotation, ~20 cycles each for a lone wave: 900 cycles per rotation, 7.6 of the 10.3 M cycles a
+// matrix takes in eig_ql_kernel) and only two matrices fit a CU's LDS: 64 ms of chain per CU and epoch whatever is done to the rest.
+// But the chain needs the tridiagonal matrix alone -- 200 doubles, not the eigenvectors: eig_ql_chain_kernel runs the chains of ALL
+// matrices at once (a wave each, four per SIMD) and RECORDS the rotations (c, s) with the (l, m) of every iteration;
+// eig_ql_apply_kernel then turns the eigenvector rows with them, a thread per row and no scalar work.  Same operations on the
+// same values in the same order as orc_eig_ql: same bits.  A matrix whose rotations do not fit the record (3 n^2; nearly degenerate
+// 100 x 100 spectra take 0.8 n^2) is flagged and redone by the apply kernel with the chain and the rows together.
+typedef double qls_d2 __attribute__((ext_vector_type(2)));
+struct QlScratch {
+    double *z;          // [nmat][n][n]  the accumulated transformations, row-major
+    qls_d2 *de;         // [nmat][n]     {d[i], e[i]} (subdiagonal shifted: e[i] couples i and i + 1)
+    double *ev;         // [nmat][n]     the eigenvalues the chains end with
+    qls_d2 *rot;        // [nmat][cap]   the rotations, in the order they are applied
+    int32_t *hdr;       // [nmat][2 capit]  l, m of every QL iteration
+    int32_t *cnt;       // [nmat][2]     iterations recorded, overflow flag
+    int cap, capit;
+};
+__global__ __launch_bounds__(QL_THREADS) void eig_ql_reduce_kernel(const double *cov, int n, QlScratch q)
+{
+    extern __shared__ __attribute__((aligned(16))) double qsm[];
+    double *z = qsm, *e = qsm + (((size_t)n * n + 1) & ~(size_t)1), *pq = e + n;
+    const int t = (int)threadIdx.x;
+    const double *A = cov + (size_t)blockIdx.x * n * n;
+#define QZ(i, j) z[(i) * n + (j)]
+    for (int i = t; i < n * n; i += QL_THREADS) z[i] = A[i];
+    unsigned long long hmask[2] = {0ull, 0ull};
+    __syncthreads();
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0;
+        if (l > 0) h = ql_dot8(l + 1, [&](int k) { return QZ(i, k); }, [&](int k) { return QZ(i, k); });
+        if (l == 0 || h == 0.0) {
+            if (t == 0) e[i] = QZ(i, l);
+            __syncthreads();
+            continue;
+        }
+        const double f0 = QZ(i, l);
+        const double g0 = f0 >= 0.0 ? -det_sqrt(h) : det_sqrt(h);
+        h = h - f0 * g0;
+        __syncthreads();
+        if (t == 0) { e[i] = g0; QZ(i, l) = f0 - g0; }
+        __syncthreads();
+        for (int j = t; j <= l; j += QL_THREADS) {
+            QZ(j, i) = QZ(i, j) / h;
+            const double g = ql_dot8(l + 1, [&](int k) { return k <= j ? QZ(j, k) : QZ(k, j); }, [&](int k) { return QZ(i, k); });
+            pq[j] = g / h;
+        }
+        __syncthreads();
+        const double f = ql_dot8(l + 1, [&](int k) { return pq[k]; }, [&](int k) { return QZ(i, k); });
+        const double hh = f / (h + h);
+        __syncthreads();
+        for (int j = t; j <= l; j += QL_THREADS) pq[j] = pq[j] - hh * QZ(i, j);
+        __syncthreads();
+        for (int j = t; j <= l; j += QL_THREADS) {
+            const double uj = QZ(i, j), qj = pq[j];
+            for (int k = 0; k <= j; ++k) QZ(j, k) = QZ(j, k) - (uj * pq[k] + qj * QZ(i, k));
+        }
+        hmask[i >> 6] |= 1ull << (i & 63);
+        __syncthreads();
+    }
+    if (t == 0) e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int l = i - 1;
+        if ((hmask[i >> 6] >> (i & 63)) & 1ull) {
+            for (int j = t; j <= l; j += QL_THREADS) {
+                const double g = ql_dot8(l + 1, [&](int k) { return QZ(i, k); }, [&](int k) { return QZ(k, j); });
+                for (int k = 0; k <= l; ++k) QZ(k, j) = QZ(k, j) - g * QZ(k, i);
+            }
+        }
+        __syncthreads();
+        if (t == 0) { pq[i] = QZ(i, i); QZ(i, i) = 1.0; }
+        for (int j = t; j <= l; j += QL_THREADS) { QZ(j, i) = 0.0; QZ(i, j) = 0.0; }
+        __syncthreads();
+    }
+#undef QZ
+    double *zo = q.z + (size_t)blockIdx.x * n * n;
+    for (int i = t; i < n * n; i += QL_THREADS) zo[i] = z[i];
+    qls_d2 *deo = q.de + (size_t)blockIdx.x * n;
+    for (int i = t; i < n; i += QL_THREADS) deo[i] = qls_d2{pq[i], i + 1 < n ? e[i + 1] : 0.0};
+}
+
+// the QL iterations on {d, e} pairs in LDS (one wave; every lane runs the scalar recurrence).  ROWS: the lane also turns rows t and
+// t + 64 of zt (the eigenvector matrix TRANSPOSED in LDS: column c at zt[c n ...], so that the lanes' rows sit side by side);
+// else the rotations and the iterations' (l, m) are recorded.  Returns the iterations (negative: an eigenvalue did not converge).
+template <bool ROWS>
+__device__ __forceinline__ int ql_iterate(qls_d2 *de, int n, int t, double *zt, qls_d2 *rot, int32_t *hdr, int cap, int capit, int *overflow)
+{
+    const int k0 = t, k1 = t + 64;
+    const bool r0 = ROWS && k0 < n, r1 = ROWS && k1 < n;
+    int iters = 0, nrot = 0;
+    bool over = false, failed = false;
+    double f = 0.0, tst1 = 0.0;
+    for (int l = 0; l < n && !failed; ++l) {
+        const qls_d2 del = de[l];
+        const double t0 = __builtin_fabs(del.x) + __builtin_fabs(del.y);
+        if (tst1 < t0) tst1 = t0;
+        int m = l;
+        while (m < n - 1 && tst1 + __builtin_fabs(de[m].y) != tst1) ++m;
+        double dlf = del.x;
+        if (m > l) {
+            int it = 0;
+            double el;
+            do {
+                if (++it > QL_MAXIT) { failed = true; break; }
+                if (!ROWS) {
+                    if (iters >= capit || nrot + (m - l) > cap) over = true;
+                    if (!over && t == 0) { hdr[2 * iters] = l; hdr[2 * iters + 1] = m; }
+                }
+                ++iters;
+                const qls_d2 pl = de[l], pl1 = de[l + 1];
+                const double g = pl.x, e_l = pl.y;
+                const double p0 = (pl1.x - g) / (2.0 * e_l);
+                const double rr0 = det_sqrt(p0 * p0 + 1.0);
+                const double pr = p0 + (p0 >= 0.0 ? rr0 : -rr0);
+                const double dl = e_l / pr, dl1 = e_l * pr;
+                const double h = g - dl;
+                const double el1 = pl1.y;
+                double p = de[m].x;
+                asm volatile("" ::: "memory");
+                if (t == 0) { de[l].x = dl; de[l + 1].x = dl1; }
+                for (int i = l + 2 + t; i < n; i += 64) de[i].x = de[i].x - h;
+                asm volatile("" ::: "memory");
+                f = f + h;
+                if (m == l + 1) p = dl1; else if (m >= l + 2) p = p - h;
+                double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+                qls_d2 nx = de[m - 1];
+                double zb0 = r0 ? zt[m * n + k0] : 0.0, zb1 = r1 ? zt[m * n + k1] : 0.0;
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    const double di = nx.x, ei = nx.y;
+                    if (i > l) nx = de[i - 1];
+                    double za0 = 0.0, za1 = 0.0;
+                    if (ROWS) { za0 = r0 ? zt[i * n + k0] : 0.0; za1 = r1 ? zt[i * n + k1] : 0.0; }
+                    const double gg = c * ei, hh = c * p;
+                    const double r = det_sqrt(p * p + ei * ei);
+                    const double ri = 1.0 / r;
+                    const double e1 = s * r;
+                    s = ei * ri;
+                    c = p * ri;
+                    p = c * di - s * gg;
+                    const double d1 = hh + s * (c * gg + s * di);
+                    if (t == 0) de[i + 1] = qls_d2{d1, e1};
+                    if (ROWS) {
+                        if (r0) zt[(i + 1) * n + k0] = s * za0 + c * zb0;
+                        if (r1) zt[(i + 1) * n + k1] = s * za1 + c * zb1;
+                        zb0 = c * za0 - s * zb0;
+                        zb1 = c * za1 - s * zb1;
+                    } else if (!over && t == 0) {
+                        rot[nrot + (m - 1 - i)] = qls_d2{c, s};
+                    }
+                }
+                if (ROWS) {
+                    if (r0) zt[l * n + k0] = zb0;
+                    if (r1) zt[l * n + k1] = zb1;
+                }
+                nrot += m - l;
+                p = -s * s2 * c3 * el1 * e_l / dl1;
+                el = s * p;
+                dlf = c * p;
+                asm volatile("" ::: "memory");
+                if (t == 0) de[l] = qls_d2{dlf, el};
+                asm volatile("" ::: "memory");
+            } while (tst1 + __builtin_fabs(el) != tst1);
+        }
+        asm volatile("" ::: "memory");
+        if (t == 0) de[l] = qls_d2{dlf + f, 0.0};
+        asm volatile("" ::: "memory");
+    }
+    if (overflow) *overflow = over ? 1 : 0;
+    return failed ? -iters - 1 : iters;
+}
+
+__global__ __launch_bounds__(64) void eig_ql_chain_kernel(int n, QlScratch q)
+{
+    extern __shared__ __attribute__((aligned(16))) double qsm[];
+    qls_d2 *de = reinterpret_cast<qls_d2 *>(qsm);
+    const int t = (int)threadIdx.x;
+    const size_t b = blockIdx.x;
+    for (int i = t; i < n; i += 64) de[i] = q.de[b * n + i];
+    asm volatile("" ::: "memory");
+    int over = 0;
+    const int iters = ql_iterate<false>(de, n, t, nullptr, q.rot + b * (size_t)q.cap, q.hdr + b * 2 * (size_t)q.capit, q.cap, q.capit, &over);
+    asm volatile("" ::: "memory");
+    for (int i = t; i < n; i += 64) q.ev[b * n + i] = de[i].x;
+    if (t == 0) { q.cnt[2 * b] = iters < 0 ? 0 : iters; q.cnt[2 * b + 1] = (over || iters < 0) ? 1 : 0; }
+}
+
+__global__ __launch_bounds__(QL_THREADS) void eig_ql_apply_kernel(double *Ut, double *S, int n, int ut_stride, int s_stride, QlScratch q)
+{
+    extern __shared__ __attribute__((aligned(16))) double qsm[];
+    double *zt = qsm;                                              // zt[c n + k] = Z(k, c)
+    qls_d2 *de = reinterpret_cast<qls_d2 *>(qsm + (((size_t)n * n + 1) & ~(size_t)1));
+    const int t = (int)threadIdx.x;
+    const size_t b = blockIdx.x;
+    const double *zi = q.z + b * n * n;
+    for (int i = t; i < n * n; i += QL_THREADS) { const int r = i / n, c = i % n; zt[c * n + r] = zi[i]; }
+    const bool redo = q.cnt[2 * b + 1] != 0;                       // the record did not hold this matrix's rotations
+    if (redo) { for (int i = t; i < n; i += QL_THREADS) de[i] = q.de[b * n + i]; }
+    else { for (int i = t; i < n; i += QL_THREADS) de[i] = qls_d2{q.ev[b * n + i], 0.0}; }
+    __syncthreads();
+    if (redo) {
+        if (t < 64) ql_iterate<true>(de, n, t, zt, nullptr, nullptr, 0, 0, nullptr);
+    } else if (t < n) {
+        // a thread per row: the recorded rotations in their order; of the two columns a rotation turns, the lower one is the
+        // next rotation's upper one and stays in a register
+        const int nit = q.cnt[2 * b];
+        const int32_t *hdr = q.hdr + b * 2 * (size_t)q.capit;
+        const qls_d2 *rot = q.rot + b * (size_t)q.cap;
+        int r = 0;
+        for (int itn = 0; itn < nit; ++itn) {
+            const int l = hdr[2 * itn], m = hdr[2 * itn + 1];
+            double zb = zt[m * n + t];
+            for (int i = m - 1; i >= l; --i) {
+                const qls_d2 cs = rot[r++];
+                const double za = zt[i * n + t];
+                zt[(i + 1) * n + t] = cs.y * za + cs.x * zb;
+                zb = cs.x * za - cs.y * zb;
+            }
+            zt[l * n + t] = zb;
+        }
+    }
+    __syncthreads();
+    double *Uo = Ut + b * ut_stride, *So = S + b * s_stride;
+    for (int k = t; k < n; k += QL_THREADS) {
+        const double mine = __builtin_fabs(de[k].x);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const double o = __builtin_fabs(de[j].x); rank += (o > mine) || (o == mine && j < k); }
+        const double *col = zt + (size_t)k * n;                    // Z(i, k), i = 0 .. n - 1
+        int im = 0;
+        for (int i = 1; i < n; ++i) if (__builtin_fabs(col[i]) > __builtin_fabs(col[im])) im = i;
+        const double sg = col[im] < 0.0 ? -1.0 : 1.0;
+        for (int i = 0; i < n; ++i) Uo[(size_t)rank * n + i] = sg * col[i];
+        So[rank] = mine;
+    }
+}
+
 // ------------------------------------------------ launch order of the gradient-jump kernel
 // Counting sort of the chains by the NUTS step size of their rank (half-octave classes, smallest first = longest
 // trees first; a rank that has no step size yet is in class 0: its first call searches for one), then dealt across the
@@ -1797,6 +2034,7 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
+    (void)hipFree(h->d_ql_scr);
     (void)hipFree(h->d_rle_src); (void)hipFree(h->d_rle_wgt); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
@@ -2388,8 +2626,38 @@ int ptmi_eig_ql(ptmi_handle h)
     const int d = c.ndim;
     const size_t lds = sizeof(double) * ((((size_t)d * d + 1) & ~(size_t)1) + 2 * (size_t)d);
     if (lds > 160 * 1024 || d > 128) return fail(PTMI_EUNSUPPORTED, "the QL eigensolver keeps the %d x %d matrix in LDS: ndim <= 128", d, d);
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eig_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nmat = c.cov_per_walker ? c.nwalkers : 1;
+    const char *sp = getenv("PTMI_QL_SPLIT");                           // 1 / 0 forces the three-kernel / the one-kernel form (tests, measurements)
+    const bool split = sp ? atoi(sp) != 0 : nmat >= 64;
+    if (split) {
+        // many matrices: reduce -> the scalar chains of all of them at once -> apply (see eig_ql_chain_kernel)
+        const int cap = 3 * d * d, capit = 8 * d;
+        if (!h->d_ql_scr) {
+            const size_t bytes = sizeof(double) * (size_t)nmat * ((size_t)d * d + 2 * (size_t)d + (size_t)d + 2 * (size_t)cap) +
+                                 sizeof(int32_t) * (size_t)nmat * (2 * (size_t)capit + 2) + 64;
+            HIPCHK(hipMalloc((void **)&h->d_ql_scr, bytes));
+        }
+        QlScratch q;
+        char *pb = (char *)h->d_ql_scr;
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        q.z = (double *)pb; pb += up16(sizeof(double) * (size_t)nmat * d * d);
+        q.de = (qls_d2 *)pb; pb += sizeof(double) * 2 * (size_t)nmat * d;
+        q.rot = (qls_d2 *)pb; pb += sizeof(double) * 2 * (size_t)nmat * cap;
+        q.ev = (double *)pb; pb += up16(sizeof(double) * (size_t)nmat * d);
+        q.hdr = (int32_t *)pb; pb += sizeof(int32_t) * 2 * (size_t)nmat * capit;
+        q.cnt = (int32_t *)pb;
+        q.cap = cap; q.capit = capit;
+        if (lds > 64 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void *)eig_ql_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute((const void *)eig_ql_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        hipLaunchKernelGGL(eig_ql_reduce_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, (const double *)h->buf.cov, d, q);
+        hipLaunchKernelGGL(eig_ql_chain_kernel, dim3(nmat), dim3(64), sizeof(double) * 2 * (size_t)d, h->stream, d, q);
+        hipLaunchKernelGGL(eig_ql_apply_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, h->buf.Ut, h->buf.S, d, d * d, d, q);
+        HIPCHK(hipGetLastError());
+        return PTMI_OK;
+    }
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eig_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(eig_ql_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, (const double *)h->buf.cov, h->buf.Ut, h->buf.S, d, d * d, d,
                        (int32_t *)nullptr);
     HIPCHK(hipGetLastError());

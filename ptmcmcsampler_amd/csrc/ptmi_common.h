@@ -135,6 +135,7 @@ struct ptmi_engine {
     hipEvent_t ev0, ev1;
     hipStream_t side;            // pooled statistics at ndim > 111: the diagonal macro tiles run beside the off-diagonal ones
     hipEvent_t side_go, side_done;
+    void *d_ql_scr;              // ptmi_eig_ql with many matrices: the transformations, tridiagonal matrices and recorded rotations (QlScratch)
     int32_t *d_rle_src;          // pooled statistics over run-length-compacted rows: the stored rows of each slab [nrows] ...
     double *d_rle_wgt;           // ... the square roots of their run lengths [nrows] ...
     int32_t *d_rle_cnt;          // ... and how many each slab has [nslab]

@@ -106,8 +106,12 @@ def test_oracle_ql_degenerate_inputs():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", ["0", "1"])
 @pytest.mark.parametrize("d", [1, 2, 7, 50, 99, 100, 101, 128])
-def test_device_ql_is_bit_identical_to_the_oracle(d):
+def test_device_ql_is_bit_identical_to_the_oracle(d, split, monkeypatch):
+    """ptmi_eig_ql in both forms: one kernel per matrix (few matrices), and reduce -> the scalar chains of all matrices at once ->
+    apply (many matrices: per-walker covariances)."""
+    monkeypatch.setenv("PTMI_QL_SPLIT", split)
     from ptmcmcsampler_amd import _lib
     from ptmcmcsampler_amd.engine import PTEngine
     rs = np.random.RandomState(200 + d)
