@@ -1558,29 +1558,59 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_apply_kernel(double *Ut, do
     const double *zi = q.z + b * n * n;
     for (int i = t; i < n * n; i += QL_THREADS) { const int r = i / n, c = i % n; zt[c * n + r] = zi[i]; }
     const bool redo = q.cnt[2 * b + 1] != 0;                       // the record did not hold this matrix's rotations
-    if (redo) { for (int i = t; i < n; i += QL_THREADS) de[i] = q.de[b * n + i]; }
-    else { for (int i = t; i < n; i += QL_THREADS) de[i] = qls_d2{q.ev[b * n + i], 0.0}; }
-    __syncthreads();
     if (redo) {
+        for (int i = t; i < n; i += QL_THREADS) de[i] = q.de[b * n + i];
+        __syncthreads();
         if (t < 64) ql_iterate<true>(de, n, t, zt, nullptr, nullptr, 0, 0, nullptr);
-    } else if (t < n) {
-        // a thread per row: the recorded rotations in their order; of the two columns a rotation turns, the lower one is the
-        // next rotation's upper one and stays in a register
+    } else {
+        // A thread per row.  The rotations of ONE iteration (at most n - 1 of them) are staged in LDS -- the pairs' 2 n doubles,
+        // free until the eigenvalues go there -- by all threads at once, the next iteration's requested before this one's are
+        // applied (a read of the record per rotation sat on every row's chain with its whole memory round trip: 300 cycles per
+        // rotation).  Of the two columns a rotation turns, the lower one is the next rotation's upper one and stays in a register.
         const int nit = q.cnt[2 * b];
         const int32_t *hdr = q.hdr + b * 2 * (size_t)q.capit;
         const qls_d2 *rot = q.rot + b * (size_t)q.cap;
         int r = 0;
+        int l = nit > 0 ? hdr[0] : 0, m = nit > 0 ? hdr[1] : 0;
+        int ln = nit > 1 ? hdr[2] : 0, mn = nit > 1 ? hdr[3] : 0;  // the (l, m) of the iteration after: known two iterations ahead
+        qls_d2 mine = (nit > 0 && t < m - l) ? rot[t] : qls_d2{0.0, 0.0};
         for (int itn = 0; itn < nit; ++itn) {
-            const int l = hdr[2 * itn], m = hdr[2 * itn + 1];
-            double zb = zt[m * n + t];
-            for (int i = m - 1; i >= l; --i) {
-                const qls_d2 cs = rot[r++];
-                const double za = zt[i * n + t];
-                zt[(i + 1) * n + t] = cs.y * za + cs.x * zb;
-                zb = cs.x * za - cs.y * zb;
+            const int cntr = m - l;
+            __syncthreads();                                        // the previous iteration's rotations have been applied
+            if (t < cntr) de[t] = mine;
+            __syncthreads();
+            r += cntr;
+            const int lnn = itn + 2 < nit ? hdr[2 * itn + 4] : 0, mnn = itn + 2 < nit ? hdr[2 * itn + 5] : 0;
+            if (itn + 1 < nit && t < mn - ln) mine = rot[r + t];
+            if (t < n) {
+                double zb = zt[m * n + t];
+                const double *zp = zt + (size_t)(m - 1) * n + t;    // column i of this thread's row, i descending
+                int j = 0;
+                for (; j + 4 <= cntr; j += 4, zp -= 4 * n) {       // four rotations a trip: their reads go out together
+                    const qls_d2 c0 = de[j], c1 = de[j + 1], c2 = de[j + 2], c3 = de[j + 3];
+                    const double a0 = zp[0], a1 = zp[-n], a2 = zp[-2 * n], a3 = zp[-3 * n];
+                    const_cast<double *>(zp)[n] = c0.y * a0 + c0.x * zb;
+                    zb = c0.x * a0 - c0.y * zb;
+                    const_cast<double *>(zp)[0] = c1.y * a1 + c1.x * zb;
+                    zb = c1.x * a1 - c1.y * zb;
+                    const_cast<double *>(zp)[-n] = c2.y * a2 + c2.x * zb;
+                    zb = c2.x * a2 - c2.y * zb;
+                    const_cast<double *>(zp)[-2 * n] = c3.y * a3 + c3.x * zb;
+                    zb = c3.x * a3 - c3.y * zb;
+                }
+                for (; j < cntr; ++j, zp -= n) {
+                    const qls_d2 cs = de[j];
+                    const double za = zp[0];
+                    const_cast<double *>(zp)[n] = cs.y * za + cs.x * zb;
+                    zb = cs.x * za - cs.y * zb;
+                }
+                zt[l * n + t] = zb;
             }
-            zt[l * n + t] = zb;
+            l = ln; m = mn;
+            ln = lnn; mn = mnn;
         }
+        __syncthreads();
+        for (int i = t; i < n; i += QL_THREADS) de[i] = qls_d2{q.ev[b * n + i], 0.0};
     }
     __syncthreads();
     double *Uo = Ut + b * ut_stride, *So = S + b * s_stride;
