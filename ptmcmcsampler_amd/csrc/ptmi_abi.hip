@@ -1378,21 +1378,32 @@ struct QlScratch {
     int32_t *cnt;       // [nmat][2]     iterations recorded, overflow flag
     int cap, capit;
 };
-__global__ __launch_bounds__(QL_THREADS) void eig_ql_reduce_kernel(const double *cov, int n, QlScratch q)
+// Reduction and accumulation for the three-kernel form, 256 threads: a dot product is the work of an OCT of lanes -- lane c runs chain
+// c of QL_DOT8 (terms k = c, c + 8, ...), the butterfly xor 4, xor 2, xor 1 is the oracle's ((s0 + s4) + (s2 + s6)) + ((s1 + s5) +
+// (s3 + s7)) in every lane -- 32 products at a time; the rank-two update and the column updates are 16 x 16 tilings of their
+// elements.  (A thread per row with the eight chains side by side left the threads of short rows idle and every wave alone on its
+// SIMD: 17 000 cycles per row of the reduction.)
+constexpr int QLR_THREADS = 256;
+__global__ __launch_bounds__(QLR_THREADS) void eig_ql_reduce_kernel(const double *cov, int n, QlScratch q)
 {
     extern __shared__ __attribute__((aligned(16))) double qsm[];
     double *z = qsm, *e = qsm + (((size_t)n * n + 1) & ~(size_t)1), *pq = e + n;
     const int t = (int)threadIdx.x;
+    const int oct = t >> 3, c8 = t & 7, ty = t >> 4, tx = t & 15;
     const double *A = cov + (size_t)blockIdx.x * n * n;
 #define QZ(i, j) z[(i) * n + (j)]
-    for (int i = t; i < n * n; i += QL_THREADS) z[i] = A[i];
+    for (int i = t; i < n * n; i += QLR_THREADS) z[i] = A[i];
     unsigned long long hmask[2] = {0ull, 0ull};
     __syncthreads();
     for (int i = n - 1; i >= 1; --i) {
         const int l = i - 1;
         double h = 0.0;
-        if (l > 0) h = ql_dot8(l + 1, [&](int k) { return QZ(i, k); }, [&](int k) { return QZ(i, k); });
-        if (l == 0 || h == 0.0) {
+        if (l > 0) {
+            double sc = 0.0;
+            for (int k = c8; k <= l; k += 8) { const double v = QZ(i, k); sc = __builtin_fma(v, v, sc); }
+            h = jac_oct_sum(sc);
+        }
+        if (l == 0 || h == 0.0) {                                 // uniform
             if (t == 0) e[i] = QZ(i, l);
             __syncthreads();
             continue;
@@ -1400,23 +1411,26 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_reduce_kernel(const double 
         const double f0 = QZ(i, l);
         const double g0 = f0 >= 0.0 ? -det_sqrt(h) : det_sqrt(h);
         h = h - f0 * g0;
-        __syncthreads();
+        __syncthreads();                                          // every thread has read Z(i, l)
         if (t == 0) { e[i] = g0; QZ(i, l) = f0 - g0; }
         __syncthreads();
-        for (int j = t; j <= l; j += QL_THREADS) {
-            QZ(j, i) = QZ(i, j) / h;
-            const double g = ql_dot8(l + 1, [&](int k) { return k <= j ? QZ(j, k) : QZ(k, j); }, [&](int k) { return QZ(i, k); });
-            pq[j] = g / h;
+        for (int j = oct; j <= l; j += QLR_THREADS / 8) {
+            double sc = 0.0;
+            for (int k = c8; k <= l; k += 8) sc = __builtin_fma(k <= j ? QZ(j, k) : QZ(k, j), QZ(i, k), sc);
+            const double g = jac_oct_sum(sc);
+            if (c8 == 0) { QZ(j, i) = QZ(i, j) / h; pq[j] = g / h; }
         }
         __syncthreads();
-        const double f = ql_dot8(l + 1, [&](int k) { return pq[k]; }, [&](int k) { return QZ(i, k); });
+        double fc = 0.0;
+        for (int k = c8; k <= l; k += 8) fc = __builtin_fma(pq[k], QZ(i, k), fc);
+        const double f = jac_oct_sum(fc);
         const double hh = f / (h + h);
+        __syncthreads();                                          // every thread has its f
+        for (int j = t; j <= l; j += QLR_THREADS) pq[j] = pq[j] - hh * QZ(i, j);
         __syncthreads();
-        for (int j = t; j <= l; j += QL_THREADS) pq[j] = pq[j] - hh * QZ(i, j);
-        __syncthreads();
-        for (int j = t; j <= l; j += QL_THREADS) {
+        for (int j = ty; j <= l; j += 16) {
             const double uj = QZ(i, j), qj = pq[j];
-            for (int k = 0; k <= j; ++k) QZ(j, k) = QZ(j, k) - (uj * pq[k] + qj * QZ(i, k));
+            for (int k = tx; k <= j; k += 16) QZ(j, k) = QZ(j, k) - (uj * pq[k] + qj * QZ(i, k));
         }
         hmask[i >> 6] |= 1ull << (i & 63);
         __syncthreads();
@@ -1424,22 +1438,35 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_reduce_kernel(const double 
     if (t == 0) e[0] = 0.0;
     for (int i = 0; i < n; ++i) {
         const int l = i - 1;
-        if ((hmask[i >> 6] >> (i & 63)) & 1ull) {
-            for (int j = t; j <= l; j += QL_THREADS) {
-                const double g = ql_dot8(l + 1, [&](int k) { return QZ(i, k); }, [&](int k) { return QZ(k, j); });
-                for (int k = 0; k <= l; ++k) QZ(k, j) = QZ(k, j) - g * QZ(k, i);
+        if ((hmask[i >> 6] >> (i & 63)) & 1ull) {                  // uniform
+            // the products g_j of the leading block's columns with row i; row i is dead afterwards (zeroed below) and keeps them
+            double gj[4] = {0.0, 0.0, 0.0, 0.0};
+            int nj = 0;
+            for (int j = oct; j <= l; j += QLR_THREADS / 8, ++nj) {
+                double sc = 0.0;
+                for (int k = c8; k <= l; k += 8) sc = __builtin_fma(QZ(i, k), QZ(k, j), sc);
+                gj[nj & 3] = jac_oct_sum(sc);
+            }
+            __syncthreads();                                      // every product has read row i
+            nj = 0;
+            for (int j = oct; j <= l; j += QLR_THREADS / 8, ++nj)
+                if (c8 == 0) QZ(i, j) = gj[nj & 3];
+            __syncthreads();
+            for (int k = ty; k <= l; k += 16) {
+                const double zki = QZ(k, i);
+                for (int j = tx; j <= l; j += 16) QZ(k, j) = QZ(k, j) - QZ(i, j) * zki;
             }
         }
         __syncthreads();
         if (t == 0) { pq[i] = QZ(i, i); QZ(i, i) = 1.0; }
-        for (int j = t; j <= l; j += QL_THREADS) { QZ(j, i) = 0.0; QZ(i, j) = 0.0; }
+        for (int j = t; j <= l; j += QLR_THREADS) { QZ(j, i) = 0.0; QZ(i, j) = 0.0; }
         __syncthreads();
     }
 #undef QZ
     double *zo = q.z + (size_t)blockIdx.x * n * n;
-    for (int i = t; i < n * n; i += QL_THREADS) zo[i] = z[i];
+    for (int i = t; i < n * n; i += QLR_THREADS) zo[i] = z[i];
     qls_d2 *deo = q.de + (size_t)blockIdx.x * n;
-    for (int i = t; i < n; i += QL_THREADS) deo[i] = qls_d2{pq[i], i + 1 < n ? e[i + 1] : 0.0};
+    for (int i = t; i < n; i += QLR_THREADS) deo[i] = qls_d2{pq[i], i + 1 < n ? e[i + 1] : 0.0};
 }
 
 // the QL iterations on {d, e} pairs in LDS (one wave; every lane runs the scalar recurrence).  ROWS: the lane also turns rows t and
@@ -2681,7 +2708,7 @@ int ptmi_eig_ql(ptmi_handle h)
             HIPCHK(hipFuncSetAttribute((const void *)eig_ql_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(hipFuncSetAttribute((const void *)eig_ql_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        hipLaunchKernelGGL(eig_ql_reduce_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, (const double *)h->buf.cov, d, q);
+        hipLaunchKernelGGL(eig_ql_reduce_kernel, dim3(nmat), dim3(QLR_THREADS), lds, h->stream, (const double *)h->buf.cov, d, q);
         hipLaunchKernelGGL(eig_ql_chain_kernel, dim3(nmat), dim3(64), sizeof(double) * 2 * (size_t)d, h->stream, d, q);
         hipLaunchKernelGGL(eig_ql_apply_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, h->buf.Ut, h->buf.S, d, d * d, d, q);
         HIPCHK(hipGetLastError());
