@@ -891,7 +891,8 @@ __device__ __forceinline__ int logical_block()
 // over one LDS copy of the table; every wave walks over units of 16 chains on its own (no barrier after the set-up), so the
 // occupancy is no longer tied to the number of table copies that fit the LDS,
 // the table is staged 256 times per launch instead of 4096 times, and a block's waves do not wait for its cold wave.
-template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false, int PERS = 0, int PRI = -1 /* PERS: the prior kind */>
+template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false, int PERS = 0, int PRI = -1 /* PERS: the prior kind */,
+          bool TLDS = false /* ULDS with a table copy per block: the draw tables are in LDS too (host: a.tab_off >= 0) */>
 __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
 {
     static_assert(!ULDS || (!STAGE && !FULL && !GRP), "ULDS is the SCAM-only contiguous-layout kernel");
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
             // PERS: the host always places the tables (launch_mh_k), so the read is an LDS read at COMPILE time: with the run-time
             // choice (TM = 2) the two paths merged in an s_waitcnt vmcnt(0) -- every draw pass of a cold wave waited for its AM-row
             // stores to retire, although it never took the global path
-            scam_draws_for_step<STR, PERS ? 1 : (ULDS ? 2 : 0)>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
+            scam_draws_for_step<STR, (PERS || TLDS) ? 1 : (ULDS ? 2 : 0)>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
                 if (ULDS && !ulds_box) return smem[d * d + kk];
                 return det_sqrt(S[kk]);
             }, smem);
@@ -2031,12 +2032,18 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 a.tab_off = (int)even(tab / sizeof(double));
                 tab = sizeof(double) * (size_t)a.tab_off + DRAWT;
             }
-            auto kern = mh_steps_kernel<G, EPL, LOGL, false, false, false, true>;
-            if (tab > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab);
-                if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", tab, hipGetErrorString(e));
-            }
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), tab, h->stream, a);
+            // with the draw tables placed the kernel reads them from LDS at compile time (no vector-memory wait in the step loop: see
+            // the persistent kernel); without room for them the run-time choice stays
+            auto launch_u = [&](auto kern) -> int {
+                if (tab > 64 * 1024) {
+                    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab);
+                    if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", tab, hipGetErrorString(e));
+                }
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), tab, h->stream, a);
+                return PTMI_OK;
+            };
+            if (int rc = a.tab_off >= 0 ? launch_u(mh_steps_kernel<G, EPL, LOGL, false, false, false, true, 0, -1, true>)
+                                        : launch_u(mh_steps_kernel<G, EPL, LOGL, false, false, false, true>)) return rc;
             h->last_variant = PTMI_VAR_LDS_UT | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0) | (a.tab_off >= 0 ? PTMI_VAR_LDS_DRAWT : 0);
             return PTMI_OK;
         }

@@ -16,7 +16,8 @@ b dense_mix_walker --no-cpu-baseline --logl dense --mix default --pick walker --
 b dense_mix_chain --no-cpu-baseline --logl dense --mix default --steps 30 --warmup 110 --ess-window 0
 b scam_rows_nolag --no-cpu-baseline --am-mode rows --eig-lag 0 --ess-window 0        # config 2 as round 3 ran it: every row stored, table applied at once
 b per_walker_lapack --no-cpu-baseline --cov-mode per_walker --steps 20 --warmup 10 --ess-window 0
-b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10 --ess-window 0
+b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_jacobi --steps 30 --warmup 10 --ess-window 0
+b per_walker_ql --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10 --ess-window 0       # tridiagonal QL on the device
 b callback --no-cpu-baseline --callback --steps 10 --warmup 2 --ess-window 0
 b c4_share --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 40 --warmup 20 --ess-window 0
 b c4_mix --no-cpu-baseline --ndim 1000 --nwalkers 512 --mix default --steps 6 --warmup 2 --ess-window 0

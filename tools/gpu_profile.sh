@@ -36,8 +36,8 @@ run mix_stats --stats -- --mix default --steps 20 --warmup 105
 run mix_sq --pmc $MF -- --mix default --steps 10 --warmup 105
 run mix_sq2 --pmc $SQ -- --mix default --steps 10 --warmup 105
 run mixw_stats --stats -- --mix default --pick walker --steps 20 --warmup 105
-# per-walker covariance: device Jacobi eigensolver
-run pwd_stats --stats -- --cov-mode per_walker_device --steps 20 --warmup 5
+# per-walker covariance: the device's tridiagonal QL eigensolver (reduce / chain / apply kernels)
+run pwd_stats --stats -- --cov-mode per_walker_device --steps 20 --warmup 10
 # config 5 shape on one GPU (curved likelihood, SCAM / DE / NUTS) and config 4's share of one GPU (1000-d, 64 x 512 chains)
 run c5_stats --stats -- --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 4 --warmup 2
 run c4_stats --stats -- --ndim 1000 --nwalkers 512 --steps 30 --warmup 20
