@@ -558,19 +558,59 @@ __host__ __device__ inline int pool_groups(int d) { return (d + 1 + PS_W - 1) / 
 // part of the definition (summation order): oracle/oracle.py pool_slab is the same rule
 static inline int pool_slab(int nwalkers, int d) { const int target = d + 1 <= PS_W ? 512 : 32; const int s = (nwalkers + target - 1) / target; return s < 1 ? 1 : s; }
 // RLE (AM row flags, ptmi_common.h): a slab's matrix is not its rows but its STORED rows, each scaled by the square root of the
-// length of its run (pool_rle_kernel lists them: src = the row, wgt = sqrt(run length)): sum over runs of n dx dx^T as
-// (sqrt(n) dx) (sqrt(n) dx)^T, column d of the staged matrix holding sqrt(n) so that the column sums come out as sum n dx.
+// length of its run (pool_rle_kernel lists them: PoolEnt = the row inside the slab and sqrt(run length)): sum over runs of n dx dx^T
+// as (sqrt(n) dx) (sqrt(n) dx)^T, column d of the staged matrix holding sqrt(n) so that the column sums come out as sum n dx.
 // The oracle defines the same sums (orc_pool_update_rle): 43 % fewer rows to read, stage and multiply at the stationary
 // acceptance of a SCAM cycle.  A stager needs the list entry before it can ask for the row: the entries of chunk i + 2 are
 // requested while the rows of chunk i + 1 are in flight and chunk i is multiplied.
-struct PoolRle { const int32_t *src; const double *wgt; const int32_t *cnt; };
-template <bool DIAG, bool RLE>
+// Round 4, second form (the first took 1.22 ms per epoch at 4096 x 1000 x 100 against 0.42 ms of matrix instructions: 350 vector
+// instructions of 64-bit index arithmetic and selects per wave and chunk beside the 56 matrix ones, which the f64 matrix pipe does
+// not overlap): the macro tile lives in POSITION space -- column p of the staged matrix is position p of a buffered row, whatever
+// parameter am_pos put there; an element's k-ascending fma chain does not care where its column sits, the epilogue maps the
+// pair back with am_inv -- so a stager takes 16 bytes of a row per load (PAIR: d even) at a 32-bit offset from the slab's base;
+// a dead row is a zero weight, not a select per element; the waves' tiles are compile-time lists (row-major runs: a wave's
+// fragments are read from LDS once per k-step, 7 instead of 14 on the diagonal, 10 instead of 26 off it).
+struct PoolEnt { double wgt; int32_t src; int32_t pad; };
+struct PoolRle { const PoolEnt *ent; const int32_t *cnt; };
+typedef double ps_d2 __attribute__((ext_vector_type(2)));
+// tiles of wave wv: on the diagonal tile rows wv and 7 - wv (7 tiles each wave), off it the row-major run [1 + 12 wv, ...) of the 49
+constexpr int ps_nt(bool diag, int wv) { return diag ? 7 : (wv == 0 ? 13 : 12); }
+constexpr int ps_t0(int wv) { return wv == 0 ? 0 : 1 + 12 * wv; }
+constexpr int ps_ti(bool diag, int wv, int n) { return diag ? (n < 7 - wv ? wv : 7 - wv) : (ps_t0(wv) + n) / 7; }
+constexpr int ps_tj(bool diag, int wv, int n) { return diag ? (n < 7 - wv ? wv + n : n) : (ps_t0(wv) + n) % 7; }
+template <bool DIAG, int WV>
+__device__ __forceinline__ void ps_mma(const double *Ab, const double *Bb, ps_d4 (&acc)[DIAG ? 7 : 13])
+{
+#pragma unroll
+    for (int k0 = 0; k0 < ps_rc(DIAG); k0 += 4)
+#pragma unroll
+        for (int n = 0; n < ps_nt(DIAG, WV); ++n)
+            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + 16 * ps_ti(DIAG, WV, n)], Bb[k0 * PS_W + 16 * ps_tj(DIAG, WV, n)], acc[n], 0, 0, 0);
+}
+template <bool DIAG, int WV>
+__device__ __forceinline__ void ps_store(const ps_d4 (&acc)[DIAG ? 7 : 13], double *out, int I, int J, int d, int am_epl, int g, int c)
+{
+#pragma unroll
+    for (int n = 0; n < ps_nt(DIAG, WV); ++n) {
+        const int ti = ps_ti(DIAG, WV, n), tj = ps_tj(DIAG, WV, n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pi = I * PS_W + 16 * ti + g + 4 * r, pj = J * PS_W + 16 * tj + c;
+            if (pi < d && pj <= d && (!(DIAG && ti == tj) || pi <= pj)) {
+                const int ci = am_inv(pi, am_epl), cj = pj < d ? am_inv(pj, am_epl) : d;
+                const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
+                out[(size_t)lo * (d + 1) + hi] = acc[n][r];
+            }
+        }
+    }
+}
+template <bool DIAG, bool RLE, bool PAIR>
 __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, long long nrows, int d, const double *shift,
                                                                      long long rows_per_slab, double *part, int am_epl,
                                                                      int shift_epl /* row format of `shift` (an AM row at the first epoch) */,
                                                                      PoolRle rl)
 {
-    constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG);
+    constexpr int NTW = DIAG ? 7 : 13, NA = DIAG ? 1 : 2, PS_RC = ps_rc(DIAG), NU = PS_RC / 4;
     __shared__ double Dl[NA][2][PS_RC][PS_W];
     const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, g = lane >> 4;
@@ -583,123 +623,130 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
         J = I + 1 + p;
     }
     const long long beg = (long long)blockIdx.x * rows_per_slab;
-    // RLE: the loop runs over the slab's LIST (entries beg .. beg + count - 1 of src / wgt), not over its rows
-    const long long end = RLE ? beg + rl.cnt[blockIdx.x] : (beg + rows_per_slab < nrows ? beg + rows_per_slab : nrows);
-    // tiles of this wave: offsets of their A (rows of the output) and B (columns) fragments inside the macro tile
-    int offa[NTW], offb[NTW];
-    bool on[NTW];
+    // the loop runs over the slab's LIST: RLE its stored rows (entries 0 .. count - 1 of ent), else its rows
+    const int nlist = RLE ? rl.cnt[blockIdx.x] : (int)(beg + rows_per_slab < nrows ? rows_per_slab : nrows - beg);
+    const char *slab = (const char *)(rows + beg * d);      // byte offsets inside a slab fit 32 bits (checked by the host)
+    const PoolEnt *ent = RLE ? rl.ent + beg : nullptr;
     ps_d4 acc[NTW];
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        int ti, tj;
-        if (DIAG) {
-            int t = 7 * wave + n, row = 7;
-            ti = 0;
-            while (t >= row) { t -= row; ++ti; --row; }
-            tj = ti + t;
-            on[n] = true;
-        } else {
-            const int t = wave + 4 * n;
-            on[n] = t < 49;
-            ti = on[n] ? t / 7 : 0;
-            tj = on[n] ? t % 7 : 0;
+    for (int n = 0; n < NTW; ++n) acc[n] = ps_d4{0.0, 0.0, 0.0, 0.0};
+    // staging: a wave's lanes 16 r4 + (q & 15) own the position pair (2 q, 2 q + 1) of the macro tile(s) and rows r4, r4 + 4, ... of a
+    // chunk: a load instruction takes 256 contiguous bytes of four rows, an LDS store fills all the banks
+    const int q = 16 * wave + c, r4 = g;
+    const bool stager = q < PS_W / 2;
+    unsigned colb[NA][2];           // byte offset of the elements' positions inside a row (clamped into it)
+    double sh[NA][2], one[NA][2];
+    bool dat[NA][2];
+    bool plain = true;
+#pragma unroll
+    for (int a2 = 0; a2 < NA; ++a2)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int p = (a2 == 0 ? I : J) * PS_W + 2 * q + e;
+            dat[a2][e] = p < d;
+            const int pc = PAIR ? (p - e < d ? p : d - 2 + e) : (p < d ? p : d - 1);
+            colb[a2][e] = 8u * (unsigned)pc;
+            sh[a2][e] = (stager && p < d) ? shift[am_pos(am_inv(p, am_epl), shift_epl)] : 0.0;
+            one[a2][e] = p == d ? 1.0 : 0.0;
+            plain = plain && (dat[a2][e] || !stager);
         }
-        offa[n] = __builtin_amdgcn_readfirstlane(ti * 16);
-        offb[n] = __builtin_amdgcn_readfirstlane(tj * 16);
-        acc[n] = ps_d4{0.0, 0.0, 0.0, 0.0};
-    }
-    // staging: threads 0..223 own one column of the macro tile(s) and every other row of a chunk
-    const int scol = (int)threadIdx.x % PS_W, srow = (int)threadIdx.x / PS_W;     // srow 0 / 1 (2: idle)
-    const bool stager = srow < 2;
-    int gc[NA];
-    double sh[NA];
-#pragma unroll
-    for (int a2 = 0; a2 < NA; ++a2) {
-        gc[a2] = (a2 == 0 ? I : J) * PS_W + scol;
-        sh[a2] = (stager && gc[a2] < d) ? shift[am_pos(gc[a2], shift_epl)] : 0.0;
-    }
-    // Loads are unconditional (row and column clamped into the slab: a branch per load made every one of them wait for its
-    // own round trip, 2.6 ms per epoch); what a slot really holds is decided when it is staged.
-    double v[NA][PS_RC / 2];
-    double wg[RLE ? PS_RC / 2 : 1];              // RLE: sqrt(run length) of the rows in v
-    int nsrc[RLE ? PS_RC / 2 : 1];               // RLE: the rows of the chunk after the one in v
-    int gcl[NA];
-#pragma unroll
-    for (int a2 = 0; a2 < NA; ++a2) gcl[a2] = am_pos(gc[a2] < d ? gc[a2] : d - 1, am_epl);      // where the column sits in a buffered row
-    long long vr0 = beg;
-    auto list = [&](long long r0) {              // RLE: request the list entries of the chunk that starts at entry r0
+    const bool wave_plain = __all(plain);                   // no ones / padding column among this wave's stagers: no selects at all
+    const unsigned rstride = 8u * (unsigned)d;
+    // Loads are unconditional (list index and column clamped: a branch per load made every one of them wait for its own round
+    // trip, 2.6 ms per epoch); what a slot really holds is decided when it is staged.
+    ps_d2 v[NA][NU];
+    double wg[NU];                 // weight of the rows in v: sqrt(run length) (RLE) or 1, zero past the end of the list
+    int nsrc[RLE ? NU : 1];        // RLE: rows and weights of the chunk after the one in v
+    double nwg[RLE ? NU : 1];
+    auto list = [&](int j0) {      // RLE: request the list entries of the chunk that starts at entry j0
         if constexpr (RLE) {
 #pragma unroll
-            for (int u = 0; u < PS_RC / 2; ++u) {
-                const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
-                nsrc[u] = rl.src[rc];
+            for (int u = 0; u < NU; ++u) {
+                const int j = j0 + 4 * u + r4, jc = j < nlist ? j : nlist - 1;
+                const ps_d2 e2 = *(const ps_d2 *)(ent + jc);
+                nwg[u] = e2.x;
+                nsrc[u] = (int)(__double_as_longlong(e2.y) & 0xffffffffll);
             }
         }
     };
-    auto fetch = [&](long long r0) {
-        vr0 = r0;
+    auto fetch = [&](int j0) {
 #pragma unroll
-        for (int u = 0; u < PS_RC / 2; ++u) {
-            const long long r = r0 + 2 * u + srow, rc = r < end ? r : end - 1;
-            const long long row = RLE ? (long long)nsrc[u] : rc;
-            if constexpr (RLE) wg[u] = rl.wgt[rc];
+        for (int u = 0; u < NU; ++u) {
+            const int j = j0 + 4 * u + r4, jc = j < nlist ? j : nlist - 1;
+            const unsigned rb = (unsigned)(RLE ? nsrc[u] : jc) * rstride;
+            wg[u] = j < nlist ? (RLE ? nwg[u] : 1.0) : 0.0;
 #pragma unroll
-            for (int a2 = 0; a2 < NA; ++a2) v[a2][u] = rows[row * d + gcl[a2]];
+            for (int a2 = 0; a2 < NA; ++a2) {
+                if constexpr (PAIR) v[a2][u] = *(const ps_d2 *)(slab + (rb + colb[a2][0]));
+                else {
+                    v[a2][u].x = *(const double *)(slab + (rb + colb[a2][0]));
+                    v[a2][u].y = *(const double *)(slab + (rb + colb[a2][1]));
+                }
+            }
         }
     };
     auto stage = [&](int buf) {
-        if (stager) {
+        if (!stager) return;
+        if (wave_plain) {
 #pragma unroll
             for (int a2 = 0; a2 < NA; ++a2)
 #pragma unroll
-                for (int u = 0; u < PS_RC / 2; ++u) {
-                    const bool live = vr0 + 2 * u + srow < end;
-                    double x = gc[a2] < d ? v[a2][u] - sh[a2] : (gc[a2] == d ? 1.0 : 0.0);
-                    if constexpr (RLE) x = x * wg[u];
-                    Dl[a2][buf][2 * u + srow][scol] = live ? x : 0.0;
+                for (int u = 0; u < NU; ++u) {
+                    ps_d2 x;
+                    x.x = (v[a2][u].x - sh[a2][0]) * wg[u];
+                    x.y = (v[a2][u].y - sh[a2][1]) * wg[u];
+                    *(ps_d2 *)&Dl[a2][buf][4 * u + r4][2 * q] = x;
+                }
+        } else {
+#pragma unroll
+            for (int a2 = 0; a2 < NA; ++a2)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    ps_d2 x;
+                    x.x = (dat[a2][0] ? v[a2][u].x - sh[a2][0] : one[a2][0]) * wg[u];
+                    x.y = (dat[a2][1] ? v[a2][u].y - sh[a2][1] : one[a2][1]) * wg[u];
+                    *(ps_d2 *)&Dl[a2][buf][4 * u + r4][2 * q] = x;
                 }
         }
     };
-    list(beg);
-    fetch(beg);
-    list(beg + PS_RC);
-    stage(0);
+    if (nlist > 0) {
+        list(0);
+        fetch(0);
+        list(PS_RC);
+        stage(0);
+    }
     __syncthreads();
     int buf = 0;
-    for (long long r0 = beg; r0 < end; r0 += PS_RC) {
-        const bool more = r0 + PS_RC < end;
+    for (int j0 = 0; j0 < nlist; j0 += PS_RC) {
+        const bool more = j0 + PS_RC < nlist;
         if (more) {
-            fetch(r0 + PS_RC);
-            list(r0 + 2 * PS_RC);
+            fetch(j0 + PS_RC);
+            list(j0 + 2 * PS_RC);
         }
         const double *Ab = &Dl[0][buf][0][0] + g * PS_W + c, *Bb = &Dl[NA - 1][buf][0][0] + g * PS_W + c;
-#pragma unroll
-        for (int k0 = 0; k0 < PS_RC; k0 += 4) {
-#pragma unroll
-            for (int n = 0; n < NTW; ++n)
-                if (on[n]) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + offa[n]], Bb[k0 * PS_W + offb[n]], acc[n], 0, 0, 0);
+        switch (wave) {
+        case 0: ps_mma<DIAG, 0>(Ab, Bb, acc); break;
+        case 1: ps_mma<DIAG, 1>(Ab, Bb, acc); break;
+        case 2: ps_mma<DIAG, 2>(Ab, Bb, acc); break;
+        default: ps_mma<DIAG, 3>(Ab, Bb, acc); break;
         }
         if (more) stage(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
     double *out = part + (size_t)blockIdx.x * d * (d + 1);
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        if (!on[n]) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = I * PS_W + offa[n] + g + 4 * r, j = J * PS_W + offb[n] + c;
-            if (i < d && j <= d && i <= j) out[(size_t)i * (d + 1) + j] = acc[n][r];
-        }
+    switch (wave) {
+    case 0: ps_store<DIAG, 0>(acc, out, I, J, d, am_epl, g, c); break;
+    case 1: ps_store<DIAG, 1>(acc, out, I, J, d, am_epl, g, c); break;
+    case 2: ps_store<DIAG, 2>(acc, out, I, J, d, am_epl, g, c); break;
+    default: ps_store<DIAG, 3>(acc, out, I, J, d, am_epl, g, c); break;
     }
 }
 
 // The list of a slab's stored rows (AM row flags) and the square roots of their run lengths: entry j of slab s (at beg + j) is the
 // j-th row of the slab whose flag word says NEW or KEY; its run ends where the next stored row begins (ring row 0 of every walker is
 // a KEY row, so a run never crosses into another walker's ring) or at the slab's end.  One block per slab, rows in order.
-__global__ __launch_bounds__(256) void pool_rle_kernel(const AmFlag *flag, long long nrows, long long rows_per_slab, int32_t *src, double *wgt,
-                                                       int32_t *cnt)
+__global__ __launch_bounds__(256) void pool_rle_kernel(const AmFlag *flag, long long nrows, long long rows_per_slab, PoolEnt *ent, int32_t *cnt)
 {
     __shared__ int wsum[4], base_s;
     const long long beg = (long long)blockIdx.x * rows_per_slab;
@@ -715,7 +762,7 @@ __global__ __launch_bounds__(256) void pool_rle_kernel(const AmFlag *flag, long 
         __syncthreads();
         int off = base_s + (int)__popcll(m & ((1ull << lane) - 1ull));
         for (int k = 0; k < wave; ++k) off += wsum[k];
-        if (em) src[beg + off] = (int32_t)r;
+        if (em) ent[beg + off].src = (int32_t)(r - beg);
         __syncthreads();
         if (threadIdx.x == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
@@ -723,8 +770,8 @@ __global__ __launch_bounds__(256) void pool_rle_kernel(const AmFlag *flag, long 
     const int n = base_s;
     if (threadIdx.x == 0) cnt[blockIdx.x] = n;
     for (int j = (int)threadIdx.x; j < n; j += 256) {
-        const long long here = src[beg + j], next = j + 1 < n ? (long long)src[beg + j + 1] : end;
-        wgt[beg + j] = det_sqrt((double)(next - here));
+        const long long here = ent[beg + j].src, next = j + 1 < n ? (long long)ent[beg + j + 1].src : end - beg;
+        ent[beg + j].wgt = det_sqrt((double)(next - here));
     }
 }
 
@@ -2057,8 +2104,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_pool_T, sizeof(double) * (size_t)c.ndim * (c.ndim + 1));
         if (buf->AMflag) {                                                // the slabs' lists of stored rows (pool_rle_kernel)
             const size_t nrows = (size_t)c.nwalkers * c.cov_update;
-            if (e == hipSuccess) e = hipMalloc((void **)&h->d_rle_src, sizeof(int32_t) * nrows);
-            if (e == hipSuccess) e = hipMalloc((void **)&h->d_rle_wgt, sizeof(double) * nrows);
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_rle_ent, sizeof(PoolEnt) * nrows);
             if (e == hipSuccess) e = hipMalloc((void **)&h->d_rle_cnt, sizeof(int32_t) * (size_t)nslab);
         }
     }
@@ -2092,7 +2138,7 @@ int ptmi_destroy(ptmi_handle h)
     if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
     (void)hipFree(h->d_ql_scr);
-    (void)hipFree(h->d_rle_src); (void)hipFree(h->d_rle_wgt); (void)hipFree(h->d_rle_cnt);
+    (void)hipFree(h->d_rle_ent); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->side_go); (void)hipEventDestroy(h->side_done); }
@@ -2617,12 +2663,25 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
         // (1000-d, 512 walkers: 288 blocks beside 1152 with 512 resident at a time).
         hipStream_t diag_stream = h->stream;
         // AM row flags: the slabs' lists of stored rows and run lengths first, then the sums over them
-        const bool rle = h->buf.AMflag != nullptr;
-        const PoolRle pr = {h->d_rle_src, h->d_rle_wgt, h->d_rle_cnt};
+        const bool rle = h->buf.AMflag != nullptr, pair = d % 2 == 0;
+        const PoolRle pr = {(const PoolEnt *)h->d_rle_ent, h->d_rle_cnt};
         const long long rps = (long long)SL * c.cov_update;
+        if (rps * d * 8 >= (1ll << 32)) return fail(PTMI_EUNSUPPORTED, "pooled statistics: a slab of %d walkers x %d rows x %d parameters exceeds 4 GB", SL, c.cov_update, d);
         const int aepl = am_row_epl(h->G, h->EPL), sepl = first ? am_row_epl(h->G, h->EPL) : 0;
-        if (rle) hipLaunchKernelGGL(pool_rle_kernel, dim3(nslab), dim3(256), 0, h->stream, (const AmFlag *)h->buf.AMflag, nrows, rps, h->d_rle_src,
-                                    h->d_rle_wgt, h->d_rle_cnt);
+        if (rle) hipLaunchKernelGGL(pool_rle_kernel, dim3(nslab), dim3(256), 0, h->stream, (const AmFlag *)h->buf.AMflag, nrows, rps, (PoolEnt *)h->d_rle_ent,
+                                    h->d_rle_cnt);
+        auto syrk = [&](auto diag, dim3 grid, hipStream_t st) {
+            constexpr bool DG = decltype(diag)::value;
+            const void *fn = rle ? (pair ? (const void *)pool_syrk_kernel<DG, true, true> : (const void *)pool_syrk_kernel<DG, true, false>)
+                                 : (pair ? (const void *)pool_syrk_kernel<DG, false, true> : (const void *)pool_syrk_kernel<DG, false, false>);
+            const double *rows = (const double *)h->buf.AM;
+            long long nr = nrows, rp = rps;
+            int dd = d, ae = aepl, se = sepl;
+            double *part = h->d_pool_part;
+            PoolRle prl = pr;
+            void *args[] = {&rows, &nr, &dd, (void *)&shift, &rp, &part, &ae, &se, &prl};
+            return hipLaunchKernel(fn, grid, dim3(256), args, 0, st);
+        };
         if (ng > 1) {
             if (!h->side) {
                 HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -2631,16 +2690,10 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
             }
             HIPCHK(hipEventRecord(h->side_go, h->stream));
             HIPCHK(hipStreamWaitEvent(h->side, h->side_go, 0));
-            if (rle) hipLaunchKernelGGL((pool_syrk_kernel<false, true>), dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
-                                        shift, rps, h->d_pool_part, aepl, sepl, pr);
-            else hipLaunchKernelGGL((pool_syrk_kernel<false, false>), dim3(nslab, ng * (ng - 1) / 2), dim3(256), 0, h->stream, (const double *)h->buf.AM, nrows, d,
-                                    shift, rps, h->d_pool_part, aepl, sepl, pr);
+            HIPCHK(syrk(std::false_type{}, dim3(nslab, ng * (ng - 1) / 2), h->stream));
             diag_stream = h->side;
         }
-        if (rle) hipLaunchKernelGGL((pool_syrk_kernel<true, true>), dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
-                                    rps, h->d_pool_part, aepl, sepl, pr);
-        else hipLaunchKernelGGL((pool_syrk_kernel<true, false>), dim3(nslab, ng), dim3(256), 0, diag_stream, (const double *)h->buf.AM, nrows, d, shift,
-                                rps, h->d_pool_part, aepl, sepl, pr);
+        HIPCHK(syrk(std::true_type{}, dim3(nslab, ng), diag_stream));
         if (ng > 1) {
             HIPCHK(hipEventRecord(h->side_done, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->side_done, 0));

@@ -29,6 +29,13 @@ __host__ __device__ inline int am_pos(int i, int epl)
     const int e = i >> 2, ln = i & 3;
     return e < 2 * (epl / 2) ? 8 * (e >> 1) + 2 * ln + (e & 1) : 8 * (epl / 2) + ln;
 }
+// the parameter held at position p of such a row (the inverse of am_pos)
+__host__ __device__ inline int am_inv(int p, int epl)
+{
+    if (epl == 0) return p;
+    const int h = 8 * (epl / 2);
+    return p < h ? ((p & 7) >> 1) + 4 * (2 * (p >> 3) + (p & 1)) : (p - h) + 4 * (epl - 1);
+}
 constexpr int am_row_epl(int G, int EPL) { return (G == 4 && EPL == 25) ? EPL : 0; }      // = ptmi_shape_exact (declared below)
 
 // AM row flags (ptmi_buffers.AMflag, include/ptmi.h): one 8-byte word beside every row of the AM buffer.  A rejected proposal
@@ -136,8 +143,8 @@ struct ptmi_engine {
     hipStream_t side;            // pooled statistics at ndim > 111: the diagonal macro tiles run beside the off-diagonal ones
     hipEvent_t side_go, side_done;
     void *d_ql_scr;              // ptmi_eig_ql with many matrices: the transformations, tridiagonal matrices and recorded rotations (QlScratch)
-    int32_t *d_rle_src;          // pooled statistics over run-length-compacted rows: the stored rows of each slab [nrows] ...
-    double *d_rle_wgt;           // ... the square roots of their run lengths [nrows] ...
+    void *d_rle_ent;             // pooled statistics over run-length-compacted rows: the stored rows of each slab, 16 bytes each [nrows]
+                                 // (PoolEnt, ptmi_abi.hip: the row inside its slab, the square root of its run length) ...
     int32_t *d_rle_cnt;          // ... and how many each slab has [nslab]
     const double *rp_swap_u;     // TEST HOOK (ptmi_test_replay): the swap's uniforms [W][ntemps_global - 1] instead of the Philox ones
     const u64 *rp_draws;         // TEST HOOK: see KArgs
