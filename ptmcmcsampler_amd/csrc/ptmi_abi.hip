@@ -541,7 +541,8 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
 // dx = x - (the running pooled mean): a symmetric rank-k update with no recurrence in it, so the rows go straight from
 // memory through LDS into v_mfma_f64_16x16x4_f64, whose k-ascending fma chain is the oracle's row-ascending definition.
 // The column sums come out of the same instructions: column d of dx is the constant 1.
-// Grid: (slab, macro tile).  A slab is a contiguous run of rows (pool_slab walkers); a macro tile is 112 x 112 outputs
+// Grid: (macro tile, slab): the tiles of a slab are neighbours in launch order, so that its rows, wanted by every one of them, are
+// read from memory once and from the caches after that.  A slab is a contiguous run of rows (pool_slab walkers); a macro tile is 112 x 112 outputs
 // (7 x 7 matrix tiles) of the columns [112 I, 112 I + 112) x [112 J, 112 J + 112), I <= J.  DIAG (I == J): the 28 tiles with
 // ti <= tj, seven per wave; else all 49, 13 / 12 / 12 / 12.  Rows are staged 32 at a time (eight k-steps) in a double-buffered LDS
 // chunk, the next chunk's global loads in flight during the matrix work; one barrier per chunk.  Each block writes its
@@ -569,13 +570,13 @@ static inline int pool_slab(int nwalkers, int d) { const int target = d + 1 <= P
 // parameter am_pos put there; an element's k-ascending fma chain does not care where its column sits, the epilogue maps the
 // pair back with am_inv -- so a stager takes 16 bytes of a row per load (PAIR: d even) at a 32-bit offset from the slab's base;
 // a dead row is a zero weight, not a select per element; the waves' tiles are compile-time lists (row-major runs: a wave's
-// fragments are read from LDS once per k-step, 7 instead of 14 on the diagonal, 10 instead of 26 off it).
+// fragments are read from LDS once per k-step on the diagonal, 7 instead of 14).
 struct PoolEnt { double wgt; int32_t src; int32_t pad; };
 struct PoolRle { const PoolEnt *ent; const int32_t *cnt; };
 typedef double ps_d2 __attribute__((ext_vector_type(2)));
 // tiles of wave wv: on the diagonal tile rows wv and 7 - wv (7 tiles each wave), off it the row-major run [1 + 12 wv, ...) of the 49
 constexpr int ps_nt(bool diag, int wv) { return diag ? 7 : (wv == 0 ? 13 : 12); }
-constexpr int ps_t0(int wv) { return wv == 0 ? 0 : 1 + 12 * wv; }
+__host__ __device__ constexpr int ps_t0(int wv) { return wv == 0 ? 0 : 1 + 12 * wv; }
 constexpr int ps_ti(bool diag, int wv, int n) { return diag ? (n < 7 - wv ? wv : 7 - wv) : (ps_t0(wv) + n) / 7; }
 constexpr int ps_tj(bool diag, int wv, int n) { return diag ? (n < 7 - wv ? wv + n : n) : (ps_t0(wv) + n) % 7; }
 template <bool DIAG, int WV>
@@ -615,21 +616,32 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
     const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = lane & 15, g = lane >> 4;
     const int ng = pool_groups(d);
-    int I = (int)blockIdx.y, J = (int)blockIdx.y;
-    if (!DIAG) {                                            // blockIdx.y enumerates the pairs I < J row by row
-        int p = (int)blockIdx.y;
+    int I = (int)blockIdx.x, J = (int)blockIdx.x;
+    if (!DIAG) {                                            // blockIdx.x enumerates the pairs I < J row by row
+        int p = (int)blockIdx.x;
         I = 0;
         while (p >= ng - 1 - I) { p -= ng - 1 - I; ++I; }
         J = I + 1 + p;
     }
-    const long long beg = (long long)blockIdx.x * rows_per_slab;
+    const long long beg = (long long)blockIdx.y * rows_per_slab;
     // the loop runs over the slab's LIST: RLE its stored rows (entries 0 .. count - 1 of ent), else its rows
-    const int nlist = RLE ? rl.cnt[blockIdx.x] : (int)(beg + rows_per_slab < nrows ? rows_per_slab : nrows - beg);
+    const int nlist = RLE ? rl.cnt[blockIdx.y] : (int)(beg + rows_per_slab < nrows ? rows_per_slab : nrows - beg);
     const char *slab = (const char *)(rows + beg * d);      // byte offsets inside a slab fit 32 bits (checked by the host)
     const PoolEnt *ent = RLE ? rl.ent + beg : nullptr;
     ps_d4 acc[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) acc[n] = ps_d4{0.0, 0.0, 0.0, 0.0};
+    // off the diagonal a wave's tiles are the run [ps_t0(wave), ...) of the 49, their fragments' offsets in scalar registers (four
+    // compile-time copies of 13 accumulators' code spilled 93 registers)
+    int offa[DIAG ? 1 : NTW], offb[DIAG ? 1 : NTW];
+    if constexpr (!DIAG) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int t = ps_t0(wave) + n < 49 ? ps_t0(wave) + n : 48;
+            offa[n] = __builtin_amdgcn_readfirstlane(16 * (t / 7));
+            offb[n] = __builtin_amdgcn_readfirstlane(16 * (t % 7));
+        }
+    }
     // staging: a wave's lanes 16 r4 + (q & 15) own the position pair (2 q, 2 q + 1) of the macro tile(s) and rows r4, r4 + 4, ... of a
     // chunk: a load instruction takes 256 contiguous bytes of four rows, an LDS store fills all the banks
     const int q = 16 * wave + c, r4 = g;
@@ -724,22 +736,46 @@ __global__ __launch_bounds__(256, 2) void pool_syrk_kernel(const double *rows, l
             list(j0 + 2 * PS_RC);
         }
         const double *Ab = &Dl[0][buf][0][0] + g * PS_W + c, *Bb = &Dl[NA - 1][buf][0][0] + g * PS_W + c;
-        switch (wave) {
-        case 0: ps_mma<DIAG, 0>(Ab, Bb, acc); break;
-        case 1: ps_mma<DIAG, 1>(Ab, Bb, acc); break;
-        case 2: ps_mma<DIAG, 2>(Ab, Bb, acc); break;
-        default: ps_mma<DIAG, 3>(Ab, Bb, acc); break;
+        if constexpr (DIAG) {
+            switch (wave) {
+            case 0: ps_mma<DIAG, 0>(Ab, Bb, acc); break;
+            case 1: ps_mma<DIAG, 1>(Ab, Bb, acc); break;
+            case 2: ps_mma<DIAG, 2>(Ab, Bb, acc); break;
+            default: ps_mma<DIAG, 3>(Ab, Bb, acc); break;
+            }
+        } else {
+#pragma unroll
+            for (int k0 = 0; k0 < PS_RC; k0 += 4)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+                    if (n < 12 || wave == 0) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[k0 * PS_W + offa[n]], Bb[k0 * PS_W + offb[n]], acc[n], 0, 0, 0);
         }
         if (more) stage(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-    double *out = part + (size_t)blockIdx.x * d * (d + 1);
-    switch (wave) {
-    case 0: ps_store<DIAG, 0>(acc, out, I, J, d, am_epl, g, c); break;
-    case 1: ps_store<DIAG, 1>(acc, out, I, J, d, am_epl, g, c); break;
-    case 2: ps_store<DIAG, 2>(acc, out, I, J, d, am_epl, g, c); break;
-    default: ps_store<DIAG, 3>(acc, out, I, J, d, am_epl, g, c); break;
+    double *out = part + (size_t)blockIdx.y * d * (d + 1);
+    if constexpr (DIAG) {
+        switch (wave) {
+        case 0: ps_store<DIAG, 0>(acc, out, I, J, d, am_epl, g, c); break;
+        case 1: ps_store<DIAG, 1>(acc, out, I, J, d, am_epl, g, c); break;
+        case 2: ps_store<DIAG, 2>(acc, out, I, J, d, am_epl, g, c); break;
+        default: ps_store<DIAG, 3>(acc, out, I, J, d, am_epl, g, c); break;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            if (!(n < 12 || wave == 0)) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pi = I * PS_W + offa[n] + g + 4 * r, pj = J * PS_W + offb[n] + c;
+                if (pi < d && pj <= d) {
+                    const int ci = am_inv(pi, am_epl), cj = pj < d ? am_inv(pj, am_epl) : d;
+                    const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
+                    out[(size_t)lo * (d + 1) + hi] = acc[n][r];
+                }
+            }
+        }
     }
 }
 
@@ -2690,10 +2726,10 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
             }
             HIPCHK(hipEventRecord(h->side_go, h->stream));
             HIPCHK(hipStreamWaitEvent(h->side, h->side_go, 0));
-            HIPCHK(syrk(std::false_type{}, dim3(nslab, ng * (ng - 1) / 2), h->stream));
+            HIPCHK(syrk(std::false_type{}, dim3(ng * (ng - 1) / 2, nslab), h->stream));
             diag_stream = h->side;
         }
-        HIPCHK(syrk(std::true_type{}, dim3(nslab, ng), diag_stream));
+        HIPCHK(syrk(std::true_type{}, dim3(ng, nslab), diag_stream));
         if (ng > 1) {
             HIPCHK(hipEventRecord(h->side_done, h->side));
             HIPCHK(hipStreamWaitEvent(h->stream, h->side_done, 0));
