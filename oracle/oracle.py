@@ -108,6 +108,7 @@ def lib():
         L.orc_logl.argtypes = [C.POINTER(Cfg), _dp]
         L.orc_eig_jacobi.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int]
         L.orc_eig_ql.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.orc_div_by_count.argtypes = [C.c_long, _dp, _dp, _dp]
         assert L.orc_sizeof_cfg() == C.sizeof(Cfg)
         _lib = L
     return _lib
@@ -175,6 +176,15 @@ def eig_ql(cov):
     n = lib().orc_eig_ql(d, _p(cov), _p(Ut), _p(S))
     assert n >= 0, "QL did not converge"
     return Ut, S, n
+
+
+def div_by_count(a, n):
+    """a / n the way welford_rows_kernel forms it (reciprocal + two remainder corrections): must equal a / n exactly."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    n = np.ascontiguousarray(n, dtype=np.float64)
+    out = np.empty_like(a)
+    lib().orc_div_by_count(len(a), _p(a), _p(n), _p(out))
+    return out
 
 
 def welford(AM, mu, M2, it, fused=False):

@@ -1395,3 +1395,19 @@ ORC_API int orc_eig_ql(int n, const double *cov, double *Ut, double *S)
 }
 
 ORC_API int orc_sizeof_cfg(void) { return (int)sizeof(orc_cfg); }
+
+/* The running mean's division as welford_rows_kernel does it (ptmi_abi.hip div_by_count; PT:787 mean += diff / n): q = a r with
+   r = 1 / n, corrected twice through the exact remainder.  Not a definition of its own -- it must equal a / n bit for bit
+   (tests/test_welford_div.py checks that, the oracle's Welford recurrence divides plainly). */
+ORC_API void orc_div_by_count(long len, const double *a, const double *n, double *out)
+{
+    for (long i = 0; i < len; ++i) {
+        const double r = 1.0 / n[i];
+        if (fabs(a[i]) < 0x1p-900) { out[i] = a[i] / n[i]; continue; }
+        double q = a[i] * r;
+        double e = fma(-n[i], q, a[i]);
+        q = fma(e, r, q);
+        e = fma(-n[i], q, a[i]);
+        out[i] = fma(e, r, q);
+    }
+}

@@ -535,6 +535,160 @@ __global__ __launch_bounds__(256) void welford_kernel(const double *AM, double *
     if (gridDim.x == 1 && role == 0 && carrier) muw[rel] = m;
 }
 
+// One tile per walker (d <= TYN * PR, the per-walker replica mode at ndim <= 100): the same recurrence with the work split by waves.
+// welford_kernel's carriers are threads of the tile's own four waves, so every wave pays for the mean's division (a dozen
+// instructions beside the 98 of a row) and a quarter of its 7 x 7 accumulators lie outside a 100 x 100 matrix: 5.1 ms per epoch at
+// 4096 x 1000 x 100 against 2.1 ms of products and sums.  Here threads 0 .. TYN TXN - 1 hold PR x PC accumulators each (25 x 10
+// threads of 4 x 10: no padding at d = 100, the row's factors read from LDS as 16-byte pieces), and two more waves carry the mean:
+// thread 256 + i advances mu[i] through the rows one batch AHEAD of the tile (double-buffered in LDS, one barrier per RB rows).
+// The division df / n (n = the row count, the same for every lane) is Markstein's: r = 1 / n by a true division once per batch
+// and lane, then q = df r corrected twice through the exact remainder fma(-n, q, df) -- the correctly rounded quotient (r is the
+// correctly rounded reciprocal of an integer below 2^53; 4e8 random and near-tie cases against a / n: tests/test_welford_div.py
+// runs the same arithmetic on the host).
+__device__ __forceinline__ double div_by_count(double a, double n, double r)
+{
+    if (__builtin_fabs(a) < 0x1p-900) return a / n;         // a remainder in the subnormal range would not be exact
+    double q = a * r;
+    double e = __builtin_fma(-n, q, a);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-n, q, a);
+    return __builtin_fma(e, r, q);
+}
+template <int TYN, int TXN, int PR, int PC>
+__global__ __launch_bounds__(768) void welford_rows_kernel(const double *AM, double *mu, double *M2, double *cov, int d, int mem, long long iter,
+                                                           int cov_stride_per_walker, int am_epl, int nwalkers)
+{
+    // a block = TWO walkers: 2 x 4 tile waves + 2 x 2 carrier waves = three waves on every SIMD (up to 170 registers each); a block
+    // of one walker's six waves lands 2 + 2 + 1 + 1 on the SIMDs and a second block no longer fits beside it
+#ifndef PTMI_WF_RB
+#define PTMI_WF_RB 8
+#endif
+    constexpr int RB = PTMI_WF_RB, LW = TYN * PR > TXN * PC ? TYN * PR : TXN * PC;
+    __shared__ __attribute__((aligned(16))) double sh_all[2][2][RB][2][LW];      // [walker of the block][buffer][row][diff | e][element]
+    const int tb = (int)threadIdx.x;
+    const int slot = tb < 512 ? tb >> 8 : (tb - 512) >> 7;
+    const int w = 2 * (int)blockIdx.x + slot;
+    const bool wact = w < nwalkers;
+    double (*sh)[RB][2][LW] = sh_all[slot];
+    const double *am = AM + (size_t)(wact ? w : 0) * mem * d;
+    double *muw = mu + (size_t)(wact ? w : 0) * d, *M2w = M2 + (size_t)(wact ? w : 0) * d * d;
+    const long long it0 = iter - mem;
+    const bool reset = it0 == 0;
+    const int t = tb < 512 ? (tb & 255) : 256 + ((tb - 512) & 127);      // 0 .. 255 the tile, 256 .. 383 the carriers of this walker
+    const int nb = (mem + RB - 1) / RB;
+    if (t >= 256) {
+        // ------------------------------------------------ the mean's carriers
+        const int rel = t - 256;
+        const bool carrier = rel < d && wact;
+        const int pos = am_pos(carrier ? rel : 0, am_epl);
+        double m = carrier && !reset ? muw[rel] : 0.0;
+        double vc[RB], vn[RB];
+        auto load = [&](int b, double (&v)[RB]) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int row = b * RB + u;
+                v[u] = (carrier && row < mem) ? am[(size_t)row * d + pos] : 0.0;
+            }
+        };
+        auto produce = [&](int b, const double (&v)[RB]) {
+            const double nl = (double)(it0 + (long long)b * RB + 1 + (t & (RB - 1))), rl = 1.0 / nl;      // lane u of every RB: row u's count
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const double n = __shfl(nl, u, RB), r = __shfl(rl, u, RB);
+                double df = 0.0, ev = 0.0;
+#ifdef PTMI_WF_NOCARRY
+                df = v[u] + n; ev = v[u] + r;
+#else
+                if (b * RB + u < mem) {
+                    df = v[u] - m;
+                    m += div_by_count(df, n, r);            // PT:787 (mean += diff / n)
+                    ev = v[u] - m;
+                }
+#endif
+                if (rel < LW) { sh[b & 1][u][0][rel] = carrier ? df : 0.0; sh[b & 1][u][1][rel] = carrier ? ev : 0.0; }
+            }
+        };
+        load(0, vc);
+        if (nb > 1) load(1, vn);
+        produce(0, vc);
+        __syncthreads();
+        for (int b = 0; b < nb; ++b) {
+            if (b + 1 < nb) {
+#pragma unroll
+                for (int u = 0; u < RB; ++u) vc[u] = vn[u];
+                if (b + 2 < nb) load(b + 2, vn);
+                produce(b + 1, vc);
+            }
+            __syncthreads();
+        }
+        if (carrier && wact) muw[rel] = m;
+        return;
+    }
+    // ---------------------------------------------------- the tile
+    const int ty = t / TXN, tx = t % TXN;
+    const bool live = t < TYN * TXN && wact;
+    double acc[PR][PC];
+#pragma unroll
+    for (int p = 0; p < PR; ++p)
+#pragma unroll
+        for (int r = 0; r < PC; ++r) {
+            const int i = ty * PR + p, j = tx * PC + r;
+            acc[p][r] = (live && !reset && i < d && j < d) ? M2w[(size_t)i * d + j] : 0.0;
+        }
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+        if (live) {
+            // the next row's factors are requested before this row's products (two register sets): an LDS round trip per row is
+            // not covered by the one or two other waves of the SIMD
+            double dv[2][PR], ev[2][PC];
+            auto rd = [&](int u, int k) {
+#pragma unroll
+                for (int p = 0; p < PR; ++p) dv[k][p] = sh[b & 1][u][0][ty * PR + p];
+#pragma unroll
+                for (int r = 0; r < PC; ++r) ev[k][r] = sh[b & 1][u][1][tx * PC + r];
+            };
+            // PT:792, one product and one sum per element, rows ascending (fencing a row's products off from their sums cost 37
+            // spilled registers and 2 ms).  Rows past the end of the buffer carry zeros from the carriers (acc + 0 * 0: an accumulator
+            // is never -0), so the batch is straight-line code.
+            auto row = [&](int k) {
+#pragma unroll
+                for (int p = 0; p < PR; ++p)
+#pragma unroll
+                    for (int r = 0; r < PC; ++r) acc[p][r] += dv[k][p] * ev[k][r];
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                if (u + 1 < RB) {
+                    rd(u + 1, (u + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                row(u & 1);
+            }
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    const double den = (double)(iter - 1);
+    double *covw = cov ? cov + (size_t)w * cov_stride_per_walker : nullptr;
+#pragma unroll
+    for (int p = 0; p < PR; ++p)
+#pragma unroll
+        for (int r = 0; r < PC; ++r) {
+            const int i = ty * PR + p, j = tx * PC + r;
+            if (i < d && j < d) M2w[(size_t)i * d + j] = acc[p][r];
+        }
+    // the covariance in a rolled loop over the thread's own elements, read back (forty unrolled divisions beside the accumulators
+    // cost the main loop 44 spilled registers)
+    if (covw) {
+#pragma unroll 1
+        for (int e = 0; e < PR * PC; ++e) {
+            const int i = ty * PR + e / PC, j = tx * PC + e % PC;
+            if (i < d && j < d) covw[(size_t)i * d + j] = M2w[(size_t)i * d + j] / den;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- pooled covariance
 // cov_mode "pooled" (one covariance adapted from all walkers' rank-0 samples; oracle: orc_pool_update).  The epoch's chunk
 // -- the W x cov_update buffered rows as one [rows][d] matrix -- enters as shifted sums T = sum dx dx^T, t = sum dx with
@@ -1658,8 +1812,10 @@ __global__ __launch_bounds__(64) void eig_ql_chain_kernel(int n, QlScratch q)
     if (t == 0) { q.cnt[2 * b] = iters < 0 ? 0 : iters; q.cnt[2 * b + 1] = (over || iters < 0) ? 1 : 0; }
 }
 
-__global__ __launch_bounds__(QL_THREADS) void eig_ql_apply_kernel(double *Ut, double *S, int n, int ut_stride, int s_stride, QlScratch q)
+__global__ __launch_bounds__(QL_THREADS) void eig_ql_apply_kernel(double *Ut, double *S, int n, int ut_stride, int s_stride, QlScratch q, int redo_only)
 {
+    if (redo_only && q.cnt[2 * blockIdx.x + 1] == 0) return;      // eig_ql_apply_reg_kernel has done this matrix
+
     extern __shared__ __attribute__((aligned(16))) double qsm[];
     double *zt = qsm;                                              // zt[c n + k] = Z(k, c)
     qls_d2 *de = reinterpret_cast<qls_d2 *>(qsm + (((size_t)n * n + 1) & ~(size_t)1));
@@ -1734,6 +1890,117 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_apply_kernel(double *Ut, do
         const double sg = col[im] < 0.0 ? -1.0 : 1.0;
         for (int i = 0; i < n; ++i) Uo[(size_t)rank * n + i] = sg * col[i];
         So[rank] = mine;
+    }
+}
+
+// The apply step with the eigenvector matrix in REGISTERS (n <= 100): thread t holds row t of Z, z[0 .. n - 1], and a rotation of
+// columns (i, i + 1) is six instructions on two registers of every thread -- the record's (c, s) and the iterations' (l, m) are the
+// same for all rows: uniform branches, (c, s) an LDS broadcast staged by each wave for itself; no barrier until the end, four matrices (eight waves)
+// per CU instead of the two that fit with Z in LDS.  Register indices are compile-time: an iteration's sweep i = m - 1 ... l is the
+// unrolled sweep 98 ... 0 entered block by block (QLA_BLK steps; a block outside [l, m) is one uniform branch, a block inside it
+// runs without tests).  eig_ql_apply_kernel: 4.15 ms per epoch at 4096 x 100 x 100 (a wave per SIMD, an LDS round trip on every
+// row's chain per four rotations).  Matrices whose record overflowed are left to that kernel (redo_only).
+constexpr int QLA_N = 100, QLA_BLK = 4;
+template <int LO, int HI, bool CHECK>
+__device__ __forceinline__ void qla_steps(double (&z)[QLA_N], const qls_d2 *cs_of_step, int l, int m)
+{
+#pragma unroll
+    for (int i = HI; i >= LO; --i) {
+        if (!CHECK || (i >= l && i < m)) {
+            const qls_d2 cs = cs_of_step[i];                        // {c, s}: an LDS broadcast at a compile-time offset
+            const double za = z[i], zb = z[i + 1];
+            z[i + 1] = cs.y * za + cs.x * zb;
+            z[i] = cs.x * za - cs.y * zb;
+        }
+    }
+}
+template <int BLKI>
+__device__ __forceinline__ void qla_sweep(double (&z)[QLA_N], const qls_d2 *cs_of_step, int l, int m)
+{
+    constexpr int LO = QLA_BLK * BLKI, HI = LO + QLA_BLK - 1 < QLA_N - 2 ? LO + QLA_BLK - 1 : QLA_N - 2;
+    if (HI >= l && LO < m) {
+        if (LO >= l && HI < m) qla_steps<LO, HI, false>(z, cs_of_step, l, m);
+        else qla_steps<LO, HI, true>(z, cs_of_step, l, m);
+    }
+    if constexpr (BLKI > 0) qla_sweep<BLKI - 1>(z, cs_of_step, l, m);
+}
+__global__ __launch_bounds__(128, 2) void eig_ql_apply_reg_kernel(double *Ut, double *S, int n, int ut_stride, int s_stride,
+                                                                  const double *__restrict__ zin, const double *__restrict__ evin,
+                                                                  const qls_d2 *__restrict__ rot_all, const int32_t *__restrict__ hdr_all,
+                                                                  const int32_t *__restrict__ cnt, int cap, int capit)
+{
+    __shared__ double wmax[2][QLA_N], wsv[2][QLA_N], sgs[QLA_N];
+    __shared__ int rk[QLA_N];
+    // an iteration's rotations, staged by each wave for itself (no barrier): slot i = the rotation of step i; the next iteration's
+    // are requested before this one's sweep and stored behind it (a scalar load per block of the sweep waited 600 cycles each)
+    __shared__ __attribute__((aligned(16))) qls_d2 stg[2][2][QLA_N];
+    const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t b = blockIdx.x;
+    if (cnt[2 * b + 1] != 0) return;                                // the record did not hold this matrix's rotations
+    const bool rowok = t < n;
+    double z[QLA_N];
+    {
+        const double *zi = zin + b * n * n + (size_t)(rowok ? t : 0) * n;
+#pragma unroll
+        for (int c = 0; c < QLA_N; ++c) z[c] = c < n ? zi[c] : 0.0;
+    }
+    const int nit = cnt[2 * b];
+    const int32_t *hdr = hdr_all + b * 2 * (size_t)capit;
+    const qls_d2 *rot = rot_all + b * (size_t)cap;
+    int l = nit > 0 ? hdr[0] : 0, m = nit > 0 ? hdr[1] : 0;
+    int ln = nit > 1 ? hdr[2] : 0, mn = nit > 1 ? hdr[3] : 0;      // the (l, m) of the iteration after: known two iterations ahead
+    int r = 0;
+    {
+        const int cn = m - l;
+        if (lane < cn) stg[wave][0][m - 1 - lane] = rot[lane];
+        if (lane + 64 < cn) stg[wave][0][m - 1 - lane - 64] = rot[lane + 64];
+    }
+    for (int itn = 0; itn < nit; ++itn) {
+        r += m - l;
+        const int lnn = itn + 2 < nit ? hdr[2 * itn + 4] : 0, mnn = itn + 2 < nit ? hdr[2 * itn + 5] : 0;
+        const int cn = itn + 1 < nit ? mn - ln : 0;
+        qls_d2 nx0 = qls_d2{0.0, 0.0}, nx1 = qls_d2{0.0, 0.0};
+        if (lane < cn) nx0 = rot[r + lane];
+        if (lane + 64 < cn) nx1 = rot[r + lane + 64];
+        __builtin_amdgcn_wave_barrier();
+        qla_sweep<(QLA_N - 2) / QLA_BLK>(z, stg[wave][itn & 1], l, m);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cn) stg[wave][(itn + 1) & 1][mn - 1 - lane] = nx0;
+        if (lane + 64 < cn) stg[wave][(itn + 1) & 1][mn - 1 - lane - 64] = nx1;
+        l = ln; m = mn;
+        ln = lnn; mn = mnn;
+    }
+    // the sign of every eigenvector: its first component of largest magnitude becomes positive (row ascending, strict >)
+#pragma unroll
+    for (int k = 0; k < QLA_N; ++k) {
+        if (k < n) {
+            const double a = rowok ? __builtin_fabs(z[k]) : -1.0;
+            double mx = a;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { const double ot = __shfl_xor(mx, o, 64); mx = ot > mx ? ot : mx; }
+            const unsigned long long eq = __ballot(a == mx);
+            const int first = __builtin_ctzll(eq);
+            const double sv = __shfl(z[k], first, 64);
+            if (lane == 0) { wmax[wave][k] = mx; wsv[wave][k] = sv; }
+        }
+    }
+    __syncthreads();
+    if (rowok) {
+        const int k = t;
+        const double sv = wmax[1][k] > wmax[0][k] ? wsv[1][k] : wsv[0][k];
+        sgs[k] = sv < 0.0 ? -1.0 : 1.0;
+        const double *ev = evin + b * n;
+        const double mine = __builtin_fabs(ev[k]);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const double o = __builtin_fabs(ev[j]); rank += (o > mine) || (o == mine && j < k); }
+        rk[k] = rank;
+        S[b * s_stride + rank] = mine;
+    }
+    __syncthreads();
+    double *Uo = Ut + b * ut_stride;
+#pragma unroll
+    for (int k = 0; k < QLA_N; ++k) {
+        if (k < n && rowok) Uo[(size_t)rk[k] * n + t] = sgs[k] * z[k];
     }
 }
 
@@ -2683,6 +2950,10 @@ int ptmi_update_cov(ptmi_handle h, int64_t iter)
     if (iter < c.cov_update || iter % c.cov_update) return fail(PTMI_EINVAL, "iter must be a positive multiple of cov_update");
     const int d = c.ndim, nt = (d + WTILE - 1) / WTILE;
     if (c.cov_per_walker) {
+        if (d <= 100 && !getenv("PTMI_WELFORD_TILES"))
+            hipLaunchKernelGGL((welford_rows_kernel<25, 10, 4, 10>), dim3((c.nwalkers + 1) / 2), dim3(768), 0, h->stream, (const double *)h->buf.AM,
+                               h->buf.mu, h->buf.M2, h->buf.cov, d, c.cov_update, (long long)iter, d * d, am_row_epl(h->G, h->EPL), c.nwalkers);
+        else
         hipLaunchKernelGGL(welford_kernel<false>, dim3(nt, nt, c.nwalkers), dim3(256), 0, h->stream, (const double *)h->buf.AM,
                            h->buf.mu, h->buf.M2, h->buf.cov, d, c.cov_update, (long long)iter, d * d, am_row_epl(h->G, h->EPL));
         if (nt > 1)
@@ -2799,7 +3070,11 @@ int ptmi_eig_ql(ptmi_handle h)
         }
         hipLaunchKernelGGL(eig_ql_reduce_kernel, dim3(nmat), dim3(QLR_THREADS), lds, h->stream, (const double *)h->buf.cov, d, q);
         hipLaunchKernelGGL(eig_ql_chain_kernel, dim3(nmat), dim3(64), sizeof(double) * 2 * (size_t)d, h->stream, d, q);
-        hipLaunchKernelGGL(eig_ql_apply_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, h->buf.Ut, h->buf.S, d, d * d, d, q);
+        const bool regs = d <= QLA_N && !getenv("PTMI_QL_APPLY_LDS");
+        if (regs)
+            hipLaunchKernelGGL(eig_ql_apply_reg_kernel, dim3(nmat), dim3(128), 0, h->stream, h->buf.Ut, h->buf.S, d, d * d, d, (const double *)q.z,
+                               (const double *)q.ev, (const qls_d2 *)q.rot, (const int32_t *)q.hdr, (const int32_t *)q.cnt, cap, capit);
+        hipLaunchKernelGGL(eig_ql_apply_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, h->buf.Ut, h->buf.S, d, d * d, d, q, regs ? 1 : 0);
         HIPCHK(hipGetLastError());
         return PTMI_OK;
     }
