@@ -1375,6 +1375,34 @@ __global__ __launch_bounds__(JAC_THREADS) void eig_jacobi_kernel(const double *c
     }
 }
 
+// sqrt(x) and 1 / sqrt(x)'s partner 1 / r of a rotation, for x in the middle of the exponent range: the compiler's own correctly
+// rounded sequences (v_rsq_f64 / v_rcp_f64 + the fma refinements of its sqrt and division lowerings) without their range scaling,
+// special-value tests and fix-ups -- 17 instead of 29 instructions on the chain that bounds eig_ql_chain_kernel, the same bits
+// wherever no scaling would have been applied; anything else takes the plain operations.
+__device__ __forceinline__ void ql_root_and_reciprocal(double x, double &r, double &ri)
+{
+    if (x > 0x1p-600 && x < 0x1p600) {                              // uniform in the chain kernel
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, hh = 0.5 * y;
+        const double r0 = __builtin_fma(-hh, g, 0.5);
+        g = __builtin_fma(g, r0, g);
+        hh = __builtin_fma(hh, r0, hh);
+        double dd = __builtin_fma(-g, g, x);
+        g = __builtin_fma(dd, hh, g);
+        dd = __builtin_fma(-g, g, x);
+        r = __builtin_fma(dd, hh, g);
+        double q = __builtin_amdgcn_rcp(r);
+        double e = __builtin_fma(-r, q, 1.0);
+        q = __builtin_fma(q, e, q);
+        e = __builtin_fma(-r, q, 1.0);
+        q = __builtin_fma(q, e, q);
+        e = __builtin_fma(-r, q, 1.0);
+        ri = __builtin_fma(e, q, q);
+    } else {
+        r = det_sqrt(x);
+        ri = 1.0 / r;
+    }
+}
 // ----------------------------------------------------------- tridiagonal QL eigensolver (eig_mode "ql")
 // The eigendecomposition of PT:797-803 by Householder tridiagonalization with the transformations accumulated, then implicit QL
 // iterations on the tridiagonal matrix (oracle: orc_eig_ql -- the kernel does the oracle's operations in the oracle's order, dot products
@@ -1544,8 +1572,8 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_kernel(const double *cov, d
                         if (i > l) nx = de[i - 1];
                         const double za0 = r0 ? z[k0 * n + i] : 0.0, za1 = r1 ? z[k1 * n + i] : 0.0;
                         const double gg = c * ei, hh = c * p;
-                        const double r = det_sqrt(p * p + ei * ei);
-                        const double ri = 1.0 / r;
+                        double r, ri;
+                        ql_root_and_reciprocal(p * p + ei * ei, r, ri);
                         const double e1 = s * r;
                         s = ei * ri;
                         c = p * ri;
@@ -1759,8 +1787,8 @@ __device__ __forceinline__ int ql_iterate(qls_d2 *de, int n, int t, double *zt, 
                     double za0 = 0.0, za1 = 0.0;
                     if (ROWS) { za0 = r0 ? zt[i * n + k0] : 0.0; za1 = r1 ? zt[i * n + k1] : 0.0; }
                     const double gg = c * ei, hh = c * p;
-                    const double r = det_sqrt(p * p + ei * ei);
-                    const double ri = 1.0 / r;
+                    double r, ri;
+                    ql_root_and_reciprocal(p * p + ei * ei, r, ri);
                     const double e1 = s * r;
                     s = ei * ri;
                     c = p * ri;
@@ -1897,10 +1925,13 @@ __global__ __launch_bounds__(QL_THREADS) void eig_ql_apply_kernel(double *Ut, do
 // columns (i, i + 1) is six instructions on two registers of every thread -- the record's (c, s) and the iterations' (l, m) are the
 // same for all rows: uniform branches, (c, s) an LDS broadcast staged by each wave for itself; no barrier until the end, four matrices (eight waves)
 // per CU instead of the two that fit with Z in LDS.  Register indices are compile-time: an iteration's sweep i = m - 1 ... l is the
-// unrolled sweep 98 ... 0 entered block by block (QLA_BLK steps; a block outside [l, m) is one uniform branch, a block inside it
+// unrolled sweep 98 ... 0 entered block by block (QLA_BLK = 8 steps, 2.29 ms against 2.41 with 4; a block outside [l, m) is one uniform branch, a block inside it
 // runs without tests).  eig_ql_apply_kernel: 4.15 ms per epoch at 4096 x 100 x 100 (a wave per SIMD, an LDS round trip on every
 // row's chain per four rotations).  Matrices whose record overflowed are left to that kernel (redo_only).
-constexpr int QLA_N = 100, QLA_BLK = 4;
+#ifndef PTMI_QLA_BLK
+#define PTMI_QLA_BLK 8
+#endif
+constexpr int QLA_N = 100, QLA_BLK = PTMI_QLA_BLK;
 template <int LO, int HI, bool CHECK>
 __device__ __forceinline__ void qla_steps(double (&z)[QLA_N], const qls_d2 *cs_of_step, int l, int m)
 {
