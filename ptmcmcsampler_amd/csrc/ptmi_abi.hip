@@ -1683,7 +1683,10 @@ __global__ __launch_bounds__(QLR_THREADS) void eig_ql_reduce_kernel(const double
             double sc = 0.0;
             for (int k = c8; k <= l; k += 8) sc = __builtin_fma(k <= j ? QZ(j, k) : QZ(k, j), QZ(i, k), sc);
             const double g = jac_oct_sum(sc);
-            if (c8 == 0) { QZ(j, i) = QZ(i, j) / h; pq[j] = g / h; }
+            // the two quotients of row j by two lanes of its oct: one division sequence instead of two on the critical path
+            const double quo = (c8 == 0 ? g : QZ(i, j)) / h;
+            if (c8 == 0) pq[j] = quo;
+            else if (c8 == 1) QZ(j, i) = quo;
         }
         __syncthreads();
         double fc = 0.0;
