@@ -1648,7 +1648,10 @@ struct QlScratch {
 // (s3 + s7)) in every lane -- 32 products at a time; the rank-two update and the column updates are 16 x 16 tilings of their
 // elements.  (A thread per row with the eight chains side by side left the threads of short rows idle and every wave alone on its
 // SIMD: 17 000 cycles per row of the reduction.)
-constexpr int QLR_THREADS = 256;
+#ifndef PTMI_QLR_THREADS
+#define PTMI_QLR_THREADS 512
+#endif
+constexpr int QLR_THREADS = PTMI_QLR_THREADS, QLR_TY = QLR_THREADS / 16;
 __global__ __launch_bounds__(QLR_THREADS) void eig_ql_reduce_kernel(const double *cov, int n, QlScratch q)
 {
     extern __shared__ __attribute__((aligned(16))) double qsm[];
@@ -1696,7 +1699,7 @@ __global__ __launch_bounds__(QLR_THREADS) void eig_ql_reduce_kernel(const double
         __syncthreads();                                          // every thread has its f
         for (int j = t; j <= l; j += QLR_THREADS) pq[j] = pq[j] - hh * QZ(i, j);
         __syncthreads();
-        for (int j = ty; j <= l; j += 16) {
+        for (int j = ty; j <= l; j += QLR_TY) {
             const double uj = QZ(i, j), qj = pq[j];
             for (int k = tx; k <= j; k += 16) QZ(j, k) = QZ(j, k) - (uj * pq[k] + qj * QZ(i, k));
         }
@@ -1720,7 +1723,7 @@ __global__ __launch_bounds__(QLR_THREADS) void eig_ql_reduce_kernel(const double
             for (int j = oct; j <= l; j += QLR_THREADS / 8, ++nj)
                 if (c8 == 0) QZ(i, j) = gj[nj & 3];
             __syncthreads();
-            for (int k = ty; k <= l; k += 16) {
+            for (int k = ty; k <= l; k += QLR_TY) {
                 const double zki = QZ(k, i);
                 for (int j = tx; j <= l; j += 16) QZ(k, j) = QZ(k, j) - QZ(i, j) * zki;
             }
