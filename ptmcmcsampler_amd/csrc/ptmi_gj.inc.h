@@ -919,7 +919,10 @@ struct GradJumpWide {
 // SIMDs as soon as a wave's chains are through their (very unequal) trees.
 constexpr int GJ_BLOCK = 64;
 template <int G, int EPL, int LOGL>
-__global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? 2 : 1) void mh_steps_gj_kernel(const KArgs a)
+#ifndef PTMI_GJ_WPE
+#define PTMI_GJ_WPE 2
+#endif
+__global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) void mh_steps_gj_kernel(const KArgs a)
 {
     constexpr int CPB = GJ_BLOCK / G;
     constexpr bool WIDE = G == 4;                // a gradient jump takes the whole wave (GradJumpWide)
