@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--logl", default="iso", choices=["iso", "dense", "curved"])
     ap.add_argument("--prior", default="flat", choices=["flat", "box"],
                     help="flat: the headline workload; box: uniform on [-10, 10]^d, the usual lnpriorfn of a reference run")
-    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "pooled_hipsolver", "per_walker", "per_walker_device", "per_walker_jacobi"],
+    ap.add_argument("--cov-mode", default="pooled", choices=["pooled", "pooled_device", "pooled_hipsolver", "pooled_sytrd", "per_walker", "per_walker_device", "per_walker_jacobi"],
                     help="pooled: one covariance from all walkers; per_walker: every walker adapts its own (a replica of a reference run); "
                          "_device: the covariance epochs are factorized on the device (tridiagonal QL kernel) instead of host LAPACK, "
                          "_jacobi: by the device Jacobi kernel; "
@@ -192,7 +192,9 @@ def main():
 
     d, nt, W = a.ndim, a.ntemps, a.nwalkers
     if a.cov_mode == "pooled" and d >= 512:
-        a.cov_mode = "pooled_hipsolver"     # one ndim x ndim factorization per epoch: the ROCm library on the stream beats the host's LAPACK from here on
+        # one ndim x ndim factorization per epoch: from here on the device beats the host's LAPACK -- ptmi_eig_sytrd (tridiagonalization
+        # in one kernel + the library's divide-and-conquer) up to 1024, the ROCm library's eigensolver beyond
+        a.cov_mode = "pooled_sytrd" if d <= 1024 else "pooled_hipsolver"
     logl = ("iso",)
     if a.logl == "dense":
         A = np.random.default_rng(0).standard_normal((d, d))
@@ -200,11 +202,11 @@ def main():
     kw = dict(weights=weights, cov_update=1000, burn=10000, tskip=TSKIP, seed=1234, logl=logl, device=local, swap_mode=a.swap_mode,
               pick_mode=a.pick, cov_mode="per_walker" if a.cov_mode.startswith("per_walker") else "pooled", am_mode=a.am_mode,
               eig_mode="ql" if a.cov_mode.endswith("_device") else ("jacobi" if a.cov_mode.endswith("_jacobi") else (
-                  "hipsolver" if a.cov_mode.endswith("_hipsolver") else "lapack")))
+                  "hipsolver" if a.cov_mode.endswith("_hipsolver") else ("sytrd" if a.cov_mode.endswith("_sytrd") else "lapack"))))
     eig_lag = 0
-    if kw["cov_mode"] == "pooled" and kw["eig_mode"] in ("lapack", "hipsolver"):
+    if kw["cov_mode"] == "pooled" and kw["eig_mode"] in ("lapack", "hipsolver", "sytrd"):
         eig_lag = a.eig_lag if a.eig_lag >= 0 else (1 if kw["eig_mode"] == "lapack" else 9)
-        if kw["eig_mode"] == "hipsolver" and not (world == 1 and not a.sharded or a.partition == "walkers"):
+        if kw["eig_mode"] != "lapack" and not (world == 1 and not a.sharded or a.partition == "walkers"):
             eig_lag = 0                      # the sharded engine broadcasts the table of the host path only
     kw.update(eig_lag=eig_lag)
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)

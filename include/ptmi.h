@@ -281,6 +281,13 @@ int ptmi_eig_jacobi(ptmi_handle h);
  * Jacobi kernel's time on the nearly degenerate spectra an isotropic target adapts to.  Eigenvalues in absolute value, descending;
  * sign rule as ptmi_eig_jacobi.  Asynchronous on the handle's stream. */
 int ptmi_eig_ql(ptmi_handle h);
+/* The same for ONE large pooled covariance (3 <= ndim <= 1024; the engine's eig_mode "sytrd"): Householder tridiagonalization in one
+ * kernel with the matrix in the LDS of its blocks, then the ROCm library's divide-and-conquer solver of the tridiagonal matrix and its
+ * back-transformation (rocsolver_dstedc, rocsolver_dormtr, looked up in the librocsolver the process has loaded: import torch first).
+ * Replaces the np.linalg.svd of :797-803 where the library's own eigensolver (torch.linalg.eigh: 35 ms of small kernels at 1000 x 1000)
+ * is the epoch.  On `stream` (NULL: the handle's), results into Ut_out [ndim][ndim] / S_out [ndim] (NULL: the handle's Ut / S):
+ * eigenvalues in absolute value, descending; no sign rule (the library's vectors).  Its last bits are the library's. */
+int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out);
 
 /* _updateDEbuffer (:806-817): drop the oldest cov_update rows of each DE history and
  * append the AM buffer (pooled mode: row r comes from walker r mod W). */

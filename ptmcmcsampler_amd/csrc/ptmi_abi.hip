@@ -2,6 +2,7 @@
 // (swap sweep, Welford / pooling, DE ring, self-tests).  See include/ptmi.h for the boundary and DESIGN.md.
 #include <math.h>
 #include <stdlib.h>
+#include <dlfcn.h>
 
 #include <new>
 #include <vector>
@@ -2477,7 +2478,12 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
-    (void)hipFree(h->d_ql_scr);
+    (void)hipFree(h->d_ql_scr); (void)hipFree(h->d_sy_scr);
+    if (h->sy_lib) {                                                // SyLib: the library's handle, its destructor
+        void **sl = (void **)h->sy_lib;
+        if (sl[0] && sl[1]) ((int (*)(void *))sl[1])(sl[0]);
+        free(h->sy_lib);
+    }
     (void)hipFree(h->d_rle_ent); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
@@ -3118,6 +3124,284 @@ int ptmi_eig_ql(ptmi_handle h)
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eig_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(eig_ql_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, (const double *)h->buf.cov, h->buf.Ut, h->buf.S, d, d * d, d,
                        (int32_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+// ---------------------------------------------------------------- one large matrix: tridiagonalization in one kernel
+// eig_mode "sytrd" (ptmi_eig_sytrd; ndim <= 1024, one pooled covariance).  The ROCm library's symmetric eigensolver spends two thirds
+// of its time reducing the matrix to tridiagonal form in some 7000 launches of one-block kernels (1000 x 1000: 25 of 35 ms of kernel
+// time, 3 us each).  Here that step is ONE kernel: the matrix lives in the LDS of its blocks (block b owns the full columns
+// b, b + NB, ...: 64 KB of 160 at 1000 x 1000 over 128 blocks), a Householder step is
+//   the owner of column k forms v (its own LDS)                                         -> v to all      [grid barrier]
+//   every block: p_j = tau (column j . v) for ITS columns (A symmetric: column j is row j)  -> p to all      [grid barrier]
+//   every block: w = p - (tau/2 p.v) v, its columns -= v w_j + w v_j
+// -- no reduction across blocks, two barriers per column (a few microseconds each on an atomic counter).  Output in LAPACK's
+// dsytrd format (uplo = lower: d, e, tau, the reflectors below the subdiagonal), so that the library's divide-and-conquer solver
+// for the tridiagonal matrix (rocsolver_dstedc) and its back-transformation (rocsolver_dormtr) take it from there.
+struct SytrdArgs {
+    double *A;             // [n][n] column-major = row-major (symmetric in); out: the reflectors
+    double *D, *E, *tau;   // [n], [n - 1], [n - 1]
+    double *vbuf;          // [2][n + 2]: column m as its owner holds it before the update (by parity of m)
+    double *pbuf;          // [2][n]: the products p_j (by parity of m)
+    unsigned *bar;
+    int n;
+};
+#ifndef PTMI_SY_THREADS
+#define PTMI_SY_THREADS 256
+#endif
+constexpr int SY_THREADS = PTMI_SY_THREADS, SY_NW = SY_THREADS / 64, SY_CMAX = 16, SY_PT = 1024 / SY_THREADS;       // SY_PT: elements of a vector per thread (n <= 1024)
+// exchanged data goes through agent-scope relaxed atomics (write-through stores, loads past the caches of the other XCDs): no
+// cache write-back / invalidation beside the barrier's own counter
+__device__ __forceinline__ void sy_grid_sync(unsigned *bar, unsigned &target, unsigned nb)
+{
+    __syncthreads();                                               // the block's stores have been acknowledged
+#ifdef PTMI_SY_NOBAR
+    return;
+#endif
+    if (threadIdx.x == 0) {
+        target += nb;
+        // RELAXED: a release / acquire at agent scope writes back / invalidates the XCD's whole L2 at every barrier -- under the step
+        // kernel running beside this one (its table rows live there): launches of 3.2 ms instead of 2.5.  The exchanged vectors
+        // need neither: they are written and read with agent-scope atomics themselves, and __syncthreads has waited for the stores.
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef PTMI_SY_SLEEP
+#define PTMI_SY_SLEEP 8
+#endif
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(PTMI_SY_SLEEP);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double sy_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sy_store(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// elements lo .. n - 1 of an exchanged vector into LDS: every load of a thread in flight at once
+__device__ __forceinline__ void sy_fetch(const double *src, double *dst, int lo, int n)
+{
+    double tmp[SY_PT];
+#pragma unroll
+    for (int u = 0; u < SY_PT; ++u) { const int i = lo + (int)threadIdx.x + u * SY_THREADS; tmp[u] = i < n ? sy_load(src + i) : 0.0; }
+#pragma unroll
+    for (int u = 0; u < SY_PT; ++u) { const int i = lo + (int)threadIdx.x + u * SY_THREADS; if (i < n) dst[i] = tmp[u]; }
+}
+__device__ __forceinline__ double sy_block_sum(double x, double *red)      // red: [SY_NW] doubles of LDS
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < SY_THREADS / 64; ++w) s += red[w];
+    return s;
+}
+// 256 threads and at most 64 registers: a wave per SIMD that fits beside FOUR waves of the config-4 step kernel (112 registers each);
+// with 512 threads of 72 registers the step kernel lost a wave per SIMD on every CU that holds a block of this one (launches 3.1 ms
+// against 2.5)
+__global__ __launch_bounds__(SY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void sytrd_lds_kernel(SytrdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sy[];
+    const int n = a.n, nb = (int)gridDim.x, b = (int)blockIdx.x, t = (int)threadIdx.x;
+    const int ncol = b < n ? (n - 1 - b) / nb + 1 : 0;               // owned columns b, b + nb, ...
+    double *col = sy;                                                // [ncol][n]
+    double *v = sy + (size_t)SY_CMAX * n, *w = v + n, *xr = w + n, *red = xr + n;    // [n] each, [1 + SY_CMAX][SY_NW]
+    unsigned target = 0;
+    for (int c = 0; c < ncol; ++c)
+        for (int i = t; i < n; i += SY_THREADS) col[(size_t)c * n + i] = a.A[(size_t)(b + c * nb) * n + i];
+    for (int i = t; i < n; i += SY_THREADS) { v[i] = 0.0; w[i] = 0.0; }
+    double tau = 0.0;                                                // of the reflector in v (m - 1)
+    __syncthreads();
+    // Iteration m: the update by reflector m - 1 (in v, known to every block) and the generation of reflector m, with ONE grid
+    // barrier: beside its p_j every block would need column m after the update to form the next reflector -- the column's owner
+    // sends it as it is BEFORE the update, and every block applies the update to its copy and forms v_m for itself (the same
+    // operations on the same values in every block).
+    for (int m = 0; m + 1 < n; ++m) {
+        const int par = m & 1;
+        double *pb = a.pbuf + (size_t)par * n, *rb = a.vbuf + (size_t)par * (n + 2);
+        const int c0 = m <= b ? 0 : (m - b + nb - 1) / nb;             // this block's columns j >= m: those from c0 on
+        if (m >= 1 && tau != 0.0) {
+            double acc[SY_CMAX];
+#pragma unroll
+            for (int c = 0; c < SY_CMAX; ++c) acc[c] = 0.0;
+            for (int i = m + t; i < n; i += SY_THREADS) {
+                const double vi = v[i];
+#pragma unroll
+                for (int c = 0; c < SY_CMAX; ++c)
+                    if (c >= c0 && c < ncol) acc[c] = __builtin_fma(col[(size_t)c * n + i], vi, acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < SY_CMAX; ++c) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+                if ((t & 63) == 0) red[(1 + c) * SY_NW + (t >> 6)] = acc[c];
+            }
+            __syncthreads();
+            if (t >= c0 && t < ncol) {
+                double dot = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < SY_NW; ++wv) dot += red[(1 + t) * SY_NW + wv];
+                sy_store(pb + b + t * nb, tau * dot);
+            }
+        }
+        if (b == m % nb) {
+            const double *x = col + (size_t)(m / nb) * n;
+            for (int i = m + 1 + t; i < n; i += SY_THREADS) sy_store(rb + i, x[i]);
+        }
+        sy_grid_sync(a.bar, target, (unsigned)nb);
+        if (m >= 1 && tau != 0.0) {
+            // both vectors' loads in flight at once (a round trip to memory each)
+            double tx[SY_PT], tp[SY_PT];
+#pragma unroll
+            for (int u = 0; u < SY_PT; ++u) {
+                const int i = m + t + u * SY_THREADS;
+                tx[u] = (i > m && i < n) ? sy_load(rb + i) : 0.0;
+                tp[u] = i < n ? sy_load(pb + i) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < SY_PT; ++u) {
+                const int i = m + t + u * SY_THREADS;
+                if (i > m && i < n) xr[i] = tx[u];
+                if (i < n) w[i] = tp[u];
+            }
+            __syncthreads();
+            double pv = 0.0;
+            for (int i = m + t; i < n; i += SY_THREADS) pv = __builtin_fma(w[i], v[i], pv);
+            const double ptv = sy_block_sum(pv, red);
+            const double al = -0.5 * tau * ptv;
+            for (int i = m + t; i < n; i += SY_THREADS) w[i] = __builtin_fma(al, v[i], w[i]);
+            __syncthreads();
+            for (int c = c0; c < ncol; ++c) {
+                const int j = b + c * nb;
+                const double vj = v[j], wj = w[j];
+                double *cj = col + (size_t)c * n;
+                for (int i = m + t; i < n; i += SY_THREADS) cj[i] -= v[i] * wj + w[i] * vj;
+            }
+            const double vm = v[m], wm = w[m];
+            for (int i = m + 1 + t; i < n; i += SY_THREADS) xr[i] -= v[i] * wm + w[i] * vm;       // column m as its owner now has it
+        } else {
+            sy_fetch(rb, xr, m + 1, n);
+        }
+        __syncthreads();
+        // reflector m from xr[m + 1 .. n - 1] (dlarfg)
+        double ss = 0.0;
+        for (int i = m + 2 + t; i < n; i += SY_THREADS) ss = __builtin_fma(xr[i], xr[i], ss);
+        const double xn2 = sy_block_sum(ss, red);
+        const double alpha = xr[m + 1];
+        double beta = alpha, scal = 0.0;
+        tau = 0.0;
+        if (xn2 != 0.0) {
+            const double nrm = det_sqrt(alpha * alpha + xn2);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scal = 1.0 / (alpha - beta);
+        }
+        __syncthreads();                                              // every thread has read alpha
+        for (int i = m + 2 + t; i < n; i += SY_THREADS) v[i] = xr[i] * scal;
+        if (t == 0) v[m + 1] = 1.0;
+        if (b == m % nb) {
+            for (int i = m + 2 + t; i < n; i += SY_THREADS) a.A[(size_t)m * n + i] = xr[i] * scal;      // LAPACK's storage of reflector m
+            if (t == 0) {
+                a.D[m] = col[(size_t)(m / nb) * n + m];
+                a.E[m] = beta;
+                a.tau[m] = tau;
+            }
+        }
+        __syncthreads();
+    }
+    if ((n - 1) % nb == b && t == 0) a.D[n - 1] = col[(size_t)((n - 1) / nb) * n + (n - 1)];
+}
+// eigenvalues ascending (the library's order) -> by decreasing size in absolute value, the eigenvectors (rows of C) along
+__global__ __launch_bounds__(256) void eig_sort_rows_kernel(const double *D, const double *Cm, int n, double *Ut, double *S)
+{
+    __shared__ int rank_s;
+    const int k = (int)blockIdx.x;
+    if (threadIdx.x == 0) {
+        const double mine = __builtin_fabs(D[k]);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const double o = __builtin_fabs(D[j]); rank += (o > mine) || (o == mine && j > k); }
+        rank_s = rank;
+        S[rank] = mine;
+    }
+    __syncthreads();
+    const int rank = rank_s;
+    for (int i = (int)threadIdx.x; i < n; i += 256) Ut[(size_t)rank * n + i] = Cm[(size_t)k * n + i];
+}
+// the library's entry points, looked up in the copies the process has loaded already (torch brings its own librocsolver / librocblas;
+// a second copy from /opt/rocm beside them is not wanted)
+struct SyLib {
+    void *blas_handle;                     // first two members: ptmi_destroy releases the handle through them
+    int (*destroy_handle)(void *);
+    int (*create_handle)(void **);
+    int (*set_stream)(void *, hipStream_t);
+    int (*dstedc)(void *, int, int, double *, double *, double *, int, int *);
+    int (*dormtr)(void *, int, int, int, int, int, double *, int, double *, double *, int);
+};
+static int sy_lib_get(ptmi_engine *h, SyLib **out)
+{
+    if (h->sy_lib) { *out = (SyLib *)h->sy_lib; return PTMI_OK; }
+    void *sol = nullptr, *bla = nullptr;
+    for (const char *nm : {"librocsolver.so.0", "librocsolver.so"}) if (!sol) sol = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *nm : {"librocblas.so.5", "librocblas.so.4", "librocblas.so"}) if (!bla) bla = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    if (!sol) sol = dlopen("librocsolver.so.0", RTLD_NOW);
+    if (!bla) bla = dlopen("librocblas.so.5", RTLD_NOW);
+    if (!sol || !bla) return fail(PTMI_EUNSUPPORTED, "ptmi_eig_sytrd needs the ROCm libraries librocsolver / librocblas in the process (import torch first): %s", dlerror());
+    SyLib *L = (SyLib *)calloc(1, sizeof(SyLib));
+    if (!L) return fail(PTMI_EHIP, "out of memory");
+    L->destroy_handle = (int (*)(void *))dlsym(bla, "rocblas_destroy_handle");
+    L->create_handle = (int (*)(void **))dlsym(bla, "rocblas_create_handle");
+    L->set_stream = (int (*)(void *, hipStream_t))dlsym(bla, "rocblas_set_stream");
+    L->dstedc = (int (*)(void *, int, int, double *, double *, double *, int, int *))dlsym(sol, "rocsolver_dstedc");
+    L->dormtr = (int (*)(void *, int, int, int, int, int, double *, int, double *, double *, int))dlsym(sol, "rocsolver_dormtr");
+    if (!L->create_handle || !L->set_stream || !L->dstedc || !L->dormtr) { free(L); return fail(PTMI_EUNSUPPORTED, "rocsolver_dstedc / rocsolver_dormtr not found"); }
+    if (L->create_handle(&L->blas_handle) != 0) { free(L); return fail(PTMI_EHIP, "rocblas_create_handle failed"); }
+    h->sy_lib = L;
+    *out = L;
+    return PTMI_OK;
+}
+
+int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    const ptmi_config &c = h->cfg;
+    if (!h->buf.cov) return fail(PTMI_EINVAL, "cov buffer missing");
+    if (c.cov_per_walker || c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "ptmi_eig_sytrd factorizes ONE pooled covariance (no parameter groups)");
+    const int n = c.ndim;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    double *Uo = Ut_out ? Ut_out : h->buf.Ut, *So = S_out ? S_out : h->buf.S;
+    if (!Uo || !So) return fail(PTMI_EINVAL, "Ut / S buffers missing");
+    int dev = 0, ncu = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    int nb = ncu / 4 > 0 ? ncu / 4 : 1;                             // 64 blocks: the barrier's cost grows with them (21.1 ms at 64, 23.1 at 128, 27.8 at 256)
+    while ((n + nb - 1) / nb > SY_CMAX && nb < ncu) nb *= 2;
+    if (const char *e = getenv("PTMI_SYTRD_BLOCKS")) nb = atoi(e);
+    if (nb > ncu) nb = ncu;
+    if (nb > n) nb = n;
+    if (n < 3 || (n + nb - 1) / nb > SY_CMAX) return fail(PTMI_EUNSUPPORTED, "ptmi_eig_sytrd: 3 <= ndim <= %d on this device", SY_CMAX * nb);
+    int cpb = (n + nb - 1) / nb;                                    // columns per block
+    const size_t lds = sizeof(double) * ((size_t)(SY_CMAX + 3) * n + (size_t)(1 + SY_CMAX) * SY_NW);
+    if (lds > 160 * 1024 || n > 1024) return fail(PTMI_EUNSUPPORTED, "ptmi_eig_sytrd: ndim = %d does not fit the LDS", n);
+    (void)cpb;
+    SyLib *L = nullptr;
+    if (int rc = sy_lib_get(h, &L)) return rc;
+    const size_t nn = (size_t)n * n;
+    if (!h->d_sy_scr) HIPCHK(hipMalloc(&h->d_sy_scr, sizeof(double) * (2 * nn + 8 * (size_t)n + 64) + 256));
+    double *A = (double *)h->d_sy_scr, *Cm = A + nn, *D = Cm + nn, *E = D + n, *tau = E + n, *vbuf = tau + n, *pbuf = vbuf + 2 * (n + 2);
+    unsigned *bar = (unsigned *)(pbuf + 2 * n + 2);
+    int *info = (int *)(bar + 4);
+    HIPCHK(hipMemcpyAsync(A, h->buf.cov, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemsetAsync(bar, 0, 32, st));
+    HIPCHK(hipFuncSetAttribute((const void *)sytrd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SytrdArgs sa = {A, D, E, tau, vbuf, pbuf, bar, n};
+    hipLaunchKernelGGL(sytrd_lds_kernel, dim3(nb), dim3(SY_THREADS), lds, st, sa);
+    HIPCHK(hipGetLastError());
+    if (L->set_stream(L->blas_handle, st) != 0) return fail(PTMI_EHIP, "rocblas_set_stream failed");
+    // eigenvectors of the tridiagonal matrix (columns of C), then C := Q C with the reflectors of the reduction
+    int rs = L->dstedc(L->blas_handle, 212 /* rocblas_evect_tridiagonal */, n, D, E, Cm, n, info);
+    if (rs != 0) return fail(PTMI_EHIP, "rocsolver_dstedc: status %d", rs);
+    rs = L->dormtr(L->blas_handle, 141 /* left */, 122 /* lower */, 111 /* no transpose */, n, n, A, n, tau, Cm, n);
+    if (rs != 0) return fail(PTMI_EHIP, "rocsolver_dormtr: status %d", rs);
+    hipLaunchKernelGGL(eig_sort_rows_kernel, dim3(n), dim3(256), 0, st, (const double *)D, (const double *)Cm, n, Uo, So);
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -142,6 +142,8 @@ struct ptmi_engine {
     hipEvent_t ev0, ev1;
     hipStream_t side;            // pooled statistics at ndim > 111: the diagonal macro tiles run beside the off-diagonal ones
     hipEvent_t side_go, side_done;
+    void *d_sy_scr;              // ptmi_eig_sytrd: the working matrix, d / e / tau, the eigenvectors, the exchange vectors and the barrier word
+    void *sy_lib;                // ... and the ROCm library's entry points (SyLib, ptmi_abi.hip)
     void *d_ql_scr;              // ptmi_eig_ql with many matrices: the transformations, tridiagonal matrices and recorded rotations (QlScratch)
     void *d_rle_ent;             // pooled statistics over run-length-compacted rows: the stored rows of each slab, 16 bytes each [nrows]
                                  // (PoolEnt, ptmi_abi.hip: the row inside its slab, the square root of its run length) ...

@@ -10,6 +10,8 @@ allocation, host<->device copies, and RCCL in ``sharded.py``).
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -104,6 +106,9 @@ class PTEngine(object):
     tensor: no host round trip either; one parameter group) -- the choice for large ndim, where the host's LAPACK call is the
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
+    ``"sytrd"`` = ``ptmi_eig_sytrd`` for ONE large pooled covariance (ndim <= 1024): Householder tridiagonalization in one kernel with the
+    matrix in the LDS of 128 blocks, then the library's divide-and-conquer solver of the tridiagonal matrix and its
+    back-transformation -- the library's own reduction is 7000 launches of one-block kernels, two thirds of its 35 ms.
     ``eig_lag`` (L >= 0 launches; pooled covariance): the eigenvectors of a covariance epoch take effect L launches late --
     ``run`` queues the L launches that follow the epoch (and their swaps) with the table in force, the factorization runs
     MEANWHILE, and the launch after them uses the result (a new epoch finishes a pending one first).  The reference applies the
@@ -150,8 +155,10 @@ class PTEngine(object):
         if pick_mode not in _lib.PICK_MODES:
             raise ValueError("pick_mode must be 'chain' or 'walker'")
         self.pick_mode = pick_mode
-        if eig_mode not in ("lapack", "jacobi", "ql", "hipsolver"):
-            raise ValueError("eig_mode must be 'lapack', 'jacobi', 'ql' or 'hipsolver'")
+        if eig_mode not in ("lapack", "jacobi", "ql", "hipsolver", "sytrd"):
+            raise ValueError("eig_mode must be 'lapack', 'jacobi', 'ql', 'hipsolver' or 'sytrd'")
+        if eig_mode == "sytrd" and (cov_mode != "pooled" or not 3 <= int(ndim) <= 1024):
+            raise ValueError("eig_mode='sytrd' factorizes one pooled covariance of 3 <= ndim <= 1024")
         self.eig_mode = eig_mode
         if int(eig_lag) < 0:
             raise ValueError("eig_lag must be >= 0 launches")
@@ -162,7 +169,7 @@ class PTEngine(object):
         self.ngr = len(self.groups)
         # "whole": one group that IS the full parameter vector in order (a permutation of it needs put_eig's embedding)
         self.whole = self.ngr == 1 and np.array_equal(self.groups[0], np.arange(self.d))
-        if eig_mode in ("jacobi", "ql", "hipsolver") and not self.whole:
+        if eig_mode in ("jacobi", "ql", "hipsolver", "sytrd") and not self.whole:
             raise ValueError("eig_mode=%r factorizes the full covariance: no parameter groups" % eig_mode)
         self.gsize = np.ascontiguousarray([len(g) for g in self.groups], dtype=np.int32)
         self.gmask = np.zeros((self.ngr, self.d))
@@ -349,7 +356,7 @@ class PTEngine(object):
         staging tensors until _eig_end_side."""
         torch = _torch()
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device, priority=-1)      # its small kernels go ahead of the step kernel's next blocks
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PTMI_SIDE_PRIO", "-1")))      # its small kernels go ahead of the step kernel's next blocks
             self._side_go, self._side_done = torch.cuda.Event(), torch.cuda.Event()
             self._ut_next, self._s_next = torch.empty_like(self.t["Ut"]), torch.empty_like(self.t["S"])
         self._side_go.record(self.stream)
@@ -360,10 +367,14 @@ class PTEngine(object):
             # thread from queueing the launches the factorization is meant to run beside
             torch.cuda.set_device(self.device)
             with torch.cuda.stream(self._side):
-                w, V = torch.linalg.eigh(self.t["cov"])
-                w, order = w.abs().sort(dim=-1, descending=True, stable=True)
-                self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
-                self._s_next[:, 0].copy_(w)
+                if self.eig_mode == "sytrd":
+                    _lib.check(self.lib.ptmi_eig_sytrd(self.h, C.c_void_p(self._side.cuda_stream), C.c_void_p(self._ut_next.data_ptr()),
+                                                       C.c_void_p(self._s_next.data_ptr())))
+                else:
+                    w, V = torch.linalg.eigh(self.t["cov"])
+                    w, order = w.abs().sort(dim=-1, descending=True, stable=True)
+                    self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
+                    self._s_next[:, 0].copy_(w)
                 self._side_done.record(self._side)
 
         import threading
@@ -384,7 +395,7 @@ class PTEngine(object):
     def _eig_finish(self):
         """The pending factorization of the last covariance epoch takes effect (eig_lag launches after it, or at the next epoch)."""
         if self._eig_pending:
-            if self.eig_mode == "hipsolver":
+            if self.eig_mode in ("hipsolver", "sytrd"):
                 self._eig_end_side()
             else:
                 self._eig_end()
@@ -502,12 +513,15 @@ class PTEngine(object):
             _lib.check(self.lib.ptmi_eig_jacobi(self.h) if self.eig_mode == "jacobi" else self.lib.ptmi_eig_ql(self.h))
             self.eig_epochs += 1
             return
-        if self.eig_mode == "hipsolver":
+        if self.eig_mode in ("hipsolver", "sytrd"):
             if self.eig_lag and not self.per_walker:
                 self._eig_begin_side()                                # run() puts it into force eig_lag launches later
                 self._eig_wait = self.eig_lag
                 return
-            self._eig_hipsolver()
+            if self.eig_mode == "sytrd":
+                _lib.check(self.lib.ptmi_eig_sytrd(self.h, None, None, None))      # on the engine's stream, into Ut / S
+            else:
+                self._eig_hipsolver()
             self.eig_epochs += 1
             return
         if self.Wc == 1 and not self.per_walker and self.whole:

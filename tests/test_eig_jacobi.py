@@ -174,3 +174,54 @@ def test_library_eigensolver_on_the_stream(cov_mode, d, nt, W):
     assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12)
     js = g.get("jstat").astype(np.int64)
     assert (js[..., :2, 0].sum(-1) == 130).all() and js[..., 1, 1].sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [3, 37, 130, 300, 1000])
+def test_sytrd_eigensolver_decomposes_a_covariance(d):
+    """ptmi_eig_sytrd (eig_mode="sytrd": Householder tridiagonalization in one kernel with the matrix in the LDS of its blocks, then the
+    library's rocsolver_dstedc / rocsolver_dormtr) on a random ill-scaled covariance: eigenvalues against numpy.linalg.eigvalsh,
+    orthonormal rows, U diag(S) U^T = cov.  Replaces np.linalg.svd of PTMCMCSampler.py:797-803 for one large pooled covariance."""
+    import torch
+    from ptmcmcsampler_amd import _lib
+    from ptmcmcsampler_amd.engine import PTEngine
+    g = PTEngine(d, 2, 2, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=100, burn=1000, tskip=10, seed=1, cov_mode="pooled",
+                 use_de_buffer=False, eig_mode="sytrd")
+    g.init_state(np.zeros(d))
+    rng = np.random.default_rng(d)
+    X = rng.standard_normal((4 * d, d)) * np.exp(rng.uniform(-2, 2, d))
+    cov = X.T @ X / (4 * d)
+    g.t["cov"][0].copy_(torch.from_numpy(cov))
+    for _ in range(2):                                              # twice: the scratch and the barrier word are reused
+        _lib.check(g.lib.ptmi_eig_sytrd(g.h, None, None, None))
+    g.sync()
+    Ut, S = g.get("Ut")[0, 0], g.get("S")[0, 0]
+    w = np.sort(np.abs(np.linalg.eigvalsh(cov)))[::-1]
+    assert np.allclose(S, w, rtol=0, atol=1e-12 * w.max())
+    assert np.allclose(Ut @ Ut.T, np.eye(d), atol=1e-12)
+    assert np.allclose((Ut.T * S) @ Ut, cov, rtol=0, atol=1e-12 * np.abs(cov).max())
+    assert (np.diff(S) <= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lag", [0, 3])
+def test_sytrd_eigensolver_in_a_run(lag):
+    """A pooled run adapted through eig_mode="sytrd", at once and on the side stream (eig_lag): the decomposition the proposals use
+    and the chains' own arithmetic, as for the library's eigensolver above."""
+    from ptmcmcsampler_amd.engine import PTEngine
+    d, nt, W = 300, 4, 12
+    rs = np.random.RandomState(8)
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 20, 0), cov_update=50, burn=1000, tskip=10, seed=3, cov_mode="pooled",
+                 eig_mode="sytrd", eig_lag=lag)
+    g.init_state(rs.randn(W, nt, d) * 0.2)
+    g.run(130)
+    g._eig_finish()
+    g.sync()
+    assert g.eig_epochs == 2
+    cov, Ut, S = g.get("cov")[0], g.get("Ut")[0, 0], g.get("S")[0, 0]
+    assert np.allclose(Ut.T @ np.diag(S) @ Ut, cov, rtol=0, atol=1e-12 * np.abs(cov).max())
+    assert np.allclose(Ut @ Ut.T, np.eye(d), atol=1e-12)
+    X, lnL = g.get("X"), g.get("lnL")
+    assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12)
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., :2, 0].sum(-1) == 130).all() and js[..., 1, 1].sum() > 0
