@@ -3220,27 +3220,28 @@ __global__ __launch_bounds__(SY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         double *pb = a.pbuf + (size_t)par * n, *rb = a.vbuf + (size_t)par * (n + 2);
         const int c0 = m <= b ? 0 : (m - b + nb - 1) / nb;             // this block's columns j >= m: those from c0 on
         if (m >= 1 && tau != 0.0) {
-            double acc[SY_CMAX];
+            // a wave per column (columns wave, wave + SY_NW, ...: SY_CMAX / SY_NW accumulators per lane, reduced inside the wave,
+            // no barrier): with every thread on every column the 16 accumulators' 96 shuffle steps, an LDS exchange between the
+            // waves and a barrier made this the longest part of a step (9 of 12.5 us)
+            constexpr int CW = SY_CMAX / SY_NW;
+            const int wv = t >> 6, ln = t & 63;
+            double acc[CW];
 #pragma unroll
-            for (int c = 0; c < SY_CMAX; ++c) acc[c] = 0.0;
-            for (int i = m + t; i < n; i += SY_THREADS) {
+            for (int q = 0; q < CW; ++q) acc[q] = 0.0;
+            for (int i = m + ln; i < n; i += 64) {
                 const double vi = v[i];
 #pragma unroll
-                for (int c = 0; c < SY_CMAX; ++c)
-                    if (c >= c0 && c < ncol) acc[c] = __builtin_fma(col[(size_t)c * n + i], vi, acc[c]);
+                for (int q = 0; q < CW; ++q) {
+                    const int c = wv + q * SY_NW;
+                    if (c >= c0 && c < ncol) acc[q] = __builtin_fma(col[(size_t)c * n + i], vi, acc[q]);
+                }
             }
 #pragma unroll
-            for (int c = 0; c < SY_CMAX; ++c) {
+            for (int q = 0; q < CW; ++q) {
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
-                if ((t & 63) == 0) red[(1 + c) * SY_NW + (t >> 6)] = acc[c];
-            }
-            __syncthreads();
-            if (t >= c0 && t < ncol) {
-                double dot = 0.0;
-#pragma unroll
-                for (int wv = 0; wv < SY_NW; ++wv) dot += red[(1 + t) * SY_NW + wv];
-                sy_store(pb + b + t * nb, tau * dot);
+                for (int o = 32; o >= 1; o >>= 1) acc[q] += __shfl_xor(acc[q], o, 64);
+                const int c = wv + q * SY_NW;
+                if (ln == 0 && c >= c0 && c < ncol) sy_store(pb + b + c * nb, tau * acc[q]);
             }
         }
         if (b == m % nb) {
