@@ -42,15 +42,20 @@ for N in [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8]:
         torch.cuda.synchronize()
         return ev[0].elapsed_time(ev[1]) / n
 
+    # the part's clocks need tens of milliseconds of load to come up from idle (bench.py --preheat): five launches from a cold
+    # start read 0.87 ms where a long run holds 0.72
+    for k in range(400):
+        e.mh_steps(100 * k + 1, 99)
+    torch.cuda.synchronize()
     epoch(100)
-    ms = timed(epoch)
-    mh = timed(lambda it: e.mh_steps(it + 1, 99))
+    ms = timed(epoch, 20)
+    mh = timed(lambda it: e.mh_steps(it + 1, 99), 50)
     print("N=%d (ladder of %d): swap epoch %.3f ms on the device, 100 MH steps %.3f ms -> %.1f %% of the MH time" % (N, ntg, ms, mh, 100 * ms / mh), flush=True)
     # the owner's covariance epoch (pooled statistics over the stored rows), once per covUpdate / Tskip swap epochs
     for seg in range(10):                                    # a full ring of rows and flags (no swaps: block 0 alone cannot run them)
         e.mh_steps(100 * seg + 1, 100)
     from ptmcmcsampler_amd import _lib
-    cov = timed(lambda it: _lib.check(e.lib.ptmi_update_cov(e.h, 1000)), 3)
+    cov = timed(lambda it: _lib.check(e.lib.ptmi_update_cov(e.h, 1000)), 5)
     results[N] = {"swap_epoch_device_ms": ms, "mh_100_steps_ms": mh, "cov_epoch_stats_ms": cov}
     del e
     torch.cuda.empty_cache()
