@@ -126,6 +126,10 @@ class ShardedPTEngine(object):
         if local_factory is None:
             from .engine import PTEngine
             local_factory = PTEngine
+        if kw.get("eig_lag", 0) and kw.get("eig_mode", "lapack") != "lapack":
+            # the late table is broadcast for the host path only (below); a device factorization on the owner's side stream would
+            # take effect there a period late and never reach the other blocks in step
+            raise ValueError("ShardedPTEngine: eig_lag > 0 needs eig_mode='lapack' (got %r)" % (kw.get("eig_mode"),))
         self.local = local_factory(ndim, self.nt, nwalkers, cov0, ntemps_global=ntemps_global, temp0=self.temp0, **kw)
         L = self.local
         self.t, self.owns_cold, self.device = L.t, L.owns_cold, L.device
