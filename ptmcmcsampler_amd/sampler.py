@@ -22,7 +22,9 @@ the reference runs unchanged as ONE process driving one GPU.  Differences, all a
   host; custom Python jumps cannot be mixed in;
 * engine options: ``cov_mode="pooled"`` (one covariance adapted from all walkers instead of one per walker),
   ``swap_mode="oddeven"`` (disjoint swap pairs instead of the reference's hot -> cold sweep), ``pick_mode="walker"`` (one
-  proposal-type draw per walker and iteration), ``eig_mode="jacobi"`` (covariance epochs factorized on the device),
+  proposal-type draw per walker and iteration), ``eig_mode="ql"`` / ``"jacobi"`` / ``"sytrd"`` / ``"hipsolver"`` (covariance epochs factorized on the device: per-walker matrices by
+  QL or Jacobi kernels, one large pooled matrix by a one-kernel tridiagonalization + the library's divide-and-conquer, or the ROCm
+  library's eigensolver; see PTEngine),
   ``keep_walkers``.
 
 Attributes ``_chain, _lnlike, _lnprob, naccepted, nswap_accepted, swapProposed, jumpDict, cov,
