@@ -43,3 +43,9 @@ run c5_stats --stats -- --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 4
 run c4_stats --stats -- --ndim 1000 --nwalkers 512 --steps 30 --warmup 20
 run c4mix_stats --stats -- --ndim 1000 --nwalkers 512 --mix default --steps 3 --warmup 1
 ls $OUT/*.txt
+# vector / LDS activity of the per-walker epoch kernels (Welford rows, QL reduce / chains / register apply) and of config 4's epoch
+# (step kernel, statistics, sytrd_lds_kernel): counters only, one pass each
+run pwd_sq --pmc $SQ -- --cov-mode per_walker_device --steps 20 --warmup 10
+run pwd_lds --pmc $LDS -- --cov-mode per_walker_device --steps 20 --warmup 10
+run c4_sq --pmc $SQ -- --ndim 1000 --nwalkers 512 --steps 30 --warmup 20
+ls $OUT/*.txt
