@@ -198,7 +198,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps);
 
 /* Which instantiation of the fused kernel the most recent ptmi_mh_steps launched (the parity tests assert that they
  * reached the one they mean to test): a combination of the flags below, plus lanes per chain in bits 12-19 and register
- * slots per lane in bits 20-27. */
+ * slots per lane in bits 20-27 (PTMI_VAR_UTPAD sits above them). */
 enum { PTMI_VAR_STAGED = 1,    /* strided lane layout, tables in LDS, products on the f64 matrix cores */
        PTMI_VAR_FULL = 2,      /* the cycle holds AM and / or an active DE (else SCAM only) */
        PTMI_VAR_LDS_UT = 4,    /* staged: the eigenvector table is in LDS too */
@@ -212,7 +212,9 @@ enum { PTMI_VAR_STAGED = 1,    /* strided lane layout, tables in LDS, products o
                                   * blocks (two waves per SIMD over one copy of the tables) -- what bench.py --logl dense times */
        PTMI_VAR_PERSISTENT = 1024, /* SCAM-only cycle, one eigenvector table for the launch (pooled covariance): persistent blocks, one
                                     * per CU over one LDS copy of the table, each wave walking over units of 16 chains -- what bench.py times */
-       PTMI_VAR_PC = 2048      /* cycles with AM entries, per-chain picks: stepper and AM-producer waves paired per SIMD (mh_pc_kernel) */ };
+       PTMI_VAR_PC = 2048,     /* cycles with AM entries, per-chain picks: stepper and AM-producer waves paired per SIMD (mh_pc_kernel) */
+       PTMI_VAR_UTPAD = 268435456 /* = 1 << 28, above the shape bits: 16- / 64-lane shapes, SCAM-only cycle, one table for the launch: wide draw batches (all lanes of a chain
+                                 * draw), the direction read from the library's zero-padded copy of the table -- what bench.py --ndim 1000 times */ };
 int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant);
 
 /* PTswap (:631-697) for iteration `iter` when the whole ladder is on this GPU. */
@@ -288,6 +290,10 @@ int ptmi_eig_ql(ptmi_handle h);
  * is the epoch.  On `stream` (NULL: the handle's), results into Ut_out [ndim][ndim] / S_out [ndim] (NULL: the handle's Ut / S):
  * eigenvalues in absolute value, descending; no sign rule (the library's vectors).  Its last bits are the library's. */
 int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out);
+/* The convergence word (LAPACK's `info` of dstedc: 0 = converged) of the most recent ptmi_eig_sytrd whose result has reached the
+ * host: it follows the factorization on its stream into pinned memory, so the call never waits; check it once that stream has been
+ * waited for (the engine does at its next covariance epoch and in sync()).  Non-zero: Ut / S of that epoch are not to be trusted. */
+int ptmi_eig_sytrd_info(ptmi_handle h, int32_t *info);
 
 /* _updateDEbuffer (:806-817): drop the oldest cov_update rows of each DE history and
  * append the AM buffer (pooled mode: row r comes from walker r mod W). */

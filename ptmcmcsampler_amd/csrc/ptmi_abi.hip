@@ -5,10 +5,13 @@
 #include <dlfcn.h>
 
 #include <new>
+#include <mutex>
 #include <vector>
 
 #include <type_traits>
 
+#include <rocblas/internal/rocblas-types.h>          // enum values only (ptmi_eig_sytrd calls the library through dlsym, nothing is linked)
+#include <rocsolver/rocsolver-extra-types.h>
 #include "ptmi_common.h"
 
 // ------------------------------------------------------------------ errors
@@ -2503,7 +2506,8 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
-    (void)hipFree(h->d_ql_scr); (void)hipFree(h->d_sy_scr);
+    (void)hipFree(h->d_ql_scr); (void)hipFree(h->d_sy_scr); (void)hipFree(h->d_utpad);
+    if (h->h_sy_info) (void)hipHostFree(h->h_sy_info);
     if (h->sy_lib) {                                                // SyLib: the library's handle, its destructor
         void **sl = (void **)h->sy_lib;
         if (sl[0] && sl[1]) ((int (*)(void *))sl[1])(sl[0]);
@@ -2545,6 +2549,30 @@ int ptmi_eval_state(ptmi_handle h)
     return PTMI_OK;
 }
 
+// rows of ld >= d doubles, zero beyond column d: the 16- / 64-lane step kernels read a row with unconditional loads
+__global__ __launch_bounds__(256) void ut_pad_kernel(const double *Ut, double *out, int d, int ld)
+{
+    const double *src = Ut + (size_t)blockIdx.x * d;
+    double *dst = out + (size_t)blockIdx.x * ld;
+    for (int i = (int)threadIdx.x; i < ld; i += 256) dst[i] = i < d ? src[i] : 0.0;
+}
+// ONE table for the launch and a wide shape: the padded copy the step kernels read (the caller's Ut may have changed since the
+// last launch -- an epoch, put_eig -- so it is made anew every launch: 16 MB of traffic at ndim = 1000 beside a launch of milliseconds)
+static int make_ut_pad(ptmi_engine *h, KArgs *a)
+{
+    const ptmi_config &c = h->cfg;
+    a->UtPad = nullptr;
+    a->ut_pad_ld = 0;
+    static const bool off = getenv("PTMI_NO_UTPAD") != nullptr;       // measurement / test switch: same results either way
+    if (h->G <= 4 || c.cov_per_walker || c.ngroups > 1 || off) return PTMI_OK;
+    const int ld = h->G * h->EPL;
+    if (!h->d_utpad) HIPCHK(hipMalloc((void **)&h->d_utpad, sizeof(double) * (size_t)c.ndim * ld));
+    hipLaunchKernelGGL(ut_pad_kernel, dim3(c.ndim), dim3(256), 0, h->stream, (const double *)h->buf.Ut, h->d_utpad, c.ndim, ld);
+    a->UtPad = h->d_utpad;
+    a->ut_pad_ld = ld;
+    return PTMI_OK;
+}
+
 int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
@@ -2574,6 +2602,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     const bool full = h->cfg.w_am > 0 || (h->de_on && h->cfg.w_de > 0);
     if (!full && h->cfg.w_scam <= 0) return fail(PTMI_EINVAL, "empty proposal cycle");
     const int grid = chains_grid(h);
+    if (int rc = make_ut_pad(h, &a)) return rc;
     if (h->am_piece > 0) {
         // large ndim: the launch goes in pieces, each behind the matrix product that computes its AM increments
         const ptmi_config &c = h->cfg;
@@ -2594,6 +2623,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             ap.iter0 = iter0 + s0; ap.nsteps = ns;
             if (int rc = set_step_args(h, &ap)) return rc;
             ap.am_inc = h->d_am_inc; ap.am_base = h->d_am_base;
+            ap.UtPad = a.UtPad; ap.ut_pad_ld = a.ut_pad_ld;
             if (int rc = run_shape(h, PTMI_OP_MH, ap, grid, full)) return rc;
         }
         HIPCHK(hipGetLastError());
@@ -3419,16 +3449,47 @@ int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out)
     HIPCHK(hipMemsetAsync(bar, 0, 32, st));
     HIPCHK(hipFuncSetAttribute((const void *)sytrd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SytrdArgs sa = {A, D, E, tau, vbuf, pbuf, bar, n};
-    hipLaunchKernelGGL(sytrd_lds_kernel, dim3(nb), dim3(SY_THREADS), lds, st, sa);
-    HIPCHK(hipGetLastError());
+    // The kernel's grid barrier needs all nb blocks resident at once.  One block per CU always fits an otherwise free CU (checked
+    // here against the occupancy the runtime computes); beside persistent step kernels the blocks take the CUs' remaining LDS as it
+    // is (the step kernel leaves 78 KB, a block needs up to 160: such a block starts when its CU's step block ends, and every step
+    // block ends).  What could deadlock is a SECOND factorization of another engine on the same device holding part of the CUs with
+    // blocks that spin: factorizations of one device are therefore serialized by an event chain across engines and streams.
+    int occ = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sytrd_lds_kernel, SY_THREADS, lds));
+    if (occ < 1 || (long long)occ * ncu < nb)
+        return fail(PTMI_EUNSUPPORTED, "ptmi_eig_sytrd: %d blocks of %zu B of LDS cannot be resident at once on %d CUs", nb, lds, ncu);
+    {
+        static std::mutex mu;
+        static hipEvent_t last[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        const int di = dev & 63;
+        if (last[di]) HIPCHK(hipStreamWaitEvent(st, last[di], 0));
+        else HIPCHK(hipEventCreateWithFlags(&last[di], hipEventDisableTiming));
+        hipLaunchKernelGGL(sytrd_lds_kernel, dim3(nb), dim3(SY_THREADS), lds, st, sa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(last[di], st));
+    }
     if (L->set_stream(L->blas_handle, st) != 0) return fail(PTMI_EHIP, "rocblas_set_stream failed");
     // eigenvectors of the tridiagonal matrix (columns of C), then C := Q C with the reflectors of the reduction
-    int rs = L->dstedc(L->blas_handle, 212 /* rocblas_evect_tridiagonal */, n, D, E, Cm, n, info);
+    int rs = L->dstedc(L->blas_handle, (int)rocblas_evect_tridiagonal, n, D, E, Cm, n, info);
     if (rs != 0) return fail(PTMI_EHIP, "rocsolver_dstedc: status %d", rs);
-    rs = L->dormtr(L->blas_handle, 141 /* left */, 122 /* lower */, 111 /* no transpose */, n, n, A, n, tau, Cm, n);
+    // the solver's convergence word follows the result to the host on the same stream (ptmi_eig_sytrd_info reads the last one that arrived)
+    if (!h->h_sy_info) {
+        HIPCHK(hipHostMalloc((void **)&h->h_sy_info, 2 * sizeof(int32_t)));
+        h->h_sy_info[0] = 0; h->h_sy_info[1] = 0;
+    }
+    HIPCHK(hipMemcpyAsync(h->h_sy_info, info, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    rs = L->dormtr(L->blas_handle, (int)rocblas_side_left, (int)rocblas_fill_lower, (int)rocblas_operation_none, n, n, A, n, tau, Cm, n);
     if (rs != 0) return fail(PTMI_EHIP, "rocsolver_dormtr: status %d", rs);
     hipLaunchKernelGGL(eig_sort_rows_kernel, dim3(n), dim3(256), 0, st, (const double *)D, (const double *)Cm, n, Uo, So);
     HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_eig_sytrd_info(ptmi_handle h, int32_t *info)
+{
+    if (!h || !info) return fail(PTMI_EINVAL, "NULL argument");
+    *info = h->h_sy_info ? h->h_sy_info[0] : 0;
     return PTMI_OK;
 }
 

@@ -83,6 +83,10 @@ struct KArgs {
     // chain's AM picks of this launch is am_inc[(am_base[chain] + j) * d ...]; nullptr: the kernel computes its own
     const double *am_inc;
     const long long *am_base;
+    // 16- / 64-lane shapes, ONE table for the launch: the library's zero-padded copy of Ut with rows of ut_pad_ld = G * EPL doubles
+    // (ut_pad_kernel, made ahead of the launch), so that a step reads its direction with unconditional loads; nullptr: none
+    const double *UtPad;
+    int ut_pad_ld;
     // gradient jumps (ptmi_gj.inc.h)
     int w_nuts, w_hmc, gj_nburn, hmc_min, hmc_max, nuts_maxdepth;
     double hmc_eps, nuts_delta;
@@ -142,8 +146,10 @@ struct ptmi_engine {
     hipEvent_t ev0, ev1;
     hipStream_t side;            // pooled statistics at ndim > 111: the diagonal macro tiles run beside the off-diagonal ones
     hipEvent_t side_go, side_done;
+    double *d_utpad;             // zero-padded copy of the pooled eigenvector table for the 16- / 64-lane shapes (KArgs::UtPad)
     void *d_sy_scr;              // ptmi_eig_sytrd: the working matrix, d / e / tau, the eigenvectors, the exchange vectors and the barrier word
     void *sy_lib;                // ... and the ROCm library's entry points (SyLib, ptmi_abi.hip)
+    int32_t *h_sy_info;          // pinned: the divide-and-conquer solver's convergence word of the last factorization that has finished
     void *d_ql_scr;              // ptmi_eig_ql with many matrices: the transformations, tridiagonal matrices and recorded rotations (QlScratch)
     void *d_rle_ent;             // pooled statistics over run-length-compacted rows: the stored rows of each slab, 16 bytes each [nrows]
                                  // (PoolEnt, ptmi_abi.hip: the row inside its slab, the square root of its run length) ...

@@ -43,11 +43,29 @@ __device__ __forceinline__ double quad_bcastf(double v) { return dppf64<J * 0x55
 // All-reduce (sum) over the G lanes that share a chain.  Pairing order is the xor
 // butterfly m = G/2 .. 1; after the m = 8 step the data has period 8, so a row rotate
 // by 4 pairs exactly the lanes l and l^4.
+// p[l] + p[l ^ 32] and p[l] + p[l ^ 16] without the LDS round trip of a shuffle: v_permlane32_swap trades the upper half of its first
+// operand for the lower half of its second (v_permlane16_swap: the odd rows of 16 lanes for the even rows), so a register swapped
+// with a copy of itself leaves the lower halves (even rows) in the first result and the upper halves (odd rows) in the second on
+// every lane; their sum is the pair's sum -- for the upper lane with its operands the other way round, which a sum does not see.
+__device__ __forceinline__ double sum_xor32(double p)
+{
+    const u64 b = (u64)__double_as_longlong(p);
+    const auto lo = __builtin_amdgcn_permlane32_swap((u32)b, (u32)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((u32)(b >> 32), (u32)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((u64)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((u64)hi[1] << 32) | lo[1]));
+}
+__device__ __forceinline__ double sum_xor16(double p)
+{
+    const u64 b = (u64)__double_as_longlong(p);
+    const auto lo = __builtin_amdgcn_permlane16_swap((u32)b, (u32)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((u32)(b >> 32), (u32)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((u64)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((u64)hi[1] << 32) | lo[1]));
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double p)
 {
-    if (G >= 64) p = p + __shfl_xor(p, 32, 64);
-    if (G >= 32) p = p + __shfl_xor(p, 16, 64);
+    if (G >= 64) p = sum_xor32(p);
+    if (G >= 32) p = sum_xor16(p);
     if (G >= 16) p = p + dppf64<0x128>(p);   // row_ror:8  == xor 8
     if (G >= 8) p = p + dppf64<0x124>(p);    // row_ror:4  == xor 4 on period-8 data
     if (G >= 4) p = p + dppf64<0x4E>(p);     // quad_perm [2,3,0,1] == xor 2

@@ -372,8 +372,31 @@ struct Draws {
 };
 __device__ __forceinline__ u32 h2index(u32 h, u32 n) { return __umulhi(h, n); }
 __device__ __forceinline__ double h2uniform(u32 h) { return (double)h * 0x1.0p-32; }
-template <bool STR>
+// WIDE draw batches (GW = 16 or 64 lanes per chain, contiguous layout).  The draws depend on the stream alone, so ALL GW lanes of
+// a chain take part in a draw pass: lane j -> slot j & 1 of iteration it + (j >> 1), i.e. GW / 2 iterations per pass (32 at 64
+// lanes) where the four-lane scheme served two whatever GW was -- at GW = 64 sixteen quads computed the same four Philox / log /
+// Box-Muller results sixteen times over, every second step.  Step s of the pass reads its values from lanes 2 s (P word, log u)
+// and 2 s + 1 (Q words, normal / amplitude, direction) of the chain: v_readlane at 64 lanes (the chain is the wave, the lane
+// index a scalar), ds_bpermute at 16.  Same operations on the same values: bit-identical.
+template <int GW>
+__device__ __forceinline__ u32 chain_lane32(u32 v, int j)        // lane j (wave-uniform) of the caller's chain
+{
+    if constexpr (GW == 64) return (u32)__builtin_amdgcn_readlane((int)v, j);
+    else return (u32)__builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & 63) & ~(unsigned)(GW - 1)) + (unsigned)j) << 2), (int)v);
+}
+template <int GW>
+__device__ __forceinline__ u64 chain_lane64(u64 v, int j)
+{
+    return ((u64)chain_lane32<GW>((u32)(v >> 32), j) << 32) | chain_lane32<GW>((u32)v, j);
+}
+template <int GW>
+__device__ __forceinline__ double chain_lanef(double v, int j)
+{
+    return __longlong_as_double((long long)chain_lane64<GW>((u64)__double_as_longlong(v), j));
+}
+template <bool STR, int GW = 4 /* > 4: wide batch over all GW lanes of the chain */>
 struct DrawBatch {
+    static_assert(GW == 4 || !STR, "wide batches serve the contiguous layout");
     u64 w0, w1;           // this lane's Philox words
     double lg, z;         // log of this lane's uniform; odd lanes: the SCAM normal
     u32 pw;               // pick_mode WALKER: this lane's pick word
@@ -388,7 +411,7 @@ struct DrawBatch {
     template <int TM>
     __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl, const double *tsm)
     {
-        const int j = gl & 3;
+        const int j = GW > 4 ? gl : (gl & 3);
         philox_words(a.seed, (u64)(it + (j >> 1)), sid, (u32)(j & 1), w0, w1);
         u32 aj;
         double at;
@@ -418,7 +441,7 @@ struct DrawBatch {
     __device__ __forceinline__ void refill_pick(const KArgs &a, long long it, u32 sid0, int gl)
     {
         u64 p0, p1;
-        philox_words(a.seed, (u64)(it + (gl & 3)), sid0, 0u, p0, p1);
+        philox_words(a.seed, (u64)(it + (GW > 4 ? gl : (gl & 3))), sid0, 0u, p0, p1);
         pw = (u32)(p0 >> 32);
     }
     __device__ __forceinline__ void advance_pick() { pw = rot(pw, 1); }
@@ -432,15 +455,31 @@ struct DrawBatch {
         d.z = grp_bcastf<STR, 1>(z);
         d.pickw = walker ? (u32)grp_bcast<STR, 0>((u64)pw) : (u32)(d.P0 >> 32);
     }
+    // wide batch: step s of the pass (lanes 2 s, 2 s + 1), the walker's pick word of step sp of ITS pass (lane sp)
+    __device__ __forceinline__ void take_wide(Draws &d, bool walker, int s, int sp) const
+    {
+        d.P0 = chain_lane64<GW>(w0, 2 * s);
+        d.log_u = chain_lanef<GW>(lg, 2 * s);
+        d.Q0 = chain_lane64<GW>(w0, 2 * s + 1);
+        d.Q1 = chain_lane64<GW>(w1, 2 * s + 1);
+        d.z = chain_lanef<GW>(z, 2 * s + 1);
+        d.pickw = walker ? chain_lane32<GW>(pw, sp) : (u32)(d.P0 >> 32);
+    }
 };
 // Steps k = 0, 1, ... of a launch that starts at iteration iter0: keep the batch current for step k.
-template <bool STR, bool FULL, int TM = 0>
-__device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, const KArgs &a, int k, u32 sid, u32 sid0, int gl,
+template <bool STR, bool FULL, int TM = 0, int GW = 4>
+__device__ __forceinline__ void draws_for_step(DrawBatch<STR, GW> &b, Draws &dr, const KArgs &a, int k, u32 sid, u32 sid0, int gl,
                                                const double *tsm = nullptr)
 {
+    const bool walker = FULL && a.pick_walker;
+    if constexpr (GW > 4) {                            // the caller refills at the head of every pass of GW / 2 steps (mh_steps_kernel)
+        const int s = k & (GW / 2 - 1), sp = k & (GW - 1);
+        if (walker && sp == 0) b.refill_pick(a, a.iter0 + k, sid0, gl);
+        b.take_wide(dr, walker, s, sp);
+        return;
+    }
     if ((k & 1) == 0) b.template refill<TM>(a, a.iter0 + k, sid, gl, tsm);
     else b.advance();
-    const bool walker = FULL && a.pick_walker;
     if (walker) {
         if ((k & 3) == 0) b.refill_pick(a, a.iter0 + k, sid0, gl);
         else b.advance_pick();
@@ -455,8 +494,9 @@ __device__ __forceinline__ void draws_for_step(DrawBatch<STR> &b, Draws &dr, con
 // with five lane moves, and after the first of the two steps the batch rotates by two lanes.  Same operations in the same
 // order as propose(): bit-identical.
 struct ScamDraw { double log_u, amp; int k; };
-template <bool STR>
+template <bool STR, int GW = 4 /* > 4: wide batch over all GW lanes of the chain */>
 struct ScamBatch {
+    static_assert(GW == 4 || !STR, "wide batches serve the contiguous layout");
     double lg, amp;       // log of this lane's uniform (even lanes: the accept test's); odd lanes: the jump amplitude
     int kdir;             // odd lanes: the eigen-direction
     static __device__ __forceinline__ double rot2(double v)  // value of the chain's lane (gl + 2) & 3
@@ -474,7 +514,7 @@ struct ScamBatch {
     template <int TM, class RS>
     __device__ __forceinline__ void refill(const KArgs &a, long long it, u32 sid, int gl, const ChainConst &cc, int ng, RS root_s, const double *tsm)
     {
-        const int j = gl & 3;
+        const int j = GW > 4 ? gl : (gl & 3);
         u64 w0, w1;
         philox_words(a.seed, (u64)(it + (j >> 1)), sid, (u32)(j & 1), w0, w1);
         u32 aj;
@@ -507,11 +547,21 @@ struct ScamBatch {
         if constexpr (STR) d.k = __shfl(kdir, (int)(threadIdx.x & 15) + 16, 64);
         else d.k = (int)dpp32<0x55>((u32)kdir);
     }
+    __device__ __forceinline__ void take_wide(ScamDraw &d, int s) const      // step s of the pass
+    {
+        d.log_u = chain_lanef<GW>(lg, 2 * s);
+        d.amp = chain_lanef<GW>(amp, 2 * s + 1);
+        d.k = (int)chain_lane32<GW>((u32)kdir, 2 * s + 1);
+    }
 };
-template <bool STR, int TM = 0, class RS>
-__device__ __forceinline__ void scam_draws_for_step(ScamBatch<STR> &b, ScamDraw &dr, const KArgs &a, int k, u32 sid, int gl,
+template <bool STR, int TM = 0, int GW = 4, class RS>
+__device__ __forceinline__ void scam_draws_for_step(ScamBatch<STR, GW> &b, ScamDraw &dr, const KArgs &a, int k, u32 sid, int gl,
                                                     const ChainConst &cc, int ng, RS root_s, const double *tsm = nullptr)
 {
+    if constexpr (GW > 4) {                            // the caller refills at the head of every pass of GW / 2 steps (mh_steps_kernel)
+        b.take_wide(dr, k & (GW / 2 - 1));
+        return;
+    }
     if ((k & 1) == 0) b.template refill<TM>(a, a.iter0 + k, sid, gl, cc, ng, root_s, tsm);
     else b.advance();
     b.take(dr);
@@ -715,8 +765,14 @@ __device__ __forceinline__ int propose(const KArgs &a, long long it, u32 sid, in
         const int k = (int)h2index((u32)(dr.Q1 >> 32), (u32)ng);
         const double *col = Ut + (size_t)k * uld;
         // the direction lands in dq and is scaled in place
+        if (G > 4 && !GRP && !GJ && a.UtPad != nullptr) {          // the library's zero-padded copy of the launch's one table
+            const double *colp = a.UtPad + (size_t)k * a.ut_pad_ld;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD_S(PSAFE, dq[e], col, e);
+            for (int e = 0; e < EPL; ++e) dq[e] = colp[gl + G * e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD_S(PSAFE, dq[e], col, e);
+        }
         const double amp = dr.z * cc.cd_scam(br) * root_s(k);                // PT:873
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dq[e] = amp * dq[e];
@@ -891,10 +947,27 @@ __device__ __forceinline__ int logical_block()
 // over one LDS copy of the table; every wave walks over units of 16 chains on its own (no barrier after the set-up), so the
 // occupancy is no longer tied to the number of table copies that fit the LDS,
 // the table is staged 256 times per launch instead of 4096 times, and a block's waves do not wait for its cold wave.
-template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false, int PERS = 0, int PRI = -1 /* PERS: the prior kind */,
-          bool TLDS = false /* ULDS with a table copy per block: the draw tables are in LDS too (host: a.tab_off >= 0) */>
-__global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL == PTMI_LOGL_DENSE) ? 1 : 2) void mh_steps_kernel(const KArgs a)
+// Blocks of 256 threads per CU the register budget is cut for.  The 16- / 64-lane SCAM-only kernels (ndim > 104: the chain's one
+// table row per step comes from L2 / MALL, 8 KB at ndim = 1000) hold two row-sized arrays and little else, yet were given the
+// 256 registers of two waves per SIMD and used 223 of them (hoisted loads): two chains per SIMD at 64 lanes, every round trip of
+// a row exposed.  PTMI_WIDE_MINBLK: an A/B build switch.
+#ifndef PTMI_WIDE_MINBLK
+#define PTMI_WIDE_MINBLK 0
+#endif
+constexpr int mh_min_blocks(int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, int PERS, bool UPAD, int PRI)
 {
+    if (PERS || STAGE || FULL || LOGL == PTMI_LOGL_DENSE) return 1;
+    // the flat-prior instantiation over the padded table: x, dq and the row in flight (the other variants of the wide shapes carry
+    // per-slot bounds and the box test and spill under the tighter budget)
+    if (UPAD && PRI == PTMI_LOGP_FLAT && LOGL == PTMI_LOGL_ISO) return PTMI_WIDE_MINBLK ? PTMI_WIDE_MINBLK : (EPL <= 16 ? 4 : (EPL <= 26 ? 3 : 2));
+    return 2;
+}
+template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false, int PERS = 0, int PRI = -1 /* PERS: the prior kind */,
+          bool TLDS = false /* ULDS with a table copy per block: the draw tables are in LDS too (host: a.tab_off >= 0) */,
+          bool UPAD = false /* SCAM-only wide shapes: the direction comes from the library's zero-padded table copy (a.UtPad) */>
+__global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL, STAGE, GRP, PERS, UPAD, PRI)) void mh_steps_kernel(const KArgs a)
+{
+    static_assert(!UPAD || (G > 4 && !FULL && !STAGE && !GRP && !ULDS), "UPAD is a variant of the wide SCAM-only kernel");
     static_assert(!ULDS || (!STAGE && !FULL && !GRP), "ULDS is the SCAM-only contiguous-layout kernel");
     static_assert(!PERS || (ULDS && G == 4), "persistent blocks are a variant of the ULDS kernel");
     // the draw tables (ptmi_tables.h, 1 KB): the staged full kernels read them from an LDS copy when the host found room
@@ -999,7 +1072,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         if (!ulds_box)
             for (int i = (int)threadIdx.x; i < d; i += BLK) smem[d * d + i] = det_sqrt(srcS[i]);   // sqrt(eigenvalues) too: no vector-memory read is left in the step loop
     }
-    if (!(ULDS && PERS && PRI == PTMI_LOGP_FLAT)) box_table_fill<G, EPL>(a, smem, BLK);
+    if (PRI != PTMI_LOGP_FLAT) box_table_fill<G, EPL>(a, smem, BLK);
     if (ULDS) draw_table_fill(smem, a.tab_off, BLK);
     if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
 
@@ -1034,8 +1107,9 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
     const double *Ut = a.Ut + wc * a.ngroups * d * d, *S = a.S + wc * a.ngroups * d;
     const double *DE = (FULL && a.DE) ? a.DE + wc * (size_t)a.de_size * a.de_ld : nullptr;
     double *xrow = a.X + (size_t)ch * d;
-    DrawBatch<STR> batch;
-    ScamBatch<STR> sbatch;
+    constexpr int GW = (G > 4 && !STR && !ULDS) ? G : 4;   // 16- / 64-lane shapes: wide draw batches (all lanes of the chain draw)
+    DrawBatch<STR, GW> batch;
+    ScamBatch<STR, GW> sbatch;
     const double *UtBlock = (STAGE && FULL) ? UtBlk : Ut;
 
     // ---- AM queue (staged full kernels).  An AM increment U (cd sqrt(S) z) does not depend on the chain's state, only on
@@ -1068,7 +1142,17 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
 
-    for (int k = 0; k < a.nsteps; ++k) {
+    // Wide draw batches: a pass serves GW / 2 steps, so the steps run as an inner loop under a loop over the passes -- with the
+    // refill as a rarely taken branch of ONE loop the compiler hoisted the pass's invariants (Philox key schedule, polynomial
+    // constants, per-slot bounds) over the steps and spilled the steps' own values to make room (73 registers at a budget of 128)
+    constexpr int KPASS = GW > 4 ? GW / 2 : (1 << 30);
+    for (int k0 = 0; k0 < a.nsteps; k0 += KPASS) {
+    const int kend = (GW > 4 && a.nsteps - k0 > KPASS) ? k0 + KPASS : a.nsteps;
+    if constexpr (GW > 4) {
+        if constexpr (SCAMFAST) sbatch.template refill<0>(a, a.iter0 + k0, sid, gl, cc, d, [&](int kk) { return det_sqrt(S[kk]); }, nullptr);
+        else batch.template refill<TM>(a, a.iter0 + k0, sid, gl, tsm);
+    }
+    for (int k = k0; k < kend; ++k) {
         const long long it = a.iter0 + k;
         if constexpr (AMQ) {
             if (amq_on) {
@@ -1135,7 +1219,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
             // PERS: the host always places the tables (launch_mh_k), so the read is an LDS read at COMPILE time: with the run-time
             // choice (TM = 2) the two paths merged in an s_waitcnt vmcnt(0) -- every draw pass of a cold wave waited for its AM-row
             // stores to retire, although it never took the global path
-            scam_draws_for_step<STR, (PERS || TLDS) ? 1 : (ULDS ? 2 : 0)>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
+            scam_draws_for_step<STR, (PERS || TLDS) ? 1 : (ULDS ? 2 : 0), GW>(sbatch, sd, a, k, sid, gl, cc, d, [&](int kk) {
                 if (ULDS && !ulds_box) return smem[d * d + kk];
                 return det_sqrt(S[kk]);
             }, smem);
@@ -1151,16 +1235,31 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], smem + (size_t)sd.k * d, e);
                 } else {
-                    const double *col = UtBlock + (size_t)sd.k * d;
+                    if constexpr (UPAD) {                          // the library's zero-padded copy: no bounds to check
+                        // a base per 4 KB of the row (wave-uniform at 64 lanes: scalar adds), so that every load is base + the
+                        // lane's offset + an immediate; beyond the 13-bit immediate the compiler kept one offset register per slot
+                        const double *col = a.UtPad + (size_t)sd.k * (G * EPL) + gl;
+                        constexpr int SPB = 512 / G;                // slots per 4 KB
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], col, e);
+                        for (int e = 0; e < EPL; ++e) {
+                            const double *base = col + (e / SPB) * 512;
+                            dq[e] = base[G * (e % SPB)];
+                        }
+                        // every request of the row goes out before the first product: left alone the scheduler, short of registers,
+                        // issued ten of the sixteen loads one at a time, each behind a wait for the one before
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        const double *col = UtBlock + (size_t)sd.k * d;
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) PTMI_ROW_LOAD(dq[e], col, e);
+                    }
                 }
             }
 #pragma unroll
             for (int e = 0; e < EPL; ++e) dq[e] = sd.amp * dq[e];
         } else {
         Draws dr;
-        draws_for_step<STR, FULL, TM>(batch, dr, a, k, sid, sid0, gl, tsm);
+        draws_for_step<STR, FULL, TM, GW>(batch, dr, a, k, sid, sid0, gl, tsm);
         log_u = dr.log_u;
         if (ULDS && ulds_box) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, S, DE, dq, false);
         else if (ULDS) jt = propose<G, EPL, FULL, STR, GRP>(a, it, sid, gl, cc, dr, smem, false, smem + d * d, DE, dq, true);
@@ -1186,7 +1285,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
             double q[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
-            if constexpr (PERS != 0 && PRI == PTMI_LOGP_FLAT) nlp = 0.0;
+            if constexpr (PRI == PTMI_LOGP_FLAT) nlp = 0.0;
             else if constexpr (PERS != 0 && PRI == PTMI_LOGP_BOX)
                 nlp = grp_all<G, STR>(box_inside_lds<G, EPL>(smem, a.box_off, gl, [&](int e) { return q[e]; })) ? 0.0 : -__builtin_inf();
             else nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
@@ -1235,6 +1334,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, (PERS || STAGE || FULL || LOGL =
         }
         am_row = am_row + 1 == a.cov_update ? 0 : am_row + 1;
     }
+    }       // passes of a wide draw batch (one trip otherwise)
     if (live) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -2075,6 +2175,17 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
         }
     }
     a.box_off = box_bytes ? 0 : -1;               // no other table in LDS
+    if constexpr (G > 4 && !FULL) {
+        if (a.UtPad != nullptr && a.ut_pad_ld == G * EPL && c.ngroups <= 1) {
+            // the prior kind as a template parameter: the flat prior's instantiation holds no box-test code (nor the proposal q as an array)
+            if (c.logp_kind == PTMI_LOGP_FLAT)
+                hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, false, false, false, false, 0, PTMI_LOGP_FLAT, false, true>), dim3(grid), dim3(256), 0, h->stream, a);
+            else
+                hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, false, false, false, false, 0, -1, false, true>), dim3(grid), dim3(256), box_bytes, h->stream, a);
+            h->last_variant = PTMI_VAR_UTPAD | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
+            return PTMI_OK;
+        }
+    }
     if (c.ngroups > 1) hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, true>), dim3(grid), dim3(256), box_bytes, h->stream, a);
     else hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, FULL, false, false>), dim3(grid), dim3(256), box_bytes, h->stream, a);
     h->last_variant = (FULL ? PTMI_VAR_FULL : 0) | (c.ngroups > 1 ? PTMI_VAR_GROUPS : 0) | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);

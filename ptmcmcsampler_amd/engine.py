@@ -107,7 +107,7 @@ class PTEngine(object):
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
     ``"sytrd"`` = ``ptmi_eig_sytrd`` for ONE large pooled covariance (ndim <= 1024): Householder tridiagonalization in one kernel with the
-    matrix in the LDS of 128 blocks, then the library's divide-and-conquer solver of the tridiagonal matrix and its
+    matrix in the LDS of 64 blocks (a quarter of the CUs), then the library's divide-and-conquer solver of the tridiagonal matrix and its
     back-transformation -- the library's own reduction is 7000 launches of one-block kernels, two thirds of its 35 ms.
     ``eig_lag`` (L >= 0 launches; pooled covariance): the eigenvectors of a covariance epoch take effect L launches late --
     ``run`` queues the L launches that follow the epoch (and their swaps) with the table in force, the factorization runs
@@ -307,6 +307,17 @@ class PTEngine(object):
 
     def sync(self):
         _lib.check(self.lib.ptmi_sync(self.h))
+        self._check_sytrd_info()
+
+    def _check_sytrd_info(self):
+        """eig_mode "sytrd": the divide-and-conquer solver's convergence word of the last factorization that has finished (it follows
+        the result to pinned host memory on the factorization's stream: reading it never waits)."""
+        if self.eig_mode == "sytrd":
+            v = C.c_int32(0)
+            _lib.check(self.lib.ptmi_eig_sytrd_info(self.h, C.byref(v)))
+            if v.value != 0:
+                raise _lib.PtmiError("ptmi_eig_sytrd: the tridiagonal eigensolver did not converge (info = %d); the eigenvectors of "
+                                     "that covariance epoch are not valid" % v.value)
 
     # ------------------------------------------------------------------ set-up
     def _eig_host(self, w, cov):
@@ -358,23 +369,30 @@ class PTEngine(object):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device, priority=-1)      # its small kernels go ahead of the step kernel's next blocks (priority 0: 7.1e8 against 7.3e8 at config 4)
             self._side_go, self._side_done = torch.cuda.Event(), torch.cuda.Event()
-            self._ut_next, self._s_next = torch.empty_like(self.t["Ut"]), torch.empty_like(self.t["S"])
+            # the staging tensors start as the table in force: whatever goes wrong on the side, they never hold garbage
+            self._ut_next, self._s_next = self.t["Ut"].clone(), self.t["S"].clone()
         self._side_go.record(self.stream)
         self._side.wait_event(self._side_go)
+        self._side_err = None
 
         def work():
             # on a thread of its own: the library's driver waits on the host for its status word, which would keep this
-            # thread from queueing the launches the factorization is meant to run beside
-            torch.cuda.set_device(self.device)
-            with torch.cuda.stream(self._side):
-                if self.eig_mode == "sytrd":
-                    _lib.check(self.lib.ptmi_eig_sytrd(self.h, C.c_void_p(self._side.cuda_stream), C.c_void_p(self._ut_next.data_ptr()),
-                                                       C.c_void_p(self._s_next.data_ptr())))
-                else:
-                    w, V = torch.linalg.eigh(self.t["cov"])
-                    w, order = w.abs().sort(dim=-1, descending=True, stable=True)
-                    self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
-                    self._s_next[:, 0].copy_(w)
+            # thread from queueing the launches the factorization is meant to run beside.  The thread reports through
+            # self._side_err (the library's last-error text is per thread: it is read HERE, not by the thread that joins)
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self._side):
+                    if self.eig_mode == "sytrd":
+                        _lib.check(self.lib.ptmi_eig_sytrd(self.h, C.c_void_p(self._side.cuda_stream), C.c_void_p(self._ut_next.data_ptr()),
+                                                           C.c_void_p(self._s_next.data_ptr())))
+                    else:
+                        w, V = torch.linalg.eigh(self.t["cov"])
+                        w, order = w.abs().sort(dim=-1, descending=True, stable=True)
+                        self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
+                        self._s_next[:, 0].copy_(w)
+            except BaseException as e:              # noqa: B902 -- re-raised by the thread that joins (_eig_end_side)
+                self._side_err = e
+            finally:
                 self._side_done.record(self._side)
 
         import threading
@@ -385,11 +403,14 @@ class PTEngine(object):
     def _eig_end_side(self):
         torch = _torch()
         self._side_thread.join()
+        self._eig_pending = False
+        if self._side_err is not None:                # the table in force stays; the run does not go on with a half-made one
+            err, self._side_err = self._side_err, None
+            raise _lib.PtmiError("the factorization on the side stream failed: %r" % (err,)) from err
         self.stream.wait_event(self._side_done)
         with torch.cuda.stream(self.stream):
             self.t["Ut"].copy_(self._ut_next)
             self.t["S"].copy_(self._s_next)
-        self._eig_pending = False
         self.eig_epochs += 1
 
     def _eig_finish(self):
@@ -508,7 +529,13 @@ class PTEngine(object):
         if not self.owns_cold:
             return
         self._eig_finish()                                            # a factorization still pending from the epoch before
+        self._check_sytrd_info()                                      # ... and how the last finished one went
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
+        if self.am_rle and self.t["DE"] is not None and self.burn % self.cov_update != 0:
+            # a DE epoch (every `burn` iterations, :563-571) copies ALL covUpdate ring rows; unless burn is a multiple of covUpdate
+            # some of them belong to the period that ends here, and am_expand only reaches back to the current period's start:
+            # copy that period's repeats forward now, before the ring wraps (the statistics above have taken the run lengths)
+            self.am_expand(it_lo=self.am_period(it_done)[0], it_hi=it_done)
         if self.eig_mode in ("jacobi", "ql"):                         # stays on the stream: no host synchronisation
             _lib.check(self.lib.ptmi_eig_jacobi(self.h) if self.eig_mode == "jacobi" else self.lib.ptmi_eig_ql(self.h))
             self.eig_epochs += 1
@@ -559,7 +586,9 @@ class PTEngine(object):
         self.sync()
         st = {"t_" + k: v.cpu().numpy() for k, v in self.t.items() if v is not None and k not in ("Q", "qaux")}
         st.update(iter=self.iter, de_on=int(self.de_on), de_head=self.de_head, swap_proposed=self.swap_proposed,
-                  eig_epochs=self.eig_epochs)
+                  eig_epochs=self.eig_epochs,
+                  # eig_lag: an epoch's table that is not in force yet (its covariance is in t_cov; restore() factorizes it again)
+                  eig_pending=int(self._eig_pending), eig_wait=int(self._eig_wait))
         return st
 
     def restore(self, st):
@@ -573,6 +602,22 @@ class PTEngine(object):
             self.set_de_head(int(st["de_head"]))
             if int(st["de_on"]):
                 self.set_de_active(True)
+        if self._eig_pending:                                         # whatever this engine had under way is void
+            try:
+                self._eig_finish()
+            except _lib.PtmiError:
+                pass
+            for k, v in self.t.items():
+                if k in ("Ut", "S") and "t_" + k in st:
+                    v.copy_(torch.from_numpy(np.ascontiguousarray(st["t_" + k])).to(v.dtype))
+        if int(st.get("eig_pending", 0)):
+            # the checkpoint fell between a covariance epoch and the launch its table takes effect at: the factorization is
+            # issued again from the saved covariance and becomes effective after the same number of launches
+            if self.eig_mode in ("hipsolver", "sytrd"):
+                self._eig_begin_side()
+            else:
+                self._eig_begin()
+            self._eig_wait = int(st["eig_wait"])
 
     # pieces of the swap for a ladder sharded over GPUs (see sharded.py)
     def gather_lnl(self, out):
@@ -632,7 +677,7 @@ class PTEngine(object):
         """Flags of the fused-kernel instantiation the last ``mh_steps`` launched (``_lib.VAR_*``), lanes, slots."""
         v = C.c_int32(0)
         _lib.check(self.lib.ptmi_last_mh_variant(self.h, C.byref(v)))
-        return v.value & 0xFFF, (v.value >> 12) & 0xFF, (v.value >> 20) & 0xFF
+        return (v.value & 0xFFF) | (v.value & _lib.VAR_UTPAD), (v.value >> 12) & 0xFF, (v.value >> 20) & 0xFF
 
     def swap(self, it):
         """PT swap of iteration ``it`` with the whole ladder on this GPU (:631-697)."""

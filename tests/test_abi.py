@@ -57,8 +57,10 @@ def test_variant_flags_match_the_header(lib):
     """The PTMI_VAR_* flags the GPU tests assert on (which instantiation of the fused kernel ran) are the header's."""
     hdr = open(os.path.join(ROOT, "include", "ptmi.h")).read()
     flags = {n: int(v) for n, v in re.findall(r"\bPTMI_(VAR_[A-Z_]+)\s*=\s*(\d+)", hdr)}
-    assert len(flags) >= 11 and sorted(flags.values()) == [1 << k for k in range(len(flags))]      # distinct bits, none skipped
-    assert max(flags.values()) < 1 << 12                                                           # bits 12+ carry the shape
+    high = {n: v for n, v in flags.items() if v >= 1 << 12}                                        # bits 12-27 carry the shape: a flag beyond the
+    assert high == {"VAR_UTPAD": 1 << 28}                                                          # twelve low bits sits above them
+    low = sorted(v for v in flags.values() if v < 1 << 12)
+    assert len(low) >= 11 and low == [1 << k for k in range(len(low))]                             # distinct bits, none skipped
     for n, v in flags.items():
         assert getattr(lib, n) == v, n
 

@@ -31,6 +31,9 @@ CASES = [
     (130, 4, 3, 24, 8, (20, 0, 0), {}),                         # 16 lanes per chain, two macro tiles in the statistics
     (500, 2, 2, 16, 8, (20, 0, 20), {"burn": 32}),              # 64 lanes per chain, DE
     (20, 4, 5, 30, 10, (10, 0, 10), {"nuts": True}),            # the gradient-jump kernel
+    (100, 8, 3, 40, 20, (20, 20, 20), {"burn": 60}),            # burn no multiple of covUpdate: a DE epoch reads rows of the period before
+    (100, 8, 3, 40, 10, (20, 0, 20), {"burn": 25}),             # burn < covUpdate: the DE history takes the ring's last 25 rows
+    (37, 4, 3, 30, 10, (20, 20, 20), {"burn": 70}),
 ]
 
 
@@ -181,3 +184,51 @@ def test_eig_lag_of_several_launches(mods, lag):
         _compare(g, o, "lag %d it=%d " % (lag, g.iter))
         assert_same(g.get("Ut"), o.Ut, "Ut it=%d" % g.iter)
     assert g.eig_epochs >= 5
+
+
+@pytest.mark.parametrize("lag", [1, 2, 3])
+def test_checkpoint_between_an_epoch_and_its_late_table(mods, lag):
+    """A checkpoint taken while a factorization is pending (eig_lag: between a covariance epoch and the launch its table takes effect
+    at) carries the pending state; the restored run applies the table at the same launch: bit-identical continuation."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu, tskip = 100, 8, 5, 40, 10
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=tskip, seed=3, cov_mode="pooled", eig_lag=lag)
+    a = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    a.init_state(np.zeros(d))
+    a.run(cu + tskip)                                             # the epoch at iteration cu + 1, one launch behind it
+    assert a._eig_pending == (lag > 1)
+    a.run(cu)                                                     # ... and again one launch behind the next epoch
+    st = a.checkpoint()
+    assert st["eig_pending"] == int(lag > 1)
+    ut_then = a.get("Ut").copy()
+    a.run(2 * cu + 7)
+    b = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    b.init_state(np.zeros(d))
+    b.restore(st)
+    assert_same(b.get("Ut"), ut_then, "table in force at the checkpoint")
+    b.run(2 * cu + 7)
+    for name in ("X", "lnL", "cov", "Ut", "S", "nacc"):
+        assert_same(a.get(name), b.get(name), name)
+    assert a.eig_epochs == b.eig_epochs
+
+
+def test_a_failed_side_stream_factorization_is_reported(mods, monkeypatch):
+    """eig_mode="hipsolver" with eig_lag: the library's eigensolver runs on a host thread of its own; an exception there must stop the
+    run when its table is due, not leave the sampler with an unwritten table."""
+    import torch
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu = 100, 4, 3, 20
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=10, seed=1, cov_mode="pooled",
+                 eig_mode="hipsolver", eig_lag=1)
+    g.init_state(np.zeros(d))
+    g.run(cu)
+    before = g.get("Ut").copy()
+
+    def boom(*a, **k):
+        raise RuntimeError("injected")
+
+    monkeypatch.setattr(torch.linalg, "eigh", boom)
+    with pytest.raises(_lib.PtmiError, match="side stream"):
+        g.run(cu)
+    g.sync()
+    assert_same(g.get("Ut"), before, "the table in force is untouched")

@@ -339,6 +339,50 @@ def test_ragged_and_boundary_sizes(mods, d, nt, W):
     assert_same(g.get("cov"), o.cov, "cov")
 
 
+@pytest.mark.parametrize("prior", ["flat", "box"])
+@pytest.mark.parametrize("d,nt,W,cu,tskip", [(105, 3, 5, 30, 7), (130, 1, 7, 50, 0), (208, 2, 3, 50, 45), (300, 3, 4, 40, 13), (416, 2, 3, 30, 7), (417, 2, 3, 70, 0),
+                                             (512, 1, 2, 70, 0), (641, 3, 2, 50, 45), (1000, 4, 3, 70, 33), (1024, 2, 2, 30, 7), (1025, 2, 2, 40, 39)])
+def test_wide_shapes_scam_only_on_the_padded_table(mods, d, nt, W, cu, tskip, prior, monkeypatch):
+    """16 and 64 lanes per chain (ndim > 104), SCAM-only cycle, ONE table for the launch (pooled covariance): the wide draw batches
+    (all lanes of a chain draw: 8 / 32 iterations per pass; PTMCMCSampler.py:820-876) and the direction read from the library's
+    zero-padded copy of the table (include/ptmi.h PTMI_VAR_UTPAD).  Launch lengths that are no multiple of a pass, launches longer
+    than one (tskip = 0: a launch per covariance period), covariance epochs between the launches (the copy follows the table); the
+    same run with the copy switched off (PTMI_NO_UTPAD is read once per process, so that variant is checked through per-walker tables)."""
+    orc, _lib, PTEngine = mods
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=tskip, seed=d * 10 + nt, rs=d + 2, cov_mode="pooled")
+    if prior == "box":
+        rs = np.random.RandomState(d)
+        kw.update(logp=("box", -0.6 - rs.rand(d) * 0.1, 0.6 + rs.rand(d) * 0.1), p0=rs.uniform(-0.3, 0.3, (W, nt, d)))
+    g, o = _pair(mods, d, nt, W, **kw)
+    for n in (cu + 3, 1, 37, 2 * cu):
+        g.run(n)
+        o.run(n)
+        _compare(g, o, "wide d=%d it=%d " % (d, g.iter))
+        flags, G, E = g.last_variant()
+        assert flags & _lib.VAR_UTPAD and G == (16 if d <= 416 else 64)
+    assert_same(g.get("cov"), o.cov, "cov")
+    assert_same(g.get("Ut"), o.Ut, "Ut")
+
+
+@pytest.mark.parametrize("d,cov_mode,weights", [(130, "per_walker", (20, 0, 0)), (641, "per_walker", (20, 0, 0)), (300, "pooled", (20, 20, 20)),
+                                                (1000, "pooled", (20, 0, 20)), (417, "per_walker", (20, 20, 20))])
+def test_wide_draw_batches_in_the_other_wide_kernels(mods, d, cov_mode, weights):
+    """The wide draw batches in the kernels that do not read the padded copy: a table per walker, and cycles with AM / DE entries
+    (DrawBatch: P and Q words of 8 / 32 iterations per pass), walker picks included."""
+    orc, _lib, PTEngine = mods
+    for pick in ("chain", "walker"):
+        kw = dict(weights=weights, cov_update=40, burn=80, tskip=11, seed=d + 5, rs=d, cov_mode=cov_mode, pick_mode=pick)
+        g, o = _pair(mods, d, 3, 4, **kw)
+        for n in (43, 90, 57):
+            g.run(n)
+            o.run(n)
+            _compare(g, o, "wide-other d=%d %s it=%d " % (d, pick, g.iter))
+        flags, G, E = g.last_variant()
+        assert G in (16, 64) and (sum(weights[1:]) > 0) == bool(flags & _lib.VAR_FULL)
+        if sum(weights[1:]) == 0:
+            assert not flags & _lib.VAR_UTPAD
+
+
 @pytest.mark.parametrize("pers", [512, 0])
 @pytest.mark.parametrize("d,prior", [(99, "flat"), (100, "flat"), (100, "box"), (101, "flat"), (104, "box"), (81, "flat")])
 def test_scam_only_table_kernel_around_the_exact_shape(mods, d, prior, pers, monkeypatch):
