@@ -33,7 +33,7 @@ F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector = FP64 matrix peak (SURVEY.m
 TSKIP = 100                    # iterations per step
 
 
-def parse():
+def make_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed Tskip cycles (100 MH iterations + swap each)")
@@ -73,6 +73,11 @@ def parse():
                     help="evaluate the likelihood in a batched torch callback between ptmi_propose and ptmi_accept (one launch pair per "
                          "iteration) instead of inside the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", default="auto", choices=["auto", "on", "off"],
+                    help="after the headline's timed region (untouched by them), short legs of the other BASELINE configs on the same GPU, "
+                         "reported under \"also\": dense SCAM (configs[2]), default mix, dense default mix, a replica of reference runs "
+                         "(per-walker covariance, device QL), config 4's share of one GPU, config 5's share.  auto = when the headline is "
+                         "the default workload on one GPU")
     ap.add_argument("--preheat", type=float, default=0.2,
                     help="seconds of unrelated f64 matrix products before the warmup steps, so that the timed steps run at the clocks "
                          "of a long run (0 = from cold clocks)")
@@ -81,7 +86,15 @@ def parse():
     ap.add_argument("--ess-burn", type=int, default=40000, help="the ESS window starts at this iteration at the earliest (adaptation settled)")
     ap.add_argument("--ess-window", type=int, default=80000, help="iterations of the ESS window, run AFTER the timed region (0 = no ESS)")
     ap.add_argument("--ess-max-seconds", type=float, default=60.0, help="the ESS leg is shortened to fit this (flagged when < 50 tau)")
-    return ap.parse_args()
+    return ap
+
+
+def parse():
+    return make_parser().parse_args()
+
+
+def parse_defaults():
+    return make_parser().parse_args([])
 
 
 T0 = time.perf_counter()
@@ -149,47 +162,23 @@ class ColdSamples(object):
         return out[:, have] if out is not None else None
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and "LOCAL_RANK" not in os.environ:
-        sys.exit(spawn_ranks(a.gpus))
-    # stdout must carry exactly one JSON line: park everything else the process (and RCCL's C-level banner)
-    # prints on stderr, and keep the real stdout for the result
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit("--gpus %d but the launcher started %d ranks" % (a.gpus, world))
-    weights = {"scam": (20, 0, 0), "default": (20, 20, 20), "nuts": (10, 0, 10)}[a.mix]
+def cycle_weights(a):
+    """(SCAM, AM, DE) weights of the run's proposal cycle; --weights overrides --mix (and names the mix after itself)."""
     if a.weights:
-        weights = tuple(int(v) for v in a.weights.split(","))
+        w = tuple(int(v) for v in a.weights.split(","))
         a.mix = "w" + a.weights.replace(",", "-")
-    cpu = None
-    # the CPU baseline is timed on rank 0 of the single-GPU run only; the NumPy port covers the Gaussian configs
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl == "iso":
-        cpu = cpu_baseline(a, weights)
-        log("cpu baseline %.3g updates/s on %d cores" % (cpu["value"], cpu["cores"]))
+        return w
+    if a.mix.startswith("w") and a.mix[1:].replace("-", "").isdigit():
+        return tuple(int(v) for v in a.mix[1:].split("-"))
+    return {"scam": (20, 0, 0), "default": (20, 20, 20), "nuts": (10, 0, 10)}[a.mix]
+
+
+def measure(a, rank, world, local, dist, backend):
+    """One workload on the ranks that are up: build the engine, W untimed steps, exactly K timed steps (barrier + synchronize on
+    both sides, HIP events around every fused-MH launch), the ESS leg when a.ess_window > 0.  Returns the JSON line's dict."""
     import numpy as np
     import torch
-    backend = os.environ.get("PTMI_DIST_BACKEND", "nccl")          # "gloo" only to rehearse N ranks on a one-GPU box
-    if backend == "nccl" and world > torch.cuda.device_count():
-        raise SystemExit("--gpus %d but only %d GPUs are visible (PTMI_DIST_BACKEND=gloo rehearses several ranks on one GPU)"
-                         % (world, torch.cuda.device_count()))
-    local %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1 or a.sharded:
-        import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-
+    weights = cycle_weights(a)
     d, nt, W = a.ndim, a.ntemps, a.nwalkers
     if a.cov_mode == "pooled" and d >= 512:
         # one ndim x ndim factorization per epoch: from here on the device beats the host's LAPACK -- ptmi_eig_sytrd (tridiagonalization
@@ -436,6 +425,112 @@ def main():
         out["acceptance_rank0_mean"] = float(acc[:, 0].mean() / max(1, eng.iter))        # over the whole run, ESS leg included
         out["swap_accept_rate_pair0"] = float(eng.get("nswap")[:, 0].mean() / max(1, eng.swap_proposed))
         out.update(ess_out)
+    del eng
+    import gc
+    gc.collect()                            # the legs behind the headline build their engines in this process: give the memory back
+    torch.cuda.empty_cache()
+    return out
+
+
+# The other BASELINE configs as short legs behind the headline (one GPU): name -> (argument overrides, steps, warmup).  The default
+# mixes start their DE proposals after burn = 10000 iterations = 100 steps, hence their warmup.
+ALSO = (
+    ("config3_dense_scam", dict(logl="dense"), 20, 10),
+    ("config2_default_mix", dict(mix="default"), 20, 105),
+    ("config3_dense_default_mix_walker_pick", dict(logl="dense", mix="default", pick="walker"), 12, 105),
+    ("config2_replica_per_walker_cov_device_ql", dict(cov_mode="per_walker_device"), 20, 10),
+    ("config4_share_1000d_64x512", dict(ndim=1000, nwalkers=512), 30, 20),
+    ("config5_share_curved_nuts_16x4096", dict(logl="curved", ndim=20, ntemps=16, mix="nuts"), 6, 4),
+)
+L2_PEAK_TBS = 34.5             # MI355X_MICROARCH.md: aggregate L2 bandwidth (4 MiB per XCD); profiles/r05_row_gather.txt: random 8 KB rows of a
+                               # 7.8 MB table (it does not fit one XCD's L2: half the rows come from the MALL) arrive at 16.1 TB/s
+
+
+def also_legs(a, rank, world, local, dist, backend):
+    import copy
+    res = {}
+    t_all = time.perf_counter()
+    for name, over, steps, warmup in ALSO:
+        b = copy.copy(a)
+        b.__dict__.update(over)
+        b.steps, b.warmup, b.ess_window, b.weights, b.preheat = steps, warmup, 0, None, 0.0     # the clocks are up: the headline just ran
+        t0 = time.perf_counter()
+        try:
+            o = measure(b, rank, world, local, dist, backend)
+        except Exception as e:              # noqa: BLE001 -- a leg that fails must not take the headline's line with it
+            res[name] = {"error": repr(e)[:300]}
+            log("also %s FAILED: %r" % (name, e))
+            continue
+        r = o["roofline"]
+        leg = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": steps, "warmup": warmup,
+               "workload": o["config"]["workload"], "iterations_timed": o["iterations_timed"], "cov_epochs_timed": o["cov_epochs_timed"],
+               "acceptance_rank0_mean": o.get("acceptance_rank0_mean"),
+               "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "steps_per_launch",
+                                                  "kernel_time_share_of_wall", "algorithmic_flops_per_update") if k in r},
+               "leg_seconds": time.perf_counter() - t0}
+        if b.ndim > 416 and b.mix == "scam":
+            # 64 lanes per chain: a step reads ONE table row of 8 * ndim bytes per chain from L2 / MALL (the table, 8 MB at ndim = 1000,
+            # does not fit an XCD's 4 MB L2); that gather bounds the kernel, not the 4d flop of the row arithmetic
+            tbs = 8.0 * b.ndim * b.ntemps * b.nwalkers * r["steps_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
+            leg["roofline"].update({"f64_valu_frac": r["frac"], "bound": "l2", "achieved": tbs, "peak": L2_PEAK_TBS, "unit": "TB/s",
+                                    "frac": tbs / L2_PEAK_TBS, "gather_floor_tbs": 16.1,
+                                    "note": "table rows read per launch / launch time against the aggregate L2 peak; a bare gather of random "
+                                            "8 KB rows of a table this size runs at 16.1 TB/s (tools/row_gather_bw.hip, profiles/r05_row_gather.txt)"})
+        res[name] = leg
+        log("also %-44s %.4g upd/s  launch %.3f ms  step %.3f ms  (%.1f s)" % (name, leg["value"], r["avg_launch_ms"], leg["ms_per_step"], leg["leg_seconds"]))
+    res["total_seconds"] = time.perf_counter() - t_all
+    return res
+
+
+def main():
+    a = parse()
+    if a.also == "auto":
+        dflt = parse_defaults()
+        a.also = all(getattr(a, k) == getattr(dflt, k) for k in ("ndim", "ntemps", "nwalkers", "mix", "weights", "pick", "logl", "prior", "cov_mode",
+                                                                 "swap_mode", "partition", "sharded", "callback", "am_mode", "eig_lag")) and a.gpus == 1
+    else:
+        a.also = a.also == "on"
+    if a.gpus > 1 and "LOCAL_RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+    # stdout must carry exactly one JSON line: park everything else the process (and RCCL's C-level banner)
+    # prints on stderr, and keep the real stdout for the result
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (a.gpus, world))
+    weights = cycle_weights(a)
+    cpu = None
+    # the CPU baseline is timed on rank 0 of the single-GPU run only; the NumPy port covers the Gaussian configs
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mix != "nuts" and a.logl == "iso":
+        cpu = cpu_baseline(a, weights)
+        log("cpu baseline %.3g updates/s on %d cores" % (cpu["value"], cpu["cores"]))
+    import numpy as np
+    import torch
+    backend = os.environ.get("PTMI_DIST_BACKEND", "nccl")          # "gloo" only to rehearse N ranks on a one-GPU box
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but only %d GPUs are visible (PTMI_DIST_BACKEND=gloo rehearses several ranks on one GPU)"
+                         % (world, torch.cuda.device_count()))
+    local %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1 or a.sharded:
+        import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+
+    out = measure(a, rank, world, local, dist, backend)
+    if rank == 0 and world == 1 and a.also:
+        out["also"] = also_legs(a, rank, world, local, dist, backend)
+    if rank == 0:
+        d, weights = a.ndim, cycle_weights(a)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             # the C oracle on one core, for scale (a compiled scalar port; not what a reference user gets)

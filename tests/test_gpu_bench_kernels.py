@@ -169,9 +169,10 @@ class _Subset(object):
         self.mu, self.M2 = np.zeros(d), np.zeros((d, d))
         self.DE = np.zeros((self.burn, d))
 
-    def epoch(self, AM, it_done, flags=None):
+    def epoch(self, AM, it_done, flags=None, apply=True):
         """PTMCMCSampler.py:545-585 for iteration it_done + 1, from all walkers' AM rows (flags: the device's AM row flags of an
-        engine in am_mode "rle": the statistics then weight every stored row by its run length)."""
+        engine in am_mode "rle": the statistics then weight every stored row by its run length).  apply=False (eig_lag): the new
+        covariance is kept, its factorization takes effect when apply_table() is called."""
         orc, d, W = self.orc, self.d, self.W
         if it_done % self.cu == 0:
             if flags is not None:
@@ -180,7 +181,8 @@ class _Subset(object):
                 cov_o = orc.pool_update(AM, self.mu, self.M2, it_done)
             for o in self.subs:
                 o.cov[0] = cov_o
-                o._svd(0)
+                if apply:
+                    o._svd(0)
         if it_done % self.burn == 0:
             AMc = np.ascontiguousarray(AM)
             orc.lib().orc_de_update_pooled(d, self.burn, self.cu, W, orc._p(self.DE), orc._p(AMc))
@@ -189,6 +191,11 @@ class _Subset(object):
         if it_done == self.burn:
             for o in self.subs:
                 o.cfg.de_on = 1
+
+
+    def apply_table(self):
+        for o in self.subs:
+            o._svd(0)
 
 
 def _check_subset(g, sub, what):
@@ -326,6 +333,46 @@ def test_full_size_scam_persistent_kernel_on_adapted_tables(mods):
     assert (js[..., 0, 0] == 300).all() and g.get("nswap").sum() > 0 and g.swap_proposed == 3
 
 
+def test_full_size_scam_as_benchmarked_late_table_and_run_length_rows(mods):
+    """BASELINE configs[1] at full size in the configuration bench.py times (PTMCMCSampler.py:545-560, 769-803): the persistent SCAM
+    kernel with am_mode = rle (a step stores its row only when it was accepted; run-length-weighted pooled statistics) AND
+    eig_lag = 1 (the table of a covariance epoch takes effect one launch late, the host factorizing meanwhile).  covUpdate = 100,
+    400 iterations = three epochs, each table in force one launch after its epoch; three walkers bit for bit throughout."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    cov0 = np.eye(d) * 0.01
+    kw = dict(weights=(20, 0, 0), cov_update=100, burn=10000, tskip=100, seed=97)
+    g = PTEngine(d, nt, W, cov0, cov_mode="pooled", am_mode="rle", eig_lag=1, **kw)
+    assert g.am_rle and g.eig_lag == 1
+    g.init_state(np.zeros(d))
+    sub = _Subset(orc, (1, 2048, 4094), d, nt, W, cov0, am_mode="rle", **kw)
+    for o in sub.subs:
+        o.init_state(np.zeros(d))
+    cu = kw["cov_update"]
+    tables = [g.get("Ut").copy()]
+    for k in range(4):
+        if k > 0:
+            g.sync()
+            sub.epoch(g.get("AM"), k * cu, g.get("AMflag"), apply=False)       # the statistics now, the table after the next launch
+        g.run(cu)
+        for o in sub.subs:
+            o.run(cu)
+        if k > 0:
+            sub.apply_table()
+        flags, G, E = g.last_variant()
+        assert flags & _lib.VAR_PERSISTENT and flags & _lib.VAR_LDS_UT and not flags & _lib.VAR_FULL and (G, E) == (4, 25)
+        _check_subset(g, sub, "as benchmarked, segment %d" % k)              # segment k ran with the table of epoch k - 1
+        if k > 0:
+            assert_same(g.get("cov")[0], sub.subs[0].cov[0], "pooled cov after epoch %d" % k)
+            assert_same(g.get("Ut")[0], sub.subs[0].Ut[0], "Ut in force after segment %d" % k)
+            assert_same(g.get("S")[0], sub.subs[0].S[0], "S after segment %d" % k)
+        tables.append(g.get("Ut").copy())
+    assert all(not np.array_equal(a, b) for a, b in zip(tables[1:-1], tables[2:]))       # every epoch changed the table
+    fl = g.get("AMflag")
+    assert 0 < ((fl & 3) == 0).mean() < 1                           # some rows were not stored
+    assert g.eig_epochs == 3
+
+
 def test_config4_slice_1000d_64_temps(mods):
     """BASELINE configs[3], one GPU's share: 1000-d isotropic Gaussian, 64 ranks x 512 walkers, default mix (64 lanes per
     chain); invariants on the batch and bit parity on two walkers, through a swap epoch."""
@@ -349,6 +396,38 @@ def test_config4_slice_1000d_64_temps(mods):
         o.run(n)
     _check_subset(g, sub, "config 4")
     assert g.get("nswap").sum() > 0
+
+
+def test_config4_share_scam_cycle_as_benchmarked(mods):
+    """BASELINE configs[3], one GPU's share AS bench.py --ndim 1000 times it: 64 ranks x 512 walkers x 1000-d, SCAM cycle, pooled
+    covariance -- the 64-lane kernel with wide draw batches over the library's padded table copy (PTMI_VAR_UTPAD;
+    PTMCMCSampler.py:820-876, 605-622) -- through a pooled covariance epoch (covUpdate = 100: the second segment runs on an adapted,
+    dense 1000 x 1000 table; host factorization, so that the table is the oracle's bit for bit) and two swap epochs."""
+    orc, _lib, PTEngine = mods
+    d, nt, W = 1000, 64, 512
+    cov0 = np.eye(d) * 0.01
+    kw = dict(weights=(20, 0, 0), cov_update=100, burn=10000, tskip=100, seed=5)
+    g = PTEngine(d, nt, W, cov0, cov_mode="pooled", **kw)
+    g.init_state(np.zeros(d))
+    sub = _Subset(orc, (0, 300, 511), d, nt, W, cov0, am_mode="rle" if g.am_rle else "rows", **kw)
+    for o in sub.subs:
+        o.init_state(np.zeros(d))
+    for k in range(2):
+        if k > 0:
+            g.sync()
+            sub.epoch(g.get("AM"), k * 100, g.get("AMflag") if g.am_rle else None)
+        g.run(100)
+        for o in sub.subs:
+            o.run(100)
+        flags, G, E = g.last_variant()
+        assert flags & _lib.VAR_UTPAD and not flags & _lib.VAR_FULL and (G, E) == (64, 16)
+        if k > 0:
+            assert_same(g.get("Ut")[0], sub.subs[0].Ut[0], "Ut after the epoch")
+            assert (np.abs(g.get("Ut")[0, 0]) > 1e-9).mean() > 0.9
+        _check_subset(g, sub, "config 4 share, segment %d" % k)
+    X, lnL = g.get("X"), g.get("lnL")
+    assert np.allclose(lnL, -0.5 * (X ** 2).sum(-1), rtol=1e-12, atol=1e-12)
+    assert g.get("nswap").sum() > 0 and g.swap_proposed == 2
 
 
 def test_config5_slice_curved_nuts_16_temps(mods):
