@@ -64,6 +64,9 @@ def make_parser():
                     help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): rle = a step stores its "
                          "row only when it was accepted, the pooled statistics weight every stored row by its run length; rows = every "
                          "step stores its row")
+    ap.add_argument("--stats-async", default="on", choices=["on", "off"],
+                    help="on: with eig_lag >= 1 the pooled statistics of a finished covariance period run on a side stream beside the next "
+                         "period's launches (two AM rings, PTEngine stats_async); off: on the engine's stream, as round 4")
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
@@ -195,9 +198,11 @@ def measure(a, rank, world, local, dist, backend):
     eig_lag = 0
     if kw["cov_mode"] == "pooled" and kw["eig_mode"] in ("lapack", "hipsolver", "sytrd"):
         eig_lag = a.eig_lag if a.eig_lag >= 0 else (1 if kw["eig_mode"] == "lapack" else 9)
-        if kw["eig_mode"] != "lapack" and not (world == 1 and not a.sharded or a.partition == "walkers"):
-            eig_lag = 0                      # the sharded engine broadcasts the table of the host path only
     kw.update(eig_lag=eig_lag)
+    # the statistics of a finished covariance period on a side stream beside the launches that follow (PTEngine stats_async: two AM
+    # rings; needs the late table, and burn a multiple of covUpdate when a DE history is kept -- 10000 / 1000 here)
+    stats_async = eig_lag >= 1 and a.stats_async != "off" and not a.callback
+    kw.update(stats_async=stats_async)
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.prior == "box":
         kw.update(logp=("box", np.full(d, -10.0), np.full(d, 10.0)))
@@ -350,12 +355,13 @@ def measure(a, rank, world, local, dist, backend):
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "preheat_s": a.preheat,
         "config": {"workload": "BASELINE configs[%d]: %d-d %s logl%s, %d temps x %d walkers per GPU, %s cycle (pick per %s), "
-                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s, am_mode=%s, eig_lag=%d; one step = 100 MH iterations of every chain + "
+                               "Tskip=100 (%s), covUpdate=1000, cov_mode=%s, am_mode=%s, eig_lag=%d%s; one step = 100 MH iterations of every chain + "
                                "the PT swap (+ a covariance epoch every 10 steps)" % (
                                    {"iso": 3 if d >= 1000 else 1, "dense": 2, "curved": 4}[a.logl], d,
                                    {"iso": "isotropic Gaussian", "dense": "dense Gaussian", "curved": "curved-likelihood"}[a.logl],
                                    " + box prior" if a.prior == "box" else "", nt, W, a.mix, a.pick, a.swap_mode, a.cov_mode,
-                                   "rle" if getattr(eng, "am_rle", False) else "rows", eig_lag),
+                                   "rle" if getattr(eng, "am_rle", False) else "rows", eig_lag,
+                                   ", statistics on a side stream" if getattr(eng, "stats_async", False) or getattr(getattr(eng, "local", None), "stats_async", False) else ""),
                    "ndim": d, "ntemps_per_gpu": nt, "nwalkers": W, "iterations_per_step": TSKIP,
                    "parallelism": ("temperature blocks x%d" if a.partition == "temps" else "walker blocks x%d") % world},
         "iterations_timed": it_timed, "swap_epochs_timed": it_timed // TSKIP if nt * world > 1 else 0, "cov_epochs_timed": n_cov[0],
@@ -487,7 +493,7 @@ def main():
     if a.also == "auto":
         dflt = parse_defaults()
         a.also = all(getattr(a, k) == getattr(dflt, k) for k in ("ndim", "ntemps", "nwalkers", "mix", "weights", "pick", "logl", "prior", "cov_mode",
-                                                                 "swap_mode", "partition", "sharded", "callback", "am_mode", "eig_lag")) and a.gpus == 1
+                                                                 "swap_mode", "partition", "sharded", "callback", "am_mode", "eig_lag", "stats_async")) and a.gpus == 1
     else:
         a.also = a.also == "on"
     if a.gpus > 1 and "LOCAL_RANK" not in os.environ:

@@ -262,6 +262,16 @@ int ptmi_exchange_multihop(ptmi_handle h, int32_t *flag);
  * length, oracle: orc_pool_update_rle).  The eigendecomposition (:797-803) is a
  * separate step: on the host (LAPACK, as the reference) or ptmi_eig_jacobi. */
 int ptmi_update_cov(ptmi_handle h, int64_t iter);
+/* The same on `stream` (NULL: the handle's) from the ring AM / AMflag (AM NULL: the handle's; AMflag NULL with AM given: every row
+ * is stored): the statistics of a covariance period that is OVER need nothing the next launches touch once those write another
+ * ring, so a caller that keeps two rings (ptmi_set_am_buffers at every epoch) runs them on a side stream BESIDE the launches of
+ * the next period (PTEngine stats_async; :545-560 with the table taking effect eig_lag launches late).  mu / M2 / cov and the
+ * scratch are the handle's: one statistics call at a time. */
+int ptmi_update_cov_on(ptmi_handle h, int64_t iter, void *stream, const double *AM, const uint64_t *AMflag);
+/* The ring (updateChains' buffer, :327-328) the step kernels, the swap and ptmi_update_de use from now on: a caller with two rings
+ * switches at a covariance epoch.  AMaux / AMflag exactly when the handle was created with them.  Takes effect for the calls that
+ * follow (host-side pointers of the handle; nothing is queued). */
+int ptmi_set_am_buffers(ptmi_handle h, double *AM, double *AMaux, uint64_t *AMflag);
 
 /* AM row flags (ptmi_buffers.AMflag; updateChains' buffer, :327-328).  ptmi_am_flags_ok: 1 when the configuration can keep them --
  * pooled covariance, rank 0 on this GPU (the per-walker recurrence of :778-794 takes every row in turn).  ptmi_am_expand copies, in

@@ -326,8 +326,9 @@ class OracleEngine(object):
                  grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
                  eig_mode="lapack", am_mode="auto", eig_lag=0):
         assert eig_lag >= 0
-        # the engine's eig_lag: the factorization of a covariance epoch takes effect eig_lag segments late (pooled covariance, host LAPACK)
-        self.eig_lag = int(eig_lag) if (cov_mode == "pooled" and eig_mode == "lapack" and groups is None) else 0
+        # the engine's eig_lag: the factorization of a covariance epoch takes effect eig_lag segments late (pooled covariance, one
+        # parameter group; whichever eigensolver: the host's LAPACK, or the restated device ones)
+        self.eig_lag = int(eig_lag) if (cov_mode == "pooled" and groups is None) else 0
         self._eig_pending, self._eig_wait = False, 0
         assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi", "ql")
         assert am_mode in ("auto", "rows", "rle")

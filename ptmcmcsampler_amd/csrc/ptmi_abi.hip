@@ -3039,9 +3039,28 @@ int ptmi_exchange_status(ptmi_handle h, int32_t *violations)
     return PTMI_OK;
 }
 
-int ptmi_update_cov(ptmi_handle h, int64_t iter)
+int ptmi_update_cov(ptmi_handle h, int64_t iter) { return ptmi_update_cov_on(h, iter, nullptr, nullptr, nullptr); }
+
+int ptmi_set_am_buffers(ptmi_handle h, double *AM, double *AMaux, uint64_t *AMflag)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    if (!AM || !h->buf.AM) return fail(PTMI_EINVAL, "the handle was created without an AM buffer, or AM is NULL");
+    if ((AMaux != nullptr) != (h->buf.AMaux != nullptr) || (AMflag != nullptr) != (h->buf.AMflag != nullptr))
+        return fail(PTMI_EINVAL, "AMaux / AMflag must be given exactly when the handle was created with them");
+    h->buf.AM = AM; h->buf.AMaux = AMaux; h->buf.AMflag = AMflag;
+    return PTMI_OK;
+}
+
+int ptmi_update_cov_on(ptmi_handle hh, int64_t iter, void *stream, const double *AM_in, const uint64_t *AMflag_in)
+{
+    if (!hh) return fail(PTMI_EINVAL, "NULL handle");
+    // a view of the handle with the caller's stream and ring: the statistics below read h->stream / h->buf.AM / h->buf.AMflag only
+    // (the scratch, the diagonal tiles' helper stream and mu / M2 / cov are the handle's own: one statistics call at a time)
+    ptmi_engine view = *hh;
+    if (stream) view.stream = (hipStream_t)stream;
+    if (AM_in) { view.buf.AM = const_cast<double *>(AM_in); view.buf.AMflag = const_cast<uint64_t *>(AMflag_in); }
+    ptmi_engine *h = &view;
+    struct Back { ptmi_engine *to, *from; ~Back() { to->side = from->side; to->side_go = from->side_go; to->side_done = from->side_done; } } back{hh, h};
     const ptmi_config &c = h->cfg;
     if (c.temp0 != 0) return PTMI_OK;   // only the GPU holding rank 0 adapts (PT:545)
     if (!h->buf.AM || !h->buf.mu || !h->buf.M2 || !h->buf.cov) return fail(PTMI_EINVAL, "AM/mu/M2/cov buffers missing");

@@ -124,6 +124,12 @@ class PTEngine(object):
     ``AMflag``; oracle: ``orc_pool_update_rle`` -- the same sample covariance, summed in another order).  Readers that want
     every row (``get("AM")``, the DE history, chain files) get the repeats copied forward first (``am_expand``).
     ``"auto"`` = ``"rle"`` where it applies.
+    ``stats_async`` (pooled covariance with ``eig_lag >= 1``): the statistics of a covariance period that is over need nothing the next
+    launches touch once those write ANOTHER ring -- so the engine keeps two rings (``t["AM"]`` is always the one in use), switches at
+    every covariance epoch, and runs the period's statistics (``ptmi_update_cov_on``) and the factorization behind them on a side
+    stream BESIDE the launches that follow; the table still takes effect ``eig_lag`` launches after the epoch.  A scheduling change
+    only: every result equals the run without it bit for bit (oracle: ``OracleEngine(eig_lag=L)``).  Needs burn to be a multiple of
+    cov_update when a DE history is kept (a DE epoch then reads the finished period's ring before the switch).
     """
 
     def __init__(self, ndim, ntemps, nwalkers, cov0, ladder=None, logl=("iso",), logp=("flat",),
@@ -132,7 +138,7 @@ class PTEngine(object):
                  ntemps_global=None, temp0=0, walker0=0, device=0, split=False, use_de_buffer=None,
                  w_host=0, keep_lnl=False, groups=None, swap_mode="sweep",
                  grad_weights=(0, 0), hmc=(0.1, 2, 300), nuts_delta=0.6, nuts_maxdepth=24, pick_mode="chain",
-                 eig_mode="lapack", am_mode="auto", eig_lag=0):
+                 eig_mode="lapack", am_mode="auto", eig_lag=0, stats_async=False):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available() or _lib.device_count() < 1:
@@ -162,7 +168,12 @@ class PTEngine(object):
         self.eig_mode = eig_mode
         if int(eig_lag) < 0:
             raise ValueError("eig_lag must be >= 0 launches")
-        self.eig_lag, self._eig_pending, self._eig_wait = int(eig_lag), False, 0
+        # (where the late table is not implemented -- per-walker covariances, parameter groups, the on-stream device eigensolvers
+        # "ql" / "jacobi" -- the table is applied at once, as OracleEngine defines it too)
+        if int(eig_lag) > 0 and eig_mode in ("ql", "jacobi") and cov_mode == "pooled" and groups is None:
+            raise ValueError("eig_lag > 0 is implemented for eig_mode 'lapack', 'hipsolver' and 'sytrd' (got %r)" % (eig_mode,))
+        lag_ok = cov_mode == "pooled" and groups is None and eig_mode in ("lapack", "hipsolver", "sytrd")
+        self.eig_lag, self._eig_pending, self._eig_wait = (int(eig_lag) if lag_ok else 0), False, 0
         self.Wc = self.W if self.per_walker else 1
         # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
         self.groups = [np.arange(self.d)] if groups is None else [np.asarray(g, dtype=np.int64) for g in groups]
@@ -262,6 +273,22 @@ class PTEngine(object):
         self.iter = 0
         self.swap_proposed = 0
         self.eig_epochs = 0
+        self.stats_async = False
+        if stats_async and self.owns_cold:                            # (a block without rank 0 has no statistics to run)
+            ok = (not self.per_walker and self.eig_lag >= 1 and self.whole and eig_mode in ("lapack", "hipsolver", "sytrd")
+                  and (self.t["DE"] is None or self.burn % self.cov_update == 0))
+            if not ok:
+                raise ValueError("stats_async needs a pooled covariance on the block that holds rank 0, eig_lag >= 1, eig_mode 'lapack', "
+                                 "'hipsolver' or 'sytrd', one parameter group, and burn a multiple of cov_update when a DE history is kept")
+            self.stats_async = True
+            # the second ring (and its flags): what the statistics of the period before read while this period is written
+            self._alt = dict(AM=torch.zeros_like(self.t["AM"]),
+                             AMaux=torch.zeros_like(self.t["AMaux"]) if self.t["AMaux"] is not None else None,
+                             AMflag=torch.full_like(self.t["AMflag"], _lib.AMROW_KEY) if self.t["AMflag"] is not None else None)
+            # high priority: the statistics' blocks go ahead of the step kernel's next blocks wherever a CU has room for them
+            self._st = torch.cuda.Stream(device=self.device, priority=-1)
+            self._ev_period, self._ev_stats = torch.cuda.Event(), torch.cuda.Event()
+            self._stats_queued = False
         self._eig_host(0, cov0)                                       # every walker starts from the same covariance
         if Wc > 1:
             self.t["Ut"][1:] = self.t["Ut"][0]
@@ -283,7 +310,17 @@ class PTEngine(object):
         """Device array -> numpy (counters as uint64; DE rows in parameter order whatever their device format)."""
         if name == "AM":
             self.am_expand()
+        if self.stats_async and name in ("cov", "mu", "M2"):
+            self._st.synchronize()                                    # the statistics run beside the launches
         a = self.t[name].cpu().numpy()
+        if self.stats_async and name in ("AM", "AMflag", "AMaux"):
+            # ONE ring as a reader of the reference's buffer sees it: the rows of the current period come from the ring in use,
+            # the older ones from the other ring
+            lo, hi = self.am_period()
+            cur = np.zeros(self.cov_update, dtype=bool)
+            cur[np.arange(lo, hi + 1) % self.cov_update] = True
+            b = self._alt[name].cpu().numpy()
+            a = np.where(cur.reshape((1, -1) + (1,) * (a.ndim - 2)), a, b)
         if name == "DE" and self.de_epl:
             lane, slot = np.arange(self.d) % 4, np.arange(self.d) // 4
             pos = 8 * (slot // 2) + 2 * lane + slot % 2                # where parameter i sits in a row (ptmi_de_row_stride)
@@ -307,6 +344,8 @@ class PTEngine(object):
 
     def sync(self):
         _lib.check(self.lib.ptmi_sync(self.h))
+        if self.stats_async:
+            self._st.synchronize()
         self._check_sytrd_info()
 
     def _check_sytrd_info(self):
@@ -333,17 +372,19 @@ class PTEngine(object):
         self._eig_begin()
         self._eig_end()
 
-    def _eig_begin(self):
-        """First half of _eig_host_pooled: the covariance sets out for pinned host memory behind the statistics kernels."""
+    def _eig_begin(self, stream=None):
+        """First half of _eig_host_pooled: the covariance sets out for pinned host memory behind the statistics kernels (on `stream`:
+        the engine's, or the side stream the statistics run on)."""
         torch = _torch()
         d = self.d
+        stream = self.stream if stream is None else stream
         if getattr(self, "_pin", None) is None:
             self._pin = (torch.empty((d, d), dtype=torch.float64).pin_memory(), torch.empty((d, d), dtype=torch.float64).pin_memory(),
                          torch.empty(d, dtype=torch.float64).pin_memory(), torch.cuda.Event())
         cov_h, ut_h, s_h, ev = self._pin
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(stream):
             cov_h.copy_(self.t["cov"][0], non_blocking=True)
-            ev.record(self.stream)
+            ev.record(stream)
         self._eig_pending = True
 
     def _eig_end(self):
@@ -367,12 +408,14 @@ class PTEngine(object):
         staging tensors until _eig_end_side."""
         torch = _torch()
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device, priority=-1)      # its small kernels go ahead of the step kernel's next blocks (priority 0: 7.1e8 against 7.3e8 at config 4)
+            # stats_async: the factorization follows the statistics on THEIR stream (which waits for the period's last launch itself)
+            self._side = self._st if self.stats_async else torch.cuda.Stream(device=self.device, priority=-1)      # its small kernels go ahead of the step kernel's next blocks (priority 0: 7.1e8 against 7.3e8 at config 4)
             self._side_go, self._side_done = torch.cuda.Event(), torch.cuda.Event()
             # the staging tensors start as the table in force: whatever goes wrong on the side, they never hold garbage
             self._ut_next, self._s_next = self.t["Ut"].clone(), self.t["S"].clone()
-        self._side_go.record(self.stream)
-        self._side.wait_event(self._side_go)
+        if not self.stats_async:
+            self._side_go.record(self.stream)
+            self._side.wait_event(self._side_go)
         self._side_err = None
 
         def work():
@@ -530,6 +573,9 @@ class PTEngine(object):
             return
         self._eig_finish()                                            # a factorization still pending from the epoch before
         self._check_sytrd_info()                                      # ... and how the last finished one went
+        if self.stats_async:
+            self._update_cov_async(it_done)
+            return
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
         if self.am_rle and self.t["DE"] is not None and self.burn % self.cov_update != 0:
             # a DE epoch (every `burn` iterations, :563-571) copies ALL covUpdate ring rows; unless burn is a multiple of covUpdate
@@ -563,6 +609,34 @@ class PTEngine(object):
         else:
             self._eig_host_all(self.get("cov"))
         self.eig_epochs += 1
+
+    def _update_cov_async(self, it_done):
+        """The covariance epoch with the statistics BESIDE the launches that follow (stats_async): the period that ends here stays in
+        its ring, the launches from here on write the other one, the side stream takes the statistics and the factorization."""
+        torch = _torch()
+        old = {k: self.t[k] for k in ("AM", "AMaux", "AMflag")}
+        with torch.cuda.stream(self.stream):
+            if self._stats_queued:
+                self.stream.wait_event(self._ev_stats)                # the other ring is free once the statistics that read it are done (a period ago)
+            # ring row 0 holds the period's last iteration: every reader of the next period starts from it (am_expand's walk back,
+            # am_period); it moves along with its flag
+            for k, v in old.items():
+                if v is not None:
+                    self._alt[k][:, 0] = v[:, 0]
+            self._ev_period.record(self.stream)
+        for k, v in old.items():
+            self.t[k], self._alt[k] = self._alt[k], v
+        ptr = lambda v: C.c_void_p(v.data_ptr()) if v is not None else None      # noqa: E731
+        _lib.check(self.lib.ptmi_set_am_buffers(self.h, ptr(self.t["AM"]), ptr(self.t["AMaux"]), ptr(self.t["AMflag"])))
+        self._st.wait_event(self._ev_period)
+        _lib.check(self.lib.ptmi_update_cov_on(self.h, it_done, C.c_void_p(self._st.cuda_stream), ptr(old["AM"]), ptr(old["AMflag"])))
+        self._ev_stats.record(self._st)
+        self._stats_queued = True
+        if self.eig_mode in ("hipsolver", "sytrd"):
+            self._eig_begin_side()
+        else:
+            self._eig_begin(self._st)
+        self._eig_wait = self.eig_lag
 
     def update_de(self, it_done=None):
         if self.owns_cold and self.t["DE"] is not None:
@@ -652,9 +726,12 @@ class PTEngine(object):
 
     def _epochs(self, it):
         cu, burn = self.cov_update, self.burn
+        de_now = (it - 1) % burn == 0 and it - 1 != 0
+        if de_now and self.stats_async:
+            self.update_de(it - 1)                                    # reads the ring of the period that ends here: before the switch
         if (it - 1) % cu == 0 and it - 1 != 0:
             self.update_cov(it - 1)
-        if (it - 1) % burn == 0 and it - 1 != 0:
+        if de_now and not self.stats_async:
             self.update_de(it - 1)                                    # :563-571
         if it - 1 == burn and self.weights[2] > 0 and self.t["DE"] is not None:
             self.set_de_active(True)                                  # :574-585

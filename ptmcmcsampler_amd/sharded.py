@@ -126,10 +126,6 @@ class ShardedPTEngine(object):
         if local_factory is None:
             from .engine import PTEngine
             local_factory = PTEngine
-        if kw.get("eig_lag", 0) and kw.get("eig_mode", "lapack") != "lapack":
-            # the late table is broadcast for the host path only (below); a device factorization on the owner's side stream would
-            # take effect there a period late and never reach the other blocks in step
-            raise ValueError("ShardedPTEngine: eig_lag > 0 needs eig_mode='lapack' (got %r)" % (kw.get("eig_mode"),))
         self.local = local_factory(ndim, self.nt, nwalkers, cov0, ntemps_global=ntemps_global, temp0=self.temp0, **kw)
         L = self.local
         self.t, self.owns_cold, self.device = L.t, L.owns_cold, L.device
@@ -137,12 +133,15 @@ class ShardedPTEngine(object):
         self.stream = getattr(L, "stream", None)
         self.iter, self.swap_proposed = 0, 0
         self.de_head = 0
-        # eig_lag = 1 (PTEngine): the owner of rank 0 factorizes the pooled covariance while every GPU runs the launch that follows
-        # the epoch; the table is broadcast behind that launch's swap.  Without it seven GPUs wait at the broadcast for GPU 0's
-        # statistics and factorization.  The same decision on every rank (from the configuration alone).
-        self.eig_lag = int(kw.get("eig_lag", 0)) if (kw.get("cov_mode", "per_walker") == "pooled" and kw.get("eig_mode", "lapack") == "lapack"
-                                                     and kw.get("groups") is None) else 0
+        # eig_lag = L (PTEngine): the owner of rank 0 factorizes the pooled covariance while every GPU runs the L launches that follow
+        # the epoch -- on the host (eig_mode "lapack"), or on its side stream (the device factorizations: "sytrd", "hipsolver"; with
+        # stats_async the statistics too) -- and the table is broadcast behind the L-th launch's swap: nobody waits at the broadcast
+        # for GPU 0's statistics and factorization.  The same decision on every rank (from the configuration alone).
+        self.eig_lag = int(getattr(L, "eig_lag", 0))                       # PTEngine: 0 where the late table does not apply
         self._bcast_pending, self._bcast_wait = False, 0
+        # stats_async (PTEngine): the owner switches rings at a covariance epoch, so a DE epoch that falls on it goes first -- on EVERY
+        # rank (the epochs' broadcasts are collectives: one order for all), hence from the configuration, not from the local engine
+        self._de_first = bool(kw.get("stats_async", False)) and self.eig_lag >= 1
         self._lnl_loc = torch.zeros((self.W, self.nt), dtype=torch.float64, device=self.device)
         self._map = torch.zeros((self.W, self.ntg), dtype=torch.int32, device=self.device)
         self._parts = torch.empty((self.world * self.W, self.nt), dtype=torch.float64, device=self.device)
@@ -283,9 +282,13 @@ class ShardedPTEngine(object):
 
     def _epochs(self, it):
         cu, burn = self.cov_update, self.burn
+        de_now = (it - 1) % burn == 0 and it - 1 != 0
+        de_first = self._de_first                  # the owner's DE epoch reads the finished period's ring: before its switch
+        if de_now and de_first:
+            self.update_de(it - 1)
         if (it - 1) % cu == 0 and it - 1 != 0:
             self.update_cov(it - 1)
-        if (it - 1) % burn == 0 and it - 1 != 0:
+        if de_now and not de_first:
             self.update_de(it - 1)
         if it - 1 == burn and self.weights[2] > 0 and self.local.t.get("DE") is not None:
             self.local.set_de_active(True)

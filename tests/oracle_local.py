@@ -26,6 +26,7 @@ class OracleLocal(object):
                       Ut=al(o.Ut), S=al(o.S), cov=al(o.cov), DE=al(self.ring), AM=al(o.AM) if self.owns_cold else None)
         self.iter = 0
         self._eig_pending = False
+        self.eig_lag = o.eig_lag                      # what ShardedPTEngine reads off its local engine
 
     def _eig_finish(self):
         if self._eig_pending:

@@ -232,3 +232,71 @@ def test_a_failed_side_stream_factorization_is_reported(mods, monkeypatch):
         g.run(cu)
     g.sync()
     assert_same(g.get("Ut"), before, "the table in force is untouched")
+
+
+ASYNC_CASES = [
+    # d, nt, W, cu, tskip, weights, burn, lag, am_mode
+    (100, 64, 3, 40, 20, (20, 0, 0), 1000, 1, "rle"),            # the persistent kernel, one launch of lag
+    (100, 8, 5, 40, 10, (20, 0, 0), 1000, 3, "rows"),            # every row stored; the table three launches late
+    (100, 8, 4, 40, 10, (20, 20, 20), 80, 2, "rle"),             # DE history: the DE epoch reads the finished period's ring before the switch
+    (100, 8, 4, 30, 10, (20, 20, 20), 60, 5, "rows"),            # lag longer than a period (three launches): the next epoch finishes it first
+    (130, 4, 3, 24, 8, (20, 0, 0), 1000, 1, "rle"),              # 16 lanes per chain, the padded table copy
+    (37, 6, 5, 20, 10, (20, 20, 0), 1000, 2, "rle"),
+]
+
+
+@pytest.mark.parametrize("d,nt,W,cu,tskip,weights,burn,lag,am_mode", ASYNC_CASES)
+def test_statistics_on_the_side_stream_change_nothing(mods, d, nt, W, cu, tskip, weights, burn, lag, am_mode):
+    """stats_async: two AM rings, the statistics of a finished covariance period and the factorization on a side stream beside the
+    launches of the next one (PTMCMCSampler.py:545-560 with the table eig_lag launches late).  A scheduling change only: chains,
+    covariance, table, DE history and every row a reader of the ring sees equal OracleEngine(eig_lag=L) bit for bit."""
+    orc, _lib, PTEngine = mods
+    kw = dict(weights=weights, cov_update=cu, burn=burn, tskip=tskip, seed=41, cov_mode="pooled", cov0=np.eye(d) * 0.01, am_mode=am_mode, eig_lag=lag)
+    g, o = _pair(mods, d, nt, W, stats_async=True, **{k: v for k, v in kw.items()})
+    assert g.stats_async and g.eig_lag == lag
+    for n in (cu, tskip, 3, cu - 3, 2 * cu + 7, 33, cu):
+        g.run(n)
+        o.run(n)
+        _compare(g, o, "async it=%d " % g.iter)                   # incl. the ring as a reader sees it (the two rings merged)
+        assert_same(g.get("Ut"), o.Ut, "Ut it=%d" % g.iter)
+        assert_same(g.get("cov"), o.cov, "cov it=%d" % g.iter)
+        if burn < g.iter:
+            assert_same(np.roll(g.get("DE")[0], -g.de_head, axis=0), o.DE[0], "DE history it=%d" % g.iter)
+    assert g.eig_epochs >= 4
+
+
+def test_statistics_on_the_side_stream_with_the_device_factorization(mods):
+    """stats_async with eig_mode="sytrd" (config 4's combination: statistics, tridiagonalization and the library's solver all on the
+    side stream): the same run as with everything on the engine's stream, bit for bit (no oracle for the library's last bits)."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu = 300, 4, 6, 30
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=10, seed=8, cov_mode="pooled", eig_mode="sytrd", eig_lag=2)
+    runs = []
+    for asy in (False, True):
+        g = PTEngine(d, nt, W, np.eye(d) * 0.01, stats_async=asy, **kw)
+        g.init_state(np.zeros(d))
+        for n in (cu + 10, 2 * cu, 7, 3 * cu):
+            g.run(n)
+        g.sync()
+        runs.append({k: g.get(k) for k in ("X", "lnL", "cov", "Ut", "S", "nacc")})
+        assert g.eig_epochs >= 5
+    for k in runs[0]:
+        assert_same(runs[0][k], runs[1][k], k)
+
+
+def test_checkpoint_of_a_run_with_statistics_on_the_side_stream(mods):
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu = 100, 8, 5, 40
+    kw = dict(weights=(20, 20, 20), cov_update=cu, burn=80, tskip=10, seed=12, cov_mode="pooled", eig_lag=2, stats_async=True)
+    a = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    a.init_state(np.zeros(d))
+    a.run(2 * cu + 10)                                            # one launch behind an epoch: its table is pending
+    st = a.checkpoint()
+    assert st["eig_pending"] == 1
+    a.run(3 * cu + 5)
+    b = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    b.init_state(np.zeros(d))
+    b.restore(st)
+    b.run(3 * cu + 5)
+    for name in ("X", "lnL", "cov", "Ut", "S", "nacc", "DE"):
+        assert_same(a.get(name), b.get(name), name)

@@ -132,7 +132,7 @@ def _pair(mods, d, nt, W, **kw):
     if p0 is None:
         p0 = rs.randn(W, nt, d) * 0.3
     g = PTEngine(d, nt, W, cov0, **kw)
-    okw = {k: v for k, v in kw.items() if k not in ("split", "use_de_buffer")}
+    okw = {k: v for k, v in kw.items() if k not in ("split", "use_de_buffer", "stats_async")}    # (stats_async: scheduling only, the oracle has no such thing)
     o = orc.OracleEngine(d, nt, W, cov0, **okw)
     assert o.lanes == _lib.lanes_for(d)
     g.init_state(p0)

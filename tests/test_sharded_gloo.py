@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cov_mode, swap_mode, out_dir, eig_lag=0):
+def _worker(rank, world, port, cov_mode, swap_mode, out_dir, eig_lag=0, eig_mode="lapack"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -31,7 +31,8 @@ def _worker(rank, world, port, cov_mode, swap_mode, out_dir, eig_lag=0):
         from oracle_local import OracleLocal
         from ptmcmcsampler_amd.sharded import ShardedPTEngine
         d, ntg, W, n = 6, 8, 5, 330
-        kw = dict(weights=(20, 20, 20), cov_update=50, burn=100, tskip=10, seed=99, cov_mode=cov_mode, swap_mode=swap_mode, eig_lag=eig_lag)
+        kw = dict(weights=(20, 20, 20), cov_update=50, burn=100, tskip=10, seed=99, cov_mode=cov_mode, swap_mode=swap_mode, eig_lag=eig_lag,
+                  eig_mode=eig_mode)
         rs = np.random.RandomState(1)
         cov0 = np.eye(d) * 0.05
         p0 = rs.randn(W, ntg, d) * 0.5
@@ -74,6 +75,16 @@ def test_sharded_with_the_factorization_one_launch_late(tmp_path, world):
     """eig_lag = 1 on a sharded ladder: the owner of rank 0 factorizes the pooled covariance while every block runs the launch that
     follows the epoch, the table is broadcast behind that launch's swap -- bit for bit the single-process OracleEngine(eig_lag=1)."""
     mp.spawn(_worker, args=(world, _free_port(), "pooled", "sweep", str(tmp_path), 1), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok_%d" % r for r in range(world)]
+
+
+@pytest.mark.parametrize("world,lag", [(2, 3), (4, 2), (4, 7)])
+def test_sharded_with_a_device_factorization_several_launches_late(tmp_path, world, lag):
+    """eig_lag = L with a factorization that is not the host's (here the restated device QL solver, orc_eig_ql; on the GPUs
+    ptmi_eig_sytrd / the library on the owner's side stream): every block runs L more launches with the table in force, the owner's
+    new table is broadcast behind the L-th launch's swap (L = 7 > the five launches of a covariance period: the next epoch finishes
+    it first) -- bit for bit the single-process OracleEngine(eig_lag=L, eig_mode="ql")."""
+    mp.spawn(_worker, args=(world, _free_port(), "pooled", "sweep", str(tmp_path), lag, "ql"), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok_%d" % r for r in range(world)]
 
 

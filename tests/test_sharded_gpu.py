@@ -226,6 +226,67 @@ def test_config5_ladder_8_blocks_of_16_ranks_curved_nuts():
     assert ref.jstat[..., 3, 0].sum() > 0 and ref.jstat[..., 2, 0].sum() > 0        # NUTS and DE proposals were made
 
 
+@pytest.mark.parametrize("eig_mode,lag,stats_async", [("sytrd", 2, False), ("sytrd", 3, True), ("hipsolver", 2, False), ("lapack", 2, True)])
+def test_sharded_ladder_with_the_owner_factorizing_on_its_side_stream(eig_mode, lag, stats_async):
+    """eig_lag = L with the factorization on the owner's side (PTMCMCSampler.py:545-560; ShardedPTEngine): the block that holds rank 0
+    runs statistics + ptmi_eig_sytrd / the library's eigensolver (with stats_async the statistics too on the side stream, two AM
+    rings) while EVERY block runs L more launches with the table in force; the new table is broadcast behind the L-th launch's swap.
+    Four emulated ranks on the one GPU against the single-engine run with the same eig_lag: bit for bit (the device factorizations
+    have no oracle for their last bits; the host's has: OracleEngine(eig_lag=L))."""
+    import sys
+    import threading
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from thread_comm import ThreadComm, ThreadWorld
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd.engine import PTEngine
+    from ptmcmcsampler_amd.sharded import ShardedPTEngine
+    d, nranks, ntb, W, n = 300, 4, 4, 6, 170
+    ntg = nranks * ntb
+    kw = dict(weights=(20, 0, 20), cov_update=30, burn=60, tskip=10, seed=11, cov_mode="pooled", eig_mode=eig_mode, eig_lag=lag)
+    cov0 = np.eye(d) * 0.01
+    p0 = np.random.RandomState(3).randn(W, ntg, d) * 0.2
+    if eig_mode == "lapack":
+        ref = orc.OracleEngine(d, ntg, W, cov0, **kw)
+    else:
+        ref = PTEngine(d, ntg, W, cov0, **kw)
+    ref.init_state(p0)
+    ref.run(n)
+    if eig_mode != "lapack":
+        ref.sync()
+    rget = (lambda name: getattr(ref, name)) if eig_mode == "lapack" else ref.get
+    rby = (lambda name: ref.by_temp(getattr(ref, name))) if eig_mode == "lapack" else ref.by_temp
+    world = ThreadWorld(nranks)
+    engines, errs = [None] * nranks, []
+
+    def rank_main(r):
+        try:
+            e = ShardedPTEngine(d, ntg, W, cov0, comm=ThreadComm(world, r), stats_async=stats_async, **kw)
+            assert e.eig_lag == lag and e.local.stats_async == (stats_async and r == 0)
+            engines[r] = e
+            e.init_state(p0)
+            e.run(n)
+            e.sync()
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            world.bar.abort()
+            raise
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for r, e in enumerate(engines):
+        L, sl = e.local, slice(r * ntb, (r + 1) * ntb)
+        assert L.exchange_violations() == 0
+        for name in ("X", "lnL", "lp"):
+            assert np.array_equal(L.by_temp(name), rby(name)[:, sl]), (r, name)
+        assert np.array_equal(L.get("nacc").astype(np.int64), np.asarray(rget("nacc")).astype(np.int64)[:, sl]), r
+        assert np.array_equal(L.get("Ut"), rget("Ut")) and np.array_equal(L.get("S"), rget("S")), r
+        assert np.array_equal(np.roll(L.get("DE")[0], -L.de_head, axis=0),
+                              rget("DE")[0] if eig_mode == "lapack" else np.roll(ref.get("DE")[0], -ref.de_head, axis=0)), r
+    assert engines[0].local.eig_epochs >= 4
+
+
 def test_two_real_processes_share_the_gpu_over_gloo():
     """True multi-process run of ShardedPTEngine + DistComm (two ranks on cuda:0, gloo moving device tensors),
     both swap modes, against the oracle: tools/two_proc_one_gpu.py."""
