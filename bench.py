@@ -64,9 +64,12 @@ def make_parser():
                     help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): rle = a step stores its "
                          "row only when it was accepted, the pooled statistics weight every stored row by its run length; rows = every "
                          "step stores its row")
-    ap.add_argument("--stats-async", default="on", choices=["on", "off"],
+    ap.add_argument("--stats-async", default="off", choices=["on", "off"],
                     help="on: with eig_lag >= 1 the pooled statistics of a finished covariance period run on a side stream beside the next "
-                         "period's launches (two AM rings, PTEngine stats_async); off: on the engine's stream, as round 4")
+                         "period's launches (two AM rings, PTEngine stats_async); off (default): on the engine's stream.  Measured (round 5): "
+                         "no gain on one GPU -- config 2's persistent step blocks leave no room for a statistics block on their CUs and the "
+                         "host's factorization then starts late (2.4e10 against 3.0e10 in the driver's window), config 4's launches slow "
+                         "down by what the statistics take (8.3e8 either way)")
     ap.add_argument("--swap-mode", default="sweep", choices=["sweep", "oddeven"], help="sweep: PTswap as the reference; oddeven: disjoint pairs")
     ap.add_argument("--partition", default="temps", choices=["temps", "walkers"],
                     help="N > 1: temps = one ladder of N x ntemps ranks sharded by temperature block (swap exchange over RCCL); "
@@ -201,7 +204,7 @@ def measure(a, rank, world, local, dist, backend):
     kw.update(eig_lag=eig_lag)
     # the statistics of a finished covariance period on a side stream beside the launches that follow (PTEngine stats_async: two AM
     # rings; needs the late table, and burn a multiple of covUpdate when a DE history is kept -- 10000 / 1000 here)
-    stats_async = eig_lag >= 1 and a.stats_async != "off" and not a.callback
+    stats_async = eig_lag >= 1 and a.stats_async == "on" and not a.callback
     kw.update(stats_async=stats_async)
     cov0, p0 = np.eye(d) * 0.01, np.zeros(d)
     if a.prior == "box":
