@@ -470,8 +470,23 @@ static int gj_randint(gj_rng *g, int lo, int hi)                /* np.random.ran
     return lo + (int)w2index(W[0], (uint64_t)(hi - lo));
 }
 
+/* A whitening table that is DIAGONAL (the jump objects were built from a diagonal covariance: L = cholesky(cov), NJ:53-54 --
+ * the reference's np.dot then multiplies by zeros) is applied as d products, out[i] = T[i][i] v[i]: the engine's definition for
+ * such tables (libptmi decides at ptmi_create; a whitening product is a quarter of a NUTS call on the device).  Equal to the full
+ * sum unless a zero meets an infinity or the result is a negative zero. */
+static int tab_is_diag(const double *T, int d)
+{
+    for (int k = 0; k < d; ++k)
+        for (int i = 0; i < d; ++i)
+            if (i != k && T[(size_t)k * d + i] != 0.0) return 0;
+    return 1;
+}
 static void tab_vec(const double *T, const double *v, double *out, int d)
 {
+    if (tab_is_diag(T, d)) {
+        for (int i = 0; i < d; ++i) out[i] = T[(size_t)i * d + i] * v[i];
+        return;
+    }
     for (int i = 0; i < d; ++i) out[i] = 0.0;
     for (int k = 0; k < d; ++k)
         for (int i = 0; i < d; ++i) out[i] = fma(T[(size_t)k * d + i], v[k], out[i]);

@@ -2209,7 +2209,7 @@ static KArgs make_args(ptmi_engine *h)
     a.am_epl = am_row_epl(h->G, h->EPL);
     a.w_nuts = c.w_nuts; a.w_hmc = c.w_hmc; a.gj_nburn = c.gj_nburn; a.hmc_min = c.hmc_min; a.hmc_max = c.hmc_max;
     a.nuts_maxdepth = c.nuts_maxdepth; a.hmc_eps = c.hmc_eps; a.nuts_delta = c.nuts_delta;
-    a.gj_tab = h->d_gj_tab; a.gj = b.gj; a.gj_scr = h->d_gj_scr; a.gj_scal = h->d_gj_scal;
+    a.gj_tab = h->d_gj_tab; a.gj_diag = h->gj_diag; a.gj = b.gj; a.gj_scr = h->d_gj_scr; a.gj_scal = h->d_gj_scal;
     return a;
 }
 
@@ -2461,6 +2461,13 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         if (e3 != hipSuccess || (rc = upload(&h->d_gj_tab, c.gj_tab, 3LL * c.ndim * c.ndim))) {
             ptmi_destroy(h);
             return e3 != hipSuccess ? fail(PTMI_EHIP, "gradient-jump scratch: %s", hipGetErrorString(e3)) : rc;
+        }
+        // diagonal whitening (cov0 diagonal: the curved-likelihood runs start from the identity): a product is d multiplications
+        // (the oracle's tab_vec defines the same rule); PTMI_GJ_NODIAG: the general product (a measurement / test switch)
+        h->gj_diag = getenv("PTMI_GJ_NODIAG") == nullptr;
+        for (long long i = 0; i < 3LL * c.ndim * c.ndim && h->gj_diag; ++i) {
+            const long long r = (i / c.ndim) % c.ndim, col = i % c.ndim;
+            if (r != col && c.gj_tab[i] != 0.0) h->gj_diag = 0;
         }
     }
     h->cfg.gj_tab = nullptr;

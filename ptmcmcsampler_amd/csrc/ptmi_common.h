@@ -91,6 +91,7 @@ struct KArgs {
     int w_nuts, w_hmc, gj_nburn, hmc_min, hmc_max, nuts_maxdepth;
     double hmc_eps, nuts_delta;
     const double *gj_tab;        // [3][d][d] backward, forward, gradient tables
+    int gj_diag;                 // the whitening tables are diagonal (L = cholesky of a diagonal covariance): a product is d multiplications (oracle: tab_vec)
     double *gj;                  // [W][T][8] per-rank jump state
     double *gj_scr, *gj_scal;    // scratch of the tree build: [slot][e][chain][lane], [level][scalar][chain]
     int gj_stack_off, gj_lds_levels;   // tree stack: offset (doubles) in the block's LDS and how many of the lowest heights live there
@@ -131,6 +132,7 @@ struct ptmi_engine {
     bool hop_pending;
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
+    int gj_diag;                               // ... and whether the tables are diagonal (decided at ptmi_create)
     int32_t *d_gj_order, *d_gj_bucket;         // launch order of the chains ([nch]) and its counting-sort scratch ([3][GJ_BUCKETS])
     // AM increments ahead of the launch (large ndim): events of a piece of the launch, their increments [am_cap][ndim]
     void *d_am_ev;

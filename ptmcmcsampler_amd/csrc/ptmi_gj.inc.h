@@ -97,6 +97,11 @@ struct GradJump {
             col[e] = gl + G * e < d ? gl + G * e : 0;
         }
         const double *T = WHICH < 0 ? Tg : a.gj_tab + (size_t)WHICH * d * d;
+        if (WHICH >= 0 && a.gj_diag) {                                   // diagonal whitening table: d multiplications (oracle: tab_vec)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) out[e] = gl + G * e < d ? T[(size_t)col[e] * d + col[e]] * v[e] : 0.0;
+            return;
+        }
 #pragma unroll
         for (int e2 = 0; e2 < EPL; ++e2) {
 #pragma unroll 1
@@ -588,6 +593,11 @@ struct GradJumpWide {
     {
         GJP_T0(t0);
         double acc = 0.0;
+        if (WHICH >= 0 && a.gj_diag) {                                   // diagonal whitening table: one multiplication per element (oracle: tab_vec)
+            const double r = act ? gj_lds[(WHICH * LD + col) * LD + col] * v : 0.0;
+            GJP_ADD(GJP_TABVEC, t0);
+            return r;
+        }
         // The vector goes through LDS in element order and every lane reads all of it back (same address for the whole wave:
         // a broadcast); two readlanes per term instead had each fma wait on a fresh scalar pair.  Straight-line on purpose:
         // with a (wave-uniform) branch around every term each table read waited for its own LDS round trip -- 2 400 cycles

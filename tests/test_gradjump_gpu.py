@@ -41,13 +41,21 @@ CASES = [
     dict(d=20, nt=3, W=4, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(20, 0), weights=(5, 0, 5), nuts_maxdepth=3),
     dict(d=40, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=1),
     dict(d=5, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=0),
+    # DIAGONAL initial covariances: the whitening products (nutsjump.py:53-54, 71-90) are d multiplications (oracle tab_vec; libptmi
+    # decides at ptmi_create) -- whole-wave layout (d <= 32), 16 and 64 lanes per chain; HMC and NUTS
+    dict(d=20, nt=4, W=5, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.08, 2, 50), diag=True),
+    dict(d=7, nt=3, W=4, logl=("iso",), logp=("flat",), grad_weights=(20, 5), weights=(5, 0, 5), diag=True),
+    dict(d=40, nt=2, W=3, logl=("dense",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), diag=True),
+    dict(d=150, nt=2, W=2, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0), diag=True),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else ""))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else "",
+                                                                     "-diag" if c.get("diag") else ""))
 def test_device_gradient_jumps_bit_exact(case):
     c = dict(case)
     d, nt, W = c.pop("d"), c.pop("nt"), c.pop("W")
+    diag = c.pop("diag", False)
     rs = np.random.RandomState(d)
     if c["logl"][0] == "dense":
         A = rs.randn(d, d)
@@ -56,6 +64,8 @@ def test_device_gradient_jumps_bit_exact(case):
         c["logp"] = ("box", np.full(d, c["logp"][1]), np.full(d, c["logp"][2]))
     A = rs.randn(d, d)
     cov0 = (A @ A.T / d + np.eye(d)) * (1.0 if c["logl"][0] == "curved" else 0.3)
+    if diag:
+        cov0 = np.diag(np.diag(cov0))
     kw = dict(cov_update=50, burn=100, tskip=10, seed=31, **c)
     g, o = _pair(d, nt, W, cov0, **kw)
     p0 = rs.randn(W, nt, d) * 0.3
