@@ -594,7 +594,7 @@ struct GradJumpWide {
         GJP_T0(t0);
         double acc = 0.0;
         if (WHICH >= 0 && a.gj_diag) {                                   // diagonal whitening table: one multiplication per element (oracle: tab_vec)
-            const double r = act ? gj_lds[(WHICH * LD + col) * LD + col] * v : 0.0;
+            const double r = act ? gj_lds[WHICH * LD + col] * v : 0.0;  // (the block's LDS then holds the three diagonals only)
             GJP_ADD(GJP_TABVEC, t0);
             return r;
         }
@@ -940,9 +940,16 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
     const long long nch = (long long)a.W * nt;
     if (WIDE) {
         constexpr int LD = 4 * EPL;
-        for (int i = (int)threadIdx.x; i < 3 * LD * LD; i += GJ_BLOCK) {
-            const int w = i / (LD * LD), r = (i / LD) % LD, c = i % LD;
-            gj_lds[i] = (r < d && c < d) ? a.gj_tab[((size_t)w * d + r) * d + c] : 0.0;
+        if (a.gj_diag) {                         // diagonal whitening: the three diagonals (3 LD doubles instead of 3 LD^2: 0.5 KB instead of 9.6 KB at d = 20)
+            for (int i = (int)threadIdx.x; i < 3 * LD; i += GJ_BLOCK) {
+                const int w = i / LD, c = i % LD;
+                gj_lds[i] = c < d ? a.gj_tab[((size_t)w * d + c) * d + c] : 0.0;
+            }
+        } else {
+            for (int i = (int)threadIdx.x; i < 3 * LD * LD; i += GJ_BLOCK) {
+                const int w = i / (LD * LD), r = (i / LD) % LD, c = i % LD;
+                gj_lds[i] = (r < d && c < d) ? a.gj_tab[((size_t)w * d + r) * d + c] : 0.0;
+            }
         }
     }
     box_table_fill<G, EPL>(a, gj_lds, GJ_BLOCK);
@@ -1019,11 +1026,11 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
                 const int jt_c = __builtin_amdgcn_readlane(jt, lane0);
                 const int w_c = (int)(ch_c / nt), t_c = __builtin_amdgcn_readlane(t, lane0);
                 double *stc = a.gj + ((size_t)w_c * nt + t_c) * GJ_NSTATE;
+                double qw;
                 GradJumpWide<EPL, LOGL> gj(a, ch_c, beta_c, it, sid_c, xch);
                 double st[GJ_NSTATE];
 #pragma unroll
                 for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stc[j];
-                double qw;
                 GJP_T0(tc0);
                 const double qxy_c = jt_c == PTMI_J_NUTS ? gj.nuts(st, xw, qw) : gj.hmc(st, xw, qw);
 #ifdef PTMI_GJ_PROFILE

@@ -44,9 +44,11 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
             const size_t box = h->cfg.logp_kind == PTMI_LOGP_BOX ? (size_t)box_table_doubles(G, E) : 0;
             static const char *lv = getenv("PTMI_GJ_LDS_LEVELS");       // measurement / test switch: same results for any value
             if constexpr (G == 4) {
-                off = (size_t)gjw_table_doubles(E);
+                off = a.gj_diag ? (size_t)(3 * 4 * E) : (size_t)gjw_table_doubles(E);    // diagonal whitening: the three diagonals only
                 a.gj_stack_off = (int)off;
-                int levels = h->cfg.nuts_maxdepth + 1 < 11 ? h->cfg.nuts_maxdepth + 1 : 11;    // heights 0..10 in LDS, the rest in global scratch
+                static const char *lvd = getenv("PTMI_GJ_LDS_DEFAULT");                  // measurement switch: heights kept in LDS by default
+                const int lmax = lvd ? atoi(lvd) : 11;
+                int levels = h->cfg.nuts_maxdepth + 1 < lmax ? h->cfg.nuts_maxdepth + 1 : lmax;    // heights 0..10 in LDS, the rest in global scratch
                 if (lv) levels = atoi(lv) < levels ? atoi(lv) : levels;
                 a.gj_lds_levels = levels;
                 off += (size_t)a.gj_lds_levels * gjw_level_doubles(E) + 64;
