@@ -59,7 +59,7 @@ def make_parser():
                     help="pooled covariance: the eigenvectors of a covariance epoch take effect this many launches late, the factorization "
                          "running meanwhile (PTEngine eig_lag: the host's LAPACK beside the GPU, or the ROCm library on a side stream); "
                          "0 = at once, the GPU idle / the stream blocked meanwhile (the reference's order); default: 1 with the host's LAPACK, "
-                         "9 with the library (ndim >= 512)")
+                         "10 (a covariance period) with the device factorizations (ndim >= 512)")
     ap.add_argument("--am-mode", default="auto", choices=["auto", "rows", "rle"],
                     help="how the rank-0 chain's samples are kept between covariance epochs (PTEngine am_mode): rle = a step stores its "
                          "row only when it was accepted, the pooled statistics weight every stored row by its run length; rows = every "
@@ -200,7 +200,10 @@ def measure(a, rank, world, local, dist, backend):
                   "hipsolver" if a.cov_mode.endswith("_hipsolver") else ("sytrd" if a.cov_mode.endswith("_sytrd") else "lapack"))))
     eig_lag = 0
     if kw["cov_mode"] == "pooled" and kw["eig_mode"] in ("lapack", "hipsolver", "sytrd"):
-        eig_lag = a.eig_lag if a.eig_lag >= 0 else (1 if kw["eig_mode"] == "lapack" else 9)
+        # device factorizations: a whole covariance period of launches (10); the pending table is then finished behind the next
+        # epoch's statistics, which run beside the rest of it (config 4: statistics 12 ms + tridiagonalization 12 + divide and conquer
+        # 13 beside nine launches of 2.2 ms left the stream waiting 5 ms per period at eig_lag 9)
+        eig_lag = a.eig_lag if a.eig_lag >= 0 else (1 if kw["eig_mode"] == "lapack" else 10)
     kw.update(eig_lag=eig_lag)
     # the statistics of a finished covariance period on a side stream beside the launches that follow (PTEngine stats_async: two AM
     # rings; needs the late table, and burn a multiple of covUpdate when a DE history is kept -- 10000 / 1000 here)

@@ -300,6 +300,10 @@ int ptmi_eig_ql(ptmi_handle h);
  * is the epoch.  On `stream` (NULL: the handle's), results into Ut_out [ndim][ndim] / S_out [ndim] (NULL: the handle's Ut / S):
  * eigenvalues in absolute value, descending; no sign rule (the library's vectors).  Its last bits are the library's. */
 int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out);
+/* The same from the covariance `cov_in` [ndim][ndim] (device; NULL: the handle's cov): a caller that runs the factorization BESIDE
+ * later work -- the statistics of the next covariance epoch overwrite the handle's cov -- hands in its own copy (PTEngine: eig_lag
+ * with the statistics of the next epoch ahead of the pending table, :545-560). */
+int ptmi_eig_sytrd_from(ptmi_handle h, void *stream, const double *cov_in, double *Ut_out, double *S_out);
 /* The convergence word (LAPACK's `info` of dstedc: 0 = converged) of the most recent ptmi_eig_sytrd whose result has reached the
  * host: it follows the factorization on its stream into pinned memory, so the call never waits; check it once that stream has been
  * waited for (the engine does at its next covariance epoch and in sync()).  Non-zero: Ut / S of that epoch are not to be trusted. */

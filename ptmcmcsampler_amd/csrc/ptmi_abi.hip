@@ -3441,11 +3441,14 @@ static int sy_lib_get(ptmi_engine *h, SyLib **out)
     return PTMI_OK;
 }
 
-int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out)
+int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out) { return ptmi_eig_sytrd_from(h, stream, nullptr, Ut_out, S_out); }
+
+int ptmi_eig_sytrd_from(ptmi_handle h, void *stream, const double *cov_in, double *Ut_out, double *S_out)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
     const ptmi_config &c = h->cfg;
-    if (!h->buf.cov) return fail(PTMI_EINVAL, "cov buffer missing");
+    if (!cov_in) cov_in = h->buf.cov;
+    if (!cov_in) return fail(PTMI_EINVAL, "cov buffer missing");
     if (c.cov_per_walker || c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "ptmi_eig_sytrd factorizes ONE pooled covariance (no parameter groups)");
     const int n = c.ndim;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
@@ -3471,7 +3474,7 @@ int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out)
     double *A = (double *)h->d_sy_scr, *Cm = A + nn, *D = Cm + nn, *E = D + n, *tau = E + n, *vbuf = tau + n, *pbuf = vbuf + 2 * (n + 2);
     unsigned *bar = (unsigned *)(pbuf + 2 * n + 2);
     int *info = (int *)(bar + 4);
-    HIPCHK(hipMemcpyAsync(A, h->buf.cov, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(A, cov_in, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemsetAsync(bar, 0, 32, st));
     HIPCHK(hipFuncSetAttribute((const void *)sytrd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SytrdArgs sa = {A, D, E, tau, vbuf, pbuf, bar, n};

@@ -1580,11 +1580,9 @@ __global__ __launch_bounds__(512) void mh_pc_kernel(const KArgs a)
             // size lives beside x, dq and the accumulators
             if constexpr (PRI == PTMI_LOGP_FLAT) nlp = 0.0;
             else nlp = eval_logp_q<G, EPL, STR>(a, smem, gl, [&](int e) { return x[e] + dq[e]; });
-            auto rf = [&](int e) {
-                const int i = gl + G * e;
-                const double qe = x[e] + dq[e];
-                return i < d ? qe - PTMI_PC_MU[i] : 0.0;
-            };
+            // unconditional: the LDS copy of the mean is zero beyond ndim, and so are x and dq there (a read under `i < d` was a branch
+            // and an LDS round trip of its own for every slot, twice per step: fifty of them)
+            auto rf = [&](int e) { return (x[e] + dq[e]) - PTMI_PC_MU[gl + G * e]; };
             MfmaAcc<EPL> pacc;
             mfma_half_tab_vecf<EPL>(PTMI_PC_UL, LD, d, rf, pacc);
             double pq = 0.0;

@@ -273,6 +273,9 @@ class PTEngine(object):
         self.iter = 0
         self.swap_proposed = 0
         self.eig_epochs = 0
+        # a pending device factorization is finished BEHIND the statistics of the next covariance epoch (update_cov); the same on
+        # every block of a sharded ladder (from the configuration alone: ShardedPTEngine orders its broadcasts by it)
+        self.late_finish = self.eig_lag > 0 and eig_mode in ("hipsolver", "sytrd") and not stats_async
         self.stats_async = False
         if stats_async and self.owns_cold:                            # (a block without rank 0 has no statistics to run)
             ok = (not self.per_walker and self.eig_lag >= 1 and self.whole and eig_mode in ("lapack", "hipsolver", "sytrd")
@@ -413,6 +416,9 @@ class PTEngine(object):
             self._side_go, self._side_done = torch.cuda.Event(), torch.cuda.Event()
             # the staging tensors start as the table in force: whatever goes wrong on the side, they never hold garbage
             self._ut_next, self._s_next = self.t["Ut"].clone(), self.t["S"].clone()
+            self._cov_side = torch.empty_like(self.t["cov"])          # the covariance the factorization reads: the next epoch's statistics may overwrite t["cov"] meanwhile
+        with torch.cuda.stream(self._st if self.stats_async else self.stream):
+            self._cov_side.copy_(self.t["cov"])                       # behind the statistics, on their stream
         if not self.stats_async:
             self._side_go.record(self.stream)
             self._side.wait_event(self._side_go)
@@ -426,10 +432,10 @@ class PTEngine(object):
                 torch.cuda.set_device(self.device)
                 with torch.cuda.stream(self._side):
                     if self.eig_mode == "sytrd":
-                        _lib.check(self.lib.ptmi_eig_sytrd(self.h, C.c_void_p(self._side.cuda_stream), C.c_void_p(self._ut_next.data_ptr()),
-                                                           C.c_void_p(self._s_next.data_ptr())))
+                        _lib.check(self.lib.ptmi_eig_sytrd_from(self.h, C.c_void_p(self._side.cuda_stream), C.c_void_p(self._cov_side.data_ptr()),
+                                                                C.c_void_p(self._ut_next.data_ptr()), C.c_void_p(self._s_next.data_ptr())))
                     else:
-                        w, V = torch.linalg.eigh(self.t["cov"])
+                        w, V = torch.linalg.eigh(self._cov_side)
                         w, order = w.abs().sort(dim=-1, descending=True, stable=True)
                         self._ut_next[:, 0].copy_(torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2))
                         self._s_next[:, 0].copy_(w)
@@ -571,12 +577,19 @@ class PTEngine(object):
         """Covariance epoch after iteration ``it_done`` (:545-560): device Welford, host SVD."""
         if not self.owns_cold:
             return
-        self._eig_finish()                                            # a factorization still pending from the epoch before
-        self._check_sytrd_info()                                      # ... and how the last finished one went
+        # A factorization still pending from the epoch before (eig_lag >= the launches of a period) is finished here at the latest.
+        # On the side stream (device factorizations) it goes on BESIDE this epoch's statistics, which do not read the table: they are
+        # queued first, the wait for the old table comes behind them -- the same table in force for the same launches either way.
+        late = self._eig_pending and self.late_finish
+        if not late:
+            self._eig_finish()
+        self._check_sytrd_info()                                      # how the last finished factorization went
         if self.stats_async:
             self._update_cov_async(it_done)
             return
         _lib.check(self.lib.ptmi_update_cov(self.h, it_done))
+        if late:
+            self._eig_finish()
         if self.am_rle and self.t["DE"] is not None and self.burn % self.cov_update != 0:
             # a DE epoch (every `burn` iterations, :563-571) copies ALL covUpdate ring rows; unless burn is a multiple of covUpdate
             # some of them belong to the period that ends here, and am_expand only reaches back to the current period's start:
@@ -773,7 +786,8 @@ class PTEngine(object):
                 self.swap(end)
             if self._eig_pending:                                     # eig_lag launches after the epoch its table takes effect
                 self._eig_wait -= 1
-                if self._eig_wait <= 0:
+                # (when the next iteration opens a covariance epoch, update_cov finishes it: behind that epoch's statistics)
+                if self._eig_wait <= 0 and not (end % self.cov_update == 0 and end + 1 <= last and self.owns_cold):
                     self._eig_finish()
             it = end + 1
         self.iter = last

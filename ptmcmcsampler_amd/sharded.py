@@ -142,6 +142,7 @@ class ShardedPTEngine(object):
         # stats_async (PTEngine): the owner switches rings at a covariance epoch, so a DE epoch that falls on it goes first -- on EVERY
         # rank (the epochs' broadcasts are collectives: one order for all), hence from the configuration, not from the local engine
         self._de_first = bool(kw.get("stats_async", False)) and self.eig_lag >= 1
+        self._late_finish = bool(getattr(L, "late_finish", False))           # (PTEngine derives it from the configuration: the same on every rank)
         self._lnl_loc = torch.zeros((self.W, self.nt), dtype=torch.float64, device=self.device)
         self._map = torch.zeros((self.W, self.ntg), dtype=torch.int32, device=self.device)
         self._parts = torch.empty((self.world * self.W, self.nt), dtype=torch.float64, device=self.device)
@@ -238,10 +239,17 @@ class ShardedPTEngine(object):
     # ---- covariance / DE epochs (PTMCMCSampler.py:545-576) ----------------------------------
     def update_cov(self, it_done):
         L = self.local
-        if self._bcast_pending:
-            self._finish_table()                                          # still pending from the epoch before
+        # a table still pending from the epoch before takes effect here at the latest: before this epoch's statistics -- or, with a
+        # device factorization on the owner's side stream (PTEngine.late_finish), behind them: the owner's update_cov then runs
+        # statistics, finishes the old table, starts the new factorization, and the old table is broadcast after it
+        late = self._bcast_pending and self._late_finish
+        if self._bcast_pending and not late:
+            self._finish_table()
         if self.owns_cold:
             L.update_cov(it_done)
+        if late:
+            self._bcast_table()
+            self._bcast_pending, self._bcast_wait = False, 0
         if self.eig_lag:
             self._bcast_pending, self._bcast_wait = True, self.eig_lag    # run() finishes the epoch eig_lag launches later
             return
@@ -306,7 +314,8 @@ class ShardedPTEngine(object):
                 self.swap(end)
             if self._bcast_pending:                                       # the owner factorized while those launches ran
                 self._bcast_wait -= 1
-                if self._bcast_wait <= 0:
+                # (when the next iteration opens a covariance epoch and the owner finishes behind its statistics: update_cov does it)
+                if self._bcast_wait <= 0 and not (self._late_finish and end % self.cov_update == 0 and end + 1 <= last):
                     self._finish_table()
             it = end + 1
         self.iter = last

@@ -300,3 +300,27 @@ def test_checkpoint_of_a_run_with_statistics_on_the_side_stream(mods):
     b.run(3 * cu + 5)
     for name in ("X", "lnL", "cov", "Ut", "S", "nacc", "DE"):
         assert_same(a.get(name), b.get(name), name)
+
+
+@pytest.mark.parametrize("eig_mode,lag", [("sytrd", 3), ("sytrd", 5), ("hipsolver", 3)])
+def test_pending_device_factorization_is_finished_behind_the_next_statistics(mods, eig_mode, lag):
+    """eig_lag >= the launches of a covariance period (three here) with a device factorization: the table of epoch E is still pending
+    when epoch E + 1 arrives; the engine queues that epoch's statistics FIRST (they do not read the table) and waits for the old
+    table behind them (PTEngine.late_finish), so the factorization has the statistics' time on top of the period's launches.  The
+    same table in force for the same launches: bit for bit the run that finishes it before the statistics."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu = 300, 4, 6, 30
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=10, seed=19, cov_mode="pooled", eig_mode=eig_mode, eig_lag=lag)
+    runs = []
+    for late in (True, False):
+        g = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+        assert g.late_finish
+        g.late_finish = late
+        g.init_state(np.zeros(d))
+        for n in (cu + 10, 2 * cu, 7, 3 * cu + 3):
+            g.run(n)
+        g.sync()
+        runs.append({k: g.get(k) for k in ("X", "lnL", "cov", "Ut", "S", "nacc")})
+        assert g.eig_epochs >= 5
+    for k in runs[0]:
+        assert_same(runs[0][k], runs[1][k], k)

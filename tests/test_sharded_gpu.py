@@ -226,7 +226,8 @@ def test_config5_ladder_8_blocks_of_16_ranks_curved_nuts():
     assert ref.jstat[..., 3, 0].sum() > 0 and ref.jstat[..., 2, 0].sum() > 0        # NUTS and DE proposals were made
 
 
-@pytest.mark.parametrize("eig_mode,lag,stats_async", [("sytrd", 2, False), ("sytrd", 3, True), ("hipsolver", 2, False), ("lapack", 2, True)])
+@pytest.mark.parametrize("eig_mode,lag,stats_async", [("sytrd", 2, False), ("sytrd", 3, True), ("hipsolver", 2, False), ("lapack", 2, True),
+                                                       ("sytrd", 3, False), ("sytrd", 4, False)])       # a period is three launches: the late finish
 def test_sharded_ladder_with_the_owner_factorizing_on_its_side_stream(eig_mode, lag, stats_async):
     """eig_lag = L with the factorization on the owner's side (PTMCMCSampler.py:545-560; ShardedPTEngine): the block that holds rank 0
     runs statistics + ptmi_eig_sytrd / the library's eigensolver (with stats_async the statistics too on the side stream, two AM
