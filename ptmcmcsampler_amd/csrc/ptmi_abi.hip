@@ -2506,6 +2506,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     return PTMI_OK;
 }
 
+static void dc_plan_free(ptmi_engine *h);
+
 int ptmi_destroy(ptmi_handle h)
 {
     if (!h) return PTMI_OK;
@@ -2514,6 +2516,7 @@ int ptmi_destroy(ptmi_handle h)
     if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
     (void)hipFree(h->d_ql_scr); (void)hipFree(h->d_sy_scr); (void)hipFree(h->d_utpad);
+    dc_plan_free(h);
     if (h->h_sy_info) (void)hipHostFree(h->h_sy_info);
     if (h->sy_lib) {                                                // SyLib: the library's handle, its destructor
         void **sl = (void **)h->sy_lib;
@@ -3408,6 +3411,119 @@ __global__ __launch_bounds__(256) void eig_sort_rows_kernel(const double *D, con
     const int rank = rank_s;
     for (int i = (int)threadIdx.x; i < n; i += 256) Ut[(size_t)rank * n + i] = Cm[(size_t)k * n + i];
 }
+#include "ptmi_dc.inc.h"
+
+// host side of the divide-and-conquer solver: the tree of a matrix order (all leaves at one depth, so that every level merges every
+// block and the two vector buffers alternate), built once per engine
+struct DcPlan {
+    int n = 0, nlevels = 0, nleaves = 0, nnodes = 0;
+    std::vector<int> lvl_off, lvl_cnt, lvl_nmax;       // per level (bottom-up): first node, nodes, largest node
+    dc::Node *d_nodes = nullptr;                       // all merges, level by level
+    dc::Leaf *d_leaves = nullptr;
+    char *scr = nullptr;                               // two vector buffers, U, the per-row arrays
+};
+static int dc_plan_get(ptmi_engine *h, int n, DcPlan **out)
+{
+    if (h->dc_plan) { *out = (DcPlan *)h->dc_plan; return PTMI_OK; }
+    DcPlan *P = new (std::nothrow) DcPlan();
+    if (!P) return fail(PTMI_EHIP, "out of memory");
+    int depth = 0;
+    while (((n + (1 << depth) - 1) >> depth) > dc::LEAF) ++depth;
+    std::vector<std::vector<dc::Node>> by_depth(depth);
+    std::vector<dc::Leaf> leaves;
+    struct Rec { static void go(int off, int nn, int dep, int depth, std::vector<std::vector<dc::Node>> &bd, std::vector<dc::Leaf> &lv) {
+        if (dep == depth) { lv.push_back({off, nn}); return; }
+        const int n1 = nn / 2;
+        bd[dep].push_back({off, nn, n1});
+        go(off, n1, dep + 1, depth, bd, lv);
+        go(off + n1, nn - n1, dep + 1, depth, bd, lv);
+    } };
+    Rec::go(0, n, 0, depth, by_depth, leaves);
+    std::vector<dc::Node> all;
+    for (int dep = depth - 1; dep >= 0; --dep) {       // bottom-up
+        P->lvl_off.push_back((int)all.size());
+        P->lvl_cnt.push_back((int)by_depth[dep].size());
+        int mx = 0;
+        for (const dc::Node &nd : by_depth[dep]) { all.push_back(nd); mx = nd.n > mx ? nd.n : mx; }
+        P->lvl_nmax.push_back(mx);
+    }
+    P->n = n; P->nlevels = depth; P->nleaves = (int)leaves.size(); P->nnodes = (int)all.size();
+    const size_t nn = (size_t)n * n;
+    const size_t bytes = sizeof(double) * (3 * nn + 12 * (size_t)n + 2 * all.size() + 64) + sizeof(int) * (6 * (size_t)n + 2 * all.size() + 64);
+    hipError_t e = hipMalloc((void **)&P->scr, bytes);
+    if (e == hipSuccess && !all.empty()) e = hipMalloc((void **)&P->d_nodes, sizeof(dc::Node) * all.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&P->d_leaves, sizeof(dc::Leaf) * leaves.size());
+    if (e == hipSuccess && !all.empty()) e = hipMemcpy(P->d_nodes, all.data(), sizeof(dc::Node) * all.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(P->d_leaves, leaves.data(), sizeof(dc::Leaf) * leaves.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(P->scr); (void)hipFree(P->d_nodes); (void)hipFree(P->d_leaves);
+        delete P;
+        return fail(PTMI_EHIP, "divide-and-conquer scratch: %s", hipGetErrorString(e));
+    }
+    h->dc_plan = P;
+    *out = P;
+    return PTMI_OK;
+}
+static void dc_plan_free(ptmi_engine *h)
+{
+    DcPlan *P = (DcPlan *)h->dc_plan;
+    if (!P) return;
+    (void)hipFree(P->scr); (void)hipFree(P->d_nodes); (void)hipFree(P->d_leaves);
+    delete P;
+    h->dc_plan = nullptr;
+}
+// eigenvalues (ascending, *Dres) and eigenvectors (vector-major, *Zres) of the tridiagonal matrix (D, E), back-transformed through the
+// reflectors (A, tau) of the reduction; everything queued on st
+static int dc_solve(ptmi_engine *h, hipStream_t st, int n, const double *D, const double *E, const double *A, const double *tau,
+                    const double **Dres, const double **Zres)
+{
+    DcPlan *P = nullptr;
+    if (int rc = dc_plan_get(h, n, &P)) return rc;
+    const size_t nn = (size_t)n * n;
+    double *p = (double *)P->scr;
+    double *Qa = p; p += nn;
+    double *Qb = p; p += nn;
+    dc::Args a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    a.U = p; p += nn;
+    a.d = p; p += n;
+    a.e = p; p += n;
+    double *Da = p; p += n;
+    double *Db = p; p += n;
+    a.dk = p; p += n; a.zk = p; p += n; a.Ddefl = p; p += n; a.mu = p; p += n; a.lam = p; p += n; a.zh = p; p += n;
+    a.rho = p; p += P->nnodes + 8;
+    int *q = (int *)p;
+    a.keepv = q; q += n; a.deflv = q; q += n; a.org = q; q += n; a.rankk = q; q += n; a.rankd = q; q += n;
+    a.cnt = q;
+    HIPCHK(hipMemcpyAsync(a.d, D, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(a.e, E, sizeof(double) * (n - 1), hipMemcpyDeviceToDevice, st));
+    if (P->nnodes) hipLaunchKernelGGL(dc::split_kernel, dim3((P->nnodes + 63) / 64), dim3(64), 0, st, (const dc::Node *)P->d_nodes, P->nnodes, a.d, (const double *)a.e);
+    HIPCHK(hipMemsetAsync(Qa, 0, sizeof(double) * nn, st));
+    hipLaunchKernelGGL(dc::leaf_kernel, dim3(P->nleaves), dim3(64), 0, st, (const dc::Leaf *)P->d_leaves, n, (const double *)a.d, (const double *)a.e, Da, Qa);
+    double *Qin = Qa, *Qout = Qb, *Din = Da, *Dout = Db;
+    for (int lv = 0; lv < P->nlevels; ++lv) {
+        const int cnt = P->lvl_cnt[lv], nmax = P->lvl_nmax[lv];
+        a.nodes = P->d_nodes + P->lvl_off[lv];
+        a.Qin = Qin; a.Qout = Qout; a.Din = Din; a.Dout = Dout;
+        HIPCHK(hipMemsetAsync(Qout, 0, sizeof(double) * nn, st));
+        hipLaunchKernelGGL(dc::prep_kernel, dim3(cnt), dim3(dc::PREP_THREADS), 0, st, a);
+        hipLaunchKernelGGL(dc::secular_kernel, dim3((nmax + 3) / 4, cnt), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(dc::zhat_kernel, dim3((nmax + 3) / 4, cnt), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(dc::vectors_kernel, dim3((nmax + 3) / 4, cnt), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(dc::rank_kernel, dim3(cnt), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(dc::gemm_kernel, dim3((nmax + 63) / 64, (nmax + 63) / 64, cnt), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(dc::copy_deflated_kernel, dim3(nmax, cnt), dim3(256), 0, st, a);
+        double *tq = Qin; Qin = Qout; Qout = tq;
+        double *td = Din; Din = Dout; Dout = td;
+    }
+    hipLaunchKernelGGL(dc::backtransform_kernel, dim3((n + 4 * dc::VPW - 1) / (4 * dc::VPW)), dim3(256), 0, st, A, tau, n, Qin);
+    HIPCHK(hipGetLastError());
+    *Dres = Din;
+    *Zres = Qin;
+    return PTMI_OK;
+}
+
 // the library's entry points, looked up in the copies the process has loaded already (torch brings its own librocsolver / librocblas;
 // a second copy from /opt/rocm beside them is not wanted)
 struct SyLib {
@@ -3467,8 +3583,6 @@ int ptmi_eig_sytrd_from(ptmi_handle h, void *stream, const double *cov_in, doubl
     const size_t lds = sizeof(double) * ((size_t)(SY_CMAX + 3) * n + (size_t)(1 + SY_CMAX) * SY_NW);
     if (lds > 160 * 1024 || n > 1024) return fail(PTMI_EUNSUPPORTED, "ptmi_eig_sytrd: ndim = %d does not fit the LDS", n);
     (void)cpb;
-    SyLib *L = nullptr;
-    if (int rc = sy_lib_get(h, &L)) return rc;
     const size_t nn = (size_t)n * n;
     if (!h->d_sy_scr) HIPCHK(hipMalloc(&h->d_sy_scr, sizeof(double) * (2 * nn + 8 * (size_t)n + 64) + 256));
     double *A = (double *)h->d_sy_scr, *Cm = A + nn, *D = Cm + nn, *E = D + n, *tau = E + n, *vbuf = tau + n, *pbuf = vbuf + 2 * (n + 2);
@@ -3498,6 +3612,17 @@ int ptmi_eig_sytrd_from(ptmi_handle h, void *stream, const double *cov_in, doubl
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(last[di], st));
     }
+    static const bool use_lib = getenv("PTMI_SYTRD_LIB") != nullptr;   // measurement switch: round 4's path, the library's divide-and-conquer solver and back-transformation
+    if (!use_lib) {
+        // the tridiagonal matrix's eigenvectors by the engine's own divide-and-conquer kernels, back-transformed through the reflectors
+        const double *Dres = nullptr, *Zres = nullptr;
+        if (int rc = dc_solve(h, st, n, D, E, A, tau, &Dres, &Zres)) return rc;
+        hipLaunchKernelGGL(eig_sort_rows_kernel, dim3(n), dim3(256), 0, st, Dres, Zres, n, Uo, So);
+        HIPCHK(hipGetLastError());
+        return PTMI_OK;
+    }
+    SyLib *L = nullptr;
+    if (int rc = sy_lib_get(h, &L)) return rc;
     if (L->set_stream(L->blas_handle, st) != 0) return fail(PTMI_EHIP, "rocblas_set_stream failed");
     // eigenvectors of the tridiagonal matrix (columns of C), then C := Q C with the reflectors of the reduction
     int rs = L->dstedc(L->blas_handle, (int)rocblas_evect_tridiagonal, n, D, E, Cm, n, info);

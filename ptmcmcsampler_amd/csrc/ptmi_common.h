@@ -150,7 +150,8 @@ struct ptmi_engine {
     hipEvent_t side_go, side_done;
     double *d_utpad;             // zero-padded copy of the pooled eigenvector table for the 16- / 64-lane shapes (KArgs::UtPad)
     void *d_sy_scr;              // ptmi_eig_sytrd: the working matrix, d / e / tau, the eigenvectors, the exchange vectors and the barrier word
-    void *sy_lib;                // ... and the ROCm library's entry points (SyLib, ptmi_abi.hip)
+    void *dc_plan;               // ... the divide-and-conquer solver's tree and scratch (DcPlan, ptmi_abi.hip)
+    void *sy_lib;                // ... and the ROCm library's entry points (SyLib, ptmi_abi.hip; PTMI_SYTRD_LIB=1 only)
     int32_t *h_sy_info;          // pinned: the divide-and-conquer solver's convergence word of the last factorization that has finished
     void *d_ql_scr;              // ptmi_eig_ql with many matrices: the transformations, tridiagonal matrices and recorded rotations (QlScratch)
     void *d_rle_ent;             // pooled statistics over run-length-compacted rows: the stored rows of each slab, 16 bytes each [nrows]

@@ -176,30 +176,56 @@ def test_library_eigensolver_on_the_stream(cov_mode, d, nt, W):
     assert (js[..., :2, 0].sum(-1) == 130).all() and js[..., 1, 1].sum() > 0
 
 
+def _sytrd_matrix(kind, d):
+    rng = np.random.default_rng(d)
+    if kind == "scaled":                                          # a random ill-scaled covariance
+        X = rng.standard_normal((4 * d, d)) * np.exp(rng.uniform(-2, 2, d))
+        return X.T @ X / (4 * d)
+    if kind == "isotropic":                                       # what an isotropic target adapts to: a nearly degenerate spectrum, 1 +- a few per cent
+        X = rng.standard_normal((50 * d, d))
+        return X.T @ X / (50 * d)
+    if kind == "identity":                                        # the identity up to rounding noise: everything deflates
+        E = rng.standard_normal((d, d)) * 1e-14
+        return np.eye(d) + 0.5 * (E + E.T)
+    if kind == "clusters":                                        # a few well-separated clusters of (nearly) equal eigenvalues
+        Q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        w = np.repeat([1e-3, 1.0, 1.0 + 1e-9, 50.0], (d + 3) // 4)[:d] * (1 + 1e-13 * rng.standard_normal(d))
+        C = (Q * w) @ Q.T
+        return 0.5 * (C + C.T)
+    if kind == "wilkinson":                                       # tridiagonal already: |i - d/2| on the diagonal, ones beside it (pairs of close eigenvalues)
+        return np.diag(np.abs(np.arange(d) - d // 2).astype(float)) + np.diag(np.ones(d - 1), 1) + np.diag(np.ones(d - 1), -1)
+    raise ValueError(kind)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("d", [3, 37, 130, 300, 1000])
-def test_sytrd_eigensolver_decomposes_a_covariance(d):
+@pytest.mark.parametrize("d,kind", [(3, "scaled"), (37, "scaled"), (130, "scaled"), (300, "scaled"), (1000, "scaled"), (33, "isotropic"), (65, "wilkinson"),
+                                    (500, "isotropic"), (1000, "isotropic"), (1024, "identity"), (700, "clusters"), (777, "wilkinson"), (64, "identity")])
+def test_sytrd_eigensolver_decomposes_a_covariance(d, kind):
     """ptmi_eig_sytrd (eig_mode="sytrd": Householder tridiagonalization in one kernel with the matrix in the LDS of its blocks, then the
-    library's rocsolver_dstedc / rocsolver_dormtr) on a random ill-scaled covariance: eigenvalues against numpy.linalg.eigvalsh,
-    orthonormal rows, U diag(S) U^T = cov.  Replaces np.linalg.svd of PTMCMCSampler.py:797-803 for one large pooled covariance."""
+    engine's divide-and-conquer solver of the tridiagonal matrix -- leaves by implicit QL, merges with deflation, secular roots by
+    bisection, Gu-Eisenstat's recomputed weights, the vectors multiplied on the matrix cores -- and the back-transformation through
+    the reflectors; csrc/ptmi_dc.inc.h): eigenvalues against numpy.linalg.eigvalsh, orthonormal rows, U diag(S) U^T = cov, on
+    ill-scaled, nearly degenerate, clustered, near-identity and Wilkinson matrices.  Replaces np.linalg.svd of
+    PTMCMCSampler.py:797-803 for one large pooled covariance."""
     import torch
     from ptmcmcsampler_amd import _lib
     from ptmcmcsampler_amd.engine import PTEngine
     g = PTEngine(d, 2, 2, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=100, burn=1000, tskip=10, seed=1, cov_mode="pooled",
                  use_de_buffer=False, eig_mode="sytrd")
     g.init_state(np.zeros(d))
-    rng = np.random.default_rng(d)
-    X = rng.standard_normal((4 * d, d)) * np.exp(rng.uniform(-2, 2, d))
-    cov = X.T @ X / (4 * d)
+    cov = _sytrd_matrix(kind, d)
     g.t["cov"][0].copy_(torch.from_numpy(cov))
     for _ in range(2):                                              # twice: the scratch and the barrier word are reused
         _lib.check(g.lib.ptmi_eig_sytrd(g.h, None, None, None))
     g.sync()
     Ut, S = g.get("Ut")[0, 0], g.get("S")[0, 0]
-    w = np.sort(np.abs(np.linalg.eigvalsh(cov)))[::-1]
-    assert np.allclose(S, w, rtol=0, atol=1e-12 * w.max())
-    assert np.allclose(Ut @ Ut.T, np.eye(d), atol=1e-12)
-    assert np.allclose((Ut.T * S) @ Ut, cov, rtol=0, atol=1e-12 * np.abs(cov).max())
+    ev = np.linalg.eigvalsh(cov)
+    w = np.sort(np.abs(ev))[::-1]
+    assert np.allclose(S, w, rtol=0, atol=1e-12 * w.max()), np.abs(S - w).max() / w.max()
+    assert np.allclose(Ut @ Ut.T, np.eye(d), atol=1e-12), np.abs(Ut @ Ut.T - np.eye(d)).max()
+    if ev.min() >= 0:                                             # (S holds absolute values: the reconstruction needs a definite matrix)
+        assert np.allclose((Ut.T * S) @ Ut, cov, rtol=0, atol=1e-12 * np.abs(cov).max())
+    assert np.abs(cov @ Ut.T - Ut.T * (np.sign(np.einsum("ki,ij,kj->k", Ut, cov, Ut)) * S)).max() <= 1e-12 * w.max()      # residual of every pair
     assert (np.diff(S) <= 0).all()
 
 
