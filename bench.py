@@ -289,6 +289,13 @@ def measure(a, rank, world, local, dist, backend):
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
     log("timed region %.3f s (%d iterations, %d covariance epochs)" % (wall, it_timed, n_cov[0]))
+    # share of the rank-0 rows the timed launches stored (am_mode rle: accepted steps and KEY rows only), read off the AM flags NOW:
+    # the ring holds the last covUpdate iterations of the timed region.  (Read after the ESS leg -- at the stationary acceptance --
+    # it made the byte model of the driver's window, where nearly every proposal is accepted, 27 % too small: round 4's
+    # traffic_over_model 1.27.)
+    stored_timed = None
+    if getattr(eng, "am_rle", False) and getattr(eng, "owns_cold", False) and hasattr(eng, "t") and eng.t.get("AMflag") is not None:
+        stored_timed = float(((eng.t["AMflag"] & 3) != 0).double().mean().item())
 
     # ---- ESS leg, OUTSIDE the timed wall.  ESS/sec = (walkers x iterations/s of the timed region) / tau_int, with the
     # integrated autocorrelation time of the T = 1 chains estimated where it can be: on a stationary window of >= 50 tau
@@ -385,7 +392,7 @@ def measure(a, rank, world, local, dist, backend):
     }
     # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
     # summary is per launch of 100 steps on one named workload
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -403,10 +410,7 @@ def measure(a, rank, world, local, dist, backend):
     # AM flags of the ring as it stands after the run).  The PMC figure above is a committed profile of the same workload; a
     # kernel change that adds traffic moves one of the two, and their ratio says so.
     if not a.callback and a.mix != "nuts" and getattr(eng, "owns_cold", False) and hasattr(eng, "t"):
-        stored = 1.0
-        if getattr(eng, "am_rle", False):
-            fl = eng.t["AMflag"]
-            stored = float(((fl & 3) != 0).double().mean().item())
+        stored = stored_timed if stored_timed is not None else 1.0
         per_launch_model = 2.0 * nt * W * (8 * d + 16) + W * avg_steps * (stored * 8 * d + (8 if getattr(eng, "am_rle", False) else 0))
         out["roofline"]["traffic_model_bytes"] = per_launch_model
         out["roofline"]["am_rows_stored_share"] = stored

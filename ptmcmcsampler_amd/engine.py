@@ -289,7 +289,7 @@ class PTEngine(object):
                              AMaux=torch.zeros_like(self.t["AMaux"]) if self.t["AMaux"] is not None else None,
                              AMflag=torch.full_like(self.t["AMflag"], _lib.AMROW_KEY) if self.t["AMflag"] is not None else None)
             # high priority: the statistics' blocks go ahead of the step kernel's next blocks wherever a CU has room for them
-            self._st = torch.cuda.Stream(device=self.device, priority=-1)
+            self._st = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PTMI_STATS_PRIO", "-1")))     # (0 measured the same, round 5)
             self._ev_period, self._ev_stats = torch.cuda.Event(), torch.cuda.Event()
             self._stats_queued = False
         self._eig_host(0, cov0)                                       # every walker starts from the same covariance

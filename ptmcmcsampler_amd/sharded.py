@@ -79,7 +79,30 @@ class DistComm(object):
         self.root = dist.get_global_rank(group, 0) if group is not None else 0
 
     def all_gather(self, out, inp):
-        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+        """out[q] <- rank q's inp.  xGMI is point to point with a link to EVERY peer of the node (7 per GPU): rank r sends its block
+        to all peers at once, one link each, in ONE grouped send/recv (ncclSend / ncclRecv inside a group) -- a single hop of
+        W x ntemps x 8 bytes whatever the world size, where a ring all-gather takes world - 1 hops in turn (the swap epoch's lnL
+        gather at 8 GPUs: 7 x 33 us modelled, tools/scale_model.py).  PTMI_ALLGATHER=ring keeps the library's collective."""
+        import os
+        dist = self.dist
+        if self.world <= 2 or os.environ.get("PTMI_ALLGATHER") == "ring":
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+            return
+        parts = out.view((self.world,) + tuple(inp.shape)) if out.shape != (self.world,) + tuple(inp.shape) else out
+        gr = (lambda q: dist.get_global_rank(self.group, q)) if self.group is not None else (lambda q: q)
+        staged = inp.is_cuda and dist.get_backend(self.group) != "nccl"          # gloo rehearsals move device tensors through the host
+        src = inp.cpu() if staged else inp.contiguous()
+        bufs = {q: (src.new_empty(src.shape) if staged else parts[q]) for q in range(self.world) if q != self.rank}
+        ops = []
+        for q in bufs:
+            ops.append(dist.P2POp(dist.isend, src, gr(q), group=self.group))
+            ops.append(dist.P2POp(dist.irecv, bufs[q], gr(q), group=self.group))
+        parts[self.rank].copy_(inp)
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if staged:
+            for q, b in bufs.items():
+                parts[q].copy_(b)
 
     def all_to_all(self, out, inp, out_splits=None, in_splits=None):
         self.dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)

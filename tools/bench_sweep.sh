@@ -1,13 +1,13 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes, one JSON line per workload, into gpurun_out/sweep_<tag>/ (copy the merged file to
 # profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r04'
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sweep_$TAG
 mkdir -p $OUT
 cd $ROOT
-b() { local name=$1; shift; python bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$?"; }
-b driver --steps 20 --warmup 5                                   # exactly what the driver runs (with the CPU baseline)
+b() { local name=$1; shift; python bench.py --also off "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$?"; }
+python bench.py --steps 20 --warmup 5 > $OUT/driver.json 2> $OUT/driver.err; echo "driver rc=$?"   # exactly what the driver runs (CPU baseline + the legs of the other configs under "also")
 b scam --no-cpu-baseline                                         # config 2, default length (200 steps after 100)
 b mix_chain --no-cpu-baseline --mix default --steps 100 --warmup 110
 b mix_walker --no-cpu-baseline --mix default --pick walker --steps 100 --warmup 110
@@ -23,6 +23,9 @@ b c4_share --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 40 --warmup 20 -
 b c4_mix --no-cpu-baseline --ndim 1000 --nwalkers 512 --mix default --steps 6 --warmup 2 --ess-window 0
 b c5_share --no-cpu-baseline --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 6 --warmup 4 --ess-window 0
 b oddeven --no-cpu-baseline --swap-mode oddeven --steps 100 --warmup 20 --ess-window 0
+b scam_stats_async --no-cpu-baseline --stats-async on --eig-lag 2 --ess-window 0     # statistics on a side stream (two AM rings): measured, not the default
+b c4_share_stats_async --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 40 --warmup 20 --stats-async on --ess-window 0
+PTMI_SYTRD_LIB=1 b c4_share_library_dc --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 40 --warmup 20 --ess-window 0     # PTMI_SYTRD_LIB set below: rocsolver's dstedc / dormtr (round 4)
 python - <<PY
 import json, glob, os
 out = {}

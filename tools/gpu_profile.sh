@@ -4,7 +4,7 @@
 # Writes text summaries under gpurun_out/prof_<tag>/ ; copy them to profiles/<tag>_*.txt (tracked).
 # One bench "step" = 100 MH iterations + the PT swap (bench.py).  Counter passes never combine with --stats or trace domains.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -13,7 +13,7 @@ cd /tmp
 run() {  # name, rocprof args..., -- bench args
     local name=$1; shift
     local prof=(); while [ "$1" != "--" ]; do prof+=("$1"); shift; done; shift
-    timeout 400 rocprofv3 --kernel-trace "${prof[@]}" -d $OUT/$name -o $name -- python $ROOT/bench.py --no-cpu-baseline --ess-window 0 "$@" > $OUT/$name.log 2>&1
+    timeout 400 rocprofv3 --kernel-trace "${prof[@]}" -d $OUT/$name -o $name -- python $ROOT/bench.py --no-cpu-baseline --ess-window 0 --also off "$@" > $OUT/$name.log 2>&1
     echo "$name rc=$?"
     python $ROOT/tools/rocpd_summary.py $OUT/$name/${name}_results.db $OUT/$name.txt > /dev/null
     rm -rf $OUT/$name              # the rocpd databases are large; only the text summaries travel back

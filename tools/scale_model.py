@@ -11,7 +11,9 @@ send/recv each use ONE link per hop).  The model per Tskip cycle of one GPU:
 
     t(N) = t_mh + t_swap_dev(N) + t_allgather(N) + t_edge + [owner, per covariance epoch / 10] (t_stats + t_bcast) / 10
 
- * t_allgather: ring all-gather of lnL, (N - 1) hops of W x ranks-per-GPU x 8 B (2 MB at config 2, 0.26 MB at config 4, 0.5 MB at config 5);
+ * t_allgather: the lnL gather as ShardedPTEngine's DistComm.all_gather runs it -- every GPU sends its block of W x ranks-per-GPU x 8 B
+   (2 MB at config 2, 0.26 MB at config 4, 0.5 MB at config 5) to all N - 1 peers at once, one xGMI link each, in one grouped
+   send/recv: ONE hop + PEER_US per further peer of the group; `ring` (round 4's model, the library's ring collective): N - 1 hops in turn;
  * t_edge: the grouped send/recv with the two neighbours, W x (d + 2) x 8 B each way on its own link, in parallel (3.3 MB at
    config 2; 4.1 MB of 8 KB rows at config 4; 0.7 MB at config 5);
  * the owner of rank 0 runs the pooled statistics (on its stream, or -- stats_async -- beside its launches: the same device time
@@ -28,6 +30,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINK_GBS = 100.0        # effective GB/s per xGMI link and direction (peak ~153; RCCL send/recv of MB-sized messages)
 LINK_LAT_US = 12.0      # per RCCL send/recv or ring step, launch included
+PEER_US = 2.0           # per further peer inside one grouped send/recv
 
 
 def msg_ms(nbytes):
@@ -56,16 +59,19 @@ def predict(cfg, bench_ms=None):
             continue
         t_mh = mh_mean
         t_swap = m["swap_epoch_device_ms"]
-        t_ag = (N - 1) * msg_ms(W * NT * 8) if N > 1 else 0.0
+        t_ag_ring = (N - 1) * msg_ms(W * NT * 8) if N > 1 else 0.0
+        t_ag = (msg_ms(W * NT * 8) + (N - 2) * PEER_US * 1e-3) if N > 1 else 0.0
         t_edge = msg_ms(W * (D + 2) * 8) if N > 1 else 0.0
         t_stats = m["cov_epoch_stats_ms"] / 10.0
         t_bcast = msg_ms((D * D + D) * 8) * (1 if N > 1 else 0) / 10.0
         t = t_mh + t_swap + t_ag + t_edge + t_stats + t_bcast + other
         rows.append(dict(n_gpus=N, ms_per_step=t, updates_per_s=N * NT * W * 100 / (t * 1e-3), mh_ms=t_mh, swap_device_ms=t_swap,
-                         allgather_ms=t_ag, edge_ms=t_edge, owner_stats_ms=t_stats, bcast_ms=t_bcast, other_ms=other))
+                         allgather_ms=t_ag, edge_ms=t_edge, owner_stats_ms=t_stats, bcast_ms=t_bcast, other_ms=other,
+                         ring_allgather_ms=t_ag_ring, ms_per_step_with_ring_allgather=t - t_ag + t_ag_ring))
     base = rows[0]["updates_per_s"] if rows else 1.0
     for r in rows:
         r["efficiency_vs_1gpu"] = r["updates_per_s"] / (r["n_gpus"] * base)
+        r["efficiency_with_ring_allgather"] = rows[0]["ms_per_step"] / r["ms_per_step_with_ring_allgather"]
     return rows
 
 
@@ -86,11 +92,11 @@ def main():
     for name, cfg in meas["configs"].items():
         rows = predict(cfg, bench.get(name, cfg.get("bench_1gpu_ms_per_step")))
         print("%s  (bench.py %s --gpus N: %d-d, %d ranks x %d walkers per GPU)" % (name, cfg["bench_args"], cfg["ndim"], cfg["ranks_per_gpu"], cfg["nwalkers"]))
-        print("%6s %12s %14s %8s | %8s %10s %10s %8s %10s %9s %8s" % ("N", "ms/step", "updates/s", "eff", "MH", "swap dev", "allgather", "edge", "stats/10", "bcast/10", "other"))
+        print("%6s %12s %14s %8s | %8s %10s %10s %8s %10s %9s %8s | %9s" % ("N", "ms/step", "updates/s", "eff", "MH", "swap dev", "allgather", "edge", "stats/10", "bcast/10", "other", "eff(ring)"))
         for r in rows:
-            print("%6d %12.3f %14.4g %8.3f | %8.3f %10.3f %10.3f %8.3f %10.3f %9.4f %8.3f" % (
+            print("%6d %12.3f %14.4g %8.3f | %8.3f %10.3f %10.3f %8.3f %10.3f %9.4f %8.3f | %9.3f" % (
                 r["n_gpus"], r["ms_per_step"], r["updates_per_s"], r["efficiency_vs_1gpu"], r["mh_ms"], r["swap_device_ms"], r["allgather_ms"],
-                r["edge_ms"], r["owner_stats_ms"], r["bcast_ms"], r["other_ms"]))
+                r["edge_ms"], r["owner_stats_ms"], r["bcast_ms"], r["other_ms"], r["efficiency_with_ring_allgather"]))
         out["configs"][name] = {"bench_args": cfg["bench_args"], "predicted": rows}
     json.dump(out, open(os.path.join(ROOT, "profiles", os.path.basename(path).replace("_shard_timing", "_scale_model")), "w"), indent=1)
 
