@@ -112,6 +112,10 @@ __device__ __forceinline__ void mfma_tab_vec(const double *T, int ld, int d, con
 }
 // The same product for the padded half table (PADDED, LOWER) with the vector operand FORMED where it is used (vec(e): e.g. the
 // residual (x + dq) - mu of a proposal): a caller that holds x and dq does not keep a third row-sized array alive across the product.
+#ifndef PTMI_HALF_PF
+#define PTMI_HALF_PF 2       // measured (dense default mix, 100 steps): 1: 14.58, 2: 14.45, 3: 14.55, 4: 14.77, 6: 15.1, 10: 15.2 ms; the one-step pipeline before: 15.3
+#endif
+constexpr int half_tab_pairs(int EPL) { int n = 0; for (int e = 0; e < EPL; ++e) n += (4 * e + 3) / 16 + 1; return n; }
 template <int EPL, class VF>
 __device__ __forceinline__ void mfma_half_tab_vecf(const double *T, int ld, int d, VF vec, MfmaAcc<EPL> &acc)
 {
@@ -119,6 +123,38 @@ __device__ __forceinline__ void mfma_half_tab_vecf(const double *T, int ld, int 
     const int c = (int)(threadIdx.x & 15), g = (int)((threadIdx.x & 63) >> 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc.t[t] = ptmi_d4{0.0, 0.0, 0.0, 0.0};
+    constexpr bool EXACT = safe_slots(4, EPL) == EPL;
+    if constexpr (EXACT) {
+        // ndim = 4 EPL: every k-step exists, the product is ONE straight-line block, and the table operand of matrix instruction
+        // i + PF is requested before instruction i is issued (mh_dense_scam_kernel's scheme: with a one-step software pipeline every
+        // k-step waited for the LDS round trip of its own operands; the scheduling barriers pin the order)
+        constexpr int NP = half_tab_pairs(EPL), PF = PTMI_HALF_PF;
+        double av[NP];
+        int pe = 0, pt = 0, pi = 0;                            // cursor of the requests (compile-time after unrolling)
+        auto request = [&]() {
+            av[pi] = T[(size_t)(4 * pe + g) * ld + c + 16 * pt];
+            ++pi;
+            if (16 * (pt + 1) <= 4 * pe + 3) ++pt;
+            else { pt = 0; ++pe; }
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) request();
+        __builtin_amdgcn_sched_barrier(0);
+        int i = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const double ve = vec(e);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (16 * t > 4 * e + 3) continue;
+                if (pi < NP) request();
+                acc.t[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], ve, acc.t[t], 0, 0, 0);
+                ++i;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
     double cur[NT], nxt[NT];
     auto fetch = [&](int e, double (&dst)[NT]) {
         const double *row = T + (size_t)(4 * e + g) * ld + c;
@@ -127,11 +163,10 @@ __device__ __forceinline__ void mfma_half_tab_vecf(const double *T, int ld, int 
             if (16 * t <= 4 * e + 3) dst[t] = row[16 * t];
     };
     fetch(0, cur);
-    constexpr bool EXACT = safe_slots(4, EPL) == EPL;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        if (EXACT || 4 * e < d) {                          // wave-uniform
-            if (e + 1 < EPL && (EXACT || 4 * (e + 1) < d)) fetch(e + 1, nxt);
+        if (4 * e < d) {                                       // wave-uniform
+            if (e + 1 < EPL && 4 * (e + 1) < d) fetch(e + 1, nxt);
             const double ve = vec(e);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
