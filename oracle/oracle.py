@@ -418,6 +418,18 @@ class OracleEngine(object):
             import contextlib
             threadpool_limits = lambda limits: contextlib.nullcontext()   # noqa: E731
         if self.eig_mode in ("jacobi", "ql") and getattr(self, "_initial_done", False):
+            if self.ngr > 1 or len(self.groups[0]) != self.d or not np.array_equal(self.groups[0], np.arange(self.d)):
+                # parameter groups with the device QL solver (ptmi_eig_ql): one factorization per group's block of the covariance
+                # (PTMCMCSampler.py:797-803), the block taken in ASCENDING parameter order, its vectors embedded in the full space
+                assert self.eig_mode == "ql"
+                for gi, g in enumerate(self.groups):
+                    gs = np.sort(g)
+                    Ut, S, _ = eig_ql(np.ascontiguousarray(self.cov[w][np.ix_(gs, gs)]))
+                    self.Ut[w, gi] = 0.0
+                    self.S[w, gi] = 0.0
+                    self.Ut[w, gi][np.ix_(np.arange(len(gs)), gs)] = Ut
+                    self.S[w, gi, :len(gs)] = S
+                return
             Ut, S, _ = eig_jacobi(self.cov[w]) if self.eig_mode == "jacobi" else eig_ql(self.cov[w])   # the engine's device eigensolvers (covariance epochs only)
             self.Ut[w, 0], self.S[w, 0] = Ut, S
             return

@@ -2442,7 +2442,9 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
             gdiv[(size_t)g] = sqrt(2.0 * (double)gsize[(size_t)g]);
         }
         if (c.ngroups > 1) memcpy(gmask.data(), c.group_mask, sizeof(double) * gmask.size());
-        hipError_t e2 = hipMalloc((void **)&h->d_gsize, sizeof(int32_t) * Ng);
+        h->gsize_host = (int32_t *)malloc(sizeof(int32_t) * Ng);
+        if (h->gsize_host) memcpy(h->gsize_host, gsize.data(), sizeof(int32_t) * Ng);
+        hipError_t e2 = h->gsize_host ? hipMalloc((void **)&h->d_gsize, sizeof(int32_t) * Ng) : hipErrorOutOfMemory;
         if (e2 == hipSuccess) e2 = hipMemcpy(h->d_gsize, gsize.data(), sizeof(int32_t) * Ng, hipMemcpyHostToDevice);
         if (e2 != hipSuccess || (rc = upload(&h->d_gcn, gcn.data(), Ng)) || (rc = upload(&h->d_gdiv, gdiv.data(), Ng)) ||
             (rc = upload(&h->d_gmask, gmask.data(), (long long)gmask.size()))) {
@@ -2515,7 +2517,8 @@ int ptmi_destroy(ptmi_handle h)
     (void)hipFree(h->d_pre); (void)hipFree(h->d_xint); (void)hipFree(h->d_hop);
     if (h->h_hop) { (void)hipHostFree(h->h_hop); (void)hipEventDestroy(h->hop_ev); }
     (void)hipFree(h->d_gsize); (void)hipFree(h->d_gmask); (void)hipFree(h->d_gcn); (void)hipFree(h->d_gdiv); (void)hipFree(h->d_pool_part); (void)hipFree(h->d_pool_T);
-    (void)hipFree(h->d_ql_scr); (void)hipFree(h->d_sy_scr); (void)hipFree(h->d_utpad);
+    (void)hipFree(h->d_ql_scr); (void)hipFree(h->d_qlg_scr); (void)hipFree(h->d_sy_scr); (void)hipFree(h->d_utpad);
+    free(h->gsize_host);
     dc_plan_free(h);
     if (h->h_sy_info) (void)hipHostFree(h->h_sy_info);
     if (h->sy_lib) {                                                // SyLib: the library's handle, its destructor
@@ -3161,24 +3164,22 @@ int ptmi_eig_jacobi(ptmi_handle h)
     return PTMI_OK;
 }
 
-int ptmi_eig_ql(ptmi_handle h)
+// nmat symmetric matrices of order n, packed [nmat][n][n] -> eigenvectors as rows [nmat][n][n], eigenvalues [nmat][n] (see ptmi_eig_ql)
+static int eig_ql_run(ptmi_engine *h, int n, int nmat, const double *cov, double *Ut, double *S)
 {
-    if (!h) return fail(PTMI_EINVAL, "NULL handle");
     const ptmi_config &c = h->cfg;
-    if (!h->buf.cov || !h->buf.Ut || !h->buf.S) return fail(PTMI_EINVAL, "cov / Ut / S buffers missing");
-    if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "the device eigensolver factorizes the full covariance (no parameter groups)");
-    const int d = c.ndim;
+    const int d = n, dmax = c.ndim;
     const size_t lds = sizeof(double) * ((((size_t)d * d + 1) & ~(size_t)1) + 2 * (size_t)d);
     if (lds > 160 * 1024 || d > 128) return fail(PTMI_EUNSUPPORTED, "the QL eigensolver keeps the %d x %d matrix in LDS: ndim <= 128", d, d);
-    const int nmat = c.cov_per_walker ? c.nwalkers : 1;
     const char *sp = getenv("PTMI_QL_SPLIT");                           // 1 / 0 forces the three-kernel / the one-kernel form (tests, measurements)
     const bool split = sp ? atoi(sp) != 0 : nmat >= 64;
     if (split) {
         // many matrices: reduce -> the scalar chains of all of them at once -> apply (see eig_ql_chain_kernel)
         const int cap = 3 * d * d, capit = 8 * d;
-        if (!h->d_ql_scr) {
-            const size_t bytes = sizeof(double) * (size_t)nmat * ((size_t)d * d + 2 * (size_t)d + (size_t)d + 2 * (size_t)cap) +
-                                 sizeof(int32_t) * (size_t)nmat * (2 * (size_t)capit + 2) + 64;
+        if (!h->d_ql_scr) {                                             // sized for the full order (a parameter group's matrices are smaller)
+            const int capm = 3 * dmax * dmax, capitm = 8 * dmax;
+            const size_t bytes = sizeof(double) * (size_t)nmat * ((size_t)dmax * dmax + 2 * (size_t)dmax + (size_t)dmax + 2 * (size_t)capm) +
+                                 sizeof(int32_t) * (size_t)nmat * (2 * (size_t)capitm + 2) + 256;
             HIPCHK(hipMalloc((void **)&h->d_ql_scr, bytes));
         }
         QlScratch q;
@@ -3195,19 +3196,76 @@ int ptmi_eig_ql(ptmi_handle h)
             HIPCHK(hipFuncSetAttribute((const void *)eig_ql_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(hipFuncSetAttribute((const void *)eig_ql_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        hipLaunchKernelGGL(eig_ql_reduce_kernel, dim3(nmat), dim3(QLR_THREADS), lds, h->stream, (const double *)h->buf.cov, d, q);
+        hipLaunchKernelGGL(eig_ql_reduce_kernel, dim3(nmat), dim3(QLR_THREADS), lds, h->stream, cov, d, q);
         hipLaunchKernelGGL(eig_ql_chain_kernel, dim3(nmat), dim3(64), sizeof(double) * 2 * (size_t)d, h->stream, d, q);
         const bool regs = d <= QLA_N && !getenv("PTMI_QL_APPLY_LDS");
         if (regs)
-            hipLaunchKernelGGL(eig_ql_apply_reg_kernel, dim3(nmat), dim3(128), 0, h->stream, h->buf.Ut, h->buf.S, d, d * d, d, (const double *)q.z,
+            hipLaunchKernelGGL(eig_ql_apply_reg_kernel, dim3(nmat), dim3(128), 0, h->stream, Ut, S, d, d * d, d, (const double *)q.z,
                                (const double *)q.ev, (const qls_d2 *)q.rot, (const int32_t *)q.hdr, (const int32_t *)q.cnt, cap, capit);
-        hipLaunchKernelGGL(eig_ql_apply_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, h->buf.Ut, h->buf.S, d, d * d, d, q, regs ? 1 : 0);
+        hipLaunchKernelGGL(eig_ql_apply_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, Ut, S, d, d * d, d, q, regs ? 1 : 0);
         HIPCHK(hipGetLastError());
         return PTMI_OK;
     }
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eig_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(eig_ql_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, (const double *)h->buf.cov, h->buf.Ut, h->buf.S, d, d * d, d,
-                       (int32_t *)nullptr);
+    hipLaunchKernelGGL(eig_ql_kernel, dim3(nmat), dim3(QL_THREADS), lds, h->stream, cov, Ut, S, d, d * d, d, (int32_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+// Parameter groups (PT:129-145, 797-803: one SVD per group's block of the covariance): the group's rows and columns, in ascending
+// parameter order, packed into an m x m matrix per walker ...
+__global__ __launch_bounds__(256) void group_gather_kernel(const double *cov, const double *gmask, int d, int m, double *sub)
+{
+    __shared__ int idx[128];
+    const double *mk = gmask;                                            // [d] membership of this group
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int i = 0; i < d && k < 128; ++i) if (mk[i] != 0.0) idx[k++] = i;
+    }
+    __syncthreads();
+    const double *cw = cov + (size_t)blockIdx.x * d * d;
+    double *sw = sub + (size_t)blockIdx.x * m * m;
+    for (int t = (int)threadIdx.x; t < m * m; t += 256) sw[t] = cw[(size_t)idx[t / m] * d + idx[t % m]];
+}
+// ... and its eigenvectors embedded in the full space, one per row of the group's table (zero outside the group, zero rows beyond
+// the group's size), the eigenvalues padded with zeros: the layout propose() reads (Ut[Wc][Ng][d][d], S[Wc][Ng][d])
+__global__ __launch_bounds__(256) void group_embed_kernel(const double *usub, const double *ssub, const double *gmask, int d, int m, int ng, int gi,
+                                                          double *Ut, double *S)
+{
+    __shared__ int pos[128];                                             // position of parameter i inside the group, or -1
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int i = 0; i < d; ++i) pos[i] = gmask[i] != 0.0 ? k++ : -1;
+    }
+    __syncthreads();
+    const double *uw = usub + (size_t)blockIdx.x * m * m, *sw = ssub + (size_t)blockIdx.x * m;
+    double *Uo = Ut + ((size_t)blockIdx.x * ng + gi) * d * d, *So = S + ((size_t)blockIdx.x * ng + gi) * d;
+    for (int t = (int)threadIdx.x; t < d * d; t += 256) {
+        const int k = t / d, i = t % d;
+        Uo[t] = (k < m && pos[i] >= 0) ? uw[(size_t)k * m + pos[i]] : 0.0;
+    }
+    for (int k = (int)threadIdx.x; k < d; k += 256) So[k] = k < m ? sw[k] : 0.0;
+}
+
+int ptmi_eig_ql(ptmi_handle h)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    const ptmi_config &c = h->cfg;
+    if (!h->buf.cov || !h->buf.Ut || !h->buf.S) return fail(PTMI_EINVAL, "cov / Ut / S buffers missing");
+    const int d = c.ndim, nmat = c.cov_per_walker ? c.nwalkers : 1;
+    if (c.ngroups <= 1) return eig_ql_run(h, d, nmat, (const double *)h->buf.cov, h->buf.Ut, h->buf.S);
+    if (d > 128) return fail(PTMI_EUNSUPPORTED, "the QL eigensolver keeps a matrix in LDS: ndim <= 128");
+    // one factorization per parameter group, as the reference's loop over self.groups (PT:797-803)
+    if (!h->d_qlg_scr) HIPCHK(hipMalloc((void **)&h->d_qlg_scr, sizeof(double) * (size_t)nmat * (2 * (size_t)d * d + d)));
+    double *sub = (double *)h->d_qlg_scr, *usub = sub + (size_t)nmat * d * d, *ssub = usub + (size_t)nmat * d * d;
+    for (int gi = 0; gi < c.ngroups; ++gi) {
+        const int m = h->gsize_host[gi];
+        const double *mk = h->d_gmask + (size_t)gi * d;
+        hipLaunchKernelGGL(group_gather_kernel, dim3(nmat), dim3(256), 0, h->stream, (const double *)h->buf.cov, mk, d, m, sub);
+        if (int rc = eig_ql_run(h, m, nmat, (const double *)sub, usub, ssub)) return rc;
+        hipLaunchKernelGGL(group_embed_kernel, dim3(nmat), dim3(256), 0, h->stream, (const double *)usub, (const double *)ssub, mk, d, m, c.ngroups, gi,
+                           h->buf.Ut, h->buf.S);
+    }
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

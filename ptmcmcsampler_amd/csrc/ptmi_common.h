@@ -153,6 +153,8 @@ struct ptmi_engine {
     void *dc_plan;               // ... the divide-and-conquer solver's tree and scratch (DcPlan, ptmi_abi.hip)
     void *sy_lib;                // ... and the ROCm library's entry points (SyLib, ptmi_abi.hip; PTMI_SYTRD_LIB=1 only)
     int32_t *h_sy_info;          // pinned: the divide-and-conquer solver's convergence word of the last factorization that has finished
+    void *d_qlg_scr;             // ptmi_eig_ql with parameter groups: a group's packed matrices, their eigenvectors and eigenvalues
+    int32_t *gsize_host;         // [Ng] parameters per group (host copy of d_gsize)
     void *d_ql_scr;              // ptmi_eig_ql with many matrices: the transformations, tridiagonal matrices and recorded rotations (QlScratch)
     void *d_rle_ent;             // pooled statistics over run-length-compacted rows: the stored rows of each slab, 16 bytes each [nrows]
                                  // (PoolEnt, ptmi_abi.hip: the row inside its slab, the square root of its run length) ...

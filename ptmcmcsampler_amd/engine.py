@@ -180,8 +180,10 @@ class PTEngine(object):
         self.ngr = len(self.groups)
         # "whole": one group that IS the full parameter vector in order (a permutation of it needs put_eig's embedding)
         self.whole = self.ngr == 1 and np.array_equal(self.groups[0], np.arange(self.d))
-        if eig_mode in ("jacobi", "ql", "hipsolver", "sytrd") and not self.whole:
-            raise ValueError("eig_mode=%r factorizes the full covariance: no parameter groups" % eig_mode)
+        if eig_mode in ("jacobi", "hipsolver", "sytrd") and not self.whole:
+            raise ValueError("eig_mode=%r factorizes the full covariance: no parameter groups (eig_mode='ql' takes them)" % eig_mode)
+        if eig_mode == "ql" and not self.whole and any(len(np.unique(g)) != len(g) for g in self.groups):
+            raise ValueError("eig_mode='ql' with parameter groups: a group may not repeat a parameter")
         self.gsize = np.ascontiguousarray([len(g) for g in self.groups], dtype=np.int32)
         self.gmask = np.zeros((self.ngr, self.d))
         for gi, g in enumerate(self.groups):

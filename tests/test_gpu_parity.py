@@ -495,3 +495,22 @@ def test_parameter_groups(mods, d, groups):
     assert_same(g.get("Ut"), o.Ut, "Ut")
     assert_same(g.get("S"), o.S, "S")
     assert o.jstat[..., :3, 0].sum(axis=(0, 1)).min() > 0
+
+
+@pytest.mark.parametrize("cov_mode,W", [("per_walker", 5), ("per_walker", 70), ("pooled", 6)])
+@pytest.mark.parametrize("d,groups", [(6, [[0, 1, 2], [3, 4, 5]]), (5, [[0, 1, 2, 3, 4], [3, 1], [2]]), (40, [list(range(0, 40, 2)), list(range(1, 40, 2)), [7]]),
+                                      (100, [list(range(100)), list(range(0, 50)), list(range(30, 100)), [99, 3]])])
+def test_parameter_groups_with_the_device_eigensolver(mods, d, groups, cov_mode, W):
+    """Parameter groups (PTMCMCSampler.py:129-145, 797-803: one SVD per group's block of the covariance) with eig_mode="ql": every
+    covariance epoch factorizes each group's block on the device -- gathered in ascending parameter order, ptmi_eig_ql's kernels
+    (one kernel per matrix, or reduce -> chains -> apply from 64 matrices on), the vectors embedded in the full space -- bit for bit
+    the oracle's orc_eig_ql on the same blocks.  What real PTA runs combine: groups, per-walker covariances, no host round trip."""
+    g, o = _pair(mods, d, 3, W, groups=groups, weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=17, rs=d + 1, cov_mode=cov_mode, eig_mode="ql")
+    for n in (45, 120, 85):
+        g.run(n)
+        o.run(n)
+        _compare(g, o, "groups + ql d=%d it=%d " % (d, g.iter))
+        assert_same(g.get("Ut"), o.Ut, "Ut it=%d" % g.iter)
+        assert_same(g.get("S"), o.S, "S it=%d" % g.iter)
+    assert g.eig_epochs >= 6
+    assert o.jstat[..., :3, 0].sum(axis=(0, 1)).min() > 0
