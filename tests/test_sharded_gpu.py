@@ -300,8 +300,9 @@ def test_two_real_processes_share_the_gpu_over_gloo():
     assert r.returncode == 0 and "all ranks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("extra,ntemps", [((), 16), (("--ndim", "1000", "--nwalkers", "64", "--mix", "default"), 64)])
-def test_bench_launches_its_own_ranks(extra, ntemps):
+@pytest.mark.parametrize("extra,ntemps,ngpus", [((), 16, 2), (("--ndim", "1000", "--nwalkers", "64", "--mix", "default"), 64, 2),
+                                                ((), 16, 4), (("--ndim", "1000", "--nwalkers", "32"), 64, 3)])
+def test_bench_launches_its_own_ranks(extra, ntemps, ngpus):
     """`python bench.py --gpus 2` as the driver calls it (second case: BASELINE configs[3]'s shape, 1000-d, 64 ranks per GPU): the script starts its two ranks itself.  A one-GPU box cannot give
     RCCL two devices, so the rehearsal runs over gloo with both ranks on cuda:0 (PTMI_DIST_BACKEND=gloo); the sharded
     engine, the neighbour send/recv at the block edge and the JSON contract are the ones of the RCCL run."""
@@ -314,18 +315,20 @@ def test_bench_launches_its_own_ranks(extra, ntemps):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     args = ["--nwalkers", "128", "--ntemps", "16"] if not extra else list(extra)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
+    # (three and four ranks: the lnL gather as one grouped send/recv to every peer, DistComm.all_gather; the 1000-d SCAM case: the
+    # owner's device factorization with eig_lag = a covariance period, the table broadcast behind the next epoch's statistics)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ngpus), "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
                         "--ess-burn", "0", "--ess-window", "3000"] + args,
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["n_gpus"] == ngpus and out["steps"] == 12 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["rccl_ranks"] == 0                       # gloo rehearsal: no RCCL ranks
-    assert out["config"]["parallelism"] == "temperature blocks x2" and out["config"]["ntemps_per_gpu"] == ntemps
+    assert out["config"]["parallelism"] == "temperature blocks x%d" % ngpus and out["config"]["ntemps_per_gpu"] == ntemps
     if extra:
-        assert out["config"]["ndim"] == 1000 and out["config"]["nwalkers"] == 64
+        assert out["config"]["ndim"] == 1000 and out["config"]["nwalkers"] == int(extra[3])
     assert out["swap_epochs_timed"] == 12 and out["cov_epochs_timed"] == 1 and out["swap_accept_rate_pair0"] > 0
     assert out["roofline"]["frac"] <= 1.0
     # the ESS leg ran (after the timed region) and FLAGS its 3000-iteration window as too short to trust
