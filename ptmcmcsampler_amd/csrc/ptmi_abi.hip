@@ -2563,11 +2563,19 @@ int ptmi_eval_state(ptmi_handle h)
 }
 
 // rows of ld >= d doubles, zero beyond column d: the 16- / 64-lane step kernels read a row with unconditional loads
-__global__ __launch_bounds__(256) void ut_pad_kernel(const double *Ut, double *out, int d, int ld)
+__global__ __launch_bounds__(256) void ut_pad_kernel(const double *Ut, double *out, int d, int ld, unsigned long long *absmax)
 {
     const double *src = Ut + (size_t)blockIdx.x * d;
     double *dst = out + (size_t)blockIdx.x * ld;
-    for (int i = (int)threadIdx.x; i < ld; i += 256) dst[i] = i < d ? src[i] : 0.0;
+    double am = 0.0;
+    for (int i = (int)threadIdx.x; i < ld; i += 256) {
+        const double v = i < d ? src[i] : 0.0;
+        dst[i] = v;
+        am = __builtin_fabs(v) > am ? __builtin_fabs(v) : am;
+    }
+    // max |U| of the table (non-negative doubles order like their bit patterns): the box prior's fast path bounds a SCAM jump by it
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(am, o, 64); am = t > am ? t : am; }
+    if ((threadIdx.x & 63) == 0) atomicMax(absmax, (unsigned long long)__double_as_longlong(am));
 }
 // ONE table for the launch and a wide shape: the padded copy the step kernels read (the caller's Ut may have changed since the
 // last launch -- an epoch, put_eig -- so it is made anew every launch: 16 MB of traffic at ndim = 1000 beside a launch of milliseconds)
@@ -2576,13 +2584,17 @@ static int make_ut_pad(ptmi_engine *h, KArgs *a)
     const ptmi_config &c = h->cfg;
     a->UtPad = nullptr;
     a->ut_pad_ld = 0;
+    a->ut_absmax = nullptr;
     static const bool off = getenv("PTMI_NO_UTPAD") != nullptr;       // measurement / test switch: same results either way
     if (h->G <= 4 || c.cov_per_walker || c.ngroups > 1 || off) return PTMI_OK;
     const int ld = h->G * h->EPL;
-    if (!h->d_utpad) HIPCHK(hipMalloc((void **)&h->d_utpad, sizeof(double) * (size_t)c.ndim * ld));
-    hipLaunchKernelGGL(ut_pad_kernel, dim3(c.ndim), dim3(256), 0, h->stream, (const double *)h->buf.Ut, h->d_utpad, c.ndim, ld);
+    if (!h->d_utpad) HIPCHK(hipMalloc((void **)&h->d_utpad, sizeof(double) * ((size_t)c.ndim * ld + 2)));
+    unsigned long long *amax = (unsigned long long *)(h->d_utpad + (size_t)c.ndim * ld);
+    HIPCHK(hipMemsetAsync(amax, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(ut_pad_kernel, dim3(c.ndim), dim3(256), 0, h->stream, (const double *)h->buf.Ut, h->d_utpad, c.ndim, ld, amax);
     a->UtPad = h->d_utpad;
     a->ut_pad_ld = ld;
+    a->ut_absmax = (const double *)amax;
     return PTMI_OK;
 }
 
@@ -2636,7 +2648,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             ap.iter0 = iter0 + s0; ap.nsteps = ns;
             if (int rc = set_step_args(h, &ap)) return rc;
             ap.am_inc = h->d_am_inc; ap.am_base = h->d_am_base;
-            ap.UtPad = a.UtPad; ap.ut_pad_ld = a.ut_pad_ld;
+            ap.UtPad = a.UtPad; ap.ut_pad_ld = a.ut_pad_ld; ap.ut_absmax = a.ut_absmax;
             if (int rc = run_shape(h, PTMI_OP_MH, ap, grid, full)) return rc;
         }
         HIPCHK(hipGetLastError());

@@ -87,6 +87,8 @@ struct KArgs {
     // (ut_pad_kernel, made ahead of the launch), so that a step reads its direction with unconditional loads; nullptr: none
     const double *UtPad;
     int ut_pad_ld;
+    const double *ut_absmax;     // max |U| over that table (ut_pad_kernel), for the box prior's fast path (mh_steps_kernel BOXFAST)
+    int umax_off;                // persistent SCAM kernel, box prior: where in the block's LDS (doubles) the same maximum is kept
     // gradient jumps (ptmi_gj.inc.h)
     int w_nuts, w_hmc, gj_nburn, hmc_min, hmc_max, nuts_maxdepth;
     double hmc_eps, nuts_delta;

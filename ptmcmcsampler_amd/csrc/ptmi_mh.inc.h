@@ -315,6 +315,39 @@ __device__ __forceinline__ bool box_inside_lds(const double *smem, int off, int 
     }
     return ok != 0;
 }
+// One pass over the block's bounds table for a SCAM step of a box prior's fast path (mh_steps_kernel, BOXFAST): is q = x + dq inside,
+// and how far is x from the nearest bound (the lane's elements; padding slots hold {-inf, +inf})?
+template <int G, int EPL>
+__device__ __forceinline__ void box_test_and_margin(const double *smem, int off, int gl, const double (&x)[EPL], const double (&dq)[EPL],
+                                                    bool &inside, double &margin)
+{
+    const ptmi_d2 *tab = (const ptmi_d2 *)(smem + off + 2 * EPL * gl);
+    bool in = true;
+    double mg = __builtin_inf();
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const ptmi_d2 b = tab[e];
+        const double qe = x[e] + dq[e];
+        in &= (b.x <= qe) & (b.y >= qe);
+        const double lo_gap = x[e] - b.x, hi_gap = b.y - x[e];
+        const double g2 = lo_gap < hi_gap ? lo_gap : hi_gap;           // (a NaN gap -- x outside every order -- loses every comparison below: margin stays, the test decides)
+        mg = g2 < mg ? g2 : mg;
+    }
+    inside = in;
+    margin = mg;
+}
+template <int G, bool STR>
+__device__ __forceinline__ double grp_min(double v)
+{
+    static_assert(!STR, "contiguous layout");
+    if (G >= 64) { const double o = __shfl_xor(v, 32, 64); v = o < v ? o : v; }
+    if (G >= 32) { const double o = __shfl_xor(v, 16, 64); v = o < v ? o : v; }
+    if (G >= 16) { const double o = dppf64<0x128>(v); v = o < v ? o : v; }
+    if (G >= 8) { const double o = dppf64<0x124>(v); v = o < v ? o : v; }
+    if (G >= 4) { const double o = dppf64<0x4E>(v); v = o < v ? o : v; }
+    if (G >= 2) { const double o = dppf64<0xB1>(v); v = o < v ? o : v; }
+    return v;
+}
 constexpr int box_table_doubles(int G, int EPL) { return 2 * G * EPL; }
 // Prologue of the step kernels; the caller's __syncthreads follows.
 template <int G, int EPL>
@@ -995,6 +1028,7 @@ constexpr int mh_min_blocks(int G, int EPL, int LOGL, bool FULL, bool STAGE, boo
     // the flat-prior instantiation over the padded table: x, dq and the row in flight (the other variants of the wide shapes carry
     // per-slot bounds and the box test and spill under the tighter budget)
     if (UPAD && PRI == PTMI_LOGP_FLAT && LOGL == PTMI_LOGL_ISO) return PTMI_WIDE_MINBLK ? PTMI_WIDE_MINBLK : (EPL <= 16 ? 4 : (EPL <= 26 ? 3 : 2));
+    if (UPAD && PRI == PTMI_LOGP_BOX && LOGL == PTMI_LOGL_ISO) return EPL <= 16 ? 3 : 2;       // (+ the one-pass test and margin of the box prior's slow path)
     return 2;
 }
 template <int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, bool ULDS = false, int PERS = 0, int PRI = -1 /* PERS: the prior kind */,
@@ -1020,6 +1054,17 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // SCAM-only cycle, one parameter group: the chain-scalar half of the proposal moves into the draw pass (ScamBatch)
     constexpr bool SCAMFAST = !FULL && !GRP;
+    // Box prior, SCAM cycle, one table for the launch: a SCAM jump moves no element further than |amp| max|U|, so while that REACH
+    // stays below the chain's distance to its nearest bound the proposal is inside without looking at a single bound (the test is
+    // 2 EPL comparisons and EPL 16-byte LDS reads per step: as much LDS traffic as the direction row, +75 % on the config-2 step).
+    // The margin is a lower bound kept per chain: minus the reach after every accepted step, recomputed (one pass with the full
+    // test) when a reach no longer fits under it.  Same decisions as the full test in every step: it is only skipped where its
+    // result is known (the slack factors cover the roundings of amp * u and of the margin's own arithmetic).
+    // Only where a chain is a whole wave (64 lanes): with several chains per wave the slow path runs whenever ANY of them needs it,
+    // and a tempered ladder's hot chains live near their bounds -- measured at config 2 with a box prior: 2.06 ms per 100 steps
+    // against 1.27 with the plain test in every step (16 chains per wave), 4.36 against 3.95 at ndim = 300 (4 per wave); at
+    // ndim = 1000 (one per wave): 2.40 against 5.90.
+    constexpr bool BOXFAST = SCAMFAST && PRI == PTMI_LOGP_BOX && UPAD && G == 64;
     // ULDS with the exact shape (4, 25) (ndim = 100): the table rows are stored in the lanes' order, 16-byte pieces dealt to
     // the four lanes in turn (position 8 (e / 2) + 2 lane + e % 2 holds element lane + 4 e; the odd last slot at 96 + lane), so
     // that a step reads its direction with 12 ds_read_b128 + 1 ds_read_b64 instead of 10 ds_read2_b64 + 6 ds_read_b64:
@@ -1109,7 +1154,25 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
     }
     if (PRI != PTMI_LOGP_FLAT) box_table_fill<G, EPL>(a, smem, BLK);
     if (ULDS) draw_table_fill(smem, a.tab_off, BLK);
+    if constexpr (BOXFAST && PERS != 0) {
+        if (threadIdx.x == 0) reinterpret_cast<unsigned long long *>(smem)[a.umax_off] = 0ull;
+    }
     if (ULDS || (a.logp_kind == PTMI_LOGP_BOX && a.box_off >= 0)) __syncthreads();
+    double box_umax = 0.0;                       // BOXFAST: max |U| over the launch's table
+    if constexpr (BOXFAST) {
+        if constexpr (PERS != 0) {
+            double am = 0.0;
+            for (int i = (int)threadIdx.x; i < d * d; i += BLK) { const double v = __builtin_fabs(smem[i]); am = v > am ? v : am; }
+            // non-negative doubles order like their bit patterns
+            __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(smem) + a.umax_off, (unsigned long long)__double_as_longlong(am), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            box_umax = smem[a.umax_off];
+        } else {
+            box_umax = *a.ut_absmax;             // ut_pad_kernel's
+        }
+        box_umax *= 1.0 + 0x1.0p-30;            // covers the rounding of amp * u
+    }
 
     // ---- the chains.  A block of 256 threads serves its 64 chains; a persistent block's waves walk over units of 16 chains on
     // their own (no barrier from here on)
@@ -1176,6 +1239,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
     long long am_next = (FULL && a.am_base != nullptr) ? a.am_base[ch] : 0;      // the chain's next precomputed AM increment
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
+    double box_margin = -1.0;                    // BOXFAST: a lower bound of the chain's distance to its nearest bound (negative: unknown)
 
     // Wide draw batches: a pass serves GW / 2 steps, so the steps run as an inner loop under a loop over the passes -- with the
     // refill as a rarely taken branch of ONE loop the compiler hoisted the pass's invariants (Philox key schedule, polynomial
@@ -1245,6 +1309,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
         }
         double log_u;
         int jt = PTMI_J_SCAM;
+        double scam_amp = 0.0, box_reach = 0.0;
         if constexpr (SCAMFAST) {
             ScamDraw sd;
             // sqrt(S_k): from the block's LDS copy where it has one, else from the chain's table (sqrt is correctly rounded: same bits)
@@ -1292,6 +1357,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
             }
 #pragma unroll
             for (int e = 0; e < EPL; ++e) dq[e] = sd.amp * dq[e];
+            scam_amp = sd.amp;
         } else {
         Draws dr;
         draws_for_step<STR, FULL, TM, GW>(batch, dr, a, k, sid, sid0, gl, tsm);
@@ -1321,6 +1387,18 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
 #pragma unroll
             for (int e = 0; e < EPL; ++e) q[e] = x[e] + dq[e];
             if constexpr (PRI == PTMI_LOGP_FLAT) nlp = 0.0;
+            else if constexpr (BOXFAST) {
+                box_reach = __builtin_fabs(scam_amp) * box_umax;
+                bool inside = box_reach < box_margin;
+                if (!inside) {                   // (divergent between the wave's chains; rare in a box wider than the jumps)
+                    bool in1;
+                    double mg;
+                    box_test_and_margin<G, EPL>(smem, a.box_off, gl, x, dq, in1, mg);
+                    inside = grp_all<G, STR>(in1);
+                    box_margin = grp_min<G, STR>(mg) * (1.0 - 0x1.0p-40);
+                }
+                nlp = inside ? 0.0 : -__builtin_inf();
+            }
             else if constexpr (PERS != 0 && PRI == PTMI_LOGP_BOX)
                 nlp = grp_all<G, STR>(box_inside_lds<G, EPL>(smem, a.box_off, gl, [&](int e) { return q[e]; })) ? 0.0 : -__builtin_inf();
             else nlp = eval_logp<G, EPL, STR>(a, q, gl, smem);
@@ -1349,6 +1427,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
 #pragma unroll
                 for (int j = 0; j < PTMI_J_FUSED; ++j) ja[j] += (jt == j);
             }
+            if constexpr (BOXFAST) box_margin = (box_margin - box_reach) * (1.0 - 0x1.0p-40);      // no element moved further than the reach
         }
         // PT:327-328 (the post-swap row of a swap iteration is written by the swap).  These 25 stores of four active lanes, in ONE
         // wave of every block, are 15 % of the config-2 kernel (0.90 -> 0.77 ms without them, PTMI_MEASURE_NO_AM): the wave is its
@@ -2155,6 +2234,8 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
                 if (box_bytes) { a.box_off = (int)(tp / sizeof(double)); tp += box_bytes; }
                 a.tab_off = (int)(tp / sizeof(double));
                 tp += DRAWT;
+                a.umax_off = (int)(tp / sizeof(double));              // box prior's fast path: max |U| of the table (one double)
+                tp += 16;
                 auto launch_p = [&](auto kernp, int BLKv) -> int {
                     if (tp > 64 * 1024) {
                         hipError_t e = hipFuncSetAttribute((const void *)kernp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp);
@@ -2213,6 +2294,8 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
             // the prior kind as a template parameter: the flat prior's instantiation holds no box-test code (nor the proposal q as an array)
             if (c.logp_kind == PTMI_LOGP_FLAT)
                 hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, false, false, false, false, 0, PTMI_LOGP_FLAT, false, true>), dim3(grid), dim3(256), 0, h->stream, a);
+            else if (G == 64 && c.logp_kind == PTMI_LOGP_BOX && a.ut_absmax != nullptr)
+                hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, false, false, false, false, 0, PTMI_LOGP_BOX, false, true>), dim3(grid), dim3(256), box_bytes, h->stream, a);
             else
                 hipLaunchKernelGGL((mh_steps_kernel<G, EPL, LOGL, false, false, false, false, 0, -1, false, true>), dim3(grid), dim3(256), box_bytes, h->stream, a);
             h->last_variant = PTMI_VAR_UTPAD | (a.box_off >= 0 ? PTMI_VAR_LDS_BOX : 0);
