@@ -79,6 +79,7 @@ def make_parser():
                     help="evaluate the likelihood in a batched torch callback between ptmi_propose and ptmi_accept (one launch pair per "
                          "iteration) instead of inside the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also-child", action="store_true", help=argparse.SUPPRESS)      # the process that runs the "also" legs (spawned by the headline's)
     ap.add_argument("--also", default="auto", choices=["auto", "on", "off"],
                     help="after the headline's timed region (untouched by them), short legs of the other BASELINE configs on the same GPU, "
                          "reported under \"also\": dense SCAM (configs[2]), default mix, dense default mix, a replica of reference runs "
@@ -464,7 +465,16 @@ L2_PEAK_TBS = 34.5             # MI355X_MICROARCH.md: aggregate L2 bandwidth (4 
 
 def also_legs(a, rank, world, local, dist, backend):
     import copy
+    import torch
     res = {}
+    if a.preheat > 0:                           # bring the clocks up once (bench.py --preheat), the legs then run back to back
+        hm = torch.randn(2048, 2048, dtype=torch.float64, device="cuda")
+        t_h = time.perf_counter()
+        while time.perf_counter() - t_h < a.preheat:
+            for _ in range(8):
+                hm @ hm
+            torch.cuda.synchronize()
+        del hm
     t_all = time.perf_counter()
     for name, over, steps, warmup in ALSO:
         b = copy.copy(a)
@@ -542,9 +552,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if a.also_child:                            # the legs of the other configs, in a process of their own (see below)
+        os.write(real_stdout, (json.dumps(also_legs(a, rank, world, local, dist, backend)) + "\n").encode())
+        return
     out = measure(a, rank, world, local, dist, backend)
     if rank == 0 and world == 1 and a.also:
-        out["also"] = also_legs(a, rank, world, local, dist, backend)
+        # In a process of their own: a fault in one of the other configs' kernels must not take the headline's line with it.
+        # (The headline's engine is gone and its memory returned; the child brings the clocks up itself.)
+        cmd = [sys.executable, os.path.abspath(__file__), "--also-child", "--also", "off", "--no-cpu-baseline", "--ess-window", "0", "--preheat", "0.2"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out["also"] = json.loads(lines[-1]) if lines else {"error": "no output (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+            sys.stderr.write(r.stderr[-4000:])
+        except Exception as e:                  # noqa: BLE001
+            out["also"] = {"error": repr(e)[:300]}
     if rank == 0:
         d, weights = a.ndim, cycle_weights(a)
         if cpu is not None:
