@@ -922,18 +922,462 @@ struct GradJumpWide {
     }
 };
 
+
+template <int EPL, int LOGL>
+struct GradJumpPair {
+    static constexpr int G = 4, LD = 4 * EPL;
+    // TWO chains per wave: chain slot hh = lane >> 5 owns a half-wave.  Inside its half a chain's lane group g = 2 r + sub sits in
+    // row r = (lane >> 4) & 1 at lanes 8 sub .. 8 sub + EPL - 1 (element i = g + 4 e in lane 16 r + 8 sub + e): row shifts and the
+    // xor-8 partner stay inside a row, everything else goes through ds_bpermute inside the half.  Every "scalar" of a call is a
+    // per-lane value (it was one already: f64 arithmetic is vector arithmetic), so the two calls run as one instruction stream and
+    // part ways only where their control flow does (divergent branches; the halves never read each other's lanes).
+    const KArgs &a;
+    const int d, L, hh, we, wg, wi;
+    const bool act;                  // this lane holds an element of the chain's vectors
+    const int col;                   // its index (0 on idle lanes: their reads are dropped)
+    const long long ch, nch;
+    const double beta;
+    const long long it;
+    const u32 sid;
+    const int vb;                    // 64 doubles of the block's LDS: the vector of a table product, in element order
+    double blo = 0.0, bhi = 0.0;     // this lane's bounds of a box prior
+    u32 nm = 0, ns = 0, nleap = 0;
+#ifdef PTMI_GJ_PROFILE
+    mutable unsigned long long prof[GJP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    __device__ __forceinline__ GradJumpPair(const KArgs &a_, long long ch_, double beta_, long long it_, u32 sid_, int vb_)
+        : a(a_), d(a_.d), L((int)threadIdx.x), hh(L >> 5), we(L & 7), wg(2 * ((L >> 4) & 1) + ((L >> 3) & 1)), wi(wg + 4 * we), act(we < EPL && wi < a_.d), col(act ? wi : 0),
+          ch(ch_), nch((long long)a_.W * a_.nt), beta(beta_), it(it_), sid(sid_), vb(vb_)
+    {
+        if (a.logp_kind == PTMI_LOGP_BOX) { blo = a.logp_par[col]; bhi = a.logp_par[d + col]; }
+    }
+
+    __device__ __forceinline__ u32 half_lane32(u32 v, int src) const { return (u32)__builtin_amdgcn_ds_bpermute(((hh << 5) + src) << 2, (int)v); }
+    __device__ __forceinline__ double half_lanef(double v, int src) const
+    {
+        const u64 b = (u64)__double_as_longlong(v);
+        return __longlong_as_double((long long)(((u64)half_lane32((u32)(b >> 32), src) << 32) | half_lane32((u32)b, src)));
+    }
+    __device__ __forceinline__ bool half_all(bool ok) const { return ((__ballot(ok) >> (hh << 5)) & 0xFFFFFFFFull) == 0xFFFFFFFFull; }
+    __device__ __forceinline__ bool half_any(bool v) const { return ((__ballot(v) >> (hh << 5)) & 0xFFFFFFFFull) != 0ull; }
+    // ---- draws
+    __device__ __forceinline__ double momenta()                            // NJ:92-94; directions k and k + 4 share one Box-Muller
+    {
+        const u32 block = nm++;
+        double r = 0.0;
+        if (act) {
+            const int k = wg + 4 * (we & ~1);
+            u64 e0, e1;
+            philox_words(a.seed, (u64)it, sid, SLOT_GJ + 4096u * block + (u32)k, e0, e1);
+            const double rr = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
+            double sn, cs;
+            det_sincos2pi(w2uniform(e1), sn, cs);
+            r = (we & 1) ? rr * sn : rr * cs;
+        }
+        return r;
+    }
+    // Scalar draws: slot n of the call is a Philox call of its own.  Lane j evaluates slot 64 b + j, so one pass of the
+    // generator (the same instructions a single draw would cost the wave) serves the next 64 draws of the call.
+    u64 sw_cache = 0;
+    u32 sw_base = 0xFFFFFFFFu;
+    __device__ __forceinline__ u64 scalar_word()
+    {
+        GJP_T0(t0);
+        const u32 slot = ns++;
+        if ((slot & ~31u) != sw_base) {                                  // (per half: lane j of the half evaluates slot 32 b + j of ITS chain's call)
+            sw_base = slot & ~31u;
+            u64 w0, w1;
+            philox_words(a.seed, (u64)it, sid, SLOT_GJS + sw_base + (u32)(L & 31), w0, w1);
+            sw_cache = w0;
+        }
+        const int src = (int)(slot & 31u);
+        const u32 lo = half_lane32((u32)sw_cache, src), hi = half_lane32((u32)(sw_cache >> 32), src);
+        GJP_ADD(GJP_DRAW, t0);
+        return ((u64)hi << 32) | lo;
+    }
+    __device__ __forceinline__ double uniform() { return w2uniform(scalar_word()); }
+    __device__ __forceinline__ double exponential() { return -det_log(w2uniform_open(scalar_word())); }
+    __device__ __forceinline__ int randint(int lo, int hi) { return lo + (int)w2index(scalar_word(), (u64)(hi - lo)); }
+
+    // ---- linear algebra
+    // Sum over the chain in the 4-lane order: per row the chain p = fma(x_e, y_e, p) over its slots.  Every lane recomputes
+    // its link from its left neighbour's value in each of the EPL steps: lane e is right from step e + 1 on (lane 0 has no
+    // neighbour and starts from 0), so after EPL steps lane EPL - 1 of row g holds the chain of lane group g; then (p0 + p2) + (p1 + p3).
+    __device__ __forceinline__ double row_chain(double x, double y) const
+    {
+        double p = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const double left = dppf64<0x111>(p);                       // row_shr:1
+            p = __builtin_fma(x, y, we == 0 ? 0.0 : left);              // a lane group's chain starts from 0 at its first lane
+        }
+        return p;
+    }
+    __device__ __forceinline__ double rows_sum(double p) const
+    {
+        const double p0 = half_lanef(p, EPL - 1), p1 = half_lanef(p, 8 + EPL - 1), p2 = half_lanef(p, 16 + EPL - 1), p3 = half_lanef(p, 24 + EPL - 1);
+        return (p0 + p2) + (p1 + p3);
+    }
+    __device__ __forceinline__ double dot(double x, double y) const
+    {
+        GJP_T0(t0);
+        const double r = rows_sum(row_chain(x, y));
+        GJP_ADD(GJP_DOT, t0);
+        return r;
+    }
+    // out[i] = sum_k T[k][i] v[k], k ascending, one fma per term; WHICH >= 0: the LDS copy of a whitening table (rows of LD)
+    template <int WHICH>
+    __device__ __forceinline__ double tab_vec(const double *Tg, double v) const
+    {
+        GJP_T0(t0);
+        double acc = 0.0;
+        if (WHICH >= 0 && a.gj_diag) {                                   // diagonal whitening table: one multiplication per element (oracle: tab_vec)
+            const double r = act ? gj_lds[WHICH * LD + col] * v : 0.0;  // (the block's LDS then holds the three diagonals only)
+            GJP_ADD(GJP_TABVEC, t0);
+            return r;
+        }
+        // (the pair layout runs with diagonal whitening tables and the iso / curved families only: the host picks it then)
+        __builtin_trap();
+        // The vector goes through LDS in element order and every lane reads all of it back (same address for the whole wave:
+        // a broadcast); two readlanes per term instead had each fma wait on a fresh scalar pair.  Straight-line on purpose:
+        // with a (wave-uniform) branch around every term each table read waited for its own LDS round trip -- 2 400 cycles
+        // per product, more than half of a gradient jump.  Rows k >= d of the LDS tables are zeros; their terms are computed and dropped.
+        __syncthreads();                                                 // the previous product's readers are through
+        if (act) gj_lds[vb + wi] = v;
+        __syncthreads();
+        // all reads first (the scheduling barrier keeps them there): left to the scheduler they went out two at a time
+        // and the chain of fmas waited for an LDS round trip at every other term
+        double tk[4 * EPL], vk[4 * EPL];
+#pragma unroll
+        for (int k = 0; k < 4 * EPL; ++k) {
+            tk[k] = WHICH >= 0 ? gj_lds[(WHICH * LD + k) * LD + col] : Tg[(size_t)(k < d ? k : 0) * d + col];
+            vk[k] = gj_lds[vb + k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (d == 4 * EPL) {
+#pragma unroll
+            for (int k = 0; k < 4 * EPL; ++k) acc = __builtin_fma(tk[k], vk[k], acc);
+        } else {                                                         // (a uniform branch per term instead of the select is 4x slower)
+#pragma unroll
+            for (int k = 0; k < 4 * EPL; ++k) {
+                const double nxt = __builtin_fma(tk[k], vk[k], acc);
+                acc = k < d ? nxt : acc;
+            }
+        }
+        GJP_ADD(GJP_TABVEC, t0);
+        return act ? acc : 0.0;
+    }
+    __device__ __forceinline__ double logl_grad(double x, double &g) const
+    {
+        GJP_T0(t0);
+        if (LOGL == PTMI_LOGL_ISO) {
+            g = -x;
+            const double r = -0.5 * dot(x, x);
+            GJP_ADD(GJP_LOGL, t0);
+            return r;
+        } else if (LOGL == PTMI_LOGL_DENSE) {
+            const double r = act ? x - a.logl_par[col] : 0.0;
+            const double v = tab_vec<-1>(a.logl_par + d, r);                 // the gradient -P r: the full product
+            g = -v;
+            const double vh = tab_vec<-1>(a.logl_par + d + (size_t)d * d, r);  // the value: eval_logl's half table Tl
+            const double rr = -dot(r, vh);
+            GJP_ADD(GJP_LOGL, t0);
+            return rr;
+        } else {
+            const double other = dppf64<0x128>(x);                         // the pair's other member: lane group g ^ 1 = lane ^ 8 (row_ror:8), same slot
+            const bool even = !(wg & 1);
+            const bool pair = we < EPL && (even ? wi + 1 < d : wi < d);
+            const double xx = even ? x : other, y = even ? other : x;
+            const double x2 = xx * xx;
+            const double gg = 9.0 + 4.0 * x2 + 9.0 * y;
+            const double l0 = -x2 - gg * gg;
+            const double ym = y - 2.0;
+            const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
+            // both lanes of a pair hold the same l0 and l1: the even one takes exp(l0), the odd one exp(l1), and they trade
+            const double ex = det_exp(even ? l0 : l1), ox = dppf64<0x128>(ex);
+            const double e0 = even ? ex : ox, e1 = 0.5 * (even ? ox : ex);
+            const double sum = e0 + e1;
+            const double tl = det_log(sum);                                // wanted on the even lanes only; same cost for the wave
+            const double d0 = even ? -2.0 * xx - 16.0 * gg * xx : -18.0 * gg;
+            const double d1 = even ? -16.0 * xx : -16.0 * ym;
+            const double gv = (e0 * d0 + e1 * d1) / sum;
+            g = pair ? gv : 0.0;
+            const double r = dot(pair && even ? tl : 0.0, 1.0);
+            GJP_ADD(GJP_LOGL, t0);
+            return r;
+        }
+    }
+    __device__ __forceinline__ double logp(double x) const
+    {
+        if (a.logp_kind == PTMI_LOGP_BOX) {
+            const bool ok = !act || ((blo <= x) & (bhi >= x));
+            return half_all(ok) ? 0.0 : -__builtin_inf();
+        }
+        return 0.0;
+    }
+    __device__ __forceinline__ double func_grad_white(double q, double &gradw) const       // NJ:71-90
+    {
+        const double x = tab_vec<GJT_BACKWARD>(nullptr, q);
+        double g;
+        const double ll = logl_grad(x, g);
+        const double lp = logp(x);
+        g = beta * g + 0.0;
+        gradw = tab_vec<GJT_GRADIENT>(nullptr, g);
+        return beta * ll + lp;
+    }
+    __device__ __forceinline__ double joint_of(double logl, double r) const { return logl - 0.5 * dot(r, r); }
+    __device__ __forceinline__ double leapfrog(double theta, double r, double grad, double eps, double &to, double &ro, double &go)   // NJ:149-169
+    {
+        nleap += 1;
+        const double he = 0.5 * eps;
+        const double rh = r + he * grad;
+        const double tn = theta + eps * rh;
+        double gn;
+        const double lpp = func_grad_white(tn, gn);
+        to = tn;
+        go = gn;
+        ro = rh + he * gn;
+        return lpp;
+    }
+    __device__ __forceinline__ bool keep_going(double tm, double tp, double rm, double rp) const                // NJ:465-493
+    {
+        const double dt = tp - tm;
+        const double cx = row_chain(dt, rm), cy = row_chain(dt, rp);      // two independent chains: they overlap
+        const double x = rows_sum(cx), y = rows_sum(cy);
+        return (x >= 0.0) & (y >= 0.0);
+    }
+    __device__ __forceinline__ bool any_inf(double v) const { return half_any(act && __builtin_isinf(v)); }
+
+    // ------------------------------------------------------------------ HMC (NJ:238-291)
+    __device__ __forceinline__ double hmc(double *st, double x, double &qout)
+    {
+        st[GJ_HITER] += 1.0;
+        double q = tab_vec<GJT_FORWARD>(nullptr, x), grad;
+        const double logp0 = func_grad_white(q, grad);
+        double p = momenta();
+        const double joint0 = joint_of(logp0, p);
+        const int nsteps = randint(a.hmc_min, a.hmc_max);
+        double joint1 = joint0;
+        for (int k = 0; k < nsteps; ++k) {
+            const double logp1 = leapfrog(q, p, grad, a.hmc_eps, q, p, grad);
+            joint1 = joint_of(logp1, p);
+            if (joint1 - 1000.0 < joint0) break;                         // NJ:284-286
+        }
+        qout = tab_vec<GJT_BACKWARD>(nullptr, q);
+        return joint1 - joint0;
+    }
+
+    // ------------------------------------------------------------------ NUTS
+    __device__ __forceinline__ double find_reasonable_epsilon(double theta0, double grad0, double logp0)   // NJ:435-463, loops bounded
+    {
+        double tp, rp, gp;
+        double eps = 1.0;
+        const double r0 = momenta();
+        double logpp = leapfrog(theta0, r0, grad0, eps, tp, rp, gp);
+        const bool ginf = any_inf(gp);                                   // not refreshed in the loop (NJ:449-452)
+        double k = 1.0;
+        for (int n = 0; n < 100 && (__builtin_isinf(logpp) || ginf); ++n) {
+            k *= 0.5;
+            logpp = leapfrog(theta0, r0, grad0, eps * k, tp, rp, gp);
+        }
+        eps = 0.5 * k * eps;
+        double ap = det_exp(joint_of(logpp, rp) - joint_of(logp0, r0));
+        const bool up = ap > 0.5;
+        for (int n = 0; n < 100 && ((up ? ap : 1.0 / ap) > (up ? 0.5 : 2.0)); ++n) {
+            eps = eps * (up ? 2.0 : 0.5);
+            logpp = leapfrog(theta0, r0, grad0, eps, tp, rp, gp);
+            ap = det_exp(joint_of(logpp, rp) - joint_of(logp0, r0));
+        }
+        return eps;
+    }
+
+    struct Tree {
+        double far_t, far_r, cand_t, cand_g;
+        double logp, alpha;
+        long long n, nalpha;
+        int s;
+    };
+    // the tree stack (see GradJump::build_tree): the entry of height h in slot h, pending heights in a mask.  Heights below
+    // gj_lds_levels (11: trees of up to 2^11 leapfrogs) are in the block's LDS; the higher ones -- the reference doubles without a
+    // cap (NJ:716-802), the ABI allows 24 -- in the wave's slice of the global scratch: reached once in 2^h leapfrogs, if ever,
+    // so only their correctness matters (keeping all 25 in LDS cost the config-5 kernel 25 %: five waves per CU instead of eight)
+    __device__ __forceinline__ int slot_of(int h) const { return a.gj_stack_off + (hh * a.gj_lds_levels + h) * gjw_level_doubles(EPL); }
+    __device__ __forceinline__ double *glevel(int h) const
+    {
+        return a.gj_scr + (((size_t)blockIdx.x * 2 + (size_t)hh) * (size_t)(a.nuts_maxdepth + 1) + (size_t)h) * gjw_level_doubles(EPL);
+    }
+    // NJ:495-652 as a loop, as GradJump::build_tree
+    __device__ __forceinline__ void build_tree(double &tg, double &rg, double &gg, double logu, int v, int j, double eps, double joint0, Tree &cur)
+    {
+        u32 pend = 0;
+        for (;;) {
+            const double logpp = leapfrog(tg, rg, gg, (double)v * eps, tg, rg, gg);
+            GJP_T0(tl0);
+            const double joint = joint_of(logpp, rg);
+            cur.n = logu < joint;
+            cur.s = (logu - 1000.0) < joint;
+            cur.far_t = tg; cur.far_r = rg; cur.cand_t = tg; cur.cand_g = gg;
+            cur.logp = logpp;
+            const double ex = det_exp(joint - joint0);
+            cur.alpha = ex < 1.0 ? ex : 1.0;                             // Python's min(1.0, e): 1.0 when e is NaN
+            cur.nalpha = 1;
+            GJP_ADD(GJP_LEAF, tl0);
+            int h = 0;
+            for (;;) {
+                const int top_h = pend ? (int)__builtin_ctz(pend) : -1;
+                if (top_h == h) {                                        // cur is the right sibling of the stack top
+                    GJP_T0(tm0);
+                    pend &= pend - 1u;
+                    double t_logp, t_n, t_alpha, t_nalpha, e_ct, e_cg, e_ft, e_fr;
+                    if (h < a.gj_lds_levels) {                                     // wave-uniform
+                        const int b = slot_of(h);
+                        t_logp = gj_lds[b + GJL_VECS * LD + GJS_LOGP]; t_n = gj_lds[b + GJL_VECS * LD + GJS_N];
+                        t_alpha = gj_lds[b + GJL_VECS * LD + GJS_ALPHA]; t_nalpha = gj_lds[b + GJL_VECS * LD + GJS_NALPHA];
+                        e_ct = act ? gj_lds[b + GJL_CAND_T * LD + col] : 0.0; e_cg = act ? gj_lds[b + GJL_CAND_G * LD + col] : 0.0;
+                        e_ft = act ? gj_lds[b + GJL_FAR_T * LD + col] : 0.0; e_fr = act ? gj_lds[b + GJL_FAR_R * LD + col] : 0.0;
+                    } else {
+                        const double *gp = glevel(h);
+                        t_logp = gp[GJL_VECS * LD + GJS_LOGP]; t_n = gp[GJL_VECS * LD + GJS_N];
+                        t_alpha = gp[GJL_VECS * LD + GJS_ALPHA]; t_nalpha = gp[GJL_VECS * LD + GJS_NALPHA];
+                        e_ct = act ? gp[GJL_CAND_T * LD + col] : 0.0; e_cg = act ? gp[GJL_CAND_G * LD + col] : 0.0;
+                        e_ft = act ? gp[GJL_FAR_T * LD + col] : 0.0; e_fr = act ? gp[GJL_FAR_R * LD + col] : 0.0;
+                    }
+                    const long long tot = (long long)t_n + cur.n;
+                    const double den = (double)tot > 1.0 ? (double)tot : 1.0;
+                    const bool take_u = uniform() < (double)cur.n / den;
+                    if (!take_u) {
+                        cur.cand_t = e_ct;
+                        cur.cand_g = e_cg;
+                        cur.logp = t_logp;
+                    }
+                    cur.far_t = e_ft;
+                    cur.far_r = e_fr;
+                    cur.n = tot;
+                    const bool go = v == 1 ? keep_going(cur.far_t, tg, cur.far_r, rg) : keep_going(tg, cur.far_t, rg, cur.far_r);
+                    cur.s = cur.s && go;                                 // the popped tree has s = 1
+                    cur.alpha = t_alpha + cur.alpha;
+                    cur.nalpha = (long long)t_nalpha + cur.nalpha;
+                    h += 1;
+                    GJP_ADD(GJP_MERGE, tm0);
+                    continue;
+                }
+                if (h == j) return;
+                if (cur.s == 0) {
+                    if (pend == 0) return;
+                    h = top_h;
+                    continue;
+                }
+                GJP_T0(tp0);
+                if (h < a.gj_lds_levels) {                               // push: wait for the right sibling
+                    const int b = slot_of(h);
+                    if (act) {                                           // in element order: 4 LD doubles per entry instead of 4 x 64
+                        gj_lds[b + GJL_FAR_T * LD + wi] = cur.far_t;
+                        gj_lds[b + GJL_FAR_R * LD + wi] = cur.far_r;
+                        gj_lds[b + GJL_CAND_T * LD + wi] = cur.cand_t;
+                        gj_lds[b + GJL_CAND_G * LD + wi] = cur.cand_g;
+                    }
+                    if ((L & 31) == 0) {
+                        gj_lds[b + GJL_VECS * LD + GJS_LOGP] = cur.logp;
+                        gj_lds[b + GJL_VECS * LD + GJS_N] = (double)cur.n;
+                        gj_lds[b + GJL_VECS * LD + GJS_ALPHA] = cur.alpha;
+                        gj_lds[b + GJL_VECS * LD + GJS_NALPHA] = (double)cur.nalpha;
+                    }
+                } else {
+                    double *gp = glevel(h);
+                    if (act) {
+                        gp[GJL_FAR_T * LD + wi] = cur.far_t;
+                        gp[GJL_FAR_R * LD + wi] = cur.far_r;
+                        gp[GJL_CAND_T * LD + wi] = cur.cand_t;
+                        gp[GJL_CAND_G * LD + wi] = cur.cand_g;
+                    }
+                    if ((L & 31) == 0) {
+                        gp[GJL_VECS * LD + GJS_LOGP] = cur.logp;
+                        gp[GJL_VECS * LD + GJS_N] = (double)cur.n;
+                        gp[GJL_VECS * LD + GJS_ALPHA] = cur.alpha;
+                        gp[GJL_VECS * LD + GJS_NALPHA] = (double)cur.nalpha;
+                    }
+                    __threadfence_block();                               // the wave's own global stores, visible to its other lanes
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");    // one wave: its LDS / global accesses are served in order; the fence orders the compiler (no barrier inside divergent code)
+                pend |= 1u << h;
+                GJP_ADD(GJP_PUSH, tp0);
+                break;
+            }
+        }
+    }
+
+    // NUTSJump.__call__ (NJ:654-840), as GradJump::nuts; the two ends of the trajectory and the sample stay in registers
+    __device__ __forceinline__ double nuts(double *st, double x, double &qout)
+    {
+        st[GJ_NITER] += 1.0;
+        const double q = tab_vec<GJT_FORWARD>(nullptr, x);
+        double grad;
+        const double logp0 = func_grad_white(q, grad);
+        if (st[GJ_HAVE_EPS] == 0.0) {
+            st[GJ_EPS] = find_reasonable_epsilon(q, grad, logp0);
+            st[GJ_MU] = det_log(10.0 * st[GJ_EPS]);
+            st[GJ_HAVE_EPS] = 1.0;
+        }
+        const double r0 = momenta();
+        const double joint = joint_of(logp0, r0);
+        const double logu = joint - exponential();
+        double lnprob = logp0;
+        double sample = q, tm = q, rm = r0, gm = grad, tp = q, rp = r0, gp = grad;
+        int j = 0, s = 1;
+        long long n = 1;
+        double alpha = 0.0;
+        long long nalpha = 1;
+        const double eps = st[GJ_EPS];
+        while (s == 1) {
+            const int dir = 2 * (int)(uniform() < 0.5) - 1;
+            double tg = dir == -1 ? tm : tp, rg = dir == -1 ? rm : rp, gg = dir == -1 ? gm : gp;
+            Tree t;
+            build_tree(tg, rg, gg, logu, dir, j, eps, joint, t);
+            if (dir == -1) { tm = tg; rm = rg; gm = gg; } else { tp = tg; rp = rg; gp = gg; }
+            if (t.s == 1) {
+                const double ratio = (double)t.n / (double)n;
+                if (uniform() < (1.0 < ratio ? 1.0 : ratio)) { sample = t.cand_t; lnprob = t.logp; }
+            }
+            n += t.n;
+            const bool go = keep_going(tm, tp, rm, rp);
+            s = t.s && go;
+            alpha = t.alpha;
+            nalpha = t.nalpha;
+            j += 1;
+            if (j > a.nuts_maxdepth) s = 0;                              // cap (not in the reference)
+        }
+        // dual averaging (NJ:805-816): gamma = 0.05, t0 = 10, kappa = 0.75
+        const double it_call = st[GJ_NITER];
+        double eta = 1.0 / (it_call + 10.0);
+        st[GJ_HBAR] = (1.0 - eta) * st[GJ_HBAR] + eta * (a.nuts_delta - alpha / (double)nalpha);
+        if (it <= (long long)a.gj_nburn) {
+            st[GJ_EPS] = det_exp(st[GJ_MU] - det_sqrt(it_call) / 0.05 * st[GJ_HBAR]);
+            eta = det_exp(-0.75 * det_log(it_call));
+            st[GJ_EPSBAR] = det_exp((1.0 - eta) * det_log(st[GJ_EPSBAR]) + eta * det_log(st[GJ_EPS]));
+        } else {
+            st[GJ_EPS] = st[GJ_EPSBAR];
+        }
+        qout = tab_vec<GJT_BACKWARD>(nullptr, sample);
+        return logp0 - lnprob;                                           // undoes the outer Hastings ratio (NJ:838)
+    }
+};
+
+
 // Fused MH steps with the gradient jumps in the cycle: the non-staged full kernel (ptmi_mh.inc.h) plus the NUTS / HMC
 // branch.  Every chain group runs its nsteps iterations on its own, so a long NUTS tree delays only its wave for that
 // iteration and the launch costs the longest SUM over iterations, not the sum of the per-iteration maxima.
 // One wave per block: there is no block-level cooperation, and single-wave blocks let the dispatcher backfill the
 // SIMDs as soon as a wave's chains are through their (very unequal) trees.
 constexpr int GJ_BLOCK = 64;
-template <int G, int EPL, int LOGL>
 #ifndef PTMI_GJ_WPE
 #define PTMI_GJ_WPE 2
 #endif
+// PAIR (4-lane shapes, diagonal whitening, iso / curved families): two gradient jumps at a time, a half-wave each (GradJumpPair)
+template <int G, int EPL, int LOGL, bool PAIR = false>
 __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) void mh_steps_gj_kernel(const KArgs a)
 {
+    static_assert(!PAIR || (G == 4 && EPL <= 8 && LOGL != PTMI_LOGL_DENSE), "the pair layout serves the 4-lane shapes without table products");
     constexpr int CPB = GJ_BLOCK / G;
     constexpr bool WIDE = G == 4;                // a gradient jump takes the whole wave (GradJumpWide)
     const int d = a.d, nt = a.nt;
@@ -1004,7 +1448,67 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
         const double log_u = dr.log_u;
         const int jt = propose<G, EPL, true, false, false, true>(a, it, sid, gl, cc, dr, Ut, false, S, DE, q);
         const bool is_gj = jt == PTMI_J_NUTS || jt == PTMI_J_HMC;
-        if constexpr (WIDE) {
+        if constexpr (PAIR) {
+            // two chains at a time, a half-wave each: their rows go through LDS into the pair layout (area 32 hh + 16 (g >> 1) +
+            // 8 (g & 1) + e of the exchange area), the proposals and the two qxy come back the same way
+            u64 todo = __ballot(is_gj && live);
+            const int xch = a.gj_stack_off + 2 * a.gj_lds_levels * gjw_level_doubles(EPL);
+            const int L = (int)threadIdx.x, hh = L >> 5;
+            const int myidx = 16 * (gl >> 1) + 8 * (gl & 1);              // where this lane's slots sit inside a half's area
+            while (todo) {
+                const int laneA = (int)__builtin_ctzll(todo);
+                todo &= ~(0xFull << laneA);
+                const bool two = todo != 0;
+                const int laneB = two ? (int)__builtin_ctzll(todo) : laneA;
+                if (two) todo &= ~(0xFull << laneB);
+                const bool mineA = (L & ~3) == laneA, mineB = two && (L & ~3) == laneB;
+                if (mineA || mineB) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) gj_lds[xch + (mineB ? 32 : 0) + myidx + e] = x[e];
+                }
+                __syncthreads();
+                const bool on = hh == 0 || two;                             // this half has a chain
+                const int lane0 = hh ? laneB : laneA;
+                const double xw = (L & 7) < EPL ? gj_lds[xch + L] : 0.0;
+                const long long chA = ((long long)__builtin_amdgcn_readlane((int)(ch >> 32), laneA) << 32) | (u32)__builtin_amdgcn_readlane((int)ch, laneA);
+                const long long chB = ((long long)__builtin_amdgcn_readlane((int)(ch >> 32), laneB) << 32) | (u32)__builtin_amdgcn_readlane((int)ch, laneB);
+                const long long ch_c = hh ? chB : chA;
+                const double beta_c = hh ? lane_get(beta, laneB) : lane_get(beta, laneA);
+                const u32 sid_c = hh ? (u32)__builtin_amdgcn_readlane((int)sid, laneB) : (u32)__builtin_amdgcn_readlane((int)sid, laneA);
+                const int jt_c = hh ? __builtin_amdgcn_readlane(jt, laneB) : __builtin_amdgcn_readlane(jt, laneA);
+                const int t_c = hh ? __builtin_amdgcn_readlane(t, laneB) : __builtin_amdgcn_readlane(t, laneA);
+                const int w_c = (int)(ch_c / nt);
+                (void)lane0;
+                double qw = 0.0, qxy_c = 0.0;
+                if (on) {
+                    double *stc = a.gj + ((size_t)w_c * nt + t_c) * GJ_NSTATE;
+                    GradJumpPair<EPL, LOGL> gj(a, ch_c, beta_c, it, sid_c, xch);
+                    double st[GJ_NSTATE];
+#pragma unroll
+                    for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stc[j];
+                    qxy_c = jt_c == PTMI_J_NUTS ? gj.nuts(st, xw, qw) : gj.hmc(st, xw, qw);
+                    st[GJ_NLEAP] += (double)gj.nleap;
+                    if ((L & 31) == 0) {
+#pragma unroll
+                        for (int j = 0; j < GJ_NSTATE; ++j) stc[j] = st[j];
+                    }
+                }
+                __threadfence_block();           // the wave reads the state again at the chain's next gradient jump
+                gj_lds[xch + L] = qw;
+                if ((L & 31) == 0) gj_lds[xch + 64 + hh] = qxy_c;
+                __syncthreads();
+                if (mineA || mineB) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) q[e] = gj_lds[xch + (mineB ? 32 : 0) + myidx + e];
+                    qxy = gj_lds[xch + 64 + (mineB ? 1 : 0)];
+                }
+                __syncthreads();                 // the exchange area is free for the next pair
+            }
+            if (!is_gj) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) q[e] = x[e] + q[e];            // propose() returned the increment
+            }
+        } else if constexpr (WIDE) {
             // one chain after the other, each on all 64 lanes: its row goes through LDS into the whole-wave layout and the
             // proposal comes back the same way; everything in between is wave-uniform
             u64 todo = __ballot(is_gj && live);

@@ -41,6 +41,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
             // one level per height | the exchange area of the layout change (64 doubles) | box bounds of the 4-lane test.
             // Wider shapes: lowest levels of the tree stack | box bounds.
             size_t off = 0;
+            bool pair = false;
             const size_t box = h->cfg.logp_kind == PTMI_LOGP_BOX ? (size_t)box_table_doubles(G, E) : 0;
             static const char *lv = getenv("PTMI_GJ_LDS_LEVELS");       // measurement / test switch: same results for any value
             if constexpr (G == 4) {
@@ -51,7 +52,10 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
                 int levels = h->cfg.nuts_maxdepth + 1 < lmax ? h->cfg.nuts_maxdepth + 1 : lmax;    // heights 0..10 in LDS, the rest in global scratch
                 if (lv) levels = atoi(lv) < levels ? atoi(lv) : levels;
                 a.gj_lds_levels = levels;
-                off += (size_t)a.gj_lds_levels * gjw_level_doubles(E) + 64;
+                // two jumps at a time, a half-wave each (GradJumpPair): diagonal whitening, no dense products; PTMI_GJ_NOPAIR: the
+                // one-chain-per-wave layout (a measurement / test switch, same results)
+                pair = a.gj_diag && L != PTMI_LOGL_DENSE && getenv("PTMI_GJ_NOPAIR") == nullptr;
+                off += (size_t)(pair ? 2 : 1) * a.gj_lds_levels * gjw_level_doubles(E) + (pair ? 72 : 64);
             } else {
                 const size_t budget = 40 * 1024 / sizeof(double);           // one wave per SIMD (register count): a quarter of the CU's LDS each
                 int levels = box < budget ? (int)((budget - box) / gj_level_doubles(E)) : 0;
@@ -64,6 +68,16 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
             off = (off + 1) & ~(size_t)1;
             a.box_off = box ? (int)off : -1;
             off += box;
+            if constexpr (G == 4 && L != PTMI_LOGL_DENSE) {
+                if (pair) {
+                    if (sizeof(double) * off > 64 * 1024) {
+                        hipError_t e = hipFuncSetAttribute((const void *)mh_steps_gj_kernel<G, E, L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * off));
+                        if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", sizeof(double) * off, hipGetErrorString(e));
+                    }
+                    hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L, true>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK), sizeof(double) * off, h->stream, a);
+                    return PTMI_OK;
+                }
+            }
             if (sizeof(double) * off > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void *)mh_steps_gj_kernel<G, E, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * off));
                 if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", sizeof(double) * off, hipGetErrorString(e));
