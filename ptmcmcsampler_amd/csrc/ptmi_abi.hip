@@ -3309,7 +3309,13 @@ constexpr int SY_THREADS = PTMI_SY_THREADS, SY_NW = SY_THREADS / 64, SY_CMAX = 1
 // cache write-back / invalidation beside the barrier's own counter
 __device__ __forceinline__ void sy_grid_sync(unsigned *bar, unsigned &target, unsigned nb)
 {
-    __syncthreads();                                               // the block's stores have been acknowledged
+    // every thread's exchanged stores must be ACKNOWLEDGED before the counter moves.  __syncthreads alone does not wait for them (a
+    // workgroup-scope release needs no vmcnt wait on this part: the CU's L1 is the block's own), and the counter's increment is
+    // relaxed: beside an idle GPU the stores happened to land first; beside step launches that saturate the L2 / MALL path (the wide
+    // kernels of round 5) another block could pass the barrier and read a vector's old contents -- whole runs differed from
+    // repeat to repeat (tools/repeat_check.py).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #ifdef PTMI_SY_NOBAR
     return;
 #endif

@@ -324,3 +324,30 @@ def test_pending_device_factorization_is_finished_behind_the_next_statistics(mod
         assert g.eig_epochs >= 5
     for k in runs[0]:
         assert_same(runs[0][k], runs[1][k], k)
+
+
+@pytest.mark.parametrize("d,lag", [(300, 2), (1000, 3)])
+def test_a_device_factorization_beside_step_launches_is_repeatable(mods, d, lag):
+    """The tridiagonalization's grid barrier beside the wide step kernels (eig_lag > 0: the factorization runs on the side stream
+    while the chains step): each block's exchanged vectors have to be acknowledged before the barrier's counter moves.  Without the
+    wait the same run differed from repeat to repeat (another block read a vector's old contents whenever the step launches kept
+    the memory path busy): three repeats, bit for bit -- and equal to the run with the factorization in line (eig_lag shifts which
+    launches use a table, so that one is compared through its tables only: the first epoch's, made from the same rows)."""
+    orc, _lib, PTEngine = mods
+    nt, W, cu = 4, 6, 30
+    kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=10, seed=8, cov_mode="pooled", eig_mode="sytrd", eig_lag=lag)
+    runs = []
+    for rep in range(3):
+        g = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+        g.init_state(np.zeros(d))
+        snaps = []
+        for n in (cu + 10, 2 * cu, 7, 3 * cu):
+            g.run(n)
+            g.sync()
+            snaps.append({k: g.get(k).copy() for k in ("X", "Ut", "S", "cov")})
+        runs.append(snaps)
+        del g
+    for rep in (1, 2):
+        for i, (sa, sb) in enumerate(zip(runs[0], runs[rep])):
+            for k in sa:
+                assert_same(sa[k], sb[k], "repeat %d, snapshot %d, %s" % (rep, i, k))
