@@ -1014,10 +1014,15 @@ struct GradJumpPair {
         }
         return p;
     }
+    // (p0 + p2) + (p1 + p3) of the four lane groups' chains (lane EPL - 1 of the half's four rows of eight), on every lane of the
+    // half, in the vector pipe: lanes 16 apart through v_permlane16_swap, 8 apart through a row rotation, then the row's lane
+    // EPL - 1 to the whole row (row_newbcast).  Four ds_bpermute pairs took an LDS round trip on the critical path of every
+    // dot product -- four to a leapfrog of a deep tree, whose chain of dependent instructions is what a launch lasts (§3.5).
     __device__ __forceinline__ double rows_sum(double p) const
     {
-        const double p0 = half_lanef(p, EPL - 1), p1 = half_lanef(p, 8 + EPL - 1), p2 = half_lanef(p, 16 + EPL - 1), p3 = half_lanef(p, 24 + EPL - 1);
-        return (p0 + p2) + (p1 + p3);
+        double s = sum_xor16(p);                                        // rows 0 + 1 (2 + 3) of the half: (p0 + p2) at lane EPL - 1, (p1 + p3) at lane 8 + EPL - 1
+        s = s + dppf64<0x128>(s);                                       // row_ror:8: (p0 + p2) + (p1 + p3), or the same two terms the other way round
+        return dppf64<0x150 + EPL - 1>(s);
     }
     __device__ __forceinline__ double dot(double x, double y) const
     {
@@ -1352,9 +1357,16 @@ struct GradJumpPair {
         double eta = 1.0 / (it_call + 10.0);
         st[GJ_HBAR] = (1.0 - eta) * st[GJ_HBAR] + eta * (a.nuts_delta - alpha / (double)nalpha);
         if (it <= (long long)a.gj_nburn) {
-            st[GJ_EPS] = det_exp(st[GJ_MU] - det_sqrt(it_call) / 0.05 * st[GJ_HBAR]);
-            eta = det_exp(-0.75 * det_log(it_call));
-            st[GJ_EPSBAR] = det_exp((1.0 - eta) * det_log(st[GJ_EPSBAR]) + eta * det_log(st[GJ_EPS]));
+            // seven evaluations of exp / log on values every lane of the half holds alike: the independent ones go side by side on
+            // two lanes (log it_call beside log eps_bar, then the two exponentials), four evaluations deep instead of seven; the
+            // same functions of the same arguments
+            const bool odd = L & 1;
+            const double lg = det_log(odd ? st[GJ_EPSBAR] : it_call);
+            const double log_it = half_lanef(lg, 0), log_epsbar = half_lanef(lg, 1);
+            const double ex = det_exp(odd ? -0.75 * log_it : st[GJ_MU] - det_sqrt(it_call) / 0.05 * st[GJ_HBAR]);
+            st[GJ_EPS] = half_lanef(ex, 0);
+            eta = half_lanef(ex, 1);
+            st[GJ_EPSBAR] = det_exp((1.0 - eta) * log_epsbar + eta * det_log(st[GJ_EPS]));
         } else {
             st[GJ_EPS] = st[GJ_EPSBAR];
         }
@@ -1435,6 +1447,16 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
     u32 nacc = 0, jp[PTMI_J_NTYPES] = {0, 0, 0, 0, 0}, ja[PTMI_J_NTYPES] = {0, 0, 0, 0, 0};
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
+    // PAIR: the step-size states of the wave's 16 chains live in LDS for the launch (behind the exchange area; two doubles per lane
+    // in, the same two out at the end): a call began with eight dependent reads from global memory and ended with a store the
+    // chain's next call had to see (a fence), some thousand cycles of a one-leapfrog call's twelve
+    const int stl = a.gj_stack_off + 2 * a.gj_lds_levels * gjw_level_doubles(EPL) + 72;
+    if constexpr (PAIR) {
+        static_assert(GJ_NSTATE == 2 * G, "two state words per lane of a chain");
+        gj_lds[stl + 2 * (int)threadIdx.x] = stg[2 * gl];
+        gj_lds[stl + 2 * (int)threadIdx.x + 1] = stg[2 * gl + 1];
+        __syncthreads();
+    }
 
 #ifdef PTMI_GJ_PROFILE
     unsigned long long prof_sum[GJP_N + 2] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1476,12 +1498,9 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
                 const double beta_c = hh ? lane_get(beta, laneB) : lane_get(beta, laneA);
                 const u32 sid_c = hh ? (u32)__builtin_amdgcn_readlane((int)sid, laneB) : (u32)__builtin_amdgcn_readlane((int)sid, laneA);
                 const int jt_c = hh ? __builtin_amdgcn_readlane(jt, laneB) : __builtin_amdgcn_readlane(jt, laneA);
-                const int t_c = hh ? __builtin_amdgcn_readlane(t, laneB) : __builtin_amdgcn_readlane(t, laneA);
-                const int w_c = (int)(ch_c / nt);
-                (void)lane0;
                 double qw = 0.0, qxy_c = 0.0;
                 if (on) {
-                    double *stc = a.gj + ((size_t)w_c * nt + t_c) * GJ_NSTATE;
+                    double *stc = gj_lds + stl + 2 * lane0;                  // the chain's eight words (its four lanes' pairs)
                     GradJumpPair<EPL, LOGL> gj(a, ch_c, beta_c, it, sid_c, xch);
                     double st[GJ_NSTATE];
 #pragma unroll
@@ -1493,7 +1512,6 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
                         for (int j = 0; j < GJ_NSTATE; ++j) stc[j] = st[j];
                     }
                 }
-                __threadfence_block();           // the wave reads the state again at the chain's next gradient jump
                 gj_lds[xch + L] = qw;
                 if ((L & 31) == 0) gj_lds[xch + 64 + hh] = qxy_c;
                 __syncthreads();
@@ -1629,6 +1647,10 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
                prof_sum[GJP_DOT], prof_sum[GJP_LEAF], prof_sum[GJP_MERGE], prof_sum[GJP_PUSH], prof_sum[GJP_DRAW]);
 #endif
     if (!live) return;
+    if constexpr (PAIR) {                         // (the last call's LDS stores are behind that call's barriers)
+        stg[2 * gl] = gj_lds[stl + 2 * (int)threadIdx.x];
+        stg[2 * gl + 1] = gj_lds[stl + 2 * (int)threadIdx.x + 1];
+    }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int i = gl + G * e;

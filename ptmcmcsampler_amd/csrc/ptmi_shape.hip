@@ -55,7 +55,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
                 // two jumps at a time, a half-wave each (GradJumpPair): diagonal whitening, no dense products; PTMI_GJ_NOPAIR: the
                 // one-chain-per-wave layout (a measurement / test switch, same results)
                 pair = a.gj_diag && L != PTMI_LOGL_DENSE && getenv("PTMI_GJ_NOPAIR") == nullptr;
-                off += (size_t)(pair ? 2 : 1) * a.gj_lds_levels * gjw_level_doubles(E) + (pair ? 72 : 64);
+                off += (size_t)(pair ? 2 : 1) * a.gj_lds_levels * gjw_level_doubles(E) + (pair ? 72 + 2 * GJ_BLOCK : 64);       // pair: + the 16 chains' step-size states
             } else {
                 const size_t budget = 40 * 1024 / sizeof(double);           // one wave per SIMD (register count): a quarter of the CU's LDS each
                 int levels = box < budget ? (int)((budget - box) / gj_level_doubles(E)) : 0;

@@ -331,8 +331,7 @@ def test_a_device_factorization_beside_step_launches_is_repeatable(mods, d, lag)
     """The tridiagonalization's grid barrier beside the wide step kernels (eig_lag > 0: the factorization runs on the side stream
     while the chains step): each block's exchanged vectors have to be acknowledged before the barrier's counter moves.  Without the
     wait the same run differed from repeat to repeat (another block read a vector's old contents whenever the step launches kept
-    the memory path busy): three repeats, bit for bit -- and equal to the run with the factorization in line (eig_lag shifts which
-    launches use a table, so that one is compared through its tables only: the first epoch's, made from the same rows)."""
+    the memory path busy): three repeats, bit for bit."""
     orc, _lib, PTEngine = mods
     nt, W, cu = 4, 6, 30
     kw = dict(weights=(20, 0, 0), cov_update=cu, burn=1000, tskip=10, seed=8, cov_mode="pooled", eig_mode="sytrd", eig_lag=lag)
