@@ -47,7 +47,12 @@ enum { PTMI_OK = 0, PTMI_EINVAL = -1, PTMI_EHIP = -2, PTMI_EUNSUPPORTED = -3, PT
 enum { PTMI_LOGL_ISO = 0,      /* -1/2 sum x^2 */
        PTMI_LOGL_DENSE = 1,    /* -(x-mu)^T P (x-mu) / 2 ; par = mu[d], Pt[d*d] (Pt[j*d+i] = P[i][j]).  P is a precision matrix:
                                 * the value is summed over the lower half of its symmetric part (half the products) */
-       PTMI_LOGL_CURVED = 2 }; /* d/2 copies of examples/curved_likelihood.ipynb's 2-d likelihood */
+       PTMI_LOGL_CURVED = 2,   /* d/2 copies of examples/curved_likelihood.ipynb's 2-d likelihood */
+       PTMI_LOGL_INTERVAL = 3 }; /* the reference's own NUTS workload (tests/test_nuts.py:13-47 GaussianLikelihood inside :50-140 intervalTransform):
+                                * N(0, I) on the box (a, b) in the coordinates p of all real numbers, x = (b - a) e^p / (1 + e^p) + a, the
+                                * log-Jacobian included: sum_i -x_i^2/2 - log(2 pi)/2 + log(b_i - a_i) + p_i - 2 log(1 + e^p_i);
+                                * par = a[d], w[d] = b - a, lw[d] = log w (the host's logarithm: a parameter, not part of the arithmetic).
+                                * Served by the kernel shapes of the gradient jumps (ndim <= 512, ptmi_lanes_for_grad) with or without them. */
 enum { PTMI_LOGP_FLAT = 0,     /* 0 everywhere */
        PTMI_LOGP_BOX = 1 };    /* 0 inside [lo,hi], -inf outside ; par = lo[d], hi[d] */
 

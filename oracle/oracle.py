@@ -19,7 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libptmcmc_oracle.so")
 
-LOGL = {"iso": 0, "dense": 1, "curved": 2}
+LOGL = {"iso": 0, "dense": 1, "curved": 2, "interval": 3}
 LOGP = {"flat": 0, "box": 1}
 J_SCAM, J_AM, J_DE, J_NUTS, J_HMC, J_NTYPES = 0, 1, 2, 3, 4, 5
 J = {"scam": 0, "am": 1, "de": 2, "nuts": 3, "hmc": 4}
@@ -126,6 +126,14 @@ def dense_par(mu, P):
     Ps = (Pt + Pt.T) * 0.5
     Tl = np.tril(Ps, -1) + np.diag(np.diag(Ps) * 0.5)
     return np.concatenate([mu, Pt.ravel(), Tl.ravel()])
+
+
+def interval_par(a, b, d):
+    """Parameter block of the interval family (LOGL_INTERVAL): a | w = b - a | log w."""
+    a = np.broadcast_to(np.asarray(a, dtype=np.float64), (d,))
+    b = np.broadcast_to(np.asarray(b, dtype=np.float64), (d,))
+    w = b - a
+    return np.ascontiguousarray(np.concatenate([a, w, np.log(w)]))
 
 
 def lanes_for(ndim, grad=False):
@@ -286,6 +294,8 @@ def gradjump(kind, x, it, beta, state, cov, logl=("iso",), logp=("flat",), nburn
     par_l, par_p = np.zeros(1), np.zeros(1)
     if logl[0] == "dense":
         par_l = dense_par(logl[1], logl[2])
+    if logl[0] == "interval":
+        par_l = interval_par(logl[1], logl[2], d)
     if logp[0] == "box":
         par_p = np.concatenate([np.asarray(logp[1], float), np.asarray(logp[2], float)])
     tab = gj_tables(cov)
@@ -350,7 +360,7 @@ class OracleEngine(object):
         self.cov_update, self.burn, self.tskip, self.seed = cov_update, burn, tskip, seed
         self.per_walker = cov_mode == "per_walker"
         self.Wc = nwalkers if self.per_walker else 1
-        self.lanes = lanes_for(ndim, grad=sum(grad_weights) > 0) if lanes is None else lanes
+        self.lanes = lanes_for(ndim, grad=sum(grad_weights) > 0 or logl[0] == "interval") if lanes is None else lanes
         d, nt, W = ndim, ntemps, nwalkers
         self.X = np.zeros((W, nt, d))
         self.lnL = np.zeros((W, nt))
@@ -388,6 +398,8 @@ class OracleEngine(object):
         self._par_p = np.zeros(1)
         if logl[0] == "dense":
             self._par_l = dense_par(logl[1], logl[2])
+        if logl[0] == "interval":
+            self._par_l = interval_par(logl[1], logl[2], d)
         if logp[0] == "box":
             self._par_p = np.concatenate([np.asarray(logp[1], float), np.asarray(logp[2], float)])
         self.cfg = Cfg(ndim=d, ntemps=nt, nwalkers=W, lanes=self.lanes, logl_kind=LOGL[logl[0]],

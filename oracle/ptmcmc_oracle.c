@@ -298,7 +298,7 @@ ORC_API double orc_uniform(uint64_t w) { return w2uniform(w); }
 ORC_API uint64_t orc_index(uint64_t w, uint64_t n) { return w2index(w, n); }
 
 /* ------------------------------------------------------------- config */
-enum { LOGL_ISO = 0, LOGL_DENSE = 1, LOGL_CURVED = 2 };
+enum { LOGL_ISO = 0, LOGL_DENSE = 1, LOGL_CURVED = 2, LOGL_INTERVAL = 3 };
 enum { LOGP_FLAT = 0, LOGP_BOX = 1 };
 enum { J_SCAM = 0, J_AM = 1, J_DE = 2, J_NUTS = 3, J_HMC = 4, J_NTYPES = 5 };
 enum { K_INT = 0, K_UNI = 1, K_NRM = 2, K_SHUF = 3, K_EXP = 4 };
@@ -393,6 +393,24 @@ static double eval_logp(const orc_cfg *c, const double *q)
     return 0.0;
 }
 
+/* LOGL_INTERVAL, one element: the reference's own NUTS workload, tests/test_nuts.py -- GaussianLikelihood.lnlikefn_grad (:22-25:
+ * -x^2/2 - log(2 pi)/2 per element, gradient -x) seen through intervalTransform (:50-140): backward (:81-86) x = (b - a) e^p / (1 + e^p) + a,
+ * logjacobian_grad (:88-94) log(b - a) + p - 2 log(1 + e^p) with gradient (1 - e^p) / (1 + e^p), dxdp (:96-101) (b - a) e^p / (1 + e^p)^2,
+ * lnlikefn_grad (:117-122) ll + lj, ll_grad * dxdp + lj_grad -- in the reference's operation order.  w = b - a and lw = log w are
+ * parameters (par = a | w | lw).  Returns the value term; *g (if not NULL) its derivative. */
+static double interval_elem(double p, double lo, double w, double lw, double *g)
+{
+    const double E = orc_exp(p), onepe = 1.0 + E;
+    const double wE = w * E;
+    const double x = wE / onepe + lo;
+    const double t = (-0.5 * (x * x) - 0x1.d67f1c864beb5p-1) + ((lw + p) - 2.0 * orc_log(onepe));
+    if (g) {
+        const double dxdp = wE / (onepe * onepe);
+        *g = (-x) * dxdp + (1.0 - E) / onepe;
+    }
+    return t;
+}
+
 static double eval_logl(const orc_cfg *c, const double *q, double *tmp /* 2d */)
 {
     int d = c->ndim;
@@ -421,6 +439,12 @@ static double eval_logl(const orc_cfg *c, const double *q, double *tmp /* 2d */)
             const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
             t[i] = orc_log(orc_exp(l0) + 0.5 * orc_exp(l1));
         }
+        return lane_dot(t, o, d, c->lanes);
+    }
+    if (c->logl_kind == LOGL_INTERVAL) {
+        const double *par = c->logl_par;
+        double *t = tmp, *o = tmp + d;
+        for (int i = 0; i < d; ++i) { t[i] = interval_elem(q[i], par[i], par[d + i], par[2 * d + i], NULL); o[i] = 1.0; }
         return lane_dot(t, o, d, c->lanes);
     }
     return NAN;
@@ -505,6 +529,9 @@ static double eval_logl_grad(const orc_cfg *c, const double *q, double *tmp /* 2
         for (int j = 0; j < d; ++j)
             for (int i = 0; i < d; ++i) tmp[d + i] = fma(Pt[(size_t)j * d + i], tmp[j], tmp[d + i]);
         for (int i = 0; i < d; ++i) g[i] = -tmp[d + i];
+    } else if (c->logl_kind == LOGL_INTERVAL) {
+        const double *par = c->logl_par;
+        for (int i = 0; i < d; ++i) (void)interval_elem(q[i], par[i], par[d + i], par[2 * d + i], &g[i]);
     } else {
         for (int i = 0; i < d; ++i) g[i] = 0.0;
         for (int i = 0; i + 1 < d; i += 2) {

@@ -59,7 +59,9 @@ def build(force=False, verbose=False, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     work = [(os.path.join(CSRC, "ptmi_abi.hip"), os.path.join(OBJ, "abi.o"), [])]
     for g, e in sorted(shapes(), key=lambda s: -s[0] * s[1]):       # biggest units first
-        for fam in (1, 0, 2):
+        for fam in (1, 0, 2, 3):
+            if fam == 3 and e > 8:          # the interval family (PTMI_LOGL_INTERVAL): the gradient-jump shapes only (PTMI_GJ_SHAPE_LIST)
+                continue
             # the iso / dense step kernels sit at the register limit of their occupancy: with LLVM's AMDGPU register-pressure
             # trackers the scheduler spills 20 instead of 96 bytes in the config-2 kernel (1.107 -> 1.072 ms per 100 steps,
             # dense 12.8 -> 12.5); the curved family (gradient jumps) measured 1.5 % slower with them and keeps the default
@@ -67,8 +69,8 @@ def build(force=False, verbose=False, jobs=None):
             # config-2 kernel 0.797 -> 0.782 ms per 100 steps, dense 5.81 -> 5.72); the kernels of cycles with AM / DE entries
             # (part 1) measured 1-2 % slower with it and keep the default strategy.  max-memory-clause, metric bias 0, relaxed
             # occupancy and no post-RA scheduling measured within 0.5 % of the default or worse.  PTMI_NO_ILP=1: an A/B build without it.
-            track = ["-mllvm", "-amdgpu-use-amdgpu-trackers"] if fam != 2 else []
-            ilp = [] if os.environ.get("PTMI_NO_ILP") else (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if fam != 2 else [])
+            track = ["-mllvm", "-amdgpu-use-amdgpu-trackers"] if fam < 2 else []
+            ilp = [] if os.environ.get("PTMI_NO_ILP") else (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if fam < 2 else [])
             defs = ["-DPTMI_G=%d" % g, "-DPTMI_E=%d" % e, "-DPTMI_L=%d" % fam]
             work.append((os.path.join(CSRC, "ptmi_shape.hip"), os.path.join(OBJ, "shape_%d_%d_%d.o" % (g, e, fam)), defs + ["-DPTMI_PART=0"] + track + ilp))
             work.append((os.path.join(CSRC, "ptmi_shape.hip"), os.path.join(OBJ, "shape_full_%d_%d_%d.o" % (g, e, fam)), defs + ["-DPTMI_PART=1"] + track))

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PTMI_LIB: another build of the same ABI (A/B measurements of a kernel change); the default is the in-tree library
 SO = os.environ.get("PTMI_LIB") or os.path.join(HERE, "libptmi.so")
 
-LOGL = {"iso": 0, "dense": 1, "curved": 2}
+LOGL = {"iso": 0, "dense": 1, "curved": 2, "interval": 3}
 LOGP = {"flat": 0, "box": 1}
 J_SCAM, J_AM, J_DE, J_NUTS, J_HMC, J_NTYPES = 0, 1, 2, 3, 4, 5
 GJ_NSTATE, GJ_EPSBAR = 8, 3

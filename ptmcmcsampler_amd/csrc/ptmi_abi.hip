@@ -2215,6 +2215,11 @@ static KArgs make_args(ptmi_engine *h)
 
 static ptmi_shape_fn shape_fn(int G, int EPL, int L)
 {
+    if (L == PTMI_LOGL_INTERVAL) {
+#define PTMI_PICK_SHAPE3(G_, E_) if (G == G_ && EPL == E_) return ptmi_shape_##G_##_##E_##_3;
+        PTMI_GJ_SHAPE_LIST(PTMI_PICK_SHAPE3)
+        return nullptr;
+    }
 #define PTMI_PICK_SHAPE(G_, E_)                                                                        \
     if (G == G_ && EPL == E_) return L == 0 ? ptmi_shape_##G_##_##E_##_0 : (L == 1 ? ptmi_shape_##G_##_##E_##_1 : ptmi_shape_##G_##_##E_##_2);
     PTMI_SHAPE_LIST(PTMI_PICK_SHAPE)
@@ -2362,8 +2367,12 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         return fail(PTMI_EINVAL, "No jump proposals specified! (PTMCMCSampler.py:267)");
     if (c.cov_update < 1) return fail(PTMI_EINVAL, "cov_update must be >= 1");
     if (c.w_de > 0 && c.de_size < 2) return fail(PTMI_EINVAL, "de_size must be >= 2 when DE is used");
-    if (c.logl_kind < 0 || c.logl_kind > PTMI_LOGL_CURVED || c.logp_kind < 0 || c.logp_kind > PTMI_LOGP_BOX)
+    if (c.logl_kind < 0 || c.logl_kind > PTMI_LOGL_INTERVAL || c.logp_kind < 0 || c.logp_kind > PTMI_LOGP_BOX)
         return fail(PTMI_EINVAL, "unknown logl/logp kind");
+    if (c.logl_kind == PTMI_LOGL_INTERVAL && c.logl_par_len != 3LL * c.ndim)
+        return fail(PTMI_EINVAL, "interval logl needs a[d] + w[d] + log w[d] parameters");
+    if (c.logl_kind == PTMI_LOGL_INTERVAL && (c.w_host > 0 || c.ngroups > 1))
+        return fail(PTMI_EUNSUPPORTED, "the interval logl runs in the fused kernels with one parameter group");
     if (c.logl_kind == PTMI_LOGL_DENSE && c.logl_par_len != (long long)c.ndim * (c.ndim + 1))
         return fail(PTMI_EINVAL, "dense logl needs mu[d] + Pt[d*d] parameters");
     if (c.logl_kind == PTMI_LOGL_CURVED && (c.ndim & 1)) return fail(PTMI_EINVAL, "curved logl needs an even ndim");
@@ -2378,6 +2387,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
             if (c.group_size[g] < 1 || c.group_size[g] > c.ndim) return fail(PTMI_EINVAL, "group %d has %d parameters", g, c.group_size[g]);
     }
     const bool gj = c.w_nuts + c.w_hmc > 0;
+    const bool gshape = gj || c.logl_kind == PTMI_LOGL_INTERVAL;                     // (the interval family lives in the gradient-jump shapes)
+    if (gshape && !gj && c.ndim > 512) return fail(PTMI_EUNSUPPORTED, "the interval logl is built for ndim <= 512 (got %d)", c.ndim);
     if (c.w_nuts < 0 || c.w_hmc < 0) return fail(PTMI_EINVAL, "negative gradient-jump weight");
     if (gj) {
         if (!c.gj_tab) return fail(PTMI_EINVAL, "gradient jumps need the whitening tables (gj_tab)");
@@ -2398,7 +2409,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     }
     if ((unsigned long long)c.nwalkers * (unsigned)c.ntemps_global > 0xFFFFFFFFull) return fail(PTMI_EINVAL, "too many RNG streams");
     Shape s;
-    if (!pick_shape(c.ndim, gj, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported (max 2048)", c.ndim);
+    if (!pick_shape(c.ndim, gshape, &s)) return fail(PTMI_EUNSUPPORTED, "ndim=%d not supported (max 2048)", c.ndim);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(PTMI_ENODEVICE, "no HIP device visible: libptmi has no CPU fallback");
@@ -2487,7 +2498,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         }
     }
     // AM increments ahead of the launch (am_gemm_kernel): the 16- and 64-lane shapes with one pooled table, ndim <= 1024
-    if (e == hipSuccess && !gj && c.w_am > 0 && !c.cov_per_walker && c.ngroups <= 1 && s.G > 4 && c.ndim <= 1024 && c.w_host == 0 &&
+    if (e == hipSuccess && !gshape && c.w_am > 0 && !c.cov_per_walker && c.ngroups <= 1 && s.G > 4 && c.ndim <= 1024 && c.w_host == 0 &&
         !getenv("PTMI_NO_AM_AHEAD")) {
         const long long nch = (long long)c.nwalkers * c.ntemps;
         const char *mb = getenv("PTMI_AM_BUDGET_MB");                    // scratch for the increments of one piece of a launch (default 6 GB)

@@ -183,3 +183,7 @@ typedef int (*ptmi_shape_fn)(int op, ptmi_engine *h, KArgs &a, int grid, bool fu
     int ptmi_shape_##G_##_##E_##_1(int op, ptmi_engine *h, KArgs &a, int grid, bool full); \
     int ptmi_shape_##G_##_##E_##_2(int op, ptmi_engine *h, KArgs &a, int grid, bool full);
 PTMI_SHAPE_LIST(PTMI_DECLARE_SHAPE)
+// family 3 (PTMI_LOGL_INTERVAL) is built for the gradient-jump shapes only (at most 8 slots per lane; _build.py)
+#define PTMI_GJ_SHAPE_LIST(X) X(4, 2) X(4, 5) X(4, 8) X(16, 7) X(64, 8)
+#define PTMI_DECLARE_SHAPE3(G_, E_) int ptmi_shape_##G_##_##E_##_3(int op, ptmi_engine *h, KArgs &a, int grid, bool full);
+PTMI_GJ_SHAPE_LIST(PTMI_DECLARE_SHAPE3)

@@ -139,6 +139,18 @@ struct GradJump {
             double vh[EPL];
             tab_vec<-1>(Pt + (size_t)d * d, r, vh);                        // the value: eval_logl's half table Tl
             return -dot(r, vh);
+        } else if (LOGL == PTMI_LOGL_INTERVAL) {
+            const double *par = a.logl_par;
+            double p = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = gl + G * e, ii = i < d ? i : 0;
+                double gv;
+                const double t = interval_elem<true>(x[e], par[ii], par[d + ii], par[2 * d + ii], gv);
+                g[e] = i < d ? gv : 0.0;
+                p = __builtin_fma(i < d ? t : 0.0, 1.0, p);
+            }
+            return group_sum<G>(p);
         } else {
             double p = 0.0;
 #pragma unroll
@@ -513,6 +525,7 @@ struct GradJumpWide {
     const u32 sid;
     const int vb;                    // 64 doubles of the block's LDS: the vector of a table product, in element order
     double blo = 0.0, bhi = 0.0;     // this lane's bounds of a box prior
+    double iv_lo = 0.0, iv_w = 0.0, iv_lw = 0.0;     // this lane's parameters of the interval family
     u32 nm = 0, ns = 0, nleap = 0;
 #ifdef PTMI_GJ_PROFILE
     mutable unsigned long long prof[GJP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -523,6 +536,7 @@ struct GradJumpWide {
           ch(ch_), nch((long long)a_.W * a_.nt), beta(beta_), it(it_), sid(sid_), vb(vb_)
     {
         if (a.logp_kind == PTMI_LOGP_BOX) { blo = a.logp_par[col]; bhi = a.logp_par[d + col]; }
+        if (LOGL == PTMI_LOGL_INTERVAL) { iv_lo = a.logl_par[col]; iv_w = a.logl_par[d + col]; iv_lw = a.logl_par[2 * d + col]; }
     }
 
     // ---- draws
@@ -643,6 +657,13 @@ struct GradJumpWide {
             const double rr = -dot(r, vh);
             GJP_ADD(GJP_LOGL, t0);
             return rr;
+        } else if (LOGL == PTMI_LOGL_INTERVAL) {
+            double gv;
+            const double t = interval_elem<true>(x, iv_lo, iv_w, iv_lw, gv);
+            g = act ? gv : 0.0;
+            const double r = dot(act ? t : 0.0, 1.0);
+            GJP_ADD(GJP_LOGL, t0);
+            return r;
         } else {
             const double other = lane_xor16(x);                            // the pair's other member: lane group g ^ 1, same slot
             const bool even = !(wg & 1);
@@ -941,6 +962,7 @@ struct GradJumpPair {
     const u32 sid;
     const int vb;                    // 64 doubles of the block's LDS: the vector of a table product, in element order
     double blo = 0.0, bhi = 0.0;     // this lane's bounds of a box prior
+    double iv_lo = 0.0, iv_w = 0.0, iv_lw = 0.0;     // this lane's parameters of the interval family
     u32 nm = 0, ns = 0, nleap = 0;
 #ifdef PTMI_GJ_PROFILE
     mutable unsigned long long prof[GJP_N] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -951,6 +973,7 @@ struct GradJumpPair {
           ch(ch_), nch((long long)a_.W * a_.nt), beta(beta_), it(it_), sid(sid_), vb(vb_)
     {
         if (a.logp_kind == PTMI_LOGP_BOX) { blo = a.logp_par[col]; bhi = a.logp_par[d + col]; }
+        if (LOGL == PTMI_LOGL_INTERVAL) { iv_lo = a.logl_par[col]; iv_w = a.logl_par[d + col]; iv_lw = a.logl_par[2 * d + col]; }
     }
 
     __device__ __forceinline__ u32 half_lane32(u32 v, int src) const { return (u32)__builtin_amdgcn_ds_bpermute(((hh << 5) + src) << 2, (int)v); }
@@ -1089,6 +1112,13 @@ struct GradJumpPair {
             const double rr = -dot(r, vh);
             GJP_ADD(GJP_LOGL, t0);
             return rr;
+        } else if (LOGL == PTMI_LOGL_INTERVAL) {
+            double gv;
+            const double t = interval_elem<true>(x, iv_lo, iv_w, iv_lw, gv);
+            g = act ? gv : 0.0;
+            const double r = dot(act ? t : 0.0, 1.0);
+            GJP_ADD(GJP_LOGL, t0);
+            return r;
         } else {
             const double other = dppf64<0x128>(x);                         // the pair's other member: lane group g ^ 1 = lane ^ 8 (row_ror:8), same slot
             const bool even = !(wg & 1);

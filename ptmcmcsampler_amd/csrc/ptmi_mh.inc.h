@@ -54,8 +54,13 @@ __device__ __forceinline__ double grp_xor1(double v)
 // G*EPL_prev < ndim <= G*EPL, so slots e < safe_slots(G, EPL) hold a valid element on every
 // lane for every ndim the shape serves and need no bounds check.
 // Shape (4, 25) is EXACT: it serves ndim = 100 only (ptmi_abi.hip pick_shape), so every slot of every lane is valid.
-constexpr int safe_slots(int G, int EPL)
+// The interval family (PTMI_LOGL_INTERVAL, a translation unit of its own: PTMI_L == 3) lives in the gradient-jump shapes, which
+// serve every ndim up to G*EPL: no slot is exempt there.  (static: the units disagree about this function on purpose.)
+static constexpr int safe_slots(int G, int EPL)
 {
+#if defined(PTMI_L) && PTMI_L == 3
+    return 0;
+#endif
     return G == 4 ? (EPL == 26 ? 20 : EPL == 25 ? 25 : EPL == 20 ? 14 : EPL == 14 ? 8 : EPL == 8 ? 5 : EPL == 5 ? 2 : 0)
          : G == 16 ? (EPL == 26 ? 13 : EPL == 13 ? 7 : EPL == 7 ? 6 : 0)
          : (EPL == 32 ? 16 : EPL == 16 ? 8 : EPL == 8 ? 6 : 0);
@@ -180,6 +185,22 @@ __device__ __forceinline__ void mfma_half_tab_vecf(const double *T, int ld, int 
 constexpr int mfma_ld(int EPL) { return 16 * ((4 * EPL + 15) / 16); }
 
 // ----------------------------------------------------------- log-likelihoods
+// PTMI_LOGL_INTERVAL, one element (oracle: interval_elem; the reference: tests/test_nuts.py:71-140 backward / logjacobian_grad / dxdp /
+// lnlikefn_grad around GaussianLikelihood.lnlikefn_grad :22-25, operation for operation): value term and, GRAD, d/dp of it
+template <bool GRAD>
+__device__ __forceinline__ double interval_elem(double p, double lo, double w, double lw, double &g)
+{
+    const double E = det_exp(p), onepe = 1.0 + E;
+    const double wE = w * E;
+    const double x = wE / onepe + lo;                                   // backward (:81-86)
+    const double t = (-0.5 * (x * x) - 0x1.d67f1c864beb5p-1) + ((lw + p) - 2.0 * det_log(onepe));     // :19-20 per element + :88-90
+    if (GRAD) {
+        const double dxdp = wE / (onepe * onepe);                       // :96-101
+        g = (-x) * dxdp + (1.0 - E) / onepe;                            // :117-122: ll_grad * dxdp + lj_grad (:92-93)
+    }
+    return t;
+}
+
 // All G lanes of a group hold q[e] = element (gl + G*e); pad elements are 0.
 // STR: strided lane layout; with it the dense product runs on the matrix cores from the LDS copy of Pt.
 template <int G, int EPL, int LOGL, bool STR>
@@ -228,6 +249,17 @@ __device__ __forceinline__ double eval_logl(const KArgs &a, const double (&q)[EP
 #pragma unroll
         for (int e = 0; e < EPL; ++e) p = __builtin_fma(r[e], v[e], p);
         return -grp_sum<G, STR>(p);
+    } else if (LOGL == PTMI_LOGL_INTERVAL) {
+        const double *par = a.logl_par;
+        double p = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = gl + G * e, ii = i < d ? i : 0;
+            double g;
+            const double t = interval_elem<false>(q[e], par[ii], par[d + ii], par[2 * d + ii], g);
+            p = __builtin_fma(i < d ? t : 0.0, 1.0, p);
+        }
+        return grp_sum<G, STR>(p);
     } else {  // PTMI_LOGL_CURVED: pairs (2m, 2m+1); G is even so a pair lives in lanes (gl, gl+1) of one slot
         double p = 0.0;
 #pragma unroll

@@ -78,6 +78,17 @@ def factorize(cov, per_walker):
     return np.ascontiguousarray(V[:, ::-1]), np.abs(w[::-1])
 
 
+
+def interval_par(a, b, d):
+    """Parameters of the ("interval", a, b) family (include/ptmi.h PTMI_LOGL_INTERVAL): a, w = b - a, log w."""
+    a = np.broadcast_to(np.asarray(a, np.float64), (d,))
+    b = np.broadcast_to(np.asarray(b, np.float64), (d,))
+    if not np.all(b > a):
+        raise ValueError("interval logl needs a < b")
+    w = b - a
+    return np.ascontiguousarray(np.concatenate([a, w, np.log(w)]))
+
+
 class PTEngine(object):
     """Chains of ``nwalkers`` x ``ntemps`` on one GPU.
 
@@ -87,8 +98,9 @@ class PTEngine(object):
     Tskip.  ``cov_mode``: ``"per_walker"`` makes every walker a faithful replica of a
     reference run (own covariance, eigenvectors and DE history); ``"pooled"`` adapts one
     covariance from all walkers' rank-0 samples.  ``logl`` / ``logp`` select the built-in
-    device likelihood / prior: ("iso",), ("dense", mu, P) with P a (symmetric) precision matrix, ("curved",); ("flat",),
-    ("box", lo, hi).  ``swap_mode``: ``"sweep"`` is the reference's hot -> cold PTswap; ``"oddeven"`` tries
+    device likelihood / prior: ("iso",), ("dense", mu, P) with P a (symmetric) precision matrix, ("curved",),
+    ("interval", a, b) = the unit Gaussian on the box (a, b) in the coordinates of the reference's ``intervalTransform`` (its own NUTS
+    workload, tests/test_nuts.py:13-140; ndim <= 512); ("flat",), ("box", lo, hi).  ``swap_mode``: ``"sweep"`` is the reference's hot -> cold PTswap; ``"oddeven"`` tries
     the disjoint pairs (k, k+1), k = swap epoch (mod 2), all at once (see include/ptmi.h).  ``pick_mode``: ``"chain"`` =
     every chain draws its own entry of the proposal cycle (the reference's ``_jump``); ``"walker"`` = one draw per walker
     and iteration fixes the proposal type of all its temperature ranks (wave-uniform on the device, include/ptmi.h).
@@ -207,9 +219,10 @@ class PTEngine(object):
         z = lambda shape, dt=f64: torch.zeros(shape, dtype=dt, device=self.device)  # noqa: E731
         has_de = self.weights[2] > 0 if use_de_buffer is None else use_de_buffer
         st, ep = C.c_int(0), C.c_int(0)                                # row format of the DE buffer (include/ptmi.h)
-        _lib.check(self.lib.ptmi_de_row_stride(d, int(has_gj), C.byref(st), C.byref(ep)))
+        gshape = has_gj or logl[0] == "interval"                       # the interval family lives in the gradient-jump shapes (include/ptmi.h)
+        _lib.check(self.lib.ptmi_de_row_stride(d, int(gshape), C.byref(st), C.byref(ep)))
         self.de_ld, self.de_epl = st.value, ep.value
-        _lib.check(self.lib.ptmi_am_row_format(d, int(has_gj), C.byref(ep)))         # row format of the AM buffer (include/ptmi.h)
+        _lib.check(self.lib.ptmi_am_row_format(d, int(gshape), C.byref(ep)))         # row format of the AM buffer (include/ptmi.h)
         self.am_epl = ep.value
         self.am_pos = self.am_inv = None
         if self.am_epl:
@@ -250,6 +263,8 @@ class PTEngine(object):
         if logl[0] == "dense":
             mu, P = np.asarray(logl[1], np.float64), np.asarray(logl[2], np.float64)
             self._par_l = np.concatenate([mu, np.ascontiguousarray(P.T).ravel()])
+        if logl[0] == "interval":
+            self._par_l = interval_par(logl[1], logl[2], d)
         if logp[0] == "box":
             self._par_p = np.concatenate([np.asarray(logp[1], np.float64), np.asarray(logp[2], np.float64)])
         self.stream = torch.cuda.current_stream(self.device)

@@ -10,7 +10,7 @@ the reference runs unchanged as ONE process driving one GPU.  Differences, all a
   semantics for its callbacks (``comm`` may be the size-1 dummy or ``None``);
 * ``logl`` may be a Python callable (evaluated on the host between the propose and accept
   kernels, one launch pair per iteration) **or** a tuple naming a device likelihood --
-  ``("iso",)``, ``("dense", mu, P)``, ``("curved",)`` -- and ``logp`` a callable or
+  ``("iso",)``, ``("dense", mu, P)``, ``("curved",)``, ``("interval", a, b)`` -- and ``logp`` a callable or
   ``("flat",)`` / ``("box", lo, hi)``; with device likelihoods and no host-side jumps the
   fused K-step kernel runs;
 * ``logl_grad`` / ``logp_grad`` are the reference's gradient callbacks (HMC / NUTS then run on the host,

@@ -506,6 +506,67 @@ def gen_gradjump(out):
 
 
 
+def reference_test_classes(path, names):
+    """Classes of one of the reference's TEST modules, taken out of it by name and executed here (the module itself imports mpi4py,
+    which this container does not have).  Only their outputs are stored."""
+    import ast
+    tree = ast.parse(open(path).read())
+    ns = {"np": np}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def gen_interval(out):
+    """The reference's own NUTS workload (tests/test_nuts.py): GaussianLikelihood inside intervalTransform.  Values and gradients of
+    its lnlikefn_grad / lnpriorfn at sample points, and NUTS / HMC calls of the reference's jump objects on it (global np.random
+    seeded, as gen_gradjump) -- what the ("interval", a, b) device family (include/ptmi.h PTMI_LOGL_INTERVAL) is pinned to."""
+    import contextlib
+    import io
+    from PTMCMCSampler.nutsjump import HMCJump, NUTSJump
+    Gauss, Interval = reference_test_classes(os.path.join(REF, "tests", "test_nuts.py"), ["GaussianLikelihood", "intervalTransform"])
+    rs = np.random.RandomState(77)
+    res = {}
+    # (1) values: the test's own box (0, 10) at 40-d, and an uneven box at 7-d
+    for tag, d, a, b in (("t40", 40, np.zeros(40), np.full(40, 10.0)), ("u7", 7, rs.uniform(-3, 0, 7), rs.uniform(0.5, 6, 7))):
+        glo = Gauss(ndim=d, pmin=0.0, pmax=1.0)
+        glo.a, glo.b = a.copy(), b.copy()
+        glt = Interval(glo)
+        P = np.concatenate([rs.randn(12, d) * 2.0, rs.randn(4, d) * 8.0])
+        vals = [glt.lnlikefn_grad(p) for p in P]
+        res[tag + "_a"], res[tag + "_b"], res[tag + "_p"] = a, b, P
+        res[tag + "_ll"] = np.array([v[0] for v in vals])
+        res[tag + "_grad"] = np.array([v[1] for v in vals])
+        res[tag + "_lp"] = np.array([glt.lnpriorfn(p) for p in P])
+        res[tag + "_x"] = np.array([glt.backward(p) for p in P])
+    # (2) the jumps, 8-d on (0, 10), whitened by a diagonal covariance as the pair layout of the kernels wants it
+    d = 8
+    glo = Gauss(ndim=d, pmin=0.0, pmax=10.0)
+    glt = Interval(glo)
+    cov = np.diag(rs.uniform(0.5, 2.0, d))
+    res["j_cov"], res["j_a"], res["j_b"] = cov, glo.a, glo.b
+    for tag, make, ncall in (("nuts", lambda: NUTSJump(glt.lnlikefn_grad, glt.lnpriorfn_grad, cov, nburn=25, delta=0.6), 40),
+                             ("hmc", lambda: HMCJump(glt.lnlikefn_grad, glt.lnpriorfn_grad, cov, nburn=25, stepsize=0.2, nminsteps=2, nmaxsteps=12), 25)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            j = make()
+        np.random.seed(515)
+        x = rs.randn(d) * 0.5 - 1.0
+        xs, qs, qxys, eps = [x.copy()], [], [], []
+        for it in range(1, ncall + 1):
+            beta = 1.0 if it % 5 else 0.5
+            q, qxy = j(x, it, beta)
+            qs.append(np.array(q))
+            qxys.append(float(qxy))
+            eps.append(float(j.epsilon) if j.epsilon is not None else -1.0)
+            if it % 3:
+                x = np.array(q)
+            xs.append(x.copy())
+        res[tag + "_x"], res[tag + "_q"] = np.asarray(xs), np.asarray(qs)
+        res[tag + "_qxy"], res[tag + "_eps"] = np.asarray(qxys), np.asarray(eps)
+    np.savez_compressed(os.path.join(out, "interval.npz"), **res)
+
+
 def gen_config1(PT, out):
     """BASELINE configs[0]: the workload of the reference's examples/simple.py:52-122 -- 20-d dense Gaussian
     built from the global NumPy state, box prior [0, 10], cov0 = 0.01 I, the UniformJump custom proposal with weight 5,
@@ -601,6 +662,7 @@ def main():
     gen_ptswap(PT, HERE, tmp)
     gen_trajectories(PT, HERE)
     gen_gradjump(HERE)
+    gen_interval(HERE)
     gen_config1(PT, HERE)
     gen_resume(PT, HERE)
     for f in sorted(os.listdir(HERE)):

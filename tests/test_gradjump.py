@@ -133,3 +133,53 @@ def test_oracle_gradient_jumps_replay_the_reference(golden, tag):
         if tag == "nuts":
             assert abs(st[orc.GJ_EPS] - g["nuts_eps"][it - 1]) < 1e-10 * g["nuts_eps"][it - 1]
     assert leaps > (100 if tag == "nuts" else 20)
+
+
+def _interval_callbacks(a, b):
+    """The reference's own NUTS workload (tests/test_nuts.py: GaussianLikelihood :13-47 inside intervalTransform :50-140), written out
+    with its operations in its order: what a user hands to the sampler as logl_grad / logp_grad."""
+    def ll_grad(p):
+        x = (b - a) * np.exp(p) / (1 + np.exp(p)) + a
+        ll = -0.5 * np.sum(x**2) - len(x) * 0.5 * np.log(2 * np.pi)
+        lj = np.sum(np.log(b - a) + p - 2 * np.log(1.0 + np.exp(p)))
+        dxdp = (b - a) * np.exp(p) / (1 + np.exp(p)) ** 2
+        return ll + lj, -x * dxdp + (1 - np.exp(p)) / (1 + np.exp(p))
+
+    def lp_grad(p):
+        x = (b - a) * np.exp(p) / (1 + np.exp(p)) + a
+        return (0.0 if np.all(a <= x) and np.all(b >= x) else -np.inf), np.zeros_like(p)
+
+    return ll_grad, lp_grad
+
+
+@pytest.mark.parametrize("tag", ["nuts", "hmc"])
+def test_interval_family_replays_the_reference_nuts_workload(golden, tag):
+    """``("interval", a, b)`` (include/ptmi.h PTMI_LOGL_INTERVAL) against the reference's jump objects run on the reference's own test
+    likelihood (tests/golden/make_golden.py gen_interval): the host restatement reproduces the reference's proposals bit for bit, and
+    the C oracle -- the definition the device kernels are compared with -- fed the same draws lands on them to 1e-9 (its exp / log
+    are its own, its sums run in the kernels' lane order)."""
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd.gradjump import HMCJump, NUTSJump
+    g = golden("interval")
+    a, b, cov = g["j_a"], g["j_b"], g["j_cov"]
+    ll_grad, lp_grad = _interval_callbacks(a, b)
+    with contextlib.redirect_stdout(io.StringIO()):
+        j = NUTSJump(ll_grad, lp_grad, cov, nburn=25, delta=0.6) if tag == "nuts" else \
+            HMCJump(ll_grad, lp_grad, cov, nburn=25, stepsize=0.2, nminsteps=2, nmaxsteps=12)
+    kw = dict(nburn=25) if tag == "nuts" else dict(nburn=25, hmc=(0.2, 2, 12))
+    np.random.seed(515)
+    xs, st, leaps = g[tag + "_x"], orc.gj_state(), 0
+    for it in range(1, len(g[tag + "_q"]) + 1):
+        beta = 1.0 if it % 5 else 0.5
+        with _RecordGlobalDraws(orc) as rec:
+            q, qxy = j(xs[it - 1], it, beta)
+        assert np.array_equal(q, g[tag + "_q"][it - 1]), (tag, it)
+        assert qxy == g[tag + "_qxy"][it - 1]
+        qo, qxyo, nl = orc.gradjump(tag, xs[it - 1], it, beta, st, cov, logl=("interval", a, b),
+                                    replay=(rec.k, rec.v, rec.b), lanes=4, **kw)      # asserts every draw is consumed, in kind
+        leaps += nl
+        np.testing.assert_allclose(qo, g[tag + "_q"][it - 1], rtol=0, atol=1e-9)
+        assert abs(qxyo - g[tag + "_qxy"][it - 1]) < 1e-9
+        if tag == "nuts":
+            assert abs(st[orc.GJ_EPS] - g["nuts_eps"][it - 1]) < 1e-9 * g["nuts_eps"][it - 1]
+    assert leaps > (100 if tag == "nuts" else 20)

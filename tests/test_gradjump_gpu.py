@@ -47,11 +47,20 @@ CASES = [
     dict(d=7, nt=3, W=4, logl=("iso",), logp=("flat",), grad_weights=(20, 5), weights=(5, 0, 5), diag=True),
     dict(d=40, nt=2, W=3, logl=("dense",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), diag=True),
     dict(d=150, nt=2, W=2, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0), diag=True),
+    # the interval family (include/ptmi.h PTMI_LOGL_INTERVAL): the reference's own NUTS workload -- tests/test_nuts.py:173-221: 40-d, box
+    # (0, 10), SCAM = AM = DE = NUTS = HMC = 10, HMCsteps = 100, HMCstepsize = 0.4 -- and the other layouts: two chains per wave
+    # (diagonal covariance), one per wave, 64 lanes per chain; without gradient jumps (the family still lives in their kernel shapes)
+    dict(d=40, nt=2, W=3, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.4, 2, 100)),
+    dict(d=8, nt=3, W=5, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.2, 2, 12), diag=True),
+    dict(d=20, nt=2, W=4, logl=("interval", -2.0, 3.0), logp=("flat",), grad_weights=(20, 5), weights=(5, 0, 5)),
+    dict(d=130, nt=2, W=2, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0), hmc=(0.2, 2, 20), diag=True),
+    dict(d=40, nt=3, W=4, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(0, 0), weights=(10, 10, 10)),
+    dict(d=7, nt=3, W=4, logl=("interval", -1.0, 1.0), logp=("flat",), grad_weights=(0, 0), weights=(10, 0, 10)),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else "",
-                                                                     "-diag" if c.get("diag") else ""))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else "",
+                                                                       "-diag" if c.get("diag") else "", "" if sum(c["grad_weights"]) else "-nogj"))
 def test_device_gradient_jumps_bit_exact(case, monkeypatch):
     c = dict(case)
     d, nt, W = c.pop("d"), c.pop("nt"), c.pop("W")
@@ -64,6 +73,8 @@ def test_device_gradient_jumps_bit_exact(case, monkeypatch):
         c["logl"] = ("dense", rs.randn(d) * 0.1, np.linalg.inv(A @ A.T / d + 0.5 * np.eye(d)))
     if c["logp"][0] == "box":
         c["logp"] = ("box", np.full(d, c["logp"][1]), np.full(d, c["logp"][2]))
+    if c["logl"][0] == "interval":                             # uneven boxes around the case's (a, b)
+        c["logl"] = ("interval", c["logl"][1] - rs.uniform(0, 0.5, d), c["logl"][2] + rs.uniform(0, 2.0, d))
     A = rs.randn(d, d)
     cov0 = (A @ A.T / d + np.eye(d)) * (1.0 if c["logl"][0] == "curved" else 0.3)
     if diag:
@@ -81,7 +92,8 @@ def test_device_gradient_jumps_bit_exact(case, monkeypatch):
     g.sync()
     for name in ("X", "lnL", "lp", "temp_of", "slot_of", "nacc", "jstat", "nswap", "AM"):
         _same(g.get(name), getattr(o, name), name)
-    _same(g.get("gj"), o.gj, "gradient-jump state")
+    if sum(c["grad_weights"]):
+        _same(g.get("gj"), o.gj, "gradient-jump state")
     js = o.jstat.sum(axis=(0, 1))
     if c["grad_weights"][0]:
         assert js[3, 0] > 0 and js[3, 0] == js[3, 1], "NUTS proposals are always accepted (NJ:838)"

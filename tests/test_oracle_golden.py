@@ -230,3 +230,29 @@ def test_builtin_likelihood_gradients():
         assert abs(v - f(x)) < 1e-12 * max(1.0, abs(v))
         num = np.array([(f(x + h) - f(x - h)) / 2e-6 for h in np.eye(d) * 1e-6])
         np.testing.assert_allclose(g, num, rtol=1e-6, atol=1e-6)
+
+
+def test_interval_family_values_and_gradients_are_the_reference_workloads(golden):
+    """LOGL_INTERVAL (include/ptmi.h PTMI_LOGL_INTERVAL) against the reference's own test likelihood -- tests/test_nuts.py
+    GaussianLikelihood inside intervalTransform, evaluated by the reference's classes themselves (make_golden.py gen_interval): the
+    40-d box (0, 10) of test_nuts and an uneven 7-d box; in every lane count the kernels use.  Tolerance: the oracle's own exp / log
+    (<= 1 ulp each) and a different summation order, 1e-12 relative."""
+    import ctypes as C
+    g = golden("interval")
+    for tag in ("t40", "u7"):
+        a, b, P = g[tag + "_a"], g[tag + "_b"], g[tag + "_p"]
+        d = len(a)
+        par = orc.interval_par(a, b, d)
+        assert np.all(g[tag + "_lp"] == 0.0)            # the workload's prior (the box in x) is 0 at every finite p: ("flat",)
+        for lanes in (4, 16, 64):
+            cfg = orc.Cfg(ndim=d, ntemps=1, nwalkers=1, lanes=lanes, logl_kind=orc.LOGL["interval"], logp_kind=0, logl_par=orc._p(par))
+            for k, p in enumerate(P):
+                gr = np.zeros(d)
+                v = orc.lib().orc_logl_grad(C.byref(cfg), orc._p(np.ascontiguousarray(p)), orc._p(gr))
+                assert abs(v - g[tag + "_ll"][k]) <= 1e-12 * abs(g[tag + "_ll"][k]), (tag, lanes, k)
+                np.testing.assert_allclose(gr, g[tag + "_grad"][k], rtol=1e-11, atol=1e-13)
+                assert v == orc.lib().orc_logl(C.byref(cfg), orc._p(np.ascontiguousarray(p)))
+    # overflow of e^p: inf / inf, as in the reference (its prior turns the NaN into -inf; here the NaN fails every comparison of the accept step)
+    cfg = orc.Cfg(ndim=2, ntemps=1, nwalkers=1, lanes=4, logl_kind=orc.LOGL["interval"], logp_kind=0, logl_par=orc._p(orc.interval_par(0.0, 10.0, 2)))
+    assert np.isnan(orc.lib().orc_logl(C.byref(cfg), orc._p(np.array([800.0, 0.0]))))
+    assert np.isfinite(orc.lib().orc_logl(C.byref(cfg), orc._p(np.array([-800.0, 0.0]))))

@@ -151,6 +151,38 @@ def test_gradient_jumps_through_the_facade(tmp_path, capsys):
     assert np.max(np.abs(np.cov(x.T) - C)) / np.max(C) < 0.35
 
 
+def test_the_references_nuts_test_on_the_device_family(tmp_path, capsys):
+    """The reference's tests/test_nuts.py:173-221 with its likelihood as the device family ("interval", a, b) (include/ptmi.h
+    PTMI_LOGL_INTERVAL): 40-d, box (0, 10), the covariance from the Hessian at the maximum (closed form here: the target factorizes),
+    sample(p0, 1000, burn=500, thin=1, covUpdate=500, SCAM = AM = DE = NUTS = HMC = 10, HMCsteps=100, HMCstepsize=0.4) -- the
+    reference's test only asks that this runs; here also: the chain, mapped back to x, is the unit Gaussian cut at 0 (mean
+    sqrt(2/pi) = 0.798, second moment 1)."""
+    import scipy.optimize as so
+    from ptmcmcsampler_amd import PTSampler
+    ndim, a, b = 40, 0.0, 10.0
+
+    def lnl1(p):                                              # one coordinate of the target (test_gradjump._interval_callbacks has all of it)
+        x = (b - a) * np.exp(p) / (1 + np.exp(p)) + a
+        return -0.5 * x * x + p - 2 * np.log(1.0 + np.exp(p))
+
+    pmax = so.minimize_scalar(lambda p: -lnl1(p), bounds=(-10, 5), method="bounded", options=dict(xatol=1e-12)).x
+    h = (lnl1(pmax + 1e-4) - 2 * lnl1(pmax) + lnl1(pmax - 1e-4)) / 1e-8
+    p0, cov = np.full(ndim, pmax), np.eye(ndim) / -h
+    kw = dict(burn=500, thin=1, covUpdate=500, SCAMweight=10, AMweight=10, DEweight=10, NUTSweight=10, HMCweight=10, MALAweight=0,
+              HMCsteps=100, HMCstepsize=0.4)
+    s = PTSampler(ndim, ("interval", np.full(ndim, a), np.full(ndim, b)), ("flat",), np.copy(cov), logl_grad=True, logp_grad=True,
+                  outDir=str(tmp_path / "dev"), verbose=False, seed=5)
+    s.sample(np.copy(p0), 4000, **kw)
+    assert {"HMCJump", "NUTSJUMP", "covarianceJumpProposalSCAM", "covarianceJumpProposalAM", "DEJump"} <= set(s.jumpDict)
+    prop, acc = s.jumpDict["NUTSJUMP"]
+    assert prop > 400 and acc / prop > 0.97
+    chain = np.loadtxt(str(tmp_path / "dev" / "chain_1.txt"))
+    assert chain.shape == (4001, ndim + 4)                    # row 0 is the start (PTMCMCSampler.py:479-493)
+    x = (b - a) * np.exp(chain[800:, :ndim]) / (1 + np.exp(chain[800:, :ndim])) + a
+    assert abs(x.mean() - np.sqrt(2 / np.pi)) < 0.03 and abs((x * x).mean() - 1.0) < 0.06
+    assert np.all(np.abs(x.mean(0) - np.sqrt(2 / np.pi)) < 0.25)
+
+
 def test_resume_continues_bit_identically(tmp_path):
     """resume=True: a run stopped after 600 iterations and resumed to 1200 equals one uninterrupted run,
     state and chain file alike (device checkpoint + counter-based RNG; the reference replays its text file)."""
