@@ -205,6 +205,11 @@ def measure(a, rank, world, local, dist, backend):
         # epoch's statistics, which run beside the rest of it (config 4: statistics 12 ms + tridiagonalization 12 + divide and conquer
         # 13 beside nine launches of 2.2 ms left the stream waiting 5 ms per period at eig_lag 9)
         eig_lag = a.eig_lag if a.eig_lag >= 0 else (1 if kw["eig_mode"] == "lapack" else 10)
+    elif kw["eig_mode"] == "ql" and a.gpus == 1:
+        # the device QL of every walker's covariance on a side stream beside the launches that follow (--eig-lag L): measured, no gain --
+        # 1.07e10 at every lag, the step launches slow down by what the factorization takes (0.87 -> 1.77 ms): its kernels are LDS
+        # traffic, not idle latency.  The default stays 0: in the replica mode a walker applies its table at once, as the reference does.
+        eig_lag = a.eig_lag if a.eig_lag >= 0 else 0
     kw.update(eig_lag=eig_lag)
     # the statistics of a finished covariance period on a side stream beside the launches that follow (PTEngine stats_async: two AM
     # rings; needs the late table, and burn a multiple of covUpdate when a DE history is kept -- 10000 / 1000 here)

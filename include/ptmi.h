@@ -298,6 +298,11 @@ int ptmi_eig_jacobi(ptmi_handle h);
  * Jacobi kernel's time on the nearly degenerate spectra an isotropic target adapts to.  Eigenvalues in absolute value, descending;
  * sign rule as ptmi_eig_jacobi.  Asynchronous on the handle's stream. */
 int ptmi_eig_ql(ptmi_handle h);
+/* ptmi_eig_ql on `stream` (NULL: the handle's), reading `cov_in` (NULL: the cov buffer) and writing `Ut_out` / `S_out` (NULL: the Ut / S
+ * buffers), one parameter group: the engine's eig_lag with per-walker covariances runs the factorization of a covariance epoch
+ * (:797-803) on a side stream beside the step launches that follow and puts its tables into force a fixed number of launches later
+ * (oracle: OracleEngine(eig_lag=L)).  One call at a time per handle. */
+int ptmi_eig_ql_from(ptmi_handle h, void *stream, const double *cov_in, double *Ut_out, double *S_out);
 /* The same for ONE large pooled covariance (3 <= ndim <= 1024; the engine's eig_mode "sytrd"): Householder tridiagonalization in one
  * kernel with the matrix in the LDS of its blocks, then the ROCm library's divide-and-conquer solver of the tridiagonal matrix and its
  * back-transformation (rocsolver_dstedc, rocsolver_dormtr, looked up in the librocsolver the process has loaded: import torch first).

@@ -338,7 +338,7 @@ class OracleEngine(object):
         assert eig_lag >= 0
         # the engine's eig_lag: the factorization of a covariance epoch takes effect eig_lag segments late (pooled covariance, one
         # parameter group; whichever eigensolver: the host's LAPACK, or the restated device ones)
-        self.eig_lag = int(eig_lag) if (cov_mode == "pooled" and groups is None) else 0
+        self.eig_lag = int(eig_lag) if (groups is None and (cov_mode == "pooled" or eig_mode == "ql")) else 0
         self._eig_pending, self._eig_wait = False, 0
         assert swap_mode in ("sweep", "oddeven") and pick_mode in ("chain", "walker") and eig_mode in ("lapack", "jacobi", "ql")
         assert am_mode in ("auto", "rows", "rle")

@@ -3293,6 +3293,24 @@ int ptmi_eig_ql(ptmi_handle h)
     return PTMI_OK;
 }
 
+// ptmi_eig_ql on the caller's stream, from / into the caller's buffers: the engine's eig_lag with per-walker covariances -- the
+// factorization of thousands of small matrices (chains of dependent rotations: little of the GPU each) runs BESIDE the step launches of
+// the next covariance period instead of between two of them.  One call at a time (the scratch is the handle's).
+int ptmi_eig_ql_from(ptmi_handle h, void *stream, const double *cov_in, double *Ut_out, double *S_out)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    const ptmi_config &c = h->cfg;
+    const double *cov = cov_in ? cov_in : (const double *)h->buf.cov;
+    double *Uo = Ut_out ? Ut_out : h->buf.Ut, *So = S_out ? S_out : h->buf.S;
+    if (!cov || !Uo || !So) return fail(PTMI_EINVAL, "cov / Ut / S buffers missing");
+    if (c.ngroups > 1) return fail(PTMI_EUNSUPPORTED, "ptmi_eig_ql_from: one parameter group (use ptmi_eig_ql)");
+    ptmi_engine view = *h;                                               // eig_ql_run reads the stream, the configuration and the scratch pointer
+    if (stream) view.stream = (hipStream_t)stream;
+    const int rc = eig_ql_run(&view, c.ndim, c.cov_per_walker ? c.nwalkers : 1, cov, Uo, So);
+    h->d_ql_scr = view.d_ql_scr;                                         // (made by the first call)
+    return rc;
+}
+
 // ---------------------------------------------------------------- one large matrix: tridiagonalization in one kernel
 // eig_mode "sytrd" (ptmi_eig_sytrd; ndim <= 1024, one pooled covariance).  The ROCm library's symmetric eigensolver spends two thirds
 // of its time reducing the matrix to tridiagonal form in some 7000 launches of one-block kernels (1000 x 1000: 25 of 35 ms of kernel

@@ -128,7 +128,8 @@ class PTEngine(object):
     table a tenth of a period late.  ``eig_mode="lapack"``: the host factorizes while the GPU samples (L = 1 hides it at
     ndim = 100); ``eig_mode="hipsolver"``: the library's kernels run on a side stream BESIDE the launches (22 ms at ndim = 1000
     beside 2.6 ms launches: L = 9).  Same statistics, same factorization, no GPU idle time at the epoch (oracle:
-    ``OracleEngine(eig_lag=L)``).
+    ``OracleEngine(eig_lag=L)``).  ``eig_mode="ql"`` (pooled or per-walker covariances, one GPU): ``ptmi_eig_ql_from`` on the side
+    stream; built and bit-exact, but no faster at 4096 walkers -- the step launches slow down by what the factorization takes.
     ``am_mode``: how the rank-0 chain's samples (updateChains' buffer, PTMCMCSampler.py:327-328) are kept between covariance
     epochs.  ``"rows"``: every step stores its row.  ``"rle"`` (pooled covariance): a rejected proposal leaves the chain where it
     was, so a step stores its row only when it was accepted (or is a KEY row: first step of a launch, ring rows 0 and 1, the
@@ -180,11 +181,11 @@ class PTEngine(object):
         self.eig_mode = eig_mode
         if int(eig_lag) < 0:
             raise ValueError("eig_lag must be >= 0 launches")
-        # (where the late table is not implemented -- per-walker covariances, parameter groups, the on-stream device eigensolvers
-        # "ql" / "jacobi" -- the table is applied at once, as OracleEngine defines it too)
-        if int(eig_lag) > 0 and eig_mode in ("ql", "jacobi") and cov_mode == "pooled" and groups is None:
-            raise ValueError("eig_lag > 0 is implemented for eig_mode 'lapack', 'hipsolver' and 'sytrd' (got %r)" % (eig_mode,))
-        lag_ok = cov_mode == "pooled" and groups is None and eig_mode in ("lapack", "hipsolver", "sytrd")
+        # (where the late table is not implemented -- per-walker covariances unless eig_mode is "ql", parameter groups, the on-stream
+        # device eigensolver "jacobi" -- the table is applied at once, as OracleEngine defines it too)
+        if int(eig_lag) > 0 and eig_mode == "jacobi" and cov_mode == "pooled" and groups is None:
+            raise ValueError("eig_lag > 0 is implemented for eig_mode 'lapack', 'hipsolver', 'sytrd' and 'ql' (got %r)" % (eig_mode,))
+        lag_ok = groups is None and ((cov_mode == "pooled" and eig_mode in ("lapack", "hipsolver", "sytrd")) or eig_mode == "ql")
         self.eig_lag, self._eig_pending, self._eig_wait = (int(eig_lag) if lag_ok else 0), False, 0
         self.Wc = self.W if self.per_walker else 1
         # parameter groups (PTMCMCSampler.py:129-145): per-group eigenvectors, embedded in the full space
@@ -292,7 +293,7 @@ class PTEngine(object):
         self.eig_epochs = 0
         # a pending device factorization is finished BEHIND the statistics of the next covariance epoch (update_cov); the same on
         # every block of a sharded ladder (from the configuration alone: ShardedPTEngine orders its broadcasts by it)
-        self.late_finish = self.eig_lag > 0 and eig_mode in ("hipsolver", "sytrd") and not stats_async
+        self.late_finish = self.eig_lag > 0 and eig_mode in ("hipsolver", "sytrd", "ql") and not stats_async
         self.stats_async = False
         if stats_async and self.owns_cold:                            # (a block without rank 0 has no statistics to run)
             ok = (not self.per_walker and self.eig_lag >= 1 and self.whole and eig_mode in ("lapack", "hipsolver", "sytrd")
@@ -451,6 +452,9 @@ class PTEngine(object):
                     if self.eig_mode == "sytrd":
                         _lib.check(self.lib.ptmi_eig_sytrd_from(self.h, C.c_void_p(self._side.cuda_stream), C.c_void_p(self._cov_side.data_ptr()),
                                                                 C.c_void_p(self._ut_next.data_ptr()), C.c_void_p(self._s_next.data_ptr())))
+                    elif self.eig_mode == "ql":               # every walker's matrix (or the pooled one): chains of rotations, little of the GPU each
+                        _lib.check(self.lib.ptmi_eig_ql_from(self.h, C.c_void_p(self._side.cuda_stream), C.c_void_p(self._cov_side.data_ptr()),
+                                                             C.c_void_p(self._ut_next.data_ptr()), C.c_void_p(self._s_next.data_ptr())))
                     else:
                         w, V = torch.linalg.eigh(self._cov_side)
                         w, order = w.abs().sort(dim=-1, descending=True, stable=True)
@@ -482,7 +486,7 @@ class PTEngine(object):
     def _eig_finish(self):
         """The pending factorization of the last covariance epoch takes effect (eig_lag launches after it, or at the next epoch)."""
         if self._eig_pending:
-            if self.eig_mode in ("hipsolver", "sytrd"):
+            if self.eig_mode in ("hipsolver", "sytrd", "ql"):
                 self._eig_end_side()
             else:
                 self._eig_end()
@@ -612,6 +616,10 @@ class PTEngine(object):
             # some of them belong to the period that ends here, and am_expand only reaches back to the current period's start:
             # copy that period's repeats forward now, before the ring wraps (the statistics above have taken the run lengths)
             self.am_expand(it_lo=self.am_period(it_done)[0], it_hi=it_done)
+        if self.eig_mode == "ql" and self.eig_lag:
+            self._eig_begin_side()                                    # beside the launches that follow; run() puts it into force
+            self._eig_wait = self.eig_lag
+            return
         if self.eig_mode in ("jacobi", "ql"):                         # stays on the stream: no host synchronisation
             _lib.check(self.lib.ptmi_eig_jacobi(self.h) if self.eig_mode == "jacobi" else self.lib.ptmi_eig_ql(self.h))
             self.eig_epochs += 1
@@ -717,7 +725,7 @@ class PTEngine(object):
         if int(st.get("eig_pending", 0)):
             # the checkpoint fell between a covariance epoch and the launch its table takes effect at: the factorization is
             # issued again from the saved covariance and becomes effective after the same number of launches
-            if self.eig_mode in ("hipsolver", "sytrd"):
+            if self.eig_mode in ("hipsolver", "sytrd", "ql"):
                 self._eig_begin_side()
             else:
                 self._eig_begin()

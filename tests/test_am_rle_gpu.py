@@ -350,3 +350,43 @@ def test_a_device_factorization_beside_step_launches_is_repeatable(mods, d, lag)
         for i, (sa, sb) in enumerate(zip(runs[0], runs[rep])):
             for k in sa:
                 assert_same(sa[k], sb[k], "repeat %d, snapshot %d, %s" % (rep, i, k))
+
+
+@pytest.mark.parametrize("cov_mode,lag", [("per_walker", 1), ("per_walker", 2), ("per_walker", 3), ("per_walker", 6), ("pooled", 2)])
+def test_device_ql_on_the_side_stream_with_eig_lag(mods, cov_mode, lag):
+    """eig_mode="ql" with eig_lag (round 5): every walker's covariance (the replica mode: a walker IS a reference run,
+    PTMCMCSampler.py:769-803), or the pooled one, is factorized by ptmi_eig_ql_from on a side stream beside the launches that follow
+    the epoch; the tables take effect L launches later -- three launches per covariance period here, so lag 3 and 6 finish the
+    pending factorization behind the next epoch's statistics.  HIP == OracleEngine(eig_lag=L, eig_mode="ql") bit for bit,
+    chains, covariances and tables."""
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu, tskip = 20, 4, 6, 30, 10
+    kw = dict(weights=(20, 20, 20), cov_update=cu, burn=60, tskip=tskip, seed=23, cov_mode=cov_mode, eig_mode="ql", cov0=np.eye(d) * 0.01)
+    g, o = _pair(mods, d, nt, W, eig_lag=lag, **kw)
+    assert g.eig_lag == lag and o.eig_lag == lag and g.late_finish
+    for n in (cu + tskip, 7, 3 * cu - 7, 2 * cu + 3):
+        g.run(n)
+        o.run(n)
+        _compare(g, o, "%s lag %d it=%d " % (cov_mode, lag, g.iter))
+        assert_same(g.get("cov"), o.cov, "cov it=%d" % g.iter)
+        assert_same(g.get("Ut"), o.Ut, "Ut it=%d" % g.iter)
+        assert_same(g.get("S"), o.S, "S it=%d" % g.iter)
+    assert g.eig_epochs >= 5
+
+
+def test_checkpoint_with_a_pending_per_walker_factorization(mods):
+    orc, _lib, PTEngine = mods
+    d, nt, W, cu = 20, 3, 5, 30
+    kw = dict(weights=(20, 20, 0), cov_update=cu, burn=1000, tskip=10, seed=29, cov_mode="per_walker", eig_mode="ql", eig_lag=2)
+    a = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    a.init_state(np.zeros(d))
+    a.run(2 * cu + 10)                                            # one launch behind an epoch: its tables are pending
+    st = a.checkpoint()
+    assert st["eig_pending"] == 1
+    a.run(2 * cu + 5)
+    b = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+    b.init_state(np.zeros(d))
+    b.restore(st)
+    b.run(2 * cu + 5)
+    for name in ("X", "lnL", "cov", "Ut", "S", "nacc"):
+        assert_same(a.get(name), b.get(name), name)
