@@ -161,8 +161,6 @@ class ShardedPTEngine(object):
         # stats_async the statistics too) -- and the table is broadcast behind the L-th launch's swap: nobody waits at the broadcast
         # for GPU 0's statistics and factorization.  The same decision on every rank (from the configuration alone).
         self.eig_lag = int(getattr(L, "eig_lag", 0))                       # PTEngine: 0 where the late table does not apply
-        if self.eig_lag and kw.get("eig_mode") == "ql":
-            raise ValueError("eig_lag with eig_mode='ql' is a single-GPU option (the sharded ladder's late broadcast serves 'lapack', 'hipsolver', 'sytrd')")
         self._bcast_pending, self._bcast_wait = False, 0
         # stats_async (PTEngine): the owner switches rings at a covariance epoch, so a DE epoch that falls on it goes first -- on EVERY
         # rank (the epochs' broadcasts are collectives: one order for all), hence from the configuration, not from the local engine

@@ -227,7 +227,8 @@ def test_config5_ladder_8_blocks_of_16_ranks_curved_nuts():
 
 
 @pytest.mark.parametrize("eig_mode,lag,stats_async", [("sytrd", 2, False), ("sytrd", 3, True), ("hipsolver", 2, False), ("lapack", 2, True),
-                                                       ("sytrd", 3, False), ("sytrd", 4, False)])       # a period is three launches: the late finish
+                                                       ("sytrd", 3, False), ("sytrd", 4, False),        # a period is three launches: the late finish
+                                                       ("ql", 2, False), ("ql", 4, False)])             # ptmi_eig_ql_from on the owner's side stream (ndim <= 128)
 def test_sharded_ladder_with_the_owner_factorizing_on_its_side_stream(eig_mode, lag, stats_async):
     """eig_lag = L with the factorization on the owner's side (PTMCMCSampler.py:545-560; ShardedPTEngine): the block that holds rank 0
     runs statistics + ptmi_eig_sytrd / the library's eigensolver (with stats_async the statistics too on the side stream, two AM
@@ -241,7 +242,7 @@ def test_sharded_ladder_with_the_owner_factorizing_on_its_side_stream(eig_mode, 
     from oracle import oracle as orc
     from ptmcmcsampler_amd.engine import PTEngine
     from ptmcmcsampler_amd.sharded import ShardedPTEngine
-    d, nranks, ntb, W, n = 300, 4, 4, 6, 170
+    d, nranks, ntb, W, n = (60 if eig_mode == "ql" else 300), 4, 4, 6, 170
     ntg = nranks * ntb
     kw = dict(weights=(20, 0, 20), cov_update=30, burn=60, tskip=10, seed=11, cov_mode="pooled", eig_mode=eig_mode, eig_lag=lag)
     cov0 = np.eye(d) * 0.01
