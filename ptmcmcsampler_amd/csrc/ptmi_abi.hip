@@ -1093,12 +1093,13 @@ __global__ void welford_mean_kernel(const double *AM, double *mu, int d, int mem
 // draw), am_gemm_kernel computes INC[event][:] = sum_k Ut[k][:] w_event[k] -- 64 events per block, every weight generated in the
 // block from the event's stream, v_mfma_f64_16x16x4 accumulating k ascending: the oracle's fma chain -- and the step kernel
 // reads its increment instead of computing it.
-struct AmEvent { long long it; double cd; u32 sid, pad; };
+struct AmEvent { long long it; double cd; u32 sid, pad /* the pick's parameter group */; };
 struct AmArgs {
     u64 seed;
     long long iter0, nch;
     int nsteps, nt, ntg, temp0, walker0, w_host, w_scam, w_am, w_de, pick_walker;
-    double gcn;
+    int ngroups;                       // parameter groups (PT:129-145): > 1: the pick's group is drawn as propose() draws it
+    const double *gcn;                 // [ngroups] 2.4 / sqrt(2 size of the group) (PT:928)
     const int32_t *temp_of;
     const double *temps_mh;
 };
@@ -1124,8 +1125,14 @@ __device__ __forceinline__ bool am_pick(const AmArgs &p, long long ch, long long
     const bool warm = temp <= 100.0;
     const double sT = warm ? det_sqrt(temp) : 1.0;
     const double base = plo > T97 ? 10.0 : (plo > T90 ? 0.2 : 1.0);
-    e.it = it; e.sid = sid; e.pad = 0;
-    e.cd = p.gcn * (warm ? base * sT : base);
+    u32 g = 0;
+    if (p.ngroups > 1) {               // propose()'s group draw (PT:897): its own Philox call
+        u64 g0, g1;
+        philox_words(p.seed, (u64)it, sid, 2u, g0, g1);
+        g = __umulhi((u32)(g0 >> 32), (u32)p.ngroups);
+    }
+    e.it = it; e.sid = sid; e.pad = g;
+    e.cd = p.gcn[g] * (warm ? base * sT : base);
     return true;
 }
 __global__ void am_count_kernel(const AmArgs p, int32_t *count)
@@ -1137,23 +1144,51 @@ __global__ void am_count_kernel(const AmArgs p, int32_t *count)
     for (int s = 0; s < p.nsteps; ++s) n += am_pick(p, ch, p.iter0 + s, e) ? 1 : 0;
     count[ch] = n;
 }
-// exclusive prefix sums of the chains' counts (one block); base[nch] = the number of events
-__global__ __launch_bounds__(1024) void am_scan_kernel(const int32_t *count, long long *base, long long nch)
+// exclusive prefix sums of the chains' counts, base[nch] = the number of events; two launches of 1024-chain blocks: the blocks' sums, then
+// every block adds up the sums before it and scans its own counts (one block over all chains took 0.44 ms at 262 144 chains: its
+// threads walked the counts 256 apart)
+__device__ __forceinline__ int am_block_scan(int v, int &total, int *wsum /* [16] */)
 {
-    __shared__ long long part[1024];
-    const long long per = (nch + 1023) / 1024, lo = (long long)threadIdx.x * per, hi = lo + per < nch ? lo + per : nch;
-    long long sum = 0;
-    for (long long i = lo; i < hi; ++i) sum += count[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long run = 0;
-        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
-        base[nch] = run;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
     }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    long long run = part[threadIdx.x];
-    for (long long i = lo; i < hi; ++i) { base[i] = run; run += count[i]; }
+    int before = 0, all = 0;
+    for (int w = 0; w < 16; ++w) { const int t = wsum[w]; all += t; if (w < wave) before += t; }
+    total = all;
+    return before + inc - v;                                             // exclusive
+}
+__global__ __launch_bounds__(1024) void am_scan_sums_kernel(const int32_t *count, int32_t *part, long long nch)
+{
+    __shared__ int wsum[16];
+    const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+    int total;
+    (void)am_block_scan(i < nch ? count[i] : 0, total, wsum);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void am_scan_kernel(const int32_t *count, const int32_t *part, long long *base, long long nch)
+{
+    __shared__ int wsum[16];
+    __shared__ long long off_s;
+    __shared__ long long red[16];
+    long long off = 0;
+    for (int j = (int)threadIdx.x; j < (int)blockIdx.x; j += 1024) off += part[j];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) off += __shfl_down(off, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = off;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long t = 0; for (int w = 0; w < 16; ++w) t += red[w]; off_s = t; }
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+    int total;
+    const int ex = am_block_scan(i < nch ? count[i] : 0, total, wsum);
+    if (i < nch) base[i] = off_s + ex;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) base[nch] = off_s + total;
 }
 __global__ void am_fill_kernel(const AmArgs p, const long long *base, AmEvent *ev)
 {
@@ -1169,30 +1204,38 @@ __global__ void am_fill_kernel(const AmArgs p, const long long *base, AmEvent *e
 // (ndim <= 1024) two blocks (blockIdx.y) share an event tile, each with half of the output rows and its own copy of the weights.
 // The weights of 2 G consecutive directions -- G Box-Muller pairs (k, k + G) per event, the pairing of the step kernels -- are
 // generated into LDS one super-chunk ahead of the products that use them.
+// Parameter groups (grp >= 0; PT:129-145, 897): one launch per group with the group's table (its eigenvectors embedded in the full
+// space, rows k < nk = the group's size), the events of the other groups with zero weights and no output -- a block without an event of
+// the group leaves at once.  An event's increment is the k-ascending fma chain over ITS group's rows, as the step kernel's own product.
 template <int G, int MAXT>
 __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, const long long *base, long long nch, int d, const double *Ut,
-                                                        const double *S, u64 seed, double *inc)
+                                                        const double *S, u64 seed, double *inc, int grp, int nk)
 {
     constexpr int NEV = 64, K2 = 2 * G;
     extern __shared__ __attribute__((aligned(16))) double Wl[];          // [2][K2][NEV]
+    __shared__ int evg[NEV];                                             // 1: the event is in this launch's group
     const long long nev = base[nch], e0 = (long long)blockIdx.x * NEV;
     if (e0 >= nev) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const bool ev_on = e0 + lane < nev;
-    const AmEvent me = ev[ev_on ? e0 + lane : e0];
+    const AmEvent me = ev[e0 + lane < nev ? e0 + lane : e0];
+    const bool ev_on = e0 + lane < nev && (grp < 0 || (int)me.pad == grp);
+    if (grp >= 0) {
+        if (__ballot(ev_on) == 0ull) return;                             // (every wave holds the same 64 events: a uniform exit)
+        if (wave == 0) evg[lane] = ev_on ? 1 : 0;
+    }
     ps_d4 acc[MAXT][4];
 #pragma unroll
     for (int tt = 0; tt < MAXT; ++tt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[tt][ct] = ps_d4{0.0, 0.0, 0.0, 0.0};
-    const int ntile = (d + 15) / 16, nsup = (d + K2 - 1) / K2;
+    const int ntile = (d + 15) / 16, nsup = (nk + K2 - 1) / K2;
     const int tile0 = (int)blockIdx.y * 4 * MAXT + wave;               // this wave's first output tile
     auto gen = [&](int m, int buf) {
         for (int kk = wave; kk < G; kk += 4) {                          // pair (k, k + G) of event `lane`
             const int k = m * K2 + kk;
             double wa = 0.0, wb = 0.0;
-            if (ev_on && k < d) {
+            if (ev_on && k < nk) {
                 u64 w0, w1;
                 philox_words(seed, (u64)me.it, me.sid, SLOT_AM + (u32)k, w0, w1);
                 const double r = det_sqrt(-2.0 * unit_log<0>(w0));
@@ -1201,7 +1244,7 @@ __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, cons
                 unit_angle64(w1, aj, at);
                 unit_sincos<0>(aj, at, sn, cs);
                 wa = (r * cs) * me.cd * det_sqrt(S[k]);                   // PT:930
-                if (k + G < d) wb = (r * sn) * me.cd * det_sqrt(S[k + G]);
+                if (k + G < nk) wb = (r * sn) * me.cd * det_sqrt(S[k + G]);
             }
             Wl[((size_t)buf * K2 + kk) * NEV + lane] = wa;
             Wl[((size_t)buf * K2 + kk + G) * NEV + lane] = wb;
@@ -1217,7 +1260,7 @@ __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, cons
         // requested before the 16 matrix instructions of this one -- one wave per SIMD, nothing else hides the round trip, and
         // the 256 accumulation registers leave no room to hold a whole k-step ahead.
         auto rows_of = [&](int k0, int grp, double (&dst)[4]) {
-            const int kr = k0 + g < d ? k0 + g : d - 1;                  // rows past the end: their weights are zero
+            const int kr = k0 + g < nk ? k0 + g : nk - 1;                // rows past the end: their weights are zero
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int col = 16 * (tile0 + 4 * (4 * grp + u)) + c;
@@ -1229,14 +1272,14 @@ __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, cons
 #pragma unroll 1
         for (int ks = 0; ks < K2 / 4; ++ks) {
             const int k0 = m * K2 + 4 * ks;
-            if (k0 >= d) break;                                          // uniform
+            if (k0 >= nk) break;                                         // uniform
             double bq[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) bq[ct] = Wb[(size_t)(4 * ks) * NEV + 16 * ct];
 #pragma unroll
             for (int grp = 0; grp < MAXT / 4; ++grp) {
                 if (grp + 1 < MAXT / 4) rows_of(k0, grp + 1, gn);
-                else rows_of(k0 + 4 < d ? k0 + 4 : k0, 0, gn);
+                else rows_of(k0 + 4 < nk ? k0 + 4 : k0, 0, gn);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (tile0 + 4 * (4 * grp + u) < ntile) {
@@ -1259,7 +1302,7 @@ __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, cons
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * (tile0 + 4 * tt) + g + 4 * r;
                 const long long e = e0 + 16 * ct + c;
-                if (i < d && e < nev) inc[(size_t)e * d + i] = acc[tt][ct][r];
+                if (i < d && e < nev && (grp < 0 || evg[16 * ct + c])) inc[(size_t)e * d + i] = acc[tt][ct][r];
             }
 }
 
@@ -2274,18 +2317,21 @@ static int launch_am_gemm_t(ptmi_engine *h, long long max_events)
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
     }
-    const int ntile = (h->cfg.ndim + 15) / 16, parts = (ntile + 4 * MAXT - 1) / (4 * MAXT);      // blocks per event tile
-    hipLaunchKernelGGL(kern, dim3((unsigned)((max_events + 63) / 64), parts), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
-                       (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, h->cfg.ndim, (const double *)h->buf.Ut,
-                       (const double *)h->buf.S, h->cfg.seed, h->d_am_inc);
+    const int d = h->cfg.ndim, ntile = (d + 15) / 16, parts = (ntile + 4 * MAXT - 1) / (4 * MAXT);      // blocks per event tile
+    const int ngr = h->cfg.ngroups > 1 ? h->cfg.ngroups : 1;
+    for (int g = 0; g < ngr; ++g)                                       // parameter groups: a launch per group with its table (am_gemm_kernel)
+        hipLaunchKernelGGL(kern, dim3((unsigned)((max_events + 63) / 64), parts), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
+                           (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, d, (const double *)h->buf.Ut + (size_t)g * d * d,
+                           (const double *)h->buf.S + (size_t)g * d, h->cfg.seed, h->d_am_inc, ngr > 1 ? g : -1, ngr > 1 ? h->gsize_host[g] : d);
     return PTMI_OK;
 }
 static int launch_am_gemm(ptmi_engine *h, long long max_events)
 {
     const int ntile = (h->cfg.ndim + 15) / 16;                          // output tiles of an increment
+    if (h->G == 4) return launch_am_gemm_t<4, 4>(h, max_events);        // (parameter groups at ndim <= 104: 7 tiles at most)
     if (h->G == 16) return ntile <= 16 ? launch_am_gemm_t<16, 4>(h, max_events) : launch_am_gemm_t<16, 8>(h, max_events);
     if (h->G == 64) return launch_am_gemm_t<64, 8>(h, max_events);
-    return fail(PTMI_EINVAL, "AM increments ahead of the launch are built for the 16- and 64-lane shapes");
+    return fail(PTMI_EINVAL, "AM increments ahead of the launch: unknown shape");
 }
 
 extern "C" {
@@ -2498,7 +2544,10 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         }
     }
     // AM increments ahead of the launch (am_gemm_kernel): the 16- and 64-lane shapes with one pooled table, ndim <= 1024
-    if (e == hipSuccess && !gshape && c.w_am > 0 && !c.cov_per_walker && c.ngroups <= 1 && s.G > 4 && c.ndim <= 1024 && c.w_host == 0 &&
+    // ... and every shape with parameter groups (PT:129-145: a chain's pick has its own group, hence its own table: the step kernels'
+    // matrix-core product shares one table between the 16 chains of a wave, and the vector-pipe product they fall back to takes
+    // 284 ms per 100 steps of the default mix at 64 x 4096 x 100-d with three groups -- 35 times the one-group kernel)
+    if (e == hipSuccess && !gshape && c.w_am > 0 && !c.cov_per_walker && (c.ngroups > 1 || s.G > 4) && c.ndim <= 1024 && c.w_host == 0 &&
         !getenv("PTMI_NO_AM_AHEAD")) {
         const long long nch = (long long)c.nwalkers * c.ntemps;
         const char *mb = getenv("PTMI_AM_BUDGET_MB");                    // scratch for the increments of one piece of a launch (default 6 GB)
@@ -2508,7 +2557,7 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         h->am_piece = (int)piece;
         h->am_cap = nch * piece;
         e = hipMalloc((void **)&h->d_am_ev, sizeof(AmEvent) * (size_t)h->am_cap);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_count, sizeof(int32_t) * (size_t)nch);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_count, sizeof(int32_t) * (size_t)(nch + (nch + 1023) / 1024));      // counts | the scan's block sums
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_base, sizeof(long long) * (size_t)(nch + 1));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_inc, sizeof(double) * (size_t)h->am_cap * c.ndim);
     }
@@ -2648,11 +2697,14 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             AmArgs p;
             p.seed = c.seed; p.iter0 = iter0 + s0; p.nch = nch; p.nsteps = ns; p.nt = c.ntemps; p.ntg = c.ntemps_global; p.temp0 = c.temp0;
             p.walker0 = c.walker0; p.w_host = c.w_host; p.w_scam = c.w_scam; p.w_am = c.w_am; p.w_de = h->de_on ? c.w_de : 0;
-            p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.gcn = 2.4 / sqrt(2.0 * (double)c.ndim);
+            p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.ngroups = c.ngroups > 1 ? c.ngroups : 1; p.gcn = h->d_gcn;
             p.temp_of = h->buf.temp_of; p.temps_mh = h->d_temps;
             const unsigned gch = (unsigned)((nch + 255) / 256);
             hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count);
-            hipLaunchKernelGGL(am_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, h->d_am_base, nch);
+            const unsigned gsc = (unsigned)((nch + 1023) / 1024);
+            hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, h->d_am_count + nch, nch);
+            hipLaunchKernelGGL(am_scan_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, (const int32_t *)(h->d_am_count + nch),
+                               h->d_am_base, nch);
             hipLaunchKernelGGL(am_fill_kernel, dim3(gch), dim3(256), 0, h->stream, p, (const long long *)h->d_am_base, (AmEvent *)h->d_am_ev);
             if (int rc = launch_am_gemm(h, nch * ns)) return rc;
             KArgs ap = make_args(h);
