@@ -1135,14 +1135,40 @@ __device__ __forceinline__ bool am_pick(const AmArgs &p, long long ch, long long
     e.cd = p.gcn[g] * (warm ? base * sT : base);
     return true;
 }
-__global__ void am_count_kernel(const AmArgs p, int32_t *count)
+// (gtot: with parameter groups the picks per group, [ngroups] zeroed by the caller: the block's histogram first)
+constexpr int AM_MAXG = 1024;         // = the ABI's limit on ngroups
+__global__ __launch_bounds__(256) void am_count_kernel(const AmArgs p, int32_t *count, int32_t *gtot)
 {
+    __shared__ int32_t lh[AM_MAXG];
+    if (gtot)
+        for (int g = (int)threadIdx.x; g < p.ngroups; g += 256) lh[g] = 0;
+    if (gtot) __syncthreads();
     const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= p.nch) return;
-    int n = 0;
-    AmEvent e;
-    for (int s = 0; s < p.nsteps; ++s) n += am_pick(p, ch, p.iter0 + s, e) ? 1 : 0;
-    count[ch] = n;
+    if (ch < p.nch) {
+        int n = 0;
+        AmEvent e;
+        for (int s = 0; s < p.nsteps; ++s)
+            if (am_pick(p, ch, p.iter0 + s, e)) {
+                n += 1;
+                if (gtot) atomicAdd(&lh[e.pad], 1);
+            }
+        count[ch] = n;
+    }
+    if (gtot) {
+        __syncthreads();
+        for (int g = (int)threadIdx.x; g < p.ngroups; g += 256)
+            if (lh[g]) atomicAdd(&gtot[g], lh[g]);
+    }
+}
+// gbase[g] = the picks of the groups before g (gbase[ngroups] = all), the fill's cursors zeroed: one block
+__global__ __launch_bounds__(64) void am_group_scan_kernel(const int32_t *gtot, int32_t *gbase, int32_t *cursor, int ngroups)
+{
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int g = 0; g < ngroups; ++g) { gbase[g] = run; run += gtot[g]; }
+        gbase[ngroups] = run;
+    }
+    for (int g = (int)threadIdx.x; g < ngroups; g += 64) cursor[g] = 0;
 }
 // exclusive prefix sums of the chains' counts, base[nch] = the number of events; two launches of 1024-chain blocks: the blocks' sums, then
 // every block adds up the sums before it and scans its own counts (one block over all chains took 0.44 ms at 262 144 chains: its
@@ -1190,40 +1216,62 @@ __global__ __launch_bounds__(1024) void am_scan_kernel(const int32_t *count, con
     if (i < nch) base[i] = off_s + ex;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) base[nch] = off_s + total;
 }
-__global__ void am_fill_kernel(const AmArgs p, const long long *base, AmEvent *ev)
+// The events in chain order (the step kernel walks its chain's increments in step order); with parameter groups also perm: the
+// events' indices listed group by group (group g: perm[gbase[g] ...), in no particular order inside a group -- an event's increment
+// does not depend on its neighbours), so that a block of am_gemm_kernel holds 64 events of ONE group and multiplies by that group's
+// rows only.  A block reserves its share of every group's list with one atomic per group.
+__global__ __launch_bounds__(256) void am_fill_kernel(const AmArgs p, const long long *base, AmEvent *ev, const int32_t *gbase, int32_t *cursor, int32_t *perm)
 {
+    __shared__ int32_t lh[AM_MAXG], lb[AM_MAXG];
     const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    AmEvent e;
+    if (perm) {
+        for (int g = (int)threadIdx.x; g < p.ngroups; g += 256) lh[g] = 0;
+        __syncthreads();
+        if (ch < p.nch)
+            for (int s = 0; s < p.nsteps; ++s)
+                if (am_pick(p, ch, p.iter0 + s, e)) atomicAdd(&lh[e.pad], 1);
+        __syncthreads();
+        for (int g = (int)threadIdx.x; g < p.ngroups; g += 256) {
+            lb[g] = lh[g] ? gbase[g] + atomicAdd(&cursor[g], lh[g]) : 0;
+            lh[g] = 0;
+        }
+        __syncthreads();
+    }
     if (ch >= p.nch) return;
     long long at = base[ch];
-    AmEvent e;
     for (int s = 0; s < p.nsteps; ++s)
-        if (am_pick(p, ch, p.iter0 + s, e)) ev[at++] = e;
+        if (am_pick(p, ch, p.iter0 + s, e)) {
+            if (perm) perm[lb[e.pad] + atomicAdd(&lh[e.pad], 1)] = (int32_t)at;
+            ev[at++] = e;
+        }
 }
 // 64 events per block of four waves; wave v holds the output tiles v, v + 4, ... (16 rows of the increment each) of all four event
 // tiles: at most 8 x 4 tiles of 8 registers = the 256 accumulation registers, i.e. 512 rows of the increment per block.  Beyond
 // (ndim <= 1024) two blocks (blockIdx.y) share an event tile, each with half of the output rows and its own copy of the weights.
 // The weights of 2 G consecutive directions -- G Box-Muller pairs (k, k + G) per event, the pairing of the step kernels -- are
 // generated into LDS one super-chunk ahead of the products that use them.
-// Parameter groups (grp >= 0; PT:129-145, 897): one launch per group with the group's table (its eigenvectors embedded in the full
-// space, rows k < nk = the group's size), the events of the other groups with zero weights and no output -- a block without an event of
-// the group leaves at once.  An event's increment is the k-ascending fma chain over ITS group's rows, as the step kernel's own product.
+// Parameter groups (PT:129-145, 897): one launch per group with the group's table (its eigenvectors embedded in the full space, rows
+// k < nk = the group's size) over the group's list of events (am_fill_kernel's perm): an event's increment is the k-ascending fma
+// chain over ITS group's rows, as the step kernel's own product, and lands in the event's row of inc.
 template <int G, int MAXT>
 __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, const long long *base, long long nch, int d, const double *Ut,
-                                                        const double *S, u64 seed, double *inc, int grp, int nk)
+                                                        const double *S, u64 seed, double *inc, int nk, const int32_t *gseg /* {first, end} of the group's list */,
+                                                        const int32_t *perm)
 {
     constexpr int NEV = 64, K2 = 2 * G;
     extern __shared__ __attribute__((aligned(16))) double Wl[];          // [2][K2][NEV]
-    __shared__ int evg[NEV];                                             // 1: the event is in this launch's group
-    const long long nev = base[nch], e0 = (long long)blockIdx.x * NEV;
+    __shared__ int32_t evi[NEV];                                         // parameter groups: the events' indices (their rows of inc)
+    // one group (perm == nullptr): the events e0 .. of the chain-ordered list; else entries e0 .. of the group's list
+    const long long nev = perm ? (long long)(gseg[1] - gseg[0]) : base[nch], e0 = (long long)blockIdx.x * NEV;
     if (e0 >= nev) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const AmEvent me = ev[e0 + lane < nev ? e0 + lane : e0];
-    const bool ev_on = e0 + lane < nev && (grp < 0 || (int)me.pad == grp);
-    if (grp >= 0) {
-        if (__ballot(ev_on) == 0ull) return;                             // (every wave holds the same 64 events: a uniform exit)
-        if (wave == 0) evg[lane] = ev_on ? 1 : 0;
-    }
+    const bool ev_on = e0 + lane < nev;
+    const long long mine = ev_on ? e0 + lane : e0;
+    const long long ei = perm ? (long long)perm[gseg[0] + mine] : mine;
+    const AmEvent me = ev[ei];
+    if (perm && wave == 0) evi[lane] = (int32_t)ei;
     ps_d4 acc[MAXT][4];
 #pragma unroll
     for (int tt = 0; tt < MAXT; ++tt)
@@ -1302,7 +1350,7 @@ __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, cons
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * (tile0 + 4 * tt) + g + 4 * r;
                 const long long e = e0 + 16 * ct + c;
-                if (i < d && e < nev && (grp < 0 || evg[16 * ct + c])) inc[(size_t)e * d + i] = acc[tt][ct][r];
+                if (i < d && e < nev) inc[(size_t)(perm ? (long long)evi[16 * ct + c] : e) * d + i] = acc[tt][ct][r];
             }
 }
 
@@ -2322,7 +2370,8 @@ static int launch_am_gemm_t(ptmi_engine *h, long long max_events)
     for (int g = 0; g < ngr; ++g)                                       // parameter groups: a launch per group with its table (am_gemm_kernel)
         hipLaunchKernelGGL(kern, dim3((unsigned)((max_events + 63) / 64), parts), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
                            (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, d, (const double *)h->buf.Ut + (size_t)g * d * d,
-                           (const double *)h->buf.S + (size_t)g * d, h->cfg.seed, h->d_am_inc, ngr > 1 ? g : -1, ngr > 1 ? h->gsize_host[g] : d);
+                           (const double *)h->buf.S + (size_t)g * d, h->cfg.seed, h->d_am_inc, ngr > 1 ? h->gsize_host[g] : d,
+                           ngr > 1 ? (const int32_t *)(h->d_am_grp + ngr + g) : nullptr, ngr > 1 ? (const int32_t *)h->d_am_perm : nullptr);
     return PTMI_OK;
 }
 static int launch_am_gemm(ptmi_engine *h, long long max_events)
@@ -2560,6 +2609,11 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_count, sizeof(int32_t) * (size_t)(nch + (nch + 1023) / 1024));      // counts | the scan's block sums
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_base, sizeof(long long) * (size_t)(nch + 1));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_inc, sizeof(double) * (size_t)h->am_cap * c.ndim);
+        if (e == hipSuccess && c.ngroups > 1) {                          // the events listed group by group: totals | list starts (+ the end) | cursors
+            if (h->am_cap > 0x7FFFFFFFLL) e = hipErrorInvalidValue;
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_grp, sizeof(int32_t) * (3 * (size_t)c.ngroups + 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_perm, sizeof(int32_t) * (size_t)h->am_cap);
+        }
     }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
@@ -2588,6 +2642,7 @@ int ptmi_destroy(ptmi_handle h)
     }
     (void)hipFree(h->d_rle_ent); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
+    (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->side_go); (void)hipEventDestroy(h->side_done); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2700,12 +2755,17 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.ngroups = c.ngroups > 1 ? c.ngroups : 1; p.gcn = h->d_gcn;
             p.temp_of = h->buf.temp_of; p.temps_mh = h->d_temps;
             const unsigned gch = (unsigned)((nch + 255) / 256);
-            hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count);
+            const int ngr = p.ngroups;
+            int32_t *gtot = ngr > 1 ? h->d_am_grp : nullptr, *gbase = gtot ? gtot + ngr : nullptr, *gcur = gtot ? gtot + 2 * ngr + 1 : nullptr;
+            if (gtot) HIPCHK(hipMemsetAsync(gtot, 0, sizeof(int32_t) * (size_t)ngr, h->stream));
+            hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count, gtot);
+            if (gtot) hipLaunchKernelGGL(am_group_scan_kernel, dim3(1), dim3(64), 0, h->stream, (const int32_t *)gtot, gbase, gcur, ngr);
             const unsigned gsc = (unsigned)((nch + 1023) / 1024);
             hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, h->d_am_count + nch, nch);
             hipLaunchKernelGGL(am_scan_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, (const int32_t *)(h->d_am_count + nch),
                                h->d_am_base, nch);
-            hipLaunchKernelGGL(am_fill_kernel, dim3(gch), dim3(256), 0, h->stream, p, (const long long *)h->d_am_base, (AmEvent *)h->d_am_ev);
+            hipLaunchKernelGGL(am_fill_kernel, dim3(gch), dim3(256), 0, h->stream, p, (const long long *)h->d_am_base, (AmEvent *)h->d_am_ev,
+                               (const int32_t *)gbase, gcur, gtot ? h->d_am_perm : nullptr);
             if (int rc = launch_am_gemm(h, nch * ns)) return rc;
             KArgs ap = make_args(h);
             ap.iter0 = iter0 + s0; ap.nsteps = ns;

@@ -141,6 +141,7 @@ struct ptmi_engine {
     int32_t *d_am_count;
     long long *d_am_base;
     double *d_am_inc;
+    int32_t *d_am_grp, *d_am_perm;     // parameter groups: picks per group | list starts | cursors; the events' indices group by group
     long long am_cap;
     int am_piece;       // steps per piece (0: the path is off for this engine)
     double *d_pool_part, *d_pool_T;  // pooled covariance: the slabs' partial sums [nslab][d][d+1] and their total [d][d+1] (column d: the column sums)
