@@ -512,9 +512,14 @@ __device__ __forceinline__ double lane_xor16(double v)
     return __longlong_as_double((long long)(((u64)h << 32) | l));
 }
 
-template <int EPL, int LOGL>
+// GC = 16 (round 5; kernel shape (16, 7), ndim <= 64, diagonal whitening): the chain's sixteen lane groups are the wave's sixteen quads,
+// element i = g + 16 e in lane 4 g + e -- the 16-lane order of a dot product is then a chain along the quad (quad_perm shifts) and the
+// butterfly g ^ 8, 4, 2, 1 = lane ^ 32, 16, 8, 4 in the vector pipe (v_permlane32/16_swap, row rotations); the Box-Muller partners
+// (k, k + 16) are quad neighbours.  The template's EPL is then LD / 4 = 16.
+template <int EPL, int LOGL, int GC = 4>
 struct GradJumpWide {
-    static constexpr int G = 4, LD = 4 * EPL;
+    static constexpr int G = GC, NS = GC == 4 ? EPL : 4 /* slots of a lane group */, LD = GC * NS, LEV = gjw_level_doubles(LD / 4);
+    static_assert(GC == 4 || (GC == 16 && EPL == 16), "whole-wave layouts: 4 lane groups in rows of 16 lanes, or 16 lane groups in quads");
     const KArgs &a;
     const int d, L, we, wg, wi;
     const bool act;                  // this lane holds an element of the chain's vectors
@@ -532,7 +537,7 @@ struct GradJumpWide {
 #endif
 
     __device__ __forceinline__ GradJumpWide(const KArgs &a_, long long ch_, double beta_, long long it_, u32 sid_, int vb_)
-        : a(a_), d(a_.d), L((int)threadIdx.x), we(L & 15), wg(L >> 4), wi(wg + 4 * we), act(we < EPL && wi < a_.d), col(act ? wi : 0),
+        : a(a_), d(a_.d), L((int)threadIdx.x), we(GC == 4 ? (L & 15) : (L & 3)), wg(GC == 4 ? (L >> 4) : (L >> 2)), wi(wg + GC * we), act(we < NS && wi < a_.d), col(act ? wi : 0),
           ch(ch_), nch((long long)a_.W * a_.nt), beta(beta_), it(it_), sid(sid_), vb(vb_)
     {
         if (a.logp_kind == PTMI_LOGP_BOX) { blo = a.logp_par[col]; bhi = a.logp_par[d + col]; }
@@ -545,7 +550,7 @@ struct GradJumpWide {
         const u32 block = nm++;
         double r = 0.0;
         if (act) {
-            const int k = wg + 4 * (we & ~1);
+            const int k = wg + GC * (we & ~1);
             u64 e0, e1;
             philox_words(a.seed, (u64)it, sid, SLOT_GJ + 4096u * block + (u32)k, e0, e1);
             const double rr = det_sqrt(-2.0 * det_log(w2uniform_open(e0)));
@@ -585,12 +590,27 @@ struct GradJumpWide {
     __device__ __forceinline__ double row_chain(double x, double y) const
     {
         double p = 0.0;
+        if constexpr (GC == 4) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) p = __builtin_fma(x, y, dppf64<0x111>(p));      // row_shr:1, 0 into lane 0
+            for (int e = 0; e < EPL; ++e) p = __builtin_fma(x, y, dppf64<0x111>(p));      // row_shr:1, 0 into lane 0
+        } else {                                                         // along the quad: quad_perm [0, 0, 1, 2], the first lane starts from 0
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                const double left = dppf64<0x90>(p);
+                p = __builtin_fma(x, y, we == 0 ? 0.0 : left);
+            }
+        }
         return p;
     }
     __device__ __forceinline__ double rows_sum(double p) const
     {
+        if constexpr (GC == 16) {                                       // group_sum<16>'s butterfly over the lane groups, the chains' ends in lane 3 of the quads
+            double s = sum_xor32(p);                                     // g ^ 8
+            s = sum_xor16(s);                                            // g ^ 4
+            s = s + dppf64<0x128>(s);                                    // g ^ 2: row_ror:8
+            s = s + dppf64<0x124>(s);                                    // g ^ 1: row_ror:4 on data of period 8
+            return quad_bcastf<3>(s);
+        }
         const double p0 = lane_get(p, EPL - 1), p1 = lane_get(p, 16 + EPL - 1), p2 = lane_get(p, 32 + EPL - 1), p3 = lane_get(p, 48 + EPL - 1);
         return (p0 + p2) + (p1 + p3);
     }
@@ -612,6 +632,8 @@ struct GradJumpWide {
             GJP_ADD(GJP_TABVEC, t0);
             return r;
         }
+        if constexpr (GC == 16) { __builtin_trap(); return 0.0; }       // (the 16-group layout runs with diagonal whitening and no dense likelihood: the host picks it then)
+        else {
         // The vector goes through LDS in element order and every lane reads all of it back (same address for the whole wave:
         // a broadcast); two readlanes per term instead had each fma wait on a fresh scalar pair.  Straight-line on purpose:
         // with a (wave-uniform) branch around every term each table read waited for its own LDS round trip -- 2 400 cycles
@@ -640,6 +662,7 @@ struct GradJumpWide {
         }
         GJP_ADD(GJP_TABVEC, t0);
         return act ? acc : 0.0;
+        }
     }
     __device__ __forceinline__ double logl_grad(double x, double &g) const
     {
@@ -665,9 +688,13 @@ struct GradJumpWide {
             GJP_ADD(GJP_LOGL, t0);
             return r;
         } else {
-            const double other = lane_xor16(x);                            // the pair's other member: lane group g ^ 1, same slot
+            auto partner = [&](double v) {                                 // the pair's other member: lane group g ^ 1, same slot
+                if constexpr (GC == 4) return lane_xor16(v);
+                else return __shfl_xor(v, 4, 64);
+            };
+            const double other = partner(x);
             const bool even = !(wg & 1);
-            const bool pair = we < EPL && (even ? wi + 1 < d : wi < d);
+            const bool pair = we < NS && (even ? wi + 1 < d : wi < d);
             const double xx = even ? x : other, y = even ? other : x;
             const double x2 = xx * xx;
             const double gg = 9.0 + 4.0 * x2 + 9.0 * y;
@@ -675,7 +702,7 @@ struct GradJumpWide {
             const double ym = y - 2.0;
             const double l1 = -8.0 * x2 - 8.0 * (ym * ym);
             // both lanes of a pair hold the same l0 and l1: the even one takes exp(l0), the odd one exp(l1), and they trade
-            const double ex = det_exp(even ? l0 : l1), ox = lane_xor16(ex);
+            const double ex = det_exp(even ? l0 : l1), ox = partner(ex);
             const double e0 = even ? ex : ox, e1 = 0.5 * (even ? ox : ex);
             const double sum = e0 + e1;
             const double tl = det_log(sum);                                // wanted on the even lanes only; same cost for the wave
@@ -782,10 +809,10 @@ struct GradJumpWide {
     // gj_lds_levels (11: trees of up to 2^11 leapfrogs) are in the block's LDS; the higher ones -- the reference doubles without a
     // cap (NJ:716-802), the ABI allows 24 -- in the wave's slice of the global scratch: reached once in 2^h leapfrogs, if ever,
     // so only their correctness matters (keeping all 25 in LDS cost the config-5 kernel 25 %: five waves per CU instead of eight)
-    __device__ __forceinline__ int slot_of(int h) const { return a.gj_stack_off + h * gjw_level_doubles(EPL); }
+    __device__ __forceinline__ int slot_of(int h) const { return a.gj_stack_off + h * LEV; }
     __device__ __forceinline__ double *glevel(int h) const
     {
-        return a.gj_scr + ((size_t)blockIdx.x * (size_t)(a.nuts_maxdepth + 1) + (size_t)h) * gjw_level_doubles(EPL);
+        return a.gj_scr + ((size_t)blockIdx.x * (size_t)(a.nuts_maxdepth + 1) + (size_t)h) * LEV;
     }
     // NJ:495-652 as a loop, as GradJump::build_tree
     __device__ __forceinline__ void build_tree(double &tg, double &rg, double &gg, double logu, int v, int j, double eps, double joint0, Tree &cur)
@@ -1416,16 +1443,20 @@ constexpr int GJ_BLOCK = 64;
 #define PTMI_GJ_WPE 2
 #endif
 // PAIR (4-lane shapes, diagonal whitening, iso / curved families): two gradient jumps at a time, a half-wave each (GradJumpPair)
-template <int G, int EPL, int LOGL, bool PAIR = false>
-__global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) void mh_steps_gj_kernel(const KArgs a)
+// W16 (the 16-lane shape at ndim <= 64, diagonal whitening, no dense likelihood): a gradient jump takes the whole wave there too
+// (GradJumpWide<16, LOGL, 16>: one element per lane instead of seven slots of every vector in each of the chain's 16 lanes)
+template <int G, int EPL, int LOGL, bool PAIR = false, bool W16 = false>
+__global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_WPE : 1) void mh_steps_gj_kernel(const KArgs a)
 {
     static_assert(!PAIR || (G == 4 && EPL <= 8 && LOGL != PTMI_LOGL_DENSE), "the pair layout serves the 4-lane shapes without table products");
+    static_assert(!W16 || (G == 16 && LOGL != PTMI_LOGL_DENSE && !PAIR), "the 16-group whole-wave layout serves the 16-lane shape without table products");
     constexpr int CPB = GJ_BLOCK / G;
-    constexpr bool WIDE = G == 4;                // a gradient jump takes the whole wave (GradJumpWide)
+    constexpr bool WIDE = G == 4 || W16;         // a gradient jump takes the whole wave (GradJumpWide)
+    constexpr int WEPL = W16 ? 16 : EPL, WNS = W16 ? 4 : EPL;          // GradJumpWide's EPL (LD / 4); slots of a lane that hold elements in its layout
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
     if (WIDE) {
-        constexpr int LD = 4 * EPL;
+        constexpr int LD = 4 * WEPL;
         if (a.gj_diag) {                         // diagonal whitening: the three diagonals (3 LD doubles instead of 3 LD^2: 0.5 KB instead of 9.6 KB at d = 20)
             for (int i = (int)threadIdx.x; i < 3 * LD; i += GJ_BLOCK) {
                 const int w = i / LD, c = i % LD;
@@ -1560,18 +1591,19 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
             // one chain after the other, each on all 64 lanes: its row goes through LDS into the whole-wave layout and the
             // proposal comes back the same way; everything in between is wave-uniform
             u64 todo = __ballot(is_gj && live);
-            const int xch = a.gj_stack_off + a.gj_lds_levels * gjw_level_doubles(EPL);
+            const int xch = a.gj_stack_off + a.gj_lds_levels * gjw_level_doubles(WEPL);
             const int L = (int)threadIdx.x;
+            constexpr int XS = W16 ? 4 : 16;                                     // a lane group's elements sit XS apart in the whole-wave layout
             while (todo) {
                 const int lane0 = (int)__builtin_ctzll(todo);                    // first lane of the chain
-                todo &= ~(0xFull << lane0);
-                const bool mine = (L & ~3) == lane0;
+                todo &= ~((G == 4 ? 0xFull : 0xFFFFull) << lane0);
+                const bool mine = (L & ~(G - 1)) == lane0;
                 if (mine) {
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) gj_lds[xch + 16 * gl + e] = x[e];
+                    for (int e = 0; e < WNS; ++e) gj_lds[xch + XS * gl + e] = x[e];
                 }
                 __syncthreads();
-                const double xw = (L & 15) < EPL ? gj_lds[xch + L] : 0.0;
+                const double xw = (W16 || (L & 15) < EPL) ? gj_lds[xch + L] : 0.0;
                 const long long ch_c = ((long long)__builtin_amdgcn_readlane((int)(ch >> 32), lane0) << 32) | (u32)__builtin_amdgcn_readlane((int)ch, lane0);
                 const double beta_c = lane_get(beta, lane0);
                 const u32 sid_c = (u32)__builtin_amdgcn_readlane((int)sid, lane0);
@@ -1579,7 +1611,7 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
                 const int w_c = (int)(ch_c / nt), t_c = __builtin_amdgcn_readlane(t, lane0);
                 double *stc = a.gj + ((size_t)w_c * nt + t_c) * GJ_NSTATE;
                 double qw;
-                GradJumpWide<EPL, LOGL> gj(a, ch_c, beta_c, it, sid_c, xch);
+                GradJumpWide<WEPL, LOGL, W16 ? 16 : 4> gj(a, ch_c, beta_c, it, sid_c, xch);
                 double st[GJ_NSTATE];
 #pragma unroll
                 for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stc[j];
@@ -1601,7 +1633,7 @@ __global__ __launch_bounds__(GJ_BLOCK, (G == 4 && EPL <= 5) ? PTMI_GJ_WPE : 1) v
                 __syncthreads();
                 if (mine) {
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) q[e] = gj_lds[xch + 16 * gl + e];
+                    for (int e = 0; e < EPL; ++e) q[e] = e < WNS ? gj_lds[xch + XS * gl + e] : 0.0;       // (W16: ndim <= 64, the slots beyond hold no element)
                     qxy = qxy_c;
                 }
                 __syncthreads();                 // the exchange area is free for the next chain

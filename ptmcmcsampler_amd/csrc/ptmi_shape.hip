@@ -41,7 +41,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
             // one level per height | the exchange area of the layout change (64 doubles) | box bounds of the 4-lane test.
             // Wider shapes: lowest levels of the tree stack | box bounds.
             size_t off = 0;
-            bool pair = false;
+            bool pair = false, w16 = false;
             const size_t box = h->cfg.logp_kind == PTMI_LOGP_BOX ? (size_t)box_table_doubles(G, E) : 0;
             static const char *lv = getenv("PTMI_GJ_LDS_LEVELS");       // measurement / test switch: same results for any value
             if constexpr (G == 4) {
@@ -56,6 +56,16 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
                 // one-chain-per-wave layout (a measurement / test switch, same results)
                 pair = a.gj_diag && L != PTMI_LOGL_DENSE && getenv("PTMI_GJ_NOPAIR") == nullptr;
                 off += (size_t)(pair ? 2 : 1) * a.gj_lds_levels * gjw_level_doubles(E) + (pair ? 72 + 2 * GJ_BLOCK : 64);       // pair: + the 16 chains' step-size states
+            } else if (G == 16 && L != PTMI_LOGL_DENSE && a.gj_diag && a.d <= 64 && getenv("PTMI_GJ_NOWIDE16") == nullptr) {
+                // the 16-lane shape at ndim <= 64 with diagonal whitening: a gradient jump takes the whole wave (GradJumpWide<16, L, 16>,
+                // one element per lane); PTMI_GJ_NOWIDE16: the per-chain layout (a measurement / test switch, same results)
+                w16 = true;
+                off = (size_t)(3 * 64);                                     // the three diagonals
+                a.gj_stack_off = (int)off;
+                int levels = h->cfg.nuts_maxdepth + 1 < 11 ? h->cfg.nuts_maxdepth + 1 : 11;
+                if (lv) levels = atoi(lv) < levels ? atoi(lv) : levels;
+                a.gj_lds_levels = levels;
+                off += (size_t)levels * gjw_level_doubles(16) + 64;
             } else {
                 const size_t budget = 40 * 1024 / sizeof(double);           // one wave per SIMD (register count): a quarter of the CU's LDS each
                 int levels = box < budget ? (int)((budget - box) / gj_level_doubles(E)) : 0;
@@ -75,6 +85,12 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
                         if (e != hipSuccess) return fail(PTMI_EHIP, "hipFuncSetAttribute(%zu B of LDS): %s", sizeof(double) * off, hipGetErrorString(e));
                     }
                     hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L, true>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK), sizeof(double) * off, h->stream, a);
+                    return PTMI_OK;
+                }
+            }
+            if constexpr (G == 16 && L != PTMI_LOGL_DENSE) {
+                if (w16) {
+                    hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L, false, true>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK), sizeof(double) * off, h->stream, a);
                     return PTMI_OK;
                 }
             }

@@ -55,16 +55,27 @@ CASES = [
     dict(d=20, nt=2, W=4, logl=("interval", -2.0, 3.0), logp=("flat",), grad_weights=(20, 5), weights=(5, 0, 5)),
     dict(d=130, nt=2, W=2, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0), hmc=(0.2, 2, 20), diag=True),
     dict(d=40, nt=3, W=4, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(0, 0), weights=(10, 10, 10)),
+    # the 16-lane shape at ndim <= 64 with a diagonal covariance: a gradient jump takes the whole wave, one element per lane, the chain's 16
+    # lane groups in the wave's quads (GradJumpWide<16, L, 16>; the reference's test_nuts covariance -- from the Hessian of a target that
+    # factorizes -- is diagonal); the boundaries 33 and 64, a box prior, the curved family's partner lanes, a tree cap
+    dict(d=40, nt=2, W=5, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.4, 2, 100), diag=True),
+    dict(d=33, nt=3, W=3, logl=("iso",), logp=("box", -3.0, 3.0), grad_weights=(20, 5), weights=(5, 0, 5), diag=True),
+    dict(d=64, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 0), diag=True),
+    dict(d=34, nt=2, W=3, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 0, 10), hmc=(0.08, 2, 50), diag=True),
+    dict(d=50, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=2, diag=True),
+    dict(d=40, nt=2, W=3, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0), diag=True, nowide16=True),
     dict(d=7, nt=3, W=4, logl=("interval", -1.0, 1.0), logp=("flat",), grad_weights=(0, 0), weights=(10, 0, 10)),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else "",
-                                                                       "-diag" if c.get("diag") else "", "" if sum(c["grad_weights"]) else "-nogj"))
+                                                                       "-diag" if c.get("diag") else "", ("" if sum(c["grad_weights"]) else "-nogj") + ("-nowide16" if c.get("nowide16") else "")))
 def test_device_gradient_jumps_bit_exact(case, monkeypatch):
     c = dict(case)
     d, nt, W = c.pop("d"), c.pop("nt"), c.pop("W")
     diag = c.pop("diag", False)
+    if c.pop("nowide16", False):
+        monkeypatch.setenv("PTMI_GJ_NOWIDE16", "1")               # the per-chain layout with the same diagonal tables
     if diag and d == 7:
         monkeypatch.setenv("PTMI_GJ_NOPAIR", "1")                 # the one-chain-per-wave layout with diagonal tables (the default pairs two chains per wave)
     rs = np.random.RandomState(d)
