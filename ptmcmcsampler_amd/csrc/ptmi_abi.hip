@@ -2191,7 +2191,7 @@ __global__ void gj_order_scan_kernel(int32_t *bucket)
     int32_t run = 0;
     for (int b = 0; b < GJ_BUCKETS; ++b) { bucket[GJ_BUCKETS + b] = run; run += bucket[b]; bucket[2 * GJ_BUCKETS + b] = 0; }
 }
-__global__ void gj_order_fill_kernel(const double *gj, const int32_t *temp_of, long long nch, int nt, int32_t *bucket, int32_t *order, int cpw)
+__global__ void gj_order_fill_kernel(const double *gj, const int32_t *temp_of, long long nch, int nt, int32_t *bucket, int32_t *order, int cpw, int nsolo)
 {
     // a block reserves its share of every class with one atomic per class; inside the block the order is by thread
     __shared__ int32_t local[GJ_BUCKETS], base[GJ_BUCKETS];
@@ -2208,8 +2208,12 @@ __global__ void gj_order_fill_kernel(const double *gj, const int32_t *temp_of, l
     // rank t in the sorted list (longest trees first) -> chain slot: consecutive ranks go to DIFFERENT waves, so the few
     // chains with long trees are dealt one per wave and a launch lasts as long as its slowest chain, not the slowest sum
     const long long t = bucket[GJ_BUCKETS + b] + base[b] + mine;
-    const long long nw = nch / cpw, whole = nw * cpw;
-    order[t < whole ? (t % nw) * cpw + t / nw : t] = (int32_t)ch;
+    // the first nsolo chains of the list (the longest trees) get a wave each -- its first chain slot, the others stay empty (-1: the
+    // caller fills the array with it) -- and the rest is dealt over the waves behind them
+    if (t < nsolo) { order[t * cpw] = (int32_t)ch; return; }
+    const long long tr = t - nsolo, nrest = nch - nsolo;
+    const long long nw = nrest / cpw, whole = nw * cpw;
+    order[(long long)nsolo * cpw + (tr < whole ? (tr % nw) * cpw + tr / nw : tr)] = (int32_t)ch;
 }
 
 // ----------------------------------------------------------------- selftest
@@ -2564,7 +2568,16 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         hipError_t e3 = hipMalloc((void **)&h->d_gj_scr, sizeof(double) * nvec * lanes * nch);
         if (e3 == hipSuccess) e3 = hipMalloc((void **)&h->d_gj_scal, sizeof(double) * (size_t)GJS_SCALARS * (c.nuts_maxdepth + 1) * nch);
         static const bool unordered = getenv("PTMI_GJ_UNORDERED") != nullptr;        // measurement switch: same results either way
-        if (e3 == hipSuccess && !unordered) e3 = hipMalloc((void **)&h->d_gj_order, sizeof(int32_t) * nch);
+        // chains with a wave of their own (the longest trees of the launch order): up to 1024, a 32nd of the chains at most (config-5 share
+        // with 0 / 128 / 512 / 1024 / 2048 of 65 536: 4.67e8 / 4.92e8 / 4.82e8 / 5.37e8 / 5.18e8 updates/s); PTMI_GJ_SOLO=n overrides (0: none; a
+        // measurement / test switch: the order never enters a chain's arithmetic)
+        const int cpw = 64 / s.G;
+        long long solo = cpw > 1 ? (long long)(nch / 32 < 1024 ? nch / 32 : 1024) : 0;
+        if (const char *ev = getenv("PTMI_GJ_SOLO")) solo = cpw > 1 ? atoll(ev) : 0;
+        if (solo > (long long)nch) solo = (long long)nch;
+        if (solo < 0) solo = 0;
+        h->gj_solo = (int)solo;
+        if (e3 == hipSuccess && !unordered) e3 = hipMalloc((void **)&h->d_gj_order, sizeof(int32_t) * (nch + (size_t)solo * cpw + cpw));
         if (e3 == hipSuccess && !unordered) e3 = hipMalloc((void **)&h->d_gj_bucket, sizeof(int32_t) * 3 * GJ_BUCKETS);
         if (e3 != hipSuccess || (rc = upload(&h->d_gj_tab, c.gj_tab, 3LL * c.ndim * c.ndim))) {
             ptmi_destroy(h);
@@ -2730,9 +2743,13 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             hipLaunchKernelGGL(gj_order_count_kernel, dim3(g), dim3(256), 0, h->stream, (const double *)h->buf.gj, (const int32_t *)h->buf.temp_of,
                                nch, h->cfg.ntemps, h->d_gj_bucket);
             hipLaunchKernelGGL(gj_order_scan_kernel, dim3(1), dim3(64), 0, h->stream, h->d_gj_bucket);
+            const int cpw = 64 / h->G;
+            const long long nslots = (long long)h->gj_solo * cpw + ((nch - h->gj_solo + cpw - 1) / cpw) * cpw;
+            HIPCHK(hipMemsetAsync(h->d_gj_order, 0xFF, sizeof(int32_t) * (size_t)nslots, h->stream));           // -1: an empty chain slot
             hipLaunchKernelGGL(gj_order_fill_kernel, dim3(g), dim3(256), 0, h->stream, (const double *)h->buf.gj, (const int32_t *)h->buf.temp_of,
-                               nch, h->cfg.ntemps, h->d_gj_bucket, h->d_gj_order, 64 / h->G);
+                               nch, h->cfg.ntemps, h->d_gj_bucket, h->d_gj_order, cpw, h->gj_solo);
             a.gj_order = h->d_gj_order;
+            a.gj_nslots = (int)nslots;
         }
         if (int rc = run_shape(h, PTMI_OP_MH_GJ, a, chains_grid(h), true)) return rc;
         h->last_variant = PTMI_VAR_GRADJUMP | PTMI_VAR_FULL;

@@ -97,7 +97,8 @@ struct KArgs {
     double *gj;                  // [W][T][8] per-rank jump state
     double *gj_scr, *gj_scal;    // scratch of the tree build: [slot][e][chain][lane], [level][scalar][chain]
     int gj_stack_off, gj_lds_levels;   // tree stack: offset (doubles) in the block's LDS and how many of the lowest heights live there
-    const int32_t *gj_order;     // chain handled by each chain slot of the launch (chains of similar NUTS step size share a wave)
+    const int32_t *gj_order;     // chain handled by each chain slot of the launch (chains of similar NUTS step size share a wave), -1: none
+    int gj_nslots;               // chain slots of the launch when gj_order is set (>= the chains: the longest trees' chains have a wave to themselves)
     const u64 *rp_draws;         // TEST HOOK (ptmi_test_replay): propose_kernel takes P0, Q0, Q1 and the SCAM normal's bits of every chain from here
 };
 
@@ -135,6 +136,7 @@ struct ptmi_engine {
     int32_t *d_xint;    // exchange scratch: inv[W][ntg], newslot[W][T], arr_slot[nranks][W], lv_slot[2][W], lv_rank[2][W], err[1]
     double *d_gj_tab, *d_gj_scr, *d_gj_scal;   // gradient jumps: whitening tables, tree scratch
     int gj_diag;                               // ... and whether the tables are diagonal (decided at ptmi_create)
+    int gj_solo;                 // chains with a wave of their own in the gradient-jump launches (gj_order_fill_kernel)
     int32_t *d_gj_order, *d_gj_bucket;         // launch order of the chains ([nch]) and its counting-sort scratch ([3][GJ_BUCKETS])
     // AM increments ahead of the launch (large ndim): events of a piece of the launch, their increments [am_cap][ndim]
     void *d_am_ev;

@@ -1472,16 +1472,20 @@ __global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_W
     box_table_fill<G, EPL>(a, gj_lds, GJ_BLOCK);
     __syncthreads();
     const long long cslot0 = (long long)blockIdx.x * CPB + (int)(threadIdx.x / G);
-    // a chain group past the end repeats the last chain and writes nothing (the whole wave takes part in the gradient jumps)
-    const bool live = cslot0 < nch;
+    // a chain group without a chain (past the end, or an empty slot of the launch order) repeats a chain and writes nothing (the whole
+    // wave takes part in the gradient jumps)
+    const int oslot = a.gj_order ? (cslot0 < (long long)a.gj_nslots ? a.gj_order[cslot0] : -1) : 0;
+    const bool live = a.gj_order ? oslot >= 0 : cslot0 < nch;
     if (!WIDE && !live) return;                  // no block-wide synchronisation below for the wider layouts: whole chain groups may leave
     const long long cslot = live ? cslot0 : nch - 1;
     // The chains of a wave run in lock step: every iteration costs the wave its longest tree, and the launch ends with its
     // slowest wave.  On the curved likelihood a per cent of the ranks keep a small NUTS step size (trees of ~100
     // leapfrogs) while the rest run away to huge ones (one leapfrog): the host deals the chains over the waves by step
     // size (gj_order_*), longest trees first and one per wave, so that no wave has to add up several long trees per
-    // iteration (tools/gj_census.py).  Which lanes host a chain does not enter its arithmetic.
-    const long long ch = a.gj_order ? (long long)a.gj_order[cslot] : cslot;
+    // iteration (tools/gj_census.py).  The chains with the very longest trees have a wave to themselves (the other chain slots of
+    // that wave are empty): what a launch lasts is its slowest chain's own serial work, and there it does not wait for fifteen
+    // others' jumps and steps.  Which lanes host a chain does not enter its arithmetic.
+    const long long ch = a.gj_order ? (live ? (long long)oslot : 0) : cslot;
     const int gl = (int)(threadIdx.x % G);
     const int w = (int)(ch / nt);
     const int t = a.temp_of[ch];

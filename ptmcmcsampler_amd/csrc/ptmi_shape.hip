@@ -35,7 +35,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
 #endif
     case PTMI_OP_MH_GJ:
         if constexpr (E <= 8) {                 // the tree build keeps seven chain vectors in registers
-            const long long nch = (long long)h->cfg.nwalkers * h->cfg.ntemps;
+            const long long nch = a.gj_order ? (long long)a.gj_nslots : (long long)h->cfg.nwalkers * h->cfg.ntemps;     // chain slots of the launch
             const int cpb = GJ_BLOCK / G;
             // LDS of a block (one wave).  4-lane shapes (GradJumpWide): whitening tables with rows of 4 E | the tree stack,
             // one level per height | the exchange area of the layout change (64 doubles) | box bounds of the 4-lane test.

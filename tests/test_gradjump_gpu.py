@@ -64,16 +64,24 @@ CASES = [
     dict(d=34, nt=2, W=3, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 0, 10), hmc=(0.08, 2, 50), diag=True),
     dict(d=50, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=2, diag=True),
     dict(d=40, nt=2, W=3, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0), diag=True, nowide16=True),
+    # the launch order: chains with a wave of their own (PTMI_GJ_SOLO: here 5 of 20 / 9 of 12 chains, and all of them), empty chain slots beside
+    # them -- in the pair layout, the whole-wave layout and the per-chain one
+    dict(d=20, nt=4, W=5, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.08, 2, 50), diag=True, solo=5),
+    dict(d=5, nt=3, W=4, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), solo=9),
+    dict(d=40, nt=2, W=3, logl=("dense",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), solo=6),
+    dict(d=8, nt=3, W=5, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.2, 2, 12), diag=True, solo=0),
     dict(d=7, nt=3, W=4, logl=("interval", -1.0, 1.0), logp=("flat",), grad_weights=(0, 0), weights=(10, 0, 10)),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else "",
-                                                                       "-diag" if c.get("diag") else "", ("" if sum(c["grad_weights"]) else "-nogj") + ("-nowide16" if c.get("nowide16") else "")))
+                                                                       "-diag" if c.get("diag") else "", ("" if sum(c["grad_weights"]) else "-nogj") + ("-nowide16" if c.get("nowide16") else "") + ("-solo%d" % c["solo"] if "solo" in c else "")))
 def test_device_gradient_jumps_bit_exact(case, monkeypatch):
     c = dict(case)
     d, nt, W = c.pop("d"), c.pop("nt"), c.pop("W")
     diag = c.pop("diag", False)
+    if "solo" in c:
+        monkeypatch.setenv("PTMI_GJ_SOLO", str(c.pop("solo")))
     if c.pop("nowide16", False):
         monkeypatch.setenv("PTMI_GJ_NOWIDE16", "1")               # the per-chain layout with the same diagonal tables
     if diag and d == 7:
