@@ -516,7 +516,7 @@ __device__ __forceinline__ double lane_xor16(double v)
 // element i = g + 16 e in lane 4 g + e -- the 16-lane order of a dot product is then a chain along the quad (quad_perm shifts) and the
 // butterfly g ^ 8, 4, 2, 1 = lane ^ 32, 16, 8, 4 in the vector pipe (v_permlane32/16_swap, row rotations); the Box-Muller partners
 // (k, k + 16) are quad neighbours.  The template's EPL is then LD / 4 = 16.
-template <int EPL, int LOGL, int GC = 4>
+template <int EPL, int LOGL, int GC = 4, bool FULLTAB = false /* GC = 16: full whitening tables (else diagonal ones: decided at compile time there) */>
 struct GradJumpWide {
     static constexpr int G = GC, NS = GC == 4 ? EPL : 4 /* slots of a lane group */, LD = GC * NS, LEV = gjw_level_doubles(LD / 4);
     static_assert(GC == 4 || (GC == 16 && EPL == 16), "whole-wave layouts: 4 lane groups in rows of 16 lanes, or 16 lane groups in quads");
@@ -627,12 +627,37 @@ struct GradJumpWide {
     {
         GJP_T0(t0);
         double acc = 0.0;
-        if (WHICH >= 0 && a.gj_diag) {                                   // diagonal whitening table: one multiplication per element (oracle: tab_vec)
+        if (WHICH >= 0 && (GC == 16 ? !FULLTAB : (bool)a.gj_diag)) {     // diagonal whitening table: one multiplication per element (oracle: tab_vec)
             const double r = act ? gj_lds[WHICH * LD + col] * v : 0.0;  // (the block's LDS then holds the three diagonals only)
             GJP_ADD(GJP_TABVEC, t0);
             return r;
         }
-        if constexpr (GC == 16) { __builtin_trap(); return 0.0; }       // (the 16-group layout runs with diagonal whitening and no dense likelihood: the host picks it then)
+        if constexpr (GC == 16) {
+            // 16 lane groups (ndim <= 64): the vector through LDS in element order as below, the table's rows from global memory (3 d^2
+            // doubles, cache resident: the LDS copies of 64 x 64 tables would leave one wave per CU), sixteen terms at a time
+            __syncthreads();
+            if (act) gj_lds[vb + wi] = v;
+            __syncthreads();
+            const double *T = WHICH >= 0 ? a.gj_tab + (size_t)WHICH * d * d : Tg;
+#pragma unroll 1
+            for (int k0 = 0; k0 < d; k0 += 16) {
+                double tk[16], vk[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int k = k0 + j;
+                    tk[j] = T[(size_t)(k < d ? k : 0) * d + col];
+                    vk[j] = gj_lds[vb + (k < 64 ? k : 0)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double nxt = __builtin_fma(tk[j], vk[j], acc);
+                    acc = k0 + j < d ? nxt : acc;
+                }
+            }
+            GJP_ADD(GJP_TABVEC, t0);
+            return act ? acc : 0.0;
+        }
         else {
         // The vector goes through LDS in element order and every lane reads all of it back (same address for the whole wave:
         // a broadcast); two readlanes per term instead had each fma wait on a fresh scalar pair.  Straight-line on purpose:
@@ -1443,9 +1468,9 @@ constexpr int GJ_BLOCK = 64;
 #define PTMI_GJ_WPE 2
 #endif
 // PAIR (4-lane shapes, diagonal whitening, iso / curved families): two gradient jumps at a time, a half-wave each (GradJumpPair)
-// W16 (the 16-lane shape at ndim <= 64, diagonal whitening, no dense likelihood): a gradient jump takes the whole wave there too
+// W16 (the 16-lane shape at ndim <= 64, no dense likelihood): a gradient jump takes the whole wave there too
 // (GradJumpWide<16, LOGL, 16>: one element per lane instead of seven slots of every vector in each of the chain's 16 lanes)
-template <int G, int EPL, int LOGL, bool PAIR = false, bool W16 = false>
+template <int G, int EPL, int LOGL, bool PAIR = false, int W16 = 0 /* 1: diagonal whitening tables, 2: full ones (two instantiations: the product's code costs the diagonal kernel 14 %) */>
 __global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_WPE : 1) void mh_steps_gj_kernel(const KArgs a)
 {
     static_assert(!PAIR || (G == 4 && EPL <= 8 && LOGL != PTMI_LOGL_DENSE), "the pair layout serves the 4-lane shapes without table products");
@@ -1455,7 +1480,7 @@ __global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_W
     constexpr int WEPL = W16 ? 16 : EPL, WNS = W16 ? 4 : EPL;          // GradJumpWide's EPL (LD / 4); slots of a lane that hold elements in its layout
     const int d = a.d, nt = a.nt;
     const long long nch = (long long)a.W * nt;
-    if (WIDE) {
+    if (WIDE && W16 != 2) {                      // (W16 with full whitening tables: they stay in global memory, GradJumpWide::tab_vec)
         constexpr int LD = 4 * WEPL;
         if (a.gj_diag) {                         // diagonal whitening: the three diagonals (3 LD doubles instead of 3 LD^2: 0.5 KB instead of 9.6 KB at d = 20)
             for (int i = (int)threadIdx.x; i < 3 * LD; i += GJ_BLOCK) {
@@ -1615,7 +1640,7 @@ __global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_W
                 const int w_c = (int)(ch_c / nt), t_c = __builtin_amdgcn_readlane(t, lane0);
                 double *stc = a.gj + ((size_t)w_c * nt + t_c) * GJ_NSTATE;
                 double qw;
-                GradJumpWide<WEPL, LOGL, W16 ? 16 : 4> gj(a, ch_c, beta_c, it, sid_c, xch);
+                GradJumpWide<WEPL, LOGL, W16 ? 16 : 4, W16 == 2> gj(a, ch_c, beta_c, it, sid_c, xch);
                 double st[GJ_NSTATE];
 #pragma unroll
                 for (int j = 0; j < GJ_NSTATE; ++j) st[j] = stc[j];

@@ -9,11 +9,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ptmcmcsampler_amd.engine import PTEngine
 
-nt = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-W = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+args = [v for v in sys.argv[1:] if not v.startswith("--")]
+nt = int(args[0]) if len(args) > 0 else 1
+W = int(args[1]) if len(args) > 1 else 16384
 d, a, b = 40, 0.0, 10.0
 pmax, hess = -2.3, 0.25          # near the maximum of one coordinate's density; the test takes the covariance from the Hessian there
 cov = np.eye(d) / hess
+if "--full" in sys.argv:             # a covariance with off-diagonal terms: the whitening tables are full (the whole-wave layout reads them from global memory)
+    A = np.random.default_rng(1).standard_normal((d, d))
+    cov = cov + 0.05 * (A @ A.T) / d
 for name, gw, hmc in (("SCAM/AM/DE", (0, 0), (0.4, 2, 100)), ("+ NUTS", (10, 0), (0.4, 2, 100)), ("+ NUTS + HMC(<=100 steps)", (10, 10), (0.4, 2, 100)),
                       ("+ NUTS + HMC(<=10 steps)", (10, 10), (0.4, 2, 10))):
     e = PTEngine(d, nt, W, cov, logl=("interval", np.full(d, a), np.full(d, b)), logp=("flat",), weights=(10, 10, 10), grad_weights=gw, hmc=hmc,
