@@ -1468,13 +1468,13 @@ constexpr int GJ_BLOCK = 64;
 #define PTMI_GJ_WPE 2
 #endif
 // PAIR (4-lane shapes, diagonal whitening, iso / curved families): two gradient jumps at a time, a half-wave each (GradJumpPair)
-// W16 (the 16-lane shape at ndim <= 64, no dense likelihood): a gradient jump takes the whole wave there too
+// W16 (the 16-lane shape at ndim <= 64): a gradient jump takes the whole wave there too
 // (GradJumpWide<16, LOGL, 16>: one element per lane instead of seven slots of every vector in each of the chain's 16 lanes)
 template <int G, int EPL, int LOGL, bool PAIR = false, int W16 = 0 /* 1: diagonal whitening tables, 2: full ones (two instantiations: the product's code costs the diagonal kernel 14 %) */>
 __global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_WPE : 1) void mh_steps_gj_kernel(const KArgs a)
 {
     static_assert(!PAIR || (G == 4 && EPL <= 8 && LOGL != PTMI_LOGL_DENSE), "the pair layout serves the 4-lane shapes without table products");
-    static_assert(!W16 || (G == 16 && LOGL != PTMI_LOGL_DENSE && !PAIR), "the 16-group whole-wave layout serves the 16-lane shape without table products");
+    static_assert(!W16 || (G == 16 && !PAIR), "the 16-group whole-wave layout serves the 16-lane shape");
     constexpr int CPB = GJ_BLOCK / G;
     constexpr bool WIDE = G == 4 || W16;         // a gradient jump takes the whole wave (GradJumpWide)
     constexpr int WEPL = W16 ? 16 : EPL, WNS = W16 ? 4 : EPL;          // GradJumpWide's EPL (LD / 4); slots of a lane that hold elements in its layout

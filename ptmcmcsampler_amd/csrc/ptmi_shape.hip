@@ -56,7 +56,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
                 // one-chain-per-wave layout (a measurement / test switch, same results)
                 pair = a.gj_diag && L != PTMI_LOGL_DENSE && getenv("PTMI_GJ_NOPAIR") == nullptr;
                 off += (size_t)(pair ? 2 : 1) * a.gj_lds_levels * gjw_level_doubles(E) + (pair ? 72 + 2 * GJ_BLOCK : 64);       // pair: + the 16 chains' step-size states
-            } else if (G == 16 && L != PTMI_LOGL_DENSE && a.d <= 64 && getenv("PTMI_GJ_NOWIDE16") == nullptr) {
+            } else if (G == 16 && a.d <= 64 && getenv("PTMI_GJ_NOWIDE16") == nullptr) {
                 // the 16-lane shape at ndim <= 64: a gradient jump takes the whole wave (GradJumpWide<16, L, 16>, one element per lane);
                 // PTMI_GJ_NOWIDE16: the per-chain layout (a measurement / test switch, same results)
                 w16 = true;
@@ -88,7 +88,7 @@ int PTMI_CAT(PTMI_G, PTMI_E, PTMI_L)(int op, ptmi_engine *h, KArgs &a, int grid,
                     return PTMI_OK;
                 }
             }
-            if constexpr (G == 16 && L != PTMI_LOGL_DENSE) {
+            if constexpr (G == 16) {
                 if (w16) {
                     if (a.gj_diag) hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L, false, 1>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK), sizeof(double) * off, h->stream, a);
                     else hipLaunchKernelGGL((mh_steps_gj_kernel<G, E, L, false, 2>), dim3((unsigned)((nch + cpb - 1) / cpb)), dim3(GJ_BLOCK), sizeof(double) * off, h->stream, a);
