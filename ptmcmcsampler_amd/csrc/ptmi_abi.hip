@@ -1099,6 +1099,7 @@ struct AmArgs {
     long long iter0, nch;
     int nsteps, nt, ntg, temp0, walker0, w_host, w_scam, w_am, w_de, pick_walker;
     int ngroups;                       // parameter groups (PT:129-145): > 1: the pick's group is drawn as propose() draws it
+    int per_walker;                    // per-walker covariances: an event's table is its walker's (key = walker * ngroups + group), else key = group
     const double *gcn;                 // [ngroups] 2.4 / sqrt(2 size of the group) (PT:928)
     const int32_t *temp_of;
     const double *temps_mh;
@@ -1140,35 +1141,28 @@ constexpr int AM_MAXG = 1024;         // = the ABI's limit on ngroups
 __global__ __launch_bounds__(256) void am_count_kernel(const AmArgs p, int32_t *count, int32_t *gtot)
 {
     __shared__ int32_t lh[AM_MAXG];
-    if (gtot)
+    const bool hist = gtot && !p.per_walker;                             // (per walker: thousands of keys, a handful of picks each: straight to memory)
+    if (hist)
         for (int g = (int)threadIdx.x; g < p.ngroups; g += 256) lh[g] = 0;
-    if (gtot) __syncthreads();
+    if (hist) __syncthreads();
     const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ch < p.nch) {
         int n = 0;
         AmEvent e;
+        const long long kw = p.per_walker ? (ch / p.nt) * p.ngroups : 0;
         for (int s = 0; s < p.nsteps; ++s)
             if (am_pick(p, ch, p.iter0 + s, e)) {
                 n += 1;
-                if (gtot) atomicAdd(&lh[e.pad], 1);
+                if (hist) atomicAdd(&lh[e.pad], 1);
+                else if (gtot) atomicAdd(&gtot[kw + e.pad], 1);
             }
         count[ch] = n;
     }
-    if (gtot) {
+    if (hist) {
         __syncthreads();
         for (int g = (int)threadIdx.x; g < p.ngroups; g += 256)
             if (lh[g]) atomicAdd(&gtot[g], lh[g]);
     }
-}
-// gbase[g] = the picks of the groups before g (gbase[ngroups] = all), the fill's cursors zeroed: one block
-__global__ __launch_bounds__(64) void am_group_scan_kernel(const int32_t *gtot, int32_t *gbase, int32_t *cursor, int ngroups)
-{
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int g = 0; g < ngroups; ++g) { gbase[g] = run; run += gtot[g]; }
-        gbase[ngroups] = run;
-    }
-    for (int g = (int)threadIdx.x; g < ngroups; g += 64) cursor[g] = 0;
 }
 // exclusive prefix sums of the chains' counts, base[nch] = the number of events; two launches of 1024-chain blocks: the blocks' sums, then
 // every block adds up the sums before it and scans its own counts (one block over all chains took 0.44 ms at 262 144 chains: its
@@ -1220,12 +1214,14 @@ __global__ __launch_bounds__(1024) void am_scan_kernel(const int32_t *count, con
 // events' indices listed group by group (group g: perm[gbase[g] ...), in no particular order inside a group -- an event's increment
 // does not depend on its neighbours), so that a block of am_gemm_kernel holds 64 events of ONE group and multiplies by that group's
 // rows only.  A block reserves its share of every group's list with one atomic per group.
-__global__ __launch_bounds__(256) void am_fill_kernel(const AmArgs p, const long long *base, AmEvent *ev, const int32_t *gbase, int32_t *cursor, int32_t *perm)
+__global__ __launch_bounds__(256) void am_fill_kernel(const AmArgs p, const long long *base, AmEvent *ev, const long long *gbase, int32_t *cursor, int32_t *perm)
 {
-    __shared__ int32_t lh[AM_MAXG], lb[AM_MAXG];
+    __shared__ int32_t lh[AM_MAXG];
+    __shared__ long long lb[AM_MAXG];
     const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     AmEvent e;
-    if (perm) {
+    const bool hist = perm && !p.per_walker;
+    if (hist) {
         for (int g = (int)threadIdx.x; g < p.ngroups; g += 256) lh[g] = 0;
         __syncthreads();
         if (ch < p.nch)
@@ -1240,9 +1236,11 @@ __global__ __launch_bounds__(256) void am_fill_kernel(const AmArgs p, const long
     }
     if (ch >= p.nch) return;
     long long at = base[ch];
+    const long long kw = p.per_walker ? (ch / p.nt) * p.ngroups : 0;
     for (int s = 0; s < p.nsteps; ++s)
         if (am_pick(p, ch, p.iter0 + s, e)) {
-            if (perm) perm[lb[e.pad] + atomicAdd(&lh[e.pad], 1)] = (int32_t)at;
+            if (hist) perm[lb[e.pad] + atomicAdd(&lh[e.pad], 1)] = (int32_t)at;
+            else if (perm) perm[gbase[kw + e.pad] + atomicAdd(&cursor[kw + e.pad], 1)] = (int32_t)at;      // per walker: the key's own cursor
             ev[at++] = e;
         }
 }
@@ -1256,20 +1254,25 @@ __global__ __launch_bounds__(256) void am_fill_kernel(const AmArgs p, const long
 // chain over ITS group's rows, as the step kernel's own product, and lands in the event's row of inc.
 template <int G, int MAXT>
 __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, const long long *base, long long nch, int d, const double *Ut,
-                                                        const double *S, u64 seed, double *inc, int nk, const int32_t *gseg /* {first, end} of the group's list */,
-                                                        const int32_t *perm)
+                                                        const double *S, u64 seed, double *inc, int nk, const long long *kbase /* the lists' starts (+ the end) */,
+                                                        const int32_t *perm, int grp, int ngroups)
 {
     constexpr int NEV = 64, K2 = 2 * G;
     extern __shared__ __attribute__((aligned(16))) double Wl[];          // [2][K2][NEV]
     __shared__ int32_t evi[NEV];                                         // parameter groups: the events' indices (their rows of inc)
     // one group (perm == nullptr): the events e0 .. of the chain-ordered list; else entries e0 .. of the group's list
-    const long long nev = perm ? (long long)(gseg[1] - gseg[0]) : base[nch], e0 = (long long)blockIdx.x * NEV;
+    // the list's key: the group, or (blockIdx.z = the walker, group) with per-walker covariances -- and the key's table
+    const long long key = perm ? (long long)blockIdx.z * ngroups + grp : 0;
+    const long long seg0 = perm ? kbase[key] : 0;
+    const long long nev = perm ? kbase[key + 1] - seg0 : base[nch], e0 = (long long)blockIdx.x * NEV;
     if (e0 >= nev) return;
+    Ut += (size_t)key * d * d;
+    S += (size_t)key * d;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const bool ev_on = e0 + lane < nev;
     const long long mine = ev_on ? e0 + lane : e0;
-    const long long ei = perm ? (long long)perm[gseg[0] + mine] : mine;
+    const long long ei = perm ? (long long)perm[seg0 + mine] : mine;
     const AmEvent me = ev[ei];
     if (perm && wave == 0) evi[lane] = (int32_t)ei;
     ps_d4 acc[MAXT][4];
@@ -2371,11 +2374,15 @@ static int launch_am_gemm_t(ptmi_engine *h, long long max_events)
     }
     const int d = h->cfg.ndim, ntile = (d + 15) / 16, parts = (ntile + 4 * MAXT - 1) / (4 * MAXT);      // blocks per event tile
     const int ngr = h->cfg.ngroups > 1 ? h->cfg.ngroups : 1;
-    for (int g = 0; g < ngr; ++g)                                       // parameter groups: a launch per group with its table (am_gemm_kernel)
-        hipLaunchKernelGGL(kern, dim3((unsigned)((max_events + 63) / 64), parts), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
-                           (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, d, (const double *)h->buf.Ut + (size_t)g * d * d,
-                           (const double *)h->buf.S + (size_t)g * d, h->cfg.seed, h->d_am_inc, ngr > 1 ? h->gsize_host[g] : d,
-                           ngr > 1 ? (const int32_t *)(h->d_am_grp + ngr + g) : nullptr, ngr > 1 ? (const int32_t *)h->d_am_perm : nullptr);
+    // parameter groups: a launch per group (am_gemm_kernel); with per-walker covariances a grid row per walker, its blocks enough for
+    // every pick of the walker's chains in the piece
+    const int pw = h->cfg.cov_per_walker ? 1 : 0;
+    const long long per_key = pw ? (max_events / h->cfg.nwalkers) : max_events;
+    for (int g = 0; g < ngr; ++g)
+        hipLaunchKernelGGL(kern, dim3((unsigned)((per_key + 63) / 64), parts, pw ? h->cfg.nwalkers : 1), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
+                           (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, d, (const double *)h->buf.Ut,
+                           (const double *)h->buf.S, h->cfg.seed, h->d_am_inc, ngr > 1 ? h->gsize_host[g] : d,
+                           ngr > 1 ? (const long long *)h->d_am_kbase : nullptr, ngr > 1 ? (const int32_t *)h->d_am_perm : nullptr, g, ngr);
     return PTMI_OK;
 }
 static int launch_am_gemm(ptmi_engine *h, long long max_events)
@@ -2609,7 +2616,9 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     // ... and every shape with parameter groups (PT:129-145: a chain's pick has its own group, hence its own table: the step kernels'
     // matrix-core product shares one table between the 16 chains of a wave, and the vector-pipe product they fall back to takes
     // 284 ms per 100 steps of the default mix at 64 x 4096 x 100-d with three groups -- 35 times the one-group kernel)
-    if (e == hipSuccess && !gshape && c.w_am > 0 && !c.cov_per_walker && (c.ngroups > 1 || s.G > 4) && c.ndim <= 1024 && c.w_host == 0 &&
+    // -- with groups also per-walker covariances (an event's table is then its walker's group table: lists per (walker, group)): 505 ms
+    // per 100 steps of the default mix at 64 x 4096 x 100-d with three groups before
+    if (e == hipSuccess && !gshape && c.w_am > 0 && (c.ngroups > 1 || (s.G > 4 && !c.cov_per_walker)) && c.ndim <= 1024 && c.w_host == 0 &&
         !getenv("PTMI_NO_AM_AHEAD")) {
         const long long nch = (long long)c.nwalkers * c.ntemps;
         const char *mb = getenv("PTMI_AM_BUDGET_MB");                    // scratch for the increments of one piece of a launch (default 6 GB)
@@ -2622,9 +2631,11 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_count, sizeof(int32_t) * (size_t)(nch + (nch + 1023) / 1024));      // counts | the scan's block sums
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_base, sizeof(long long) * (size_t)(nch + 1));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_inc, sizeof(double) * (size_t)h->am_cap * c.ndim);
-        if (e == hipSuccess && c.ngroups > 1) {                          // the events listed group by group: totals | list starts (+ the end) | cursors
+        if (e == hipSuccess && c.ngroups > 1) {                          // the events listed key by key: totals | cursors | the scan's block sums; list starts (+ the end)
+            const size_t nkeys = (size_t)c.ngroups * (c.cov_per_walker ? (size_t)c.nwalkers : 1);
             if (h->am_cap > 0x7FFFFFFFLL) e = hipErrorInvalidValue;
-            if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_grp, sizeof(int32_t) * (3 * (size_t)c.ngroups + 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_grp, sizeof(int32_t) * (2 * nkeys + (nkeys + 1023) / 1024 + 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_kbase, sizeof(long long) * (nkeys + 1));
             if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_perm, sizeof(int32_t) * (size_t)h->am_cap);
         }
     }
@@ -2655,7 +2666,7 @@ int ptmi_destroy(ptmi_handle h)
     }
     (void)hipFree(h->d_rle_ent); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
-    (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm);
+    (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm); (void)hipFree(h->d_am_kbase);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->side_go); (void)hipEventDestroy(h->side_done); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2770,19 +2781,25 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             p.seed = c.seed; p.iter0 = iter0 + s0; p.nch = nch; p.nsteps = ns; p.nt = c.ntemps; p.ntg = c.ntemps_global; p.temp0 = c.temp0;
             p.walker0 = c.walker0; p.w_host = c.w_host; p.w_scam = c.w_scam; p.w_am = c.w_am; p.w_de = h->de_on ? c.w_de : 0;
             p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.ngroups = c.ngroups > 1 ? c.ngroups : 1; p.gcn = h->d_gcn;
+            p.per_walker = c.cov_per_walker ? 1 : 0;
             p.temp_of = h->buf.temp_of; p.temps_mh = h->d_temps;
             const unsigned gch = (unsigned)((nch + 255) / 256);
             const int ngr = p.ngroups;
-            int32_t *gtot = ngr > 1 ? h->d_am_grp : nullptr, *gbase = gtot ? gtot + ngr : nullptr, *gcur = gtot ? gtot + 2 * ngr + 1 : nullptr;
-            if (gtot) HIPCHK(hipMemsetAsync(gtot, 0, sizeof(int32_t) * (size_t)ngr, h->stream));
+            const long long nkeys = (long long)ngr * (c.cov_per_walker ? c.nwalkers : 1);
+            int32_t *gtot = ngr > 1 ? h->d_am_grp : nullptr, *gcur = gtot ? gtot + nkeys : nullptr, *gpart = gtot ? gtot + 2 * nkeys : nullptr;
+            if (gtot) HIPCHK(hipMemsetAsync(gtot, 0, sizeof(int32_t) * 2 * (size_t)nkeys, h->stream));          // the keys' totals and the fill's cursors
             hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count, gtot);
-            if (gtot) hipLaunchKernelGGL(am_group_scan_kernel, dim3(1), dim3(64), 0, h->stream, (const int32_t *)gtot, gbase, gcur, ngr);
+            if (gtot) {                                                  // the lists' starts: the chains' scan over the keys' totals
+                const unsigned gk = (unsigned)((nkeys + 1023) / 1024);
+                hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gk), dim3(1024), 0, h->stream, (const int32_t *)gtot, gpart, nkeys);
+                hipLaunchKernelGGL(am_scan_kernel, dim3(gk), dim3(1024), 0, h->stream, (const int32_t *)gtot, (const int32_t *)gpart, h->d_am_kbase, nkeys);
+            }
             const unsigned gsc = (unsigned)((nch + 1023) / 1024);
             hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, h->d_am_count + nch, nch);
             hipLaunchKernelGGL(am_scan_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, (const int32_t *)(h->d_am_count + nch),
                                h->d_am_base, nch);
             hipLaunchKernelGGL(am_fill_kernel, dim3(gch), dim3(256), 0, h->stream, p, (const long long *)h->d_am_base, (AmEvent *)h->d_am_ev,
-                               (const int32_t *)gbase, gcur, gtot ? h->d_am_perm : nullptr);
+                               (const long long *)h->d_am_kbase, gcur, gtot ? h->d_am_perm : nullptr);
             if (int rc = launch_am_gemm(h, nch * ns)) return rc;
             KArgs ap = make_args(h);
             ap.iter0 = iter0 + s0; ap.nsteps = ns;

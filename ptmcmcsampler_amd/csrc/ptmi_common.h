@@ -143,7 +143,8 @@ struct ptmi_engine {
     int32_t *d_am_count;
     long long *d_am_base;
     double *d_am_inc;
-    int32_t *d_am_grp, *d_am_perm;     // parameter groups: picks per group | list starts | cursors; the events' indices group by group
+    int32_t *d_am_grp, *d_am_perm;     // parameter groups: picks per key (group, or walker x group) | cursors | scan scratch; the events' indices key by key
+    long long *d_am_kbase;             // where each key's list starts in d_am_perm (+ the end)
     long long am_cap;
     int am_piece;       // steps per piece (0: the path is off for this engine)
     double *d_pool_part, *d_pool_T;  // pooled covariance: the slabs' partial sums [nslab][d][d+1] and their total [d][d+1] (column d: the column sums)

@@ -501,20 +501,24 @@ def test_parameter_groups(mods, d, groups):
                                       (100, [list(range(100)), list(range(0, 50)), list(range(50, 100)), [3, 99, 41]]),
                                       (130, [list(range(130)), list(range(5, 70))]), (500, [list(range(500)), list(range(100, 140))])])
 @pytest.mark.parametrize("pieces", [False, True])
-def test_parameter_groups_with_am_increments_ahead_of_the_launch(mods, d, groups, pieces, monkeypatch):
+@pytest.mark.parametrize("cov_mode", ["pooled", "per_walker"])
+def test_parameter_groups_with_am_increments_ahead_of_the_launch(mods, d, groups, pieces, cov_mode, monkeypatch):
     """Parameter groups with ONE pooled covariance (PTMCMCSampler.py:129-145, 897-933): a chain's AM pick has its own group, hence its
     own table, so the step kernels' matrix-core product (one table for the 16 chains of a wave) does not apply; the increments
     U_g (cd sqrt(S_g) z) of a piece of the launch are computed ahead of it by am_gemm_kernel, one launch per group over the listed
     picks (round 5; every shape, 4 / 16 / 64 lanes per chain) -- the same k-ascending fma chain over the group's rows as the step
     kernel's own vector-pipe product, which the same cases run with PTMI_NO_AM_AHEAD through the oracle.  `pieces`: a scratch of
-    1 MB cuts the launches into single steps."""
+    1 MB cuts the launches into single steps.  cov_mode "per_walker" (what real PTA runs combine: groups and a covariance per
+    replica): an event's table is its walker's group table, the lists are per (walker, group), a grid row of the product per walker."""
     if pieces:
         monkeypatch.setenv("PTMI_AM_BUDGET_MB", "1")
     nt, W = 3, 5
-    g, o = _pair(mods, d, nt, W, groups=groups, weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=19, rs=d, cov_mode="pooled")
+    if cov_mode == "per_walker" and d > 130:
+        pytest.skip("per-walker covariances at 500-d: the oracle's 5 x 500 x 500 SVDs per epoch (covered at 130-d)")
+    g, o = _pair(mods, d, nt, W, groups=groups, weights=(20, 20, 20), cov_update=40, burn=80, tskip=10, seed=19, rs=d, cov_mode=cov_mode)
     g.run(250)
     o.run(250)
-    _compare(g, o, "groups (pooled) d=%d " % d)
+    _compare(g, o, "groups (%s) d=%d " % (cov_mode, d))
     assert_same(g.get("Ut"), o.Ut, "Ut")
     assert_same(g.get("S"), o.S, "S")
     assert o.jstat[..., :3, 0].sum(axis=(0, 1)).min() > 0

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B build of the ABI unit (ptmi_abi.hip: statistics, eigensolvers, swap kernels): tools/ab_abi.sh NAME [extra flags]
-#   -> ptmcmcsampler_amd/libptmi_NAME.so (run with PTMI_LIB=...).  The shape units are those of the last full build.
+#   -> ptmcmcsampler_amd/libptmi_NAME.so (run with PTMI_LIB=...).  The shape units are those of the last full build: NOT after a change of
+#   ptmi_common.h (ptmi_engine / KArgs layouts: the units would disagree about them -- do a full build then).
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift

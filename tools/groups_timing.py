@@ -1,5 +1,5 @@
 """Step time of the fused kernels with parameter groups (PTMCMCSampler.py:129-145) against the same cycle without (developer tool, one GPU).
-usage: groups_timing.py [ndim] [nwalkers]"""
+usage: groups_timing.py [ndim] [nwalkers] [--per-walker]"""
 import os
 import sys
 import time
@@ -9,13 +9,16 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ptmcmcsampler_amd.engine import PTEngine
 
-d = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-W = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+args = [v for v in sys.argv[1:] if not v.startswith("--")]
+d = int(args[0]) if len(args) > 0 else 100
+W = int(args[1]) if len(args) > 1 else 4096
+COV = "per_walker" if "--per-walker" in sys.argv else "pooled"
 nt = 64
 half = d // 2
 for name, groups, weights in (("scam, one group", None, (20, 0, 0)), ("scam, 3 groups", [np.arange(d), np.arange(half), np.arange(half, d)], (20, 0, 0)),
                               ("default mix, one group", None, (20, 20, 20)), ("default mix, 3 groups", [np.arange(d), np.arange(half), np.arange(half, d)], (20, 20, 20))):
-    e = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=weights, cov_update=1000, burn=200, tskip=100, seed=1, cov_mode="pooled", groups=groups)
+    e = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=weights, cov_update=1000, burn=200, tskip=100, seed=1, cov_mode=COV, groups=groups,
+                 eig_mode="ql" if COV == "per_walker" else "lapack")
     e.init_state(np.zeros(d))
     e.run(400)
     e.sync()
