@@ -2625,6 +2625,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         const double budget = (mb ? atof(mb) : 6144.0) * 1048576.0;
         long long piece = (long long)(budget / ((double)c.ndim * 8.0 * (double)nch));
         piece = piece < 1 ? 1 : (piece > 64 ? 64 : piece);
+        if (c.ngroups > 1 && nch * piece > 0x7FFFFFFFLL) piece = 0x7FFFFFFFLL / nch;      // (the group lists index the events with 32 bits; nch itself is below 2^32 / ntemps)
+        if (piece < 1) piece = 1;
         h->am_piece = (int)piece;
         h->am_cap = nch * piece;
         e = hipMalloc((void **)&h->d_am_ev, sizeof(AmEvent) * (size_t)h->am_cap);
