@@ -1056,6 +1056,13 @@ __device__ __forceinline__ int logical_block()
 #endif
 constexpr int mh_min_blocks(int G, int EPL, int LOGL, bool FULL, bool STAGE, bool GRP, int PERS, bool UPAD, int PRI)
 {
+    // the generic kernel of cycles with AM / DE and parameter groups takes its increments, DE rows and group masks from memory: two waves
+    // per SIMD (256 registers, 29 spilled at 100-d) against one at 308: 19.2 -> 17.2 ms per 100 steps of the default mix with three groups
+    // (three / four waves: 196 / 281 spilled, 24.5 / 29.6 ms)
+#ifndef PTMI_GRPFULL_MINBLK
+#define PTMI_GRPFULL_MINBLK 2
+#endif
+    if (FULL && GRP && !STAGE && !PERS && G == 4 && LOGL != PTMI_LOGL_DENSE) return PTMI_GRPFULL_MINBLK;
     if (PERS || STAGE || FULL || LOGL == PTMI_LOGL_DENSE) return 1;
     // the flat-prior instantiation over the padded table: x, dq and the row in flight (the other variants of the wide shapes carry
     // per-slot bounds and the box test and spill under the tighter budget)
