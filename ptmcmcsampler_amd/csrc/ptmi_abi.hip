@@ -1098,6 +1098,7 @@ struct AmArgs {
     u64 seed;
     long long iter0, nch;
     int nsteps, nt, ntg, temp0, walker0, w_host, w_scam, w_am, w_de, pick_walker;
+    int w_gj;                          // NUTS + HMC entries behind the others in the cycle (propose() with GJ)
     int ngroups;                       // parameter groups (PT:129-145): > 1: the pick's group is drawn as propose() draws it
     int per_walker;                    // per-walker covariances: an event's table is its walker's (key = walker * ngroups + group), else key = group
     const double *gcn;                 // [ngroups] 2.4 / sqrt(2 size of the group) (PT:928)
@@ -1117,7 +1118,7 @@ __device__ __forceinline__ bool am_pick(const AmArgs &p, long long ch, long long
         philox_words(p.seed, (u64)it, sid0, 0u, q0, q1);
         pickw = (u32)(q0 >> 32);
     }
-    const int L = p.w_host + p.w_scam + p.w_am + p.w_de;
+    const int L = p.w_host + p.w_scam + p.w_am + p.w_de + p.w_gj;
     const int ind = (int)__umulhi(pickw, (u32)L) - p.w_host;
     if (ind < p.w_scam || ind >= p.w_scam + p.w_am) return false;
     constexpr u32 T97 = (u32)(0.97 * 4294967296.0), T90 = (u32)(0.9 * 4294967296.0);
@@ -2618,7 +2619,9 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     // 284 ms per 100 steps of the default mix at 64 x 4096 x 100-d with three groups -- 35 times the one-group kernel)
     // -- with groups also per-walker covariances (an event's table is then its walker's group table: lists per (walker, group)): 505 ms
     // per 100 steps of the default mix at 64 x 4096 x 100-d with three groups before
-    if (e == hipSuccess && !gshape && c.w_am > 0 && (c.ngroups > 1 || (s.G > 4 && !c.cov_per_walker)) && c.ndim <= 1024 && c.w_host == 0 &&
+    // -- and the gradient-jump shapes at 16 / 64 lanes per chain (the interval family, NUTS / HMC cycles at ndim > 32): their step kernels'
+    // own AM product is the vector pipe's too
+    if (e == hipSuccess && c.w_am > 0 && (c.ngroups > 1 || (s.G > 4 && !c.cov_per_walker)) && c.ndim <= 1024 && c.w_host == 0 &&
         !getenv("PTMI_NO_AM_AHEAD")) {
         const long long nch = (long long)c.nwalkers * c.ntemps;
         const char *mb = getenv("PTMI_AM_BUDGET_MB");                    // scratch for the increments of one piece of a launch (default 6 GB)
@@ -2748,7 +2751,8 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
     a.iter0 = iter0; a.nsteps = nsteps;
     if (int rc = set_step_args(h, &a)) return rc;
     if (h->cfg.w_host > 0) return fail(PTMI_EINVAL, "host-served jumps need the split path (ptmi_propose / ptmi_accept)");
-    if (h->cfg.w_nuts + h->cfg.w_hmc > 0) {      // the fused kernel with the NUTS / HMC branch (csrc/ptmi_gj.inc.h)
+    const bool gjc = h->cfg.w_nuts + h->cfg.w_hmc > 0;       // the fused kernel with the NUTS / HMC branch (csrc/ptmi_gj.inc.h)
+    auto launch_gj = [&](KArgs &a) -> int {
         if (h->cfg.w_nuts > 0 && h->d_gj_order) {                                   // chains of similar step size share a wave
             const long long nch = (long long)h->cfg.nwalkers * h->cfg.ntemps;
             const unsigned g = (unsigned)((nch + 255) / 256);
@@ -2766,13 +2770,18 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
         }
         if (int rc = run_shape(h, PTMI_OP_MH_GJ, a, chains_grid(h), true)) return rc;
         h->last_variant = PTMI_VAR_GRADJUMP | PTMI_VAR_FULL;
+        return PTMI_OK;
+    };
+    if (gjc && h->am_piece <= 0) {
+        if (int rc = launch_gj(a)) return rc;
         HIPCHK(hipGetLastError());
         return PTMI_OK;
     }
     const bool full = h->cfg.w_am > 0 || (h->de_on && h->cfg.w_de > 0);
-    if (!full && h->cfg.w_scam <= 0) return fail(PTMI_EINVAL, "empty proposal cycle");
+    if (!full && h->cfg.w_scam <= 0 && !gjc) return fail(PTMI_EINVAL, "empty proposal cycle");
     const int grid = chains_grid(h);
-    if (int rc = make_ut_pad(h, &a)) return rc;
+    if (!gjc)
+        if (int rc = make_ut_pad(h, &a)) return rc;
     if (h->am_piece > 0) {
         // large ndim: the launch goes in pieces, each behind the matrix product that computes its AM increments
         const ptmi_config &c = h->cfg;
@@ -2782,6 +2791,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             AmArgs p;
             p.seed = c.seed; p.iter0 = iter0 + s0; p.nch = nch; p.nsteps = ns; p.nt = c.ntemps; p.ntg = c.ntemps_global; p.temp0 = c.temp0;
             p.walker0 = c.walker0; p.w_host = c.w_host; p.w_scam = c.w_scam; p.w_am = c.w_am; p.w_de = h->de_on ? c.w_de : 0;
+            p.w_gj = c.w_nuts + c.w_hmc;
             p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.ngroups = c.ngroups > 1 ? c.ngroups : 1; p.gcn = h->d_gcn;
             p.per_walker = c.cov_per_walker ? 1 : 0;
             p.temp_of = h->buf.temp_of; p.temps_mh = h->d_temps;
@@ -2808,6 +2818,10 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             if (int rc = set_step_args(h, &ap)) return rc;
             ap.am_inc = h->d_am_inc; ap.am_base = h->d_am_base;
             ap.UtPad = a.UtPad; ap.ut_pad_ld = a.ut_pad_ld; ap.ut_absmax = a.ut_absmax;
+            if (gjc) {                                                   // (the gradient-jump kernel reads its AM increments the same way)
+                if (int rc = launch_gj(ap)) return rc;
+                continue;
+            }
             if (int rc = run_shape(h, PTMI_OP_MH, ap, grid, full)) return rc;
         }
         HIPCHK(hipGetLastError());

@@ -1537,6 +1537,7 @@ __global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_W
     u32 nacc = 0, jp[PTMI_J_NTYPES] = {0, 0, 0, 0, 0}, ja[PTMI_J_NTYPES] = {0, 0, 0, 0, 0};
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
+    long long am_next = a.am_base != nullptr ? a.am_base[ch] : 0;      // the chain's next AM increment computed ahead of the launch (am_gemm_kernel)
     // PAIR: the step-size states of the wave's 16 chains live in LDS for the launch (behind the exchange area; two doubles per lane
     // in, the same two out at the end): a call began with eight dependent reads from global memory and ended with a store the
     // chain's next call had to see (a fence), some thousand cycles of a one-leapfrog call's twelve
@@ -1558,7 +1559,7 @@ __global__ __launch_bounds__(GJ_BLOCK, ((G == 4 && EPL <= 5) || W16) ? PTMI_GJ_W
         Draws dr;
         draws_for_step<false, true>(batch, dr, a, k, sid, sid0, gl);
         const double log_u = dr.log_u;
-        const int jt = propose<G, EPL, true, false, false, true>(a, it, sid, gl, cc, dr, Ut, false, S, DE, q);
+        const int jt = propose<G, EPL, true, false, false, true>(a, it, sid, gl, cc, dr, Ut, false, S, DE, q, false, true, nullptr, &am_next);
         const bool is_gj = jt == PTMI_J_NUTS || jt == PTMI_J_HMC;
         if constexpr (PAIR) {
             // two chains at a time, a half-wave each: their rows go through LDS into the pair layout (area 32 hh + 16 (g >> 1) +

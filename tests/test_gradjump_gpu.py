@@ -64,6 +64,11 @@ CASES = [
     dict(d=34, nt=2, W=3, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 0, 10), hmc=(0.08, 2, 50), diag=True),
     dict(d=50, nt=2, W=3, logl=("iso",), logp=("flat",), grad_weights=(20, 0), weights=(5, 0, 0), nuts_maxdepth=2, diag=True),
     dict(d=40, nt=2, W=3, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 0, 0), diag=True, nowide16=True),
+    # AM increments ahead of the launch in the gradient-jump kernels (16 / 64 lanes per chain, pooled covariance: am_gemm_kernel, round 5),
+    # a 1 MB scratch cutting the launches into single steps -- the per-chain layout and the whole-wave one
+    dict(d=100, nt=2, W=3, logl=("iso",), logp=("box", -4.0, 4.0), grad_weights=(10, 5), weights=(10, 10, 10), cov_mode="pooled", am_mode="rows", am_budget=1),
+    dict(d=40, nt=2, W=4, logl=("interval", 0.0, 10.0), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.4, 2, 100), diag=True, cov_mode="pooled", am_mode="rows", am_budget=1),
+    dict(d=150, nt=2, W=2, logl=("iso",), logp=("flat",), grad_weights=(10, 10), weights=(10, 10, 0), cov_mode="pooled", am_mode="rows"),
     # the launch order: chains with a wave of their own (PTMI_GJ_SOLO: here 5 of 20 / 9 of 12 chains, and all of them), empty chain slots beside
     # them -- in the pair layout, the whole-wave layout and the per-chain one
     dict(d=20, nt=4, W=5, logl=("curved",), logp=("box", -10.0, 10.0), grad_weights=(10, 10), weights=(10, 10, 10), hmc=(0.08, 2, 50), diag=True, solo=5),
@@ -75,11 +80,13 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "d%d-%s%s%s%s" % (c["d"], c["logl"][0], "-cap%d" % c["nuts_maxdepth"] if "nuts_maxdepth" in c else "",
-                                                                       "-diag" if c.get("diag") else "", ("" if sum(c["grad_weights"]) else "-nogj") + ("-nowide16" if c.get("nowide16") else "") + ("-solo%d" % c["solo"] if "solo" in c else "")))
+                                                                       "-diag" if c.get("diag") else "", ("" if sum(c["grad_weights"]) else "-nogj") + ("-nowide16" if c.get("nowide16") else "") + ("-solo%d" % c["solo"] if "solo" in c else "") + ("-" + c["cov_mode"] if "cov_mode" in c else "") + ("-pieces" if "am_budget" in c else "")))
 def test_device_gradient_jumps_bit_exact(case, monkeypatch):
     c = dict(case)
     d, nt, W = c.pop("d"), c.pop("nt"), c.pop("W")
     diag = c.pop("diag", False)
+    if "am_budget" in c:
+        monkeypatch.setenv("PTMI_AM_BUDGET_MB", str(c.pop("am_budget")))
     if "solo" in c:
         monkeypatch.setenv("PTMI_GJ_SOLO", str(c.pop("solo")))
     if c.pop("nowide16", False):
