@@ -2383,7 +2383,7 @@ static int launch_am_gemm_t(ptmi_engine *h, long long max_events)
         hipLaunchKernelGGL(kern, dim3((unsigned)((per_key + 63) / 64), parts, pw ? h->cfg.nwalkers : 1), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
                            (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, d, (const double *)h->buf.Ut,
                            (const double *)h->buf.S, h->cfg.seed, h->d_am_inc, ngr > 1 ? h->gsize_host[g] : d,
-                           ngr > 1 ? (const long long *)h->d_am_kbase : nullptr, ngr > 1 ? (const int32_t *)h->d_am_perm : nullptr, g, ngr);
+                           h->d_am_perm ? (const long long *)h->d_am_kbase : nullptr, (const int32_t *)h->d_am_perm, g, ngr);
     return PTMI_OK;
 }
 static int launch_am_gemm(ptmi_engine *h, long long max_events)
@@ -2621,14 +2621,15 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     // per 100 steps of the default mix at 64 x 4096 x 100-d with three groups before
     // -- and the gradient-jump shapes at 16 / 64 lanes per chain (the interval family, NUTS / HMC cycles at ndim > 32): their step kernels'
     // own AM product is the vector pipe's too
-    if (e == hipSuccess && c.w_am > 0 && (c.ngroups > 1 || (s.G > 4 && !c.cov_per_walker)) && c.ndim <= 1024 && c.w_host == 0 &&
+    // -- and per-walker covariances at 16 / 64 lanes per chain without groups (one key per walker)
+    if (e == hipSuccess && c.w_am > 0 && (c.ngroups > 1 || s.G > 4) && c.ndim <= 1024 && c.w_host == 0 &&
         !getenv("PTMI_NO_AM_AHEAD")) {
         const long long nch = (long long)c.nwalkers * c.ntemps;
         const char *mb = getenv("PTMI_AM_BUDGET_MB");                    // scratch for the increments of one piece of a launch (default 6 GB)
         const double budget = (mb ? atof(mb) : 6144.0) * 1048576.0;
         long long piece = (long long)(budget / ((double)c.ndim * 8.0 * (double)nch));
         piece = piece < 1 ? 1 : (piece > 64 ? 64 : piece);
-        if (c.ngroups > 1 && nch * piece > 0x7FFFFFFFLL) piece = 0x7FFFFFFFLL / nch;      // (the group lists index the events with 32 bits; nch itself is below 2^32 / ntemps)
+        if ((c.ngroups > 1 || c.cov_per_walker) && nch * piece > 0x7FFFFFFFLL) piece = 0x7FFFFFFFLL / nch;      // (the group lists index the events with 32 bits; nch itself is below 2^32 / ntemps)
         if (piece < 1) piece = 1;
         h->am_piece = (int)piece;
         h->am_cap = nch * piece;
@@ -2636,8 +2637,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_count, sizeof(int32_t) * (size_t)(nch + (nch + 1023) / 1024));      // counts | the scan's block sums
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_base, sizeof(long long) * (size_t)(nch + 1));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_inc, sizeof(double) * (size_t)h->am_cap * c.ndim);
-        if (e == hipSuccess && c.ngroups > 1) {                          // the events listed key by key: totals | cursors | the scan's block sums; list starts (+ the end)
-            const size_t nkeys = (size_t)c.ngroups * (c.cov_per_walker ? (size_t)c.nwalkers : 1);
+        if (e == hipSuccess && (c.ngroups > 1 || c.cov_per_walker)) {    // the events listed key by key: totals | cursors | the scan's block sums; list starts (+ the end)
+            const size_t nkeys = (size_t)(c.ngroups > 1 ? c.ngroups : 1) * (c.cov_per_walker ? (size_t)c.nwalkers : 1);
             if (h->am_cap > 0x7FFFFFFFLL) e = hipErrorInvalidValue;
             if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_grp, sizeof(int32_t) * (2 * nkeys + (nkeys + 1023) / 1024 + 1));
             if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_kbase, sizeof(long long) * (nkeys + 1));
@@ -2798,7 +2799,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
             const unsigned gch = (unsigned)((nch + 255) / 256);
             const int ngr = p.ngroups;
             const long long nkeys = (long long)ngr * (c.cov_per_walker ? c.nwalkers : 1);
-            int32_t *gtot = ngr > 1 ? h->d_am_grp : nullptr, *gcur = gtot ? gtot + nkeys : nullptr, *gpart = gtot ? gtot + 2 * nkeys : nullptr;
+            int32_t *gtot = h->d_am_perm ? h->d_am_grp : nullptr, *gcur = gtot ? gtot + nkeys : nullptr, *gpart = gtot ? gtot + 2 * nkeys : nullptr;
             if (gtot) HIPCHK(hipMemsetAsync(gtot, 0, sizeof(int32_t) * 2 * (size_t)nkeys, h->stream));          // the keys' totals and the fill's cursors
             hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count, gtot);
             if (gtot) {                                                  // the lists' starts: the chains' scan over the keys' totals
