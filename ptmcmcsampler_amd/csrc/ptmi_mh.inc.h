@@ -2179,7 +2179,11 @@ static int launch_mh_k(ptmi_engine *h, KArgs &a, int grid)
         // SCAM-only cycles read one row of the chain's own table per step; with AM the block needs ONE table
         const bool one_table_per_block = c.ngroups <= 1 && (!FULL || !c.cov_per_walker || c.ntemps % (256 / G) == 0);
         size_t lds = LOGL == PTMI_LOGL_DENSE ? tab : 0;
-        if (FULL && lds + tab + sizeof(double) * c.ndim <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
+        // (dense likelihood with AM in the cycle: the producer / consumer kernel below keeps the likelihood's table in LDS and reads the
+        // eigenvectors from global memory at every ndim -- with both tables in LDS the smaller shapes fell back to the one-wave kernel:
+        // 11.8 / 18.8 ms per 100 steps at 50 / 80-d against 14.2 at 100-d, now 7.5 / 11.6; up to 32-d the one-wave kernel stays ahead)
+        const bool dense_pc = FULL && LOGL == PTMI_LOGL_DENSE && EPL >= 14 && c.w_am > 0 && one_table_per_block && getenv("PTMI_NO_PC") == nullptr;
+        if (FULL && !dense_pc && lds + tab + sizeof(double) * c.ndim <= 160 * 1024) { a.lds_u = 1; lds += tab; }      // else Ut is read from global (L2)
         if (FULL) lds += sizeof(double) * c.ndim;                               // sqrt(eigenvalues)
         // AM queue of the block's four waves: 16 increments of 4 EPL + 2 doubles and 128 event entries each
         const size_t amq = FULL ? sizeof(double) * 4 * 16 * (4 * EPL + 2) + sizeof(int) * 4 * 128 : 0;

@@ -546,3 +546,22 @@ def test_full_size_dense_target_covariance(mods):
     assert np.abs(z[warm]).max() < 5.0, z[warm]
     # the pooled adaptive covariance (cumulative since p0 = 0, transient included) is on its way to the target's
     assert np.linalg.norm(g.get("cov")[0] - Ctrue) < 0.3 * np.linalg.norm(Ctrue)
+
+
+@pytest.mark.parametrize("d,nt,W,cov_mode", [(50, 64, 2, "pooled"), (80, 5, 7, "pooled"), (104, 8, 3, "pooled"), (50, 64, 2, "per_walker")])
+def test_dense_likelihood_producer_consumer_kernel_at_other_shapes(mods, d, nt, W, cov_mode):
+    """The dense Gaussian's default mix below 100-d (shapes (4, 14), (4, 20), (4, 26)): the producer / consumer kernel with the likelihood's
+    table in LDS and the eigenvectors read from global memory, as at 100-d (round 5: with both tables in LDS these shapes fell back
+    to the one-wave kernel: 11.8 / 18.8 ms per 100 steps at 50 / 80-d against 7.5 / 11.6 now).  HIP == oracle, the variant asserted."""
+    orc, _lib, _ = mods
+    rs = np.random.RandomState(d)
+    A = rs.randn(d, d)
+    logl = ("dense", rs.randn(d) * 0.1, np.linalg.inv(A @ A.T / d + 0.5 * np.eye(d)))
+    g, o = _pair(mods, d, nt, W, cov0=np.eye(d) * 0.01, weights=(20, 20, 20), cov_update=20, burn=40, tskip=7, seed=23, cov_mode=cov_mode, logl=logl)
+    for m in (97, 3, 1, 46):
+        g.run(m)
+        o.run(m)
+    flags, G, E = g.last_variant()
+    assert flags & _lib.VAR_PC and flags & _lib.VAR_FULL and not flags & _lib.VAR_LDS_UT
+    _compare(g, o, "dense pc d=%d %s " % (d, cov_mode))
+    assert o.jstat[..., :3, 0].sum(axis=(0, 1)).min() > 0
