@@ -1,5 +1,5 @@
 """Step time of the default SCAM / AM / DE mix over ndim (pooled covariance, 64 x 4096 chains up to 104-d, fewer beyond): a look for slow paths
-(developer tool, one GPU).  usage: dim_sweep.py [--per-walker] [--box] [--dense]"""
+(developer tool, one GPU).  usage: dim_sweep.py [--per-walker] [--box] [--dense] [--scam]"""
 import os
 import sys
 import time
@@ -12,7 +12,7 @@ from ptmcmcsampler_amd.engine import PTEngine
 cov_mode = "per_walker" if "--per-walker" in sys.argv else "pooled"
 for d in (5, 8, 20, 32, 50, 80, 100, 104, 105, 200, 416, 417, 1000):
     nt, W = 64, (4096 if d <= 104 else (1024 if d <= 416 else 256))
-    kw = dict(weights=(20, 20, 20), cov_update=1000, burn=200, tskip=100, seed=1, cov_mode=cov_mode, eig_mode="ql" if cov_mode == "per_walker" and d <= 128 else "lapack")
+    kw = dict(weights=(20, 0, 0) if "--scam" in sys.argv else (20, 20, 20), cov_update=1000, burn=200, tskip=100, seed=1, cov_mode=cov_mode, eig_mode="ql" if cov_mode == "per_walker" and d <= 128 else "lapack")
     if cov_mode == "per_walker" and d > 128:
         W = min(W, 64)
     if "--box" in sys.argv:
