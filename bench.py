@@ -78,6 +78,12 @@ def make_parser():
     ap.add_argument("--callback", action="store_true",
                     help="evaluate the likelihood in a batched torch callback between ptmi_propose and ptmi_accept (one launch pair per "
                          "iteration) instead of inside the fused kernel")
+    ap.add_argument("--callback-kind", default="norm", choices=["norm", "naive", "hip"],
+                    help="the callback: norm = torch, -0.5 * vector_norm(X)^2 (one pass over the proposals); naive = torch, "
+                         "-0.5 * (X * X).sum(-1) (writes and re-reads a temporary of the proposals' size); hip = a device kernel behind the C "
+                         "ABI (ptmi_rows_logl: the fused kernels' likelihood bits)")
+    ap.add_argument("--callback-launches", default="one", choices=["one", "two"],
+                    help="one: ptmi_accept_propose (the accept test and the next proposal in one launch); two: ptmi_propose + ptmi_accept")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--also-child", action="store_true", help=argparse.SUPPRESS)      # the process that runs the "also" legs (spawned by the headline's)
     ap.add_argument("--also", default="auto", choices=["auto", "on", "off"],
@@ -232,10 +238,15 @@ def measure(a, rank, world, local, dist, backend):
     if a.callback:
         if a.logl != "iso" or world != 1:
             raise SystemExit("--callback times the iso-Gaussian through a torch callback on one GPU")
-        cb_l = lambda X: -0.5 * (X * X).sum(-1)                      # noqa: E731
-        cb_p = lambda X: torch.zeros(X.shape[0], dtype=torch.float64, device=X.device)   # noqa: E731
+        if a.callback_kind == "naive":
+            cb_l = lambda X: -0.5 * (X * X).sum(-1)                  # noqa: E731
+        elif a.callback_kind == "hip":
+            cb_l = eng.builtin_logl()
+        else:
+            cb_l = lambda X: torch.linalg.vector_norm(X, dim=-1).square_().mul_(-0.5)     # noqa: E731 -- one pass over the proposals
+        cb_p = None                                                  # the flat prior: no launch
         eng.init_state_callback(p0, cb_l, cb_p)
-        eng.run = lambda n: eng.run_callback(n, cb_l, cb_p)
+        eng.run = lambda n: eng.run_callback(n, cb_l, cb_p, fused=a.callback_launches == "one")
     else:
         eng.init_state(p0)
     log("engine ready")
@@ -265,7 +276,9 @@ def measure(a, rank, world, local, dist, backend):
     # timed region: exactly --steps Tskip cycles; each fused-MH launch is bracketed by HIP events on the engine's
     # stream (= torch's current stream, the one the kernels are launched on)
     events = []
-    hot = "split_step" if a.callback else "mh_steps"                # the launch (pair) that is the dominant kernel
+    # (callback path: a segment = one proposal launch, then per iteration the torch callback and ptmi_accept_propose; or split_step's
+    # launch pair with --callback-launches two)
+    hot = ("callback_segment" if a.callback_launches == "one" else "split_step") if a.callback else "mh_steps"
     orig = getattr(eng, hot)
 
     def timed_mh(iter0, *rest):
@@ -273,7 +286,7 @@ def measure(a, rank, world, local, dist, backend):
         e0.record(eng.stream)
         orig(iter0, *rest)
         e1.record(eng.stream)
-        events.append((e0, e1, 1 if a.callback else rest[0]))
+        events.append((e0, e1, (rest[0] - iter0 + 1 if hot == "callback_segment" else 1) if a.callback else rest[0]))
 
     setattr(eng, hot, timed_mh)
     orig_cov = eng.update_cov
@@ -367,7 +380,9 @@ def measure(a, rank, world, local, dist, backend):
     flops_per_update = 4 * d
     hbm_view = bytes_per_update * upd_per_launch / (avg_launch_ms * 1e-3) / 1e9
     tf = flops_per_update * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12
-    kernel = "mh_steps_gj_kernel" if a.mix == "nuts" else ("propose_kernel + torch callback + accept_kernel" if a.callback else "mh_steps_kernel")
+    kernel = "mh_steps_gj_kernel" if a.mix == "nuts" else (
+        ("split_rows_kernel<acc,prop> + torch callback" if a.callback_launches == "one" else "split_rows_kernel<prop> + torch callback + split_rows_kernel<acc>")
+        if a.callback else "mh_steps_kernel")
     out = {
         "metric": "MH updates/sec (whole node) + ESS/sec, 100-d Gaussian, 64 temps x 4096 walkers per GPU",
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -396,6 +411,25 @@ def measure(a, rank, world, local, dist, backend):
                      "launch_ms_first": events[0][0].elapsed_time(events[0][1]) if events else None,
                      "launch_ms_last": events[-1][0].elapsed_time(events[-1][1]) if events else None},
     }
+    if a.callback:
+        out["config"]["workload"] += ("; the likelihood OUTSIDE the library: a batched torch callback (%s) on the device tensor of proposals, %s per iteration"
+                                      % ({"norm": "torch: -0.5 * vector_norm(Q)^2, one pass", "naive": "torch: -0.5 * (Q * Q).sum(-1)", "hip": "a HIP kernel behind the C ABI: ptmi_rows_logl"}[a.callback_kind],
+                                         "ptmi_accept_propose (one launch)" if a.callback_launches == "one" else "ptmi_propose + ptmi_accept (two launches)"))
+        # The split path IS bound by HBM: SURVEY 8(d)'s 16 d + 32 bytes per update are real traffic here (state in, proposal out;
+        # the callback's own read of the proposals and the accepted rows written back come on top: the split design's byte model)
+        acc_t = None
+        try:
+            acc_t = float(eng.get("nacc").astype(np.float64).mean() / max(1, eng.iter))
+        except Exception:               # noqa: BLE001
+            pass
+        model = (3.0 + (acc_t if acc_t is not None else 1.0)) * 8 * d + 64 + 32          # + qaux in / out, lnL / lp / callback values
+        out["roofline"].update({"bound": "hbm", "achieved": hbm_view, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_view / HBM_PEAK_GBS,
+                                "f64_valu_frac": tf / F64_PEAK_TFLOPS,
+                                "split_design_bytes_per_update": model, "acceptance_whole_run": acc_t,
+                                "split_design_gbs": model * upd_per_launch / (avg_launch_ms * 1e-3) / 1e9,
+                                "note": "achieved = (16 d + 32) B x updates / HIP-event time of the segments (proposal launch + per iteration "
+                                        "[torch callback, accept + next proposal]); split_design_* counts what this design must move per update: "
+                                        "state or proposal in, proposal out, the callback's read of it, the accepted share written back"})
     # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
     # summary is per launch of 100 steps on one named workload
     for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -404,6 +438,8 @@ def measure(a, rank, world, local, dist, backend):
         except (OSError, ValueError):
             continue
         key = "ndim=%d ntemps=%d nwalkers=%d mix=%s logl=%s" % (d, nt, W, a.mix, a.logl)
+        if a.callback:                          # a fused-kernel profile says nothing about the split path: its own file, below
+            break
         if tr.get("workload", "").startswith(key) and (tr.get("pick", "chain") == a.pick):
             per_launch = tr["traffic_bytes_per_launch"] * avg_steps / float(tr.get("steps_per_launch", 100))
             out["roofline"]["traffic"] = per_launch
@@ -411,6 +447,18 @@ def measure(a, rank, world, local, dist, backend):
                                                + ", ".join(tr["source"]))
             out["roofline"]["algorithmic_bytes_per_launch"] = bytes_per_update * upd_per_launch
             break
+    if a.callback:
+        # counter traffic of the split path (tools/gpu_profile.sh callback: separate rocprofv3 --pmc passes over this very command), per
+        # iteration of every chain
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r06_callback_traffic.json")))
+            if tr.get("launches") == a.callback_launches and tr.get("callback_kind") == a.callback_kind and tr.get("workload", "").startswith(
+                    "ndim=%d ntemps=%d nwalkers=%d" % (d, nt, W)):
+                out["roofline"]["traffic"] = tr["traffic_bytes_per_iteration"] * avg_steps
+                out["roofline"]["traffic_note"] = "HBM bytes per segment from rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, " + ", ".join(tr["source"])
+                out["roofline"]["traffic_over_model"] = tr["traffic_bytes_per_iteration"] / (out["roofline"]["split_design_bytes_per_update"] * nt * W)
+        except (OSError, ValueError, KeyError):
+            pass
     # What the launch MUST move, counted live from this run's own state (not a counter): every chain's row, lnL and lp in and out,
     # and the rank-0 rows and flag words it stored (am_mode rle: only the accepted steps' rows -- the stored share is read off the
     # AM flags of the ring as it stands after the run).  The PMC figure above is a committed profile of the same workload; a
@@ -463,6 +511,9 @@ ALSO = (
     ("config2_replica_per_walker_cov_device_ql", dict(cov_mode="per_walker_device"), 20, 10),
     ("config4_share_1000d_64x512", dict(ndim=1000, nwalkers=512), 30, 20),
     ("config5_share_curved_nuts_16x4096", dict(logl="curved", ndim=20, ntemps=16, mix="nuts"), 6, 4),
+    # the headline's workload with the likelihood OUTSIDE the library: a batched torch callback on the device tensor of proposals
+    # (the reference's logl / logp boundary, PTMCMCSampler.py:605-611, 1072-1086)
+    ("config2_batched_callback", dict(callback=True), 20, 5),
 )
 L2_PEAK_TBS = 34.5             # MI355X_MICROARCH.md: aggregate L2 bandwidth (4 MiB per XCD); profiles/r05_row_gather.txt: random 8 KB rows of a
                                # 7.8 MB table (it does not fit one XCD's L2: half the rows come from the MALL) arrive at 16.1 TB/s
@@ -497,7 +548,9 @@ def also_legs(a, rank, world, local, dist, backend):
                "workload": o["config"]["workload"], "iterations_timed": o["iterations_timed"], "cov_epochs_timed": o["cov_epochs_timed"],
                "acceptance_rank0_mean": o.get("acceptance_rank0_mean"),
                "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "steps_per_launch",
-                                                  "kernel_time_share_of_wall", "algorithmic_flops_per_update") if k in r},
+                                                  "kernel_time_share_of_wall", "algorithmic_flops_per_update", "algorithmic_bytes_per_update",
+                                                  "split_design_bytes_per_update", "split_design_gbs", "acceptance_whole_run", "traffic",
+                                                  "traffic_over_model", "f64_valu_frac") if k in r},
                "leg_seconds": time.perf_counter() - t0}
         if b.ndim > 416 and b.mix == "scam":
             # 64 lanes per chain: a step reads ONE table row of 8 * ndim bytes per chain from L2 / MALL (the table, 8 MB at ndim = 1000,
@@ -518,7 +571,7 @@ def main():
     if a.also == "auto":
         dflt = parse_defaults()
         a.also = all(getattr(a, k) == getattr(dflt, k) for k in ("ndim", "ntemps", "nwalkers", "mix", "weights", "pick", "logl", "prior", "cov_mode",
-                                                                 "swap_mode", "partition", "sharded", "callback", "am_mode", "eig_lag", "stats_async")) and a.gpus == 1
+                                                                 "swap_mode", "partition", "sharded", "callback", "callback_kind", "callback_launches", "am_mode", "eig_lag", "stats_async")) and a.gpus == 1
     else:
         a.also = a.also == "on"
     if a.gpus > 1 and "LOCAL_RANK" not in os.environ:

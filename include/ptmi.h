@@ -155,6 +155,12 @@ typedef struct ptmi_buffers {
                          *              was, its row repeats the one before -- and ptmi_update_cov takes every stored row once, weighted by
                          *              the length of its run.  Readers that want every row call ptmi_am_expand first.  The caller
                          *              initialises every word to KEY (2) and marks rows it writes itself as KEY */
+    double *Q2;         /* [W][T][d]   a SECOND proposal buffer (optional, with sloc): ptmi_accept_propose then writes the next proposals to
+                         *              the buffer that does NOT hold the current ones (ptmi_proposals says which is which), an accepted
+                         *              proposal stays where it is as the chain's state, and rows are copied to X only when their buffer
+                         *              is about to be overwritten or at ptmi_accept (csrc/ptmi_split.hip) */
+    int32_t *sloc;      /* [W][T]      with Q2: where a chain's state lives between ptmi_propose and ptmi_accept (0 = X, 1 = Q, 2 = Q2);
+                         *              all zero outside such a span -- the caller zeroes it once */
 } ptmi_buffers;
 
 typedef struct ptmi_engine *ptmi_handle;
@@ -332,6 +338,21 @@ int ptmi_set_de_head(ptmi_handle h, int32_t head);
  * accept applies the Hastings test with the caller's values (NaN-safe, -inf prior). */
 int ptmi_propose(ptmi_handle h, int64_t iter);
 int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL /* dev [W][T] */, const double *newlp /* dev [W][T] */);
+/* ptmi_accept(iter) and ptmi_propose(iter + 1) in ONE launch (csrc/ptmi_split.hip): a chain's row comes in once -- the accepted
+ * proposal or the old state -- and goes out once as the next proposal (and to X where accepted), where the two calls moved it twice;
+ * the inner loop of a run whose likelihood is a batched device callback (PTMCMCSampler.py:601-622 between epochs).  The caller calls
+ * it only where NOTHING sits between the two iterations: no swap (iter a multiple of Tskip: refused), no covariance / DE epoch
+ * and no DE activation at iter + 1 (the caller's schedule; PTEngine.run_callback).  qaux[.][2] then holds the next iteration's
+ * accept uniform, not this one's decision (nacc / jstat count it).  Same results as the two calls, bit for bit. */
+int ptmi_accept_propose(ptmi_handle h, int64_t iter, const double *newlnL /* dev [W][T] */, const double *newlp /* dev [W][T] */);
+/* The buffer that holds the current proposals: Q after ptmi_propose; after ptmi_accept_propose Q or Q2 in turn when the handle has
+ * both (ptmi_buffers.Q2: X is then authoritative again only after ptmi_accept), else Q.  The callback reads THIS buffer. */
+int ptmi_proposals(ptmi_handle h, double **q);
+/* The handle's built-in likelihood of n rows [n][ndim] anywhere on the device (the proposals, say), with the BITS the fused kernels
+ * give it (the same lanes, the same summation order): a likelihood "callback" that is a device kernel behind the C ABI -- with it
+ * the split path reproduces the fused path bit for bit at any size (tests), and bench.py times the split path with a callback that
+ * costs one pass over the proposals.  PTMI_LOGL_ISO only.  On the handle's stream. */
+int ptmi_rows_logl(ptmi_handle h, const double *rows /* dev [n][ndim] */, int64_t n, double *out /* dev [n] */);
 
 /* Self-test hooks used by the parity tests: evaluate the device's deterministic math on
  * n inputs (op: 0 log, 1 exp, 2 cos2pi, 3 sqrt, 4 reciprocal-free divide a/b with b=in2). */

@@ -57,7 +57,8 @@ def build(force=False, verbose=False, jobs=None):
     if not force and not stale():
         return OUT
     os.makedirs(OBJ, exist_ok=True)
-    work = [(os.path.join(CSRC, "ptmi_abi.hip"), os.path.join(OBJ, "abi.o"), [])]
+    work = [(os.path.join(CSRC, "ptmi_abi.hip"), os.path.join(OBJ, "abi.o"), []),
+            (os.path.join(CSRC, "ptmi_split.hip"), os.path.join(OBJ, "split.o"), [])]         # the split path's row kernels (shape-independent)
     for g, e in sorted(shapes(), key=lambda s: -s[0] * s[1]):       # biggest units first
         for fam in (1, 0, 2, 3):
             if fam == 3 and e > 8:          # the interval family (PTMI_LOGL_INTERVAL): the gradient-jump shapes only (PTMI_GJ_SHAPE_LIST)

@@ -2298,13 +2298,14 @@ static KArgs make_args(ptmi_engine *h)
     a.nacc = (u64 *)b.nacc; a.jstat = (u64 *)b.jstat;
     a.temps_mh = h->d_temps; a.beta = h->d_beta; a.logl_par = h->d_loglpar; a.logp_par = h->d_logppar;
     a.gsize = h->d_gsize; a.gmask = h->d_gmask; a.gcn = h->d_gcn; a.gdiv = h->d_gdiv; a.ngroups = c.ngroups > 1 ? c.ngroups : 1;
-    a.Q = b.Q; a.qaux = b.qaux;
+    a.Q = b.Q; a.qaux = b.qaux; a.Q2 = nullptr; a.sloc = nullptr; a.q_cur = 0; a.q_tgt = 0;
     a.seed = c.seed;
     a.d = c.ndim; a.nt = c.ntemps; a.W = c.nwalkers; a.ntg = c.ntemps_global; a.temp0 = c.temp0; a.walker0 = c.walker0;
     a.w_host = c.w_host; a.w_scam = c.w_scam; a.w_am = c.w_am; a.w_de = c.w_de; a.de_on = h->de_on; a.de_size = c.de_size; a.de_head = h->de_head;
     a.cov_update = c.cov_update; a.tskip = c.tskip; a.per_walker = c.cov_per_walker; a.logp_kind = c.logp_kind;
     a.pick_walker = c.pick_mode == PTMI_PICK_WALKER;
     a.de_ld = h->G == 4 ? 8 * ((h->EPL + 1) / 2) : c.ndim;
+    a.lanes = h->G;
     a.am_epl = am_row_epl(h->G, h->EPL);
     a.w_nuts = c.w_nuts; a.w_hmc = c.w_hmc; a.gj_nburn = c.gj_nburn; a.hmc_min = c.hmc_min; a.hmc_max = c.hmc_max;
     a.nuts_maxdepth = c.nuts_maxdepth; a.hmc_eps = c.hmc_eps; a.nuts_delta = c.nuts_delta;
@@ -2848,8 +2849,14 @@ int ptmi_propose(ptmi_handle h, int64_t iter)
     KArgs a = make_args(h);
     a.iter0 = iter; a.nsteps = 1;
     if (int rc = set_step_args(h, &a)) return rc;
-    const int grid = chains_grid(h);
-    if (int rc = run_shape(h, PTMI_OP_PROPOSE, a, grid, true)) return rc;
+    h->q_cur = 0;                                            // the proposals go to Q
+    if (ptmi_split_rows_ok(h)) {
+        if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; }
+        if (int rc = ptmi_split_rows(h, a, 0)) return rc;
+    } else {
+        const int grid = chains_grid(h);
+        if (int rc = run_shape(h, PTMI_OP_PROPOSE, a, grid, true)) return rc;
+    }
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }
@@ -2861,9 +2868,63 @@ int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL, const double 
     KArgs a = make_args(h);
     a.iter0 = iter; a.nsteps = 1; a.newlnL = newlnL; a.newlp = newlp;
     if (int rc = set_step_args(h, &a)) return rc;
+    if (ptmi_split_rows_ok(h)) {
+        if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; }
+        a.q_cur = h->q_cur;
+        if (int rc = ptmi_split_rows(h, a, 1)) return rc;
+    } else {
+        const int grid = chains_grid(h);
+        if (int rc = run_shape(h, PTMI_OP_ACCEPT, a, grid, true)) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_accept_propose(ptmi_handle h, int64_t iter, const double *newlnL, const double *newlp)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    if (!h->buf.Q || !h->buf.qaux || !newlnL || !newlp) return fail(PTMI_EINVAL, "split path buffers missing");
+    const ptmi_config &c = h->cfg;
+    // nothing may sit between the two iterations: a swap (iter a multiple of Tskip), a covariance or DE epoch (the caller's: they
+    // change the tables the proposal of iter + 1 reads)
+    if (c.tskip > 0 && c.ntemps_global > 1 && iter % c.tskip == 0)
+        return fail(PTMI_EINVAL, "ptmi_accept_propose(%lld): a swap iteration (Tskip=%d) is accepted with ptmi_accept, the swap follows", (long long)iter, c.tskip);
+    KArgs a = make_args(h);
+    a.iter0 = iter; a.nsteps = 1; a.newlnL = newlnL; a.newlp = newlp;
+    if (int rc = set_step_args(h, &a)) return rc;
+    if (ptmi_split_rows_ok(h)) {
+        a.q_cur = a.q_tgt = h->q_cur;
+        if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; a.q_tgt = 1 - h->q_cur; }
+        if (int rc = ptmi_split_rows(h, a, 2)) return rc;
+        h->q_cur = a.q_tgt;
+        HIPCHK(hipGetLastError());
+        return PTMI_OK;
+    }
+    // configurations the row kernels do not serve (AM entries in the cycle): the two shape kernels back to back
     const int grid = chains_grid(h);
     if (int rc = run_shape(h, PTMI_OP_ACCEPT, a, grid, true)) return rc;
+    KArgs b = make_args(h);
+    b.iter0 = iter + 1; b.nsteps = 1;
+    if (int rc = set_step_args(h, &b)) return rc;
+    if (int rc = run_shape(h, PTMI_OP_PROPOSE, b, grid, true)) return rc;
     HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_rows_logl(ptmi_handle h, const double *rows, int64_t n, double *out)
+{
+    if (!h || !rows || !out || n < 0) return fail(PTMI_EINVAL, "bad argument");
+    if (h->cfg.logl_kind != PTMI_LOGL_ISO) return fail(PTMI_EUNSUPPORTED, "ptmi_rows_logl serves the isotropic Gaussian (PTMI_LOGL_ISO)");
+    if (n == 0) return PTMI_OK;
+    if (int rc = ptmi_rows_iso(h, rows, (long long)n, out)) return rc;
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_proposals(ptmi_handle h, double **q)
+{
+    if (!h || !q) return fail(PTMI_EINVAL, "NULL argument");
+    *q = (h->q_cur && h->buf.Q2) ? h->buf.Q2 : h->buf.Q;
     return PTMI_OK;
 }
 

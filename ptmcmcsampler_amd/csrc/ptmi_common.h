@@ -62,6 +62,9 @@ struct KArgs {
     const double *gmask, *gcn, *gdiv;     // [Ng][d] membership; [Ng] 2.4/sqrt(2 n_g); [Ng] sqrt(2 n_g)
     // split path
     double *Q, *qaux;
+    double *Q2;                  // the second proposal buffer, or nullptr (ptmi_buffers.Q2)
+    int32_t *sloc;               // [W][T] where a chain's state lives between ptmi_propose and ptmi_accept: 0 = X, 1 + b = proposal buffer b; or nullptr
+    int q_cur, q_tgt;            // the buffer that holds the proposals being accepted; the buffer the next proposals go to
     const double *newlnL, *newlp;
     // scalars
     u64 seed;
@@ -72,6 +75,7 @@ struct KArgs {
     int cov_update, tskip, per_walker, logp_kind, ngroups;
     int am_row0, swap_last;      // iter0 % cov_update; the last step of the launch is a swap iteration
     int am_epl;                  // row format of the AM buffer (am_pos): 0 = parameter order, 25 = the lanes' order of the exact shape
+    int lanes;                   // lanes per chain of the handle's kernel shape (G): the DE rows' piece order depends on it (ptmi_de_row_stride)
     int de_ld;                   // doubles per row of the DE buffer (ptmi_de_row_stride: 8 * ceil(EPL / 2) with 4 lanes per chain, else ndim)
     int pick_walker;             // pick_mode WALKER: the cycle entry comes from the stream of the walker's rank 0
     int lds_u;                   // staged kernels: the block's Ut is copied to LDS (else read from global)
@@ -167,8 +171,15 @@ struct ptmi_engine {
     int32_t *d_rle_cnt;          // ... and how many each slab has [nslab]
     const double *rp_swap_u;     // TEST HOOK (ptmi_test_replay): the swap's uniforms [W][ntemps_global - 1] instead of the Philox ones
     const u64 *rp_draws;         // TEST HOOK: see KArgs
+    int q_cur;                   // split path: the proposal buffer (0 = Q, 1 = Q2) that holds the current proposals (ptmi_proposals)
 };
 
+
+// split path on contiguous rows (ptmi_split.hip): does the handle's configuration run there; mode 0 propose(iter0), 1 accept(iter0),
+// 2 accept(iter0) + propose(iter0 + 1) in one launch
+bool ptmi_split_rows_ok(const ptmi_engine *h);
+int ptmi_split_rows(ptmi_engine *h, const KArgs &a, int mode);
+int ptmi_rows_iso(ptmi_engine *h, const double *rows, long long n, double *out);
 
 // The per-chain kernels are templates over the shape (lanes per chain G, register slots per lane EPL).  Each shape
 // and likelihood family is compiled in its own translation unit (ptmi_shape.hip with -DPTMI_G -DPTMI_E -DPTMI_L) so

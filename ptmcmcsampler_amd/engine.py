@@ -248,6 +248,8 @@ class PTEngine(object):
             mu=z((Wc, d)) if self.owns_cold else None, M2=z((Wc, d, d)) if self.owns_cold else None,   # pooled: ONE running (mu, M2)
             cov=z((Wc, d, d)),
             Q=z((W, nt, d)) if split else None, qaux=z((W, nt, 4)) if split else None,
+            # the second proposal buffer and the chains' state locations (include/ptmi.h: accepted proposals stay where they are)
+            Q2=z((W, nt, d)) if split else None, sloc=z((W, nt), i32) if split else None,
             AMaux=z((W, self.cov_update, 2)) if (keep_lnl and self.owns_cold) else None,
             gj=z((W, nt, _lib.GJ_NSTATE)) if has_gj else None,
             AMflag=z((W, self.cov_update), i64) if self.am_rle else None,     # AM row flags (include/ptmi.h): every row starts as KEY
@@ -696,7 +698,7 @@ class PTEngine(object):
         """Everything needed to continue bit-identically: device arrays, ring head, DE flag, iteration.
         (The RNG is counter based: its whole state is the iteration number.)"""
         self.sync()
-        st = {"t_" + k: v.cpu().numpy() for k, v in self.t.items() if v is not None and k not in ("Q", "qaux")}
+        st = {"t_" + k: v.cpu().numpy() for k, v in self.t.items() if v is not None and k not in ("Q", "qaux", "Q2", "sloc")}
         st.update(iter=self.iter, de_on=int(self.de_on), de_head=self.de_head, swap_proposed=self.swap_proposed,
                   eig_epochs=self.eig_epochs,
                   # eig_lag: an epoch's table that is not in force yet (its covariance is in t_cov; restore() factorizes it again)
@@ -818,17 +820,27 @@ class PTEngine(object):
         self.iter = last
 
     # ------------------------------------------------------------------ batched callbacks
+    def _cb_values(self, v):
+        """A callback's return value as a contiguous f64 tensor of W * nt values on this GPU (no copy when it already is one)."""
+        torch = _torch()
+        if not (torch.is_tensor(v) and v.dtype == torch.float64 and v.device == self.device and v.is_contiguous() and v.numel() == self.W * self.nt):
+            v = torch.as_tensor(v, dtype=torch.float64, device=self.device).reshape(self.W, self.nt).contiguous()
+        return v
+
     def eval_callback(self, X, logl, logp):
         """logp then logl of every row of the device tensor X [W][nt][d] through BATCHED callbacks
         ``f(X[n, d]) -> [n]`` (torch tensors on this GPU in, the same out): the device-side form of the reference's
         ``_function_wrapper`` boundary (PTMCMCSampler.py:1072-1086, called at :605-611).  Nothing is copied to the host.
-        Where the prior is -inf the likelihood value is not used (the reference does not even call it, :607-608)."""
-        torch = _torch()
-        flat = X.reshape(-1, self.d)
-        lp = torch.as_tensor(logp(flat), dtype=torch.float64, device=self.device).reshape(self.W, self.nt).contiguous()
-        ll = torch.as_tensor(logl(flat), dtype=torch.float64, device=self.device).reshape(self.W, self.nt)
-        ll = torch.where(torch.isneginf(lp), torch.zeros_like(ll), ll).contiguous()
-        return ll, lp
+        ``logp=None`` is the flat prior (no launch at all).  Where the prior is -inf the likelihood value is not used: the reference
+        does not even call it (:607-608), here the accept test never reads it (ptmi_accept: -inf prior => -inf posterior)."""
+        flat = X.view(-1, self.d)
+        if logp is None:
+            if getattr(self, "_lp_zero", None) is None:
+                self._lp_zero = _torch().zeros((self.W, self.nt), dtype=_torch().float64, device=self.device)
+            lp = self._lp_zero
+        else:
+            lp = self._cb_values(logp(flat))
+        return self._cb_values(logl(flat)), lp
 
     def init_state_callback(self, p0, logl, logp, i0=0):
         """init_state for a likelihood that lives in a batched callback (:479-487)."""
@@ -837,6 +849,7 @@ class PTEngine(object):
         full = np.array(p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d)))
         self.t["X"].copy_(torch.from_numpy(full))
         ll, lp = self.eval_callback(self.t["X"], logl, logp)
+        ll, lp = ll.reshape(self.W, self.nt), lp.reshape(self.W, self.nt)
         self.t["lnL"].copy_(torch.where(torch.isneginf(lp), lp, ll))               # :481-483
         self.t["lp"].copy_(lp)
         self._store_initial(i0)
@@ -851,14 +864,61 @@ class PTEngine(object):
         ll, lp = self.eval_callback(self.t["Q"], logl, logp)
         _lib.check(self.lib.ptmi_accept(self.h, it, ll.data_ptr(), lp.data_ptr()))
 
-    def run_callback(self, niter, logl, logp):
-        """``run`` with the likelihood and the prior in batched callbacks (epochs and swaps as in ``run``)."""
+    def builtin_logl(self):
+        """The built-in isotropic Gaussian as a batched CALLBACK ``f(X[n, d]) -> [n]`` (``ptmi_rows_logl``: a device kernel behind the
+        C ABI, the fused kernels' bits): with it ``run_callback`` reproduces ``run`` bit for bit."""
+        torch = _torch()
+
+        def logl(X):
+            out = torch.empty(X.shape[0], dtype=torch.float64, device=X.device)
+            _lib.check(self.lib.ptmi_rows_logl(self.h, X.data_ptr(), X.shape[0], out.data_ptr()))
+            return out
+
+        return logl
+
+    def proposals(self):
+        """The device tensor that holds the current proposals (``ptmi_proposals``): Q, or Q2 in turn after ``ptmi_accept_propose``."""
+        p = C.c_void_p()
+        _lib.check(self.lib.ptmi_proposals(self.h, C.byref(p)))
+        q2 = self.t["Q2"]
+        return q2 if q2 is not None and p.value == q2.data_ptr() else self.t["Q"]
+
+    def callback_segment(self, it, end, logl, logp):
+        """Iterations ``it .. end`` with nothing between them (no epoch, no swap: a segment of ``run``): ONE proposal launch, then per
+        iteration the callbacks on the device tensor of proposals and ptmi_accept_propose -- the accept test of iteration j and the
+        proposal of j + 1 in one launch, a chain's row in once and out once (csrc/ptmi_split.hip) -- and ptmi_accept behind the last.
+        The same chains as ``split_step`` iteration by iteration, bit for bit."""
+        if self.t["Q"] is None:
+            raise _lib.PtmiError("the callback path needs the engine built with split=True")
+        lib, h = self.lib, self.h
+        _lib.check(lib.ptmi_propose(h, it))
+        for j in range(it, end):
+            ll, lp = self.eval_callback(self.proposals(), logl, logp)
+            _lib.check(lib.ptmi_accept_propose(h, j, ll.data_ptr(), lp.data_ptr()))       # (between here and ptmi_accept X is not the state: sloc)
+        ll, lp = self.eval_callback(self.proposals(), logl, logp)
+        _lib.check(lib.ptmi_accept(h, end, ll.data_ptr(), lp.data_ptr()))
+
+    def run_callback(self, niter, logl, logp, fused=True):
+        """``run`` with the likelihood and the prior in batched callbacks: the same segments (epochs and swaps between them, the
+        late table of ``eig_lag`` counted in segments as ``run`` counts it in launches).  ``fused=False``: propose / accept as two
+        launches per iteration (``split_step``; same results)."""
         last = self.iter + niter
-        for it in range(self.iter + 1, last + 1):
+        it = self.iter + 1
+        while it <= last:
             self._epochs(it)
-            self.split_step(it, logl, logp)
-            if self.tskip > 0 and self.ntg > 1 and it % self.tskip == 0:
-                self.swap(it)
+            end = self._segment_end(it, last)
+            if fused:
+                self.callback_segment(it, end, logl, logp)
+            else:
+                for j in range(it, end + 1):
+                    self.split_step(j, logl, logp)
+            if self.tskip > 0 and self.ntg > 1 and end % self.tskip == 0:
+                self.swap(end)
+            if self._eig_pending:
+                self._eig_wait -= 1
+                if self._eig_wait <= 0 and not (end % self.cov_update == 0 and end + 1 <= last and self.owns_cold):
+                    self._eig_finish()
+            it = end + 1
         self.iter = last
 
     # ------------------------------------------------------------------ timing

@@ -389,7 +389,14 @@ class PTSampler(object):
                     print("Adding DE jump with weight {0}".format(self.DEweight))
                 self.addProposalToCycle(self.DEJump, self.DEweight)
                 self.randomizeProposalCycle()
-            if self.split:
+            if self.split and self.batched:
+                # batched device callbacks: a whole segment (no epoch, swap, save or hot-rank sample inside), the accept test of an
+                # iteration and the next proposal in one launch (PTEngine.callback_segment)
+                end = min(eng._segment_end(it, self.Niter), ((it - 1) // self.isave + 1) * self.isave)
+                if self._hot_names:
+                    end = min(end, ((it - 1) // self.thin + 1) * self.thin)
+                eng.callback_segment(it, end, self.logl, self.logp)
+            elif self.split:
                 end = it
                 self._split_step(it)
             else:

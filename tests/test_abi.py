@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header(lib):
     import subprocess
     import tempfile
     assert C.sizeof(lib.Config) == 26 * 4 + 2 * 8 + 8 + 8 + 2 * 8 + 4 * 8 + 3 * 8   # 26 int32, 2 doubles, seed, stream, pointers/lengths
-    assert C.sizeof(lib.Buffers) == 20 * 8
+    assert C.sizeof(lib.Buffers) == 22 * 8
     # the C compiler's view of include/ptmi.h
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "l.c")

@@ -50,10 +50,12 @@ def test_swap_sweep_on_the_references_uniforms(mods, fused, monkeypatch):
     assert {2, 4, 64, 512} <= seen
 
 
-def test_scam_and_de_proposals_on_the_references_draws(mods):
-    """propose_kernel (the production split-path kernel: propose() of csrc/ptmi_mh.inc.h) with the reference's recorded group,
-    scale-branch, direction / row and normal / scale draws: q is the reference's q, bit for bit, at T = 1, 3.7, 100, 101 (no
-    sqrt(T) scaling above 100, :861-862) and 1e80, for ndim = 5, 20, 100."""
+@pytest.mark.parametrize("am_in_cycle", [True, False])
+def test_scam_and_de_proposals_on_the_references_draws(mods, am_in_cycle):
+    """The production split-path kernels -- propose_kernel (propose() of csrc/ptmi_mh.inc.h: cycles with AM entries) and the row
+    kernel of csrc/ptmi_split.hip (cycles without) -- with the reference's recorded group, scale-branch, direction / row and
+    normal / scale draws: q is the reference's q, bit for bit, at T = 1, 3.7, 100, 101 (no sqrt(T) scaling above 100, :861-862)
+    and 1e80, for ndim = 5, 20, 100."""
     import torch
     orc, _lib, PTEngine = mods
     g = np.load(os.path.join(GOLD, "proposals.npz"))
@@ -67,7 +69,8 @@ def test_scam_and_de_proposals_on_the_references_draws(mods):
     for (d, temp), cases in groups.items():
         W = len(cases)
         Bn = g["DE_d%d" % d].shape[0]
-        e = PTEngine(d, 1, W, np.eye(d), ladder=[temp], weights=(1, 1, 1), cov_update=4, burn=Bn, tskip=0, split=True, cov_mode="pooled")
+        e = PTEngine(d, 1, W, np.eye(d), ladder=[temp], weights=(1, 1, 1) if am_in_cycle else (1, 0, 1), cov_update=4, burn=Bn, tskip=0, split=True,
+                     cov_mode="pooled")
         e.put_eig(g["U_d%d" % d], g["S_d%d" % d])
         DE = np.zeros((1, Bn, e.de_ld))
         if e.de_epl:
@@ -83,7 +86,7 @@ def test_scam_and_de_proposals_on_the_references_draws(mods):
             kind = int(meta[ci][2])
             dk, dv, db = g["dk_%d" % ci], g["dv_%d" % ci], g["db_%d" % ci]
             assert dk[0] == 0 and db[0] == 1                        # the group draw (one group)
-            pick = _word(kind, 3)
+            pick = _word(kind, 3) if am_in_cycle else _word(kind // 2, 2)    # the cycle entry: SCAM | AM | DE, or SCAM | DE
             if kind == 0:
                 assert list(dk) == [0, 1, 0, 2] and db[2] == d
                 prob, k, z = dv[1], int(dv[2]), dv[3]

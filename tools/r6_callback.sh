@@ -1,0 +1,23 @@
+#!/bin/bash
+# rocprofv3 passes over the callback bench (the split path, csrc/ptmi_split.hip): per-kernel times of the TIMED REGION, then the HBM
+# counters in passes of their own.  gpurun --timeout 1500 -- 'bash tools/r6_callback.sh'
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_r06cb
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+ARGS="--callback --steps 20 --warmup 5 --no-cpu-baseline --ess-window 0 --also off ${CB_ARGS:-}"
+run() {  # name, window, rocprof args...
+    local name=$1 win=$2; shift 2
+    timeout 500 rocprofv3 --kernel-trace "$@" -d $OUT/$name -o $name -- python $ROOT/bench.py $ARGS > $OUT/$name.log 2>&1
+    echo "$name rc=$?"
+    python $ROOT/tools/rocpd_summary.py $OUT/$name/${name}_results.db $OUT/$name.txt --window "$win" > /dev/null
+    rm -rf $OUT/$name
+}
+WIN="20:split_rows_kernel<false, true"
+run callback_stats "$WIN" --stats
+run callback_fetch "$WIN" --pmc FETCH_SIZE
+run callback_write "$WIN" --pmc WRITE_SIZE
+grep -h '"metric"' $OUT/callback_stats.log | cut -c1-400
+head -30 $OUT/callback_stats.txt
