@@ -297,10 +297,21 @@ def measure(a, rank, world, local, dist, backend):
         orig_cov(it_done)
 
     eng.update_cov = cov_and_count
+    def gj_counts():
+        """(leapfrogs, NUTS calls, HMC calls) so far, summed over the ranks (the jump objects' own counters)."""
+        from ptmcmcsampler_amd import _lib as L
+        gj = eng.t.get("gj") if hasattr(eng, "t") else None
+        if gj is None:
+            return None
+        return tuple(float(gj[..., k].sum().item()) for k in (L.GJ_NLEAP, L.GJ_NITER, L.GJ_HITER))
+
+    gj0 = gj_counts() if a.mix == "nuts" else None
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.run(it_timed)
     fence()
     wall = time.perf_counter() - t0
+    gj1 = gj_counts() if a.mix == "nuts" else None
     setattr(eng, hot, orig)
     eng.update_cov = orig_cov
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -411,6 +422,25 @@ def measure(a, rank, world, local, dist, backend):
                      "launch_ms_first": events[0][0].elapsed_time(events[0][1]) if events else None,
                      "launch_ms_last": events[-1][0].elapsed_time(events[-1][1]) if events else None},
     }
+    if events:
+        ms_all = [e0.elapsed_time(e1) for e0, e1, _ in events]
+        out["roofline"]["launch_ms_min"], out["roofline"]["launch_ms_max"] = min(ms_all), max(ms_all)
+    if a.mix == "nuts" and gj0 is not None and gj1 is not None:
+        # Config 5: the work of a gradient-jump cycle is its leapfrogs (nutsjump.py:149-169), counted by the jump objects themselves
+        # (gj[.][GJ_NLEAP]).  Per leapfrog and parameter: 6 flop of the integrator, 4 of the diagonal whitening and
+        # tempering, ~65 of the curved likelihood's value and gradient (two exp, one log, one division per PAIR of parameters, at their
+        # polynomial lengths), 4 of the kinetic energy and the box test: ~79 d flop.  The other picks (SCAM / DE) are priced at 4 d.
+        leaps, nuts, hmcs = (b1 - b0 for b0, b1 in zip(gj0, gj1))
+        f_leap = 79.0 * d
+        total_flop = f_leap * leaps + flops_per_update * (nchains_total * it_timed - nuts - hmcs)
+        tfg = total_flop / (kern_ms * 1e-3) / 1e12
+        out["roofline"].update({"achieved": tfg, "frac": tfg / F64_PEAK_TFLOPS, "leapfrogs_timed": leaps, "nuts_calls_timed": nuts,
+                                "leapfrogs_per_nuts_call": leaps / max(1.0, nuts), "flops_per_leapfrog": f_leap,
+                                "algorithmic_flops_per_update": total_flop / (nchains_total * it_timed),
+                                "flops_note": "counted work: 79 d flop per leapfrog x the leapfrogs the jump objects counted in the timed region "
+                                              "+ 4 d per SCAM / DE update, over the launches' HIP-event time; the launch lasts as long as its slowest chain"})
+        de_in = bool(getattr(eng, "de_on", False))
+        out["config"]["workload"] += "; cycle in the timed region: SCAM + NUTS%s (DE joins after burn = %d iterations)" % (" + DE" if de_in else "", 10000)
     if a.callback:
         out["config"]["workload"] += ("; the likelihood OUTSIDE the library: a batched torch callback (%s) on the device tensor of proposals, %s per iteration"
                                       % ({"norm": "torch: -0.5 * vector_norm(Q)^2, one pass", "naive": "torch: -0.5 * (Q * Q).sum(-1)", "hip": "a HIP kernel behind the C ABI: ptmi_rows_logl"}[a.callback_kind],
@@ -422,7 +452,10 @@ def measure(a, rank, world, local, dist, backend):
             acc_t = float(eng.get("nacc").astype(np.float64).mean() / max(1, eng.iter))
         except Exception:               # noqa: BLE001
             pass
-        model = (3.0 + (acc_t if acc_t is not None else 1.0)) * 8 * d + 64 + 32          # + qaux in / out, lnL / lp / callback values
+        # state or proposal in, proposal out, the callback's read of it; a row goes to X only when its buffer is about to be overwritten:
+        # accepted one iteration ago and refused now (two proposal buffers, csrc/ptmi_split.hip) -- or every accepted row with one launch pair
+        a_ = acc_t if acc_t is not None else 1.0
+        model = (3.0 + (a_ * (1.0 - a_) if a.callback_launches == "one" else a_)) * 8 * d + 64 + 32          # + qaux in / out, lnL / lp / callback values
         out["roofline"].update({"bound": "hbm", "achieved": hbm_view, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_view / HBM_PEAK_GBS,
                                 "f64_valu_frac": tf / F64_PEAK_TFLOPS,
                                 "split_design_bytes_per_update": model, "acceptance_whole_run": acc_t,
@@ -432,7 +465,7 @@ def measure(a, rank, world, local, dist, backend):
                                         "state or proposal in, proposal out, the callback's read of it, the accepted share written back"})
     # HBM traffic of the dominant kernel comes from separate rocprofv3 PMC passes (tools/gpu_profile.sh); the committed
     # summary is per launch of 100 steps on one named workload
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -451,12 +484,12 @@ def measure(a, rank, world, local, dist, backend):
         # counter traffic of the split path (tools/gpu_profile.sh callback: separate rocprofv3 --pmc passes over this very command), per
         # iteration of every chain
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r06_callback_traffic.json")))
-            if tr.get("launches") == a.callback_launches and tr.get("callback_kind") == a.callback_kind and tr.get("workload", "").startswith(
-                    "ndim=%d ntemps=%d nwalkers=%d" % (d, nt, W)):
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r06_callback_traffic.json")))[a.callback_kind]
+            if tr.get("launches") == a.callback_launches and tr.get("workload", "").startswith("ndim=%d ntemps=%d nwalkers=%d" % (d, nt, W)):
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_iteration"] * avg_steps
                 out["roofline"]["traffic_note"] = "HBM bytes per segment from rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, " + ", ".join(tr["source"])
                 out["roofline"]["traffic_over_model"] = tr["traffic_bytes_per_iteration"] / (out["roofline"]["split_design_bytes_per_update"] * nt * W)
+                out["roofline"]["traffic_gbs"] = tr["traffic_bytes_per_iteration"] * avg_steps / (avg_launch_ms * 1e-3) / 1e9
         except (OSError, ValueError, KeyError):
             pass
     # What the launch MUST move, counted live from this run's own state (not a counter): every chain's row, lnL and lp in and out,
@@ -513,7 +546,8 @@ ALSO = (
     ("config5_share_curved_nuts_16x4096", dict(logl="curved", ndim=20, ntemps=16, mix="nuts"), 6, 4),
     # the headline's workload with the likelihood OUTSIDE the library: a batched torch callback on the device tensor of proposals
     # (the reference's logl / logp boundary, PTMCMCSampler.py:605-611, 1072-1086)
-    ("config2_batched_callback", dict(callback=True), 20, 5),
+    ("config2_batched_callback", dict(callback=True, callback_kind="hip"), 20, 5),                 # the callback is a HIP kernel behind the C ABI
+    ("config2_batched_callback_torch", dict(callback=True, callback_kind="norm"), 20, 5),         # the callback is a torch expression
 )
 L2_PEAK_TBS = 34.5             # MI355X_MICROARCH.md: aggregate L2 bandwidth (4 MiB per XCD); profiles/r05_row_gather.txt: random 8 KB rows of a
                                # 7.8 MB table (it does not fit one XCD's L2: half the rows come from the MALL) arrive at 16.1 TB/s
@@ -550,7 +584,8 @@ def also_legs(a, rank, world, local, dist, backend):
                "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "steps_per_launch",
                                                   "kernel_time_share_of_wall", "algorithmic_flops_per_update", "algorithmic_bytes_per_update",
                                                   "split_design_bytes_per_update", "split_design_gbs", "acceptance_whole_run", "traffic",
-                                                  "traffic_over_model", "f64_valu_frac") if k in r},
+                                                  "traffic_over_model", "traffic_gbs", "f64_valu_frac", "launch_ms_min", "launch_ms_max", "leapfrogs_timed",
+                                                  "nuts_calls_timed", "leapfrogs_per_nuts_call", "flops_per_leapfrog", "flops_note") if k in r},
                "leg_seconds": time.perf_counter() - t0}
         if b.ndim > 416 and b.mix == "scam":
             # 64 lanes per chain: a step reads ONE table row of 8 * ndim bytes per chain from L2 / MALL (the table, 8 MB at ndim = 1000,
@@ -564,6 +599,65 @@ def also_legs(a, rank, world, local, dist, backend):
         log("also %-44s %.4g upd/s  launch %.3f ms  step %.3f ms  (%.1f s)" % (name, leg["value"], r["avg_launch_ms"], leg["ms_per_step"], leg["leg_seconds"]))
     res["total_seconds"] = time.perf_counter() - t_all
     return res
+
+
+def sharded_selfcheck(rank, world, local, dist):
+    """Pre-flight of `--gpus N` (temperature blocks), BEFORE the warmup and outside the timed region: a small ladder -- 16 ranks per GPU
+    x 64 walkers x 100-d, default SCAM / AM / DE cycle, pooled covariance, covUpdate 100, burn 200, Tskip 10, 300 iterations: three
+    covariance epochs, a DE epoch and DE activation, 30 swap epochs whose rows cross the block edges -- runs (a) sharded over the
+    backend the bench is about to time (RCCL: lnL gather, neighbour send/recv, table and DE-row broadcasts) and (b) as ONE engine on
+    this rank's own GPU; every rank compares ITS block of (a) with (b) bit for bit (states, likelihoods, counters, table).  The
+    number the bench prints then comes with its own proof that the multi-GPU path computes what the one-GPU path does
+    (PTMCMCSampler.py:631-697, 545-576)."""
+    import numpy as np
+    import torch
+    from ptmcmcsampler_amd.engine import PTEngine
+    from ptmcmcsampler_amd.sharded import ShardedPTEngine
+    d, ntb, W, n = 100, 16, 64, 300
+    ntg = ntb * world
+    kw = dict(weights=(20, 20, 20), cov_update=100, burn=200, tskip=10, seed=777, cov_mode="pooled", device=local)
+    cov0 = np.eye(d) * 0.01
+    p0 = np.random.RandomState(5).randn(W, ntg, d) * 0.1
+    t0 = time.perf_counter()
+    s = ShardedPTEngine(d, ntg, W, cov0, group=dist.group.WORLD, **kw)
+    s.init_state(p0)
+    s.run(n)
+    s.sync()
+    g = PTEngine(d, ntg, W, cov0, **kw)
+    g.init_state(p0)
+    g.run(n)
+    g.sync()
+    L, sl = s.local, slice(rank * ntb, (rank + 1) * ntb)
+    bad = []
+    for name in ("X", "lnL", "lp"):
+        if not np.array_equal(L.by_temp(name), g.by_temp(name)[:, sl]):
+            bad.append(name)
+    for name in ("nacc", "jstat"):
+        if not np.array_equal(L.get(name), g.get(name)[:, sl]):
+            bad.append(name)
+    if not np.array_equal(L.get("nswap")[:, sl], g.get("nswap")[:, sl]):
+        bad.append("nswap")
+    for name in ("Ut", "S"):
+        if not np.array_equal(L.get(name), g.get(name)):
+            bad.append(name)
+    if L.exchange_violations() != 0:
+        bad.append("exchange_violations")
+    # rows did cross this rank's upper block edge (accepted swaps of the pair that straddles it), and some state is not where it started
+    edge = int(g.get("nswap")[:, (rank + 1) * ntb - 1].sum()) if rank + 1 < world else int(g.get("nswap")[:, rank * ntb - 1].sum())
+    allf = torch.zeros((world, 3), dtype=torch.float64, device="cuda")          # every rank fills its row; one all-reduce (as the wall time's)
+    allf[rank] = torch.tensor([0.0 if bad else 1.0, float(edge), float(s.neighbour_swaps)], dtype=torch.float64)
+    dist.all_reduce(allf, op=dist.ReduceOp.SUM)
+    allf = allf.cpu().numpy().astype(np.int64)
+    ok = bool(allf[:, 0].min() == 1 and allf[:, 1].min() > 0 and s.swap_proposed == n // 10)
+    if bad:
+        log("sharded selfcheck: rank %d differs in %s" % (rank, bad))
+    del s, g
+    torch.cuda.empty_cache()
+    return ok, {"ranks_per_gpu": ntb, "nwalkers": W, "ndim": d, "iterations": n, "swap_epochs": n // 10,
+                "neighbour_swaps": int(allf[0, 2]), "edge_swaps_accepted_min_over_edges": int(allf[:, 1].min()),
+                "blocks_equal_single_engine": [bool(v) for v in allf[:, 0]], "seconds": time.perf_counter() - t0,
+                "what": "a %d-rank ladder sharded over the %d ranks of this run vs ONE engine on each rank's own GPU: every rank's block bit for bit "
+                        "(X, lnL, lp, nacc, jstat, nswap, Ut, S), before the warmup, outside the timed region" % (ntg, world)}
 
 
 def main():
@@ -613,7 +707,13 @@ def main():
     if a.also_child:                            # the legs of the other configs, in a process of their own (see below)
         os.write(real_stdout, (json.dumps(also_legs(a, rank, world, local, dist, backend)) + "\n").encode())
         return
+    check = None
+    if dist is not None and a.partition == "temps" and world > 1:
+        check = sharded_selfcheck(rank, world, local, dist)
+        log("sharded selfcheck %s (%.1f s)" % ("ok" if check[0] else "FAILED", check[1]["seconds"]))
     out = measure(a, rank, world, local, dist, backend)
+    if check is not None:
+        out["sharded_selfcheck"], out["sharded_selfcheck_detail"] = check
     if rank == 0 and world == 1 and a.also:
         # In a process of their own: a fault in one of the other configs' kernels must not take the headline's line with it.
         # (The headline's engine is gone and its memory returned; the child brings the clocks up itself.)

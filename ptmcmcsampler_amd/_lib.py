@@ -13,6 +13,7 @@ LOGL = {"iso": 0, "dense": 1, "curved": 2, "interval": 3}
 LOGP = {"flat": 0, "box": 1}
 J_SCAM, J_AM, J_DE, J_NUTS, J_HMC, J_NTYPES = 0, 1, 2, 3, 4, 5
 GJ_NSTATE, GJ_EPSBAR = 8, 3
+GJ_NITER, GJ_HITER, GJ_NLEAP = 4, 5, 7          # per-rank jump state (csrc/ptmi_common.h): NUTS calls, HMC calls, leapfrogs taken so far
 JUMP_NAMES = ("covarianceJumpProposalSCAM", "covarianceJumpProposalAM", "DEJump")
 
 _dp = C.POINTER(C.c_double)

@@ -350,6 +350,10 @@ def test_bench_launches_its_own_ranks(extra, ntemps, ngpus):
     if extra:
         assert out["config"]["ndim"] == 1000 and out["config"]["nwalkers"] == int(extra[3])
     assert out["swap_epochs_timed"] == 12 and out["cov_epochs_timed"] == 1 and out["swap_accept_rate_pair0"] > 0
+    # the pre-flight: a small ladder sharded over THESE ranks against one engine, every rank's block bit for bit, rows across every edge
+    det = out["sharded_selfcheck_detail"]
+    assert out["sharded_selfcheck"] is True and det["blocks_equal_single_engine"] == [True] * ngpus
+    assert det["edge_swaps_accepted_min_over_edges"] > 0 and det["swap_epochs"] == 30 and 0 <= det["neighbour_swaps"] <= 30
     assert out["roofline"]["frac"] <= 1.0
     # the ESS leg ran (after the timed region) and FLAGS its 3000-iteration window as too short to trust
     assert out["ess_per_sec"] > 0 and out["tau_int"] >= 1 and out["ess_window_iters"] == 3000 and out["ess_window_ok"] is False

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over the callback bench (the split path, csrc/ptmi_split.hip): per-kernel times of the TIMED REGION, then the HBM
-# counters in passes of their own.  gpurun --timeout 1500 -- 'bash tools/r6_callback.sh'
+# counters in passes of their own.  gpurun --timeout 1500 -- 'CB_ARGS="--callback-kind hip" CB_TAG=callback bash tools/r6_callback.sh; CB_ARGS="--callback-kind norm" CB_TAG=callbacktorch bash tools/r6_callback.sh'
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_r06cb
@@ -16,8 +16,9 @@ run() {  # name, window, rocprof args...
     rm -rf $OUT/$name
 }
 WIN="20:split_rows_kernel<false, true"
-run callback_stats "$WIN" --stats
-run callback_fetch "$WIN" --pmc FETCH_SIZE
-run callback_write "$WIN" --pmc WRITE_SIZE
-grep -h '"metric"' $OUT/callback_stats.log | cut -c1-400
-head -30 $OUT/callback_stats.txt
+T=${CB_TAG:-callback}
+run ${T}_stats "$WIN" --stats
+run ${T}_fetch "$WIN" --pmc FETCH_SIZE
+run ${T}_write "$WIN" --pmc WRITE_SIZE
+grep -h '"metric"' $OUT/${T}_stats.log | cut -c1-400
+head -12 $OUT/${T}_stats.txt
