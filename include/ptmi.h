@@ -309,20 +309,24 @@ int ptmi_eig_ql(ptmi_handle h);
  * (:797-803) on a side stream beside the step launches that follow and puts its tables into force a fixed number of launches later
  * (oracle: OracleEngine(eig_lag=L)).  One call at a time per handle. */
 int ptmi_eig_ql_from(ptmi_handle h, void *stream, const double *cov_in, double *Ut_out, double *S_out);
-/* The same for ONE large pooled covariance (3 <= ndim <= 1024; the engine's eig_mode "sytrd"): Householder tridiagonalization in one
- * kernel with the matrix in the LDS of its blocks, then the ROCm library's divide-and-conquer solver of the tridiagonal matrix and its
- * back-transformation (rocsolver_dstedc, rocsolver_dormtr, looked up in the librocsolver the process has loaded: import torch first).
- * Replaces the np.linalg.svd of :797-803 where the library's own eigensolver (torch.linalg.eigh: 35 ms of small kernels at 1000 x 1000)
- * is the epoch.  On `stream` (NULL: the handle's), results into Ut_out [ndim][ndim] / S_out [ndim] (NULL: the handle's Ut / S):
- * eigenvalues in absolute value, descending; no sign rule (the library's vectors).  Its last bits are the library's. */
+/* The same for ONE large pooled covariance (3 <= ndim <= 1024; the engine's eig_mode "sytrd"), all of it the library's own kernels:
+ * Householder tridiagonalization in ONE kernel with the matrix in the LDS of its blocks (csrc/ptmi_abi.hip sytrd_lds_kernel), the
+ * tridiagonal matrix's eigenvectors by divide and conquer (csrc/ptmi_dc.inc.h: QL on leaves of 16 rows, rank-one merges with
+ * deflation, roots of the secular equation by bisection, Gu / Eisenstat weights), back-transformed through the reflectors.
+ * Replaces the np.linalg.svd of :797-803 where the ROCm library's eigensolver (torch.linalg.eigh: 35 ms of small kernels at
+ * 1000 x 1000) is the epoch.  On `stream` (NULL: the handle's), results into Ut_out [ndim][ndim] / S_out [ndim] (NULL: the handle's
+ * Ut / S): eigenvalues in absolute value, descending; no sign rule.  No oracle restates its last bits: the tests hold every table
+ * it makes to U diag(S) U^T = cov and U U^T = I at 1e-12 and step the ORACLE's chains with it (tests/test_device_tables_gpu.py).
+ * (PTMI_SYTRD_LIB=1: the tridiagonal solver and the back-transformation by rocsolver_dstedc / rocsolver_dormtr instead, an A/B switch.) */
 int ptmi_eig_sytrd(ptmi_handle h, void *stream, double *Ut_out, double *S_out);
 /* The same from the covariance `cov_in` [ndim][ndim] (device; NULL: the handle's cov): a caller that runs the factorization BESIDE
  * later work -- the statistics of the next covariance epoch overwrite the handle's cov -- hands in its own copy (PTEngine: eig_lag
  * with the statistics of the next epoch ahead of the pending table, :545-560). */
 int ptmi_eig_sytrd_from(ptmi_handle h, void *stream, const double *cov_in, double *Ut_out, double *S_out);
-/* The convergence word (LAPACK's `info` of dstedc: 0 = converged) of the most recent ptmi_eig_sytrd whose result has reached the
- * host: it follows the factorization on its stream into pinned memory, so the call never waits; check it once that stream has been
- * waited for (the engine does at its next covariance epoch and in sync()).  Non-zero: Ut / S of that epoch are not to be trusted. */
+/* The convergence word of the most recent ptmi_eig_sytrd whose result has reached the host: 0 = converged; k > 0 = leaf k - 1 of the
+ * divide-and-conquer tree did not split off an eigenvalue within 60 QL sweeps (with PTMI_SYTRD_LIB=1: LAPACK's `info` of dstedc).  It
+ * follows the factorization on its stream into pinned memory, so the call never waits; check it once that stream has been waited for
+ * (the engine does at its next covariance epoch and in sync()).  Non-zero: Ut / S of that epoch are not to be trusted. */
 int ptmi_eig_sytrd_info(ptmi_handle h, int32_t *info);
 
 /* _updateDEbuffer (:806-817): drop the oldest cov_update rows of each DE history and

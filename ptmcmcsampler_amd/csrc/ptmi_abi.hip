@@ -1256,14 +1256,14 @@ __global__ __launch_bounds__(256) void am_fill_kernel(const AmArgs p, const long
 template <int G, int MAXT>
 __global__ __launch_bounds__(256, 1) void am_gemm_kernel(const AmEvent *ev, const long long *base, long long nch, int d, const double *Ut,
                                                         const double *S, u64 seed, double *inc, int nk, const long long *kbase /* the lists' starts (+ the end) */,
-                                                        const int32_t *perm, int grp, int ngroups)
+                                                        const int32_t *perm, int grp, int ngroups, int z0 /* first walker of this launch's grid rows */)
 {
     constexpr int NEV = 64, K2 = 2 * G;
     extern __shared__ __attribute__((aligned(16))) double Wl[];          // [2][K2][NEV]
     __shared__ int32_t evi[NEV];                                         // parameter groups: the events' indices (their rows of inc)
     // one group (perm == nullptr): the events e0 .. of the chain-ordered list; else entries e0 .. of the group's list
     // the list's key: the group, or (blockIdx.z = the walker, group) with per-walker covariances -- and the key's table
-    const long long key = perm ? (long long)blockIdx.z * ngroups + grp : 0;
+    const long long key = perm ? ((long long)blockIdx.z + z0) * ngroups + grp : 0;
     const long long seg0 = perm ? kbase[key] : 0;
     const long long nev = perm ? kbase[key + 1] - seg0 : base[nch], e0 = (long long)blockIdx.x * NEV;
     if (e0 >= nev) return;
@@ -2380,11 +2380,14 @@ static int launch_am_gemm_t(ptmi_engine *h, long long max_events)
     // every pick of the walker's chains in the piece
     const int pw = h->cfg.cov_per_walker ? 1 : 0;
     const long long per_key = pw ? (max_events / h->cfg.nwalkers) : max_events;
+    // (a grid's z extent ends at 65535: more walkers than that go in several launches)
+    const int nz = pw ? h->cfg.nwalkers : 1;
     for (int g = 0; g < ngr; ++g)
-        hipLaunchKernelGGL(kern, dim3((unsigned)((per_key + 63) / 64), parts, pw ? h->cfg.nwalkers : 1), dim3(256), lds, h->stream, (const AmEvent *)h->d_am_ev,
-                           (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, d, (const double *)h->buf.Ut,
-                           (const double *)h->buf.S, h->cfg.seed, h->d_am_inc, ngr > 1 ? h->gsize_host[g] : d,
-                           h->d_am_perm ? (const long long *)h->d_am_kbase : nullptr, (const int32_t *)h->d_am_perm, g, ngr);
+        for (int z0 = 0; z0 < nz; z0 += 65535)
+            hipLaunchKernelGGL(kern, dim3((unsigned)((per_key + 63) / 64), parts, (unsigned)(nz - z0 < 65535 ? nz - z0 : 65535)), dim3(256), lds, h->stream,
+                               (const AmEvent *)h->d_am_ev, (const long long *)h->d_am_base, (long long)h->cfg.nwalkers * h->cfg.ntemps, d,
+                               (const double *)h->buf.Ut, (const double *)h->buf.S, h->cfg.seed, h->d_am_inc, ngr > 1 ? h->gsize_host[g] : d,
+                               h->d_am_perm ? (const long long *)h->d_am_kbase : nullptr, (const int32_t *)h->d_am_perm, g, ngr, z0);
     return PTMI_OK;
 }
 static int launch_am_gemm(ptmi_engine *h, long long max_events)
@@ -2644,6 +2647,17 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
             if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_grp, sizeof(int32_t) * (2 * nkeys + (nkeys + 1023) / 1024 + 1));
             if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_kbase, sizeof(long long) * (nkeys + 1));
             if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_perm, sizeof(int32_t) * (size_t)h->am_cap);
+        }
+        if (e == hipErrorOutOfMemory) {
+            // no room for the scratch: the step kernels compute their own AM products (slower, the same results) instead of failing the
+            // handle -- configurations that fitted before this path existed still do
+            (void)hipGetLastError();
+            (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
+            (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm); (void)hipFree(h->d_am_kbase);
+            h->d_am_ev = nullptr; h->d_am_count = nullptr; h->d_am_base = nullptr; h->d_am_inc = nullptr;
+            h->d_am_grp = nullptr; h->d_am_perm = nullptr; h->d_am_kbase = nullptr;
+            h->am_piece = 0; h->am_cap = 0;
+            e = hipSuccess;
         }
     }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
@@ -3804,7 +3818,7 @@ static void dc_plan_free(ptmi_engine *h)
 // eigenvalues (ascending, *Dres) and eigenvectors (vector-major, *Zres) of the tridiagonal matrix (D, E), back-transformed through the
 // reflectors (A, tau) of the reduction; everything queued on st
 static int dc_solve(ptmi_engine *h, hipStream_t st, int n, const double *D, const double *E, const double *A, const double *tau,
-                    const double **Dres, const double **Zres)
+                    const double **Dres, const double **Zres, int *info /* device: zeroed by the caller; a leaf that did not converge sets it */)
 {
     DcPlan *P = nullptr;
     if (int rc = dc_plan_get(h, n, &P)) return rc;
@@ -3829,7 +3843,7 @@ static int dc_solve(ptmi_engine *h, hipStream_t st, int n, const double *D, cons
     HIPCHK(hipMemcpyAsync(a.e, E, sizeof(double) * (n - 1), hipMemcpyDeviceToDevice, st));
     if (P->nnodes) hipLaunchKernelGGL(dc::split_kernel, dim3((P->nnodes + 63) / 64), dim3(64), 0, st, (const dc::Node *)P->d_nodes, P->nnodes, a.d, (const double *)a.e);
     HIPCHK(hipMemsetAsync(Qa, 0, sizeof(double) * nn, st));
-    hipLaunchKernelGGL(dc::leaf_kernel, dim3(P->nleaves), dim3(64), 0, st, (const dc::Leaf *)P->d_leaves, n, (const double *)a.d, (const double *)a.e, Da, Qa);
+    hipLaunchKernelGGL(dc::leaf_kernel, dim3(P->nleaves), dim3(64), 0, st, (const dc::Leaf *)P->d_leaves, n, (const double *)a.d, (const double *)a.e, Da, Qa, info);
     double *Qin = Qa, *Qout = Qb, *Din = Da, *Dout = Db;
     for (int lv = 0; lv < P->nlevels; ++lv) {
         const int cnt = P->lvl_cnt[lv], nmax = P->lvl_nmax[lv];
@@ -3945,9 +3959,15 @@ int ptmi_eig_sytrd_from(ptmi_handle h, void *stream, const double *cov_in, doubl
     if (!use_lib) {
         // the tridiagonal matrix's eigenvectors by the engine's own divide-and-conquer kernels, back-transformed through the reflectors
         const double *Dres = nullptr, *Zres = nullptr;
-        if (int rc = dc_solve(h, st, n, D, E, A, tau, &Dres, &Zres)) return rc;
+        if (int rc = dc_solve(h, st, n, D, E, A, tau, &Dres, &Zres, info)) return rc;
         hipLaunchKernelGGL(eig_sort_rows_kernel, dim3(n), dim3(256), 0, st, Dres, Zres, n, Uo, So);
         HIPCHK(hipGetLastError());
+        // the convergence word (a leaf's QL iteration: dc::leaf_kernel) follows the result to the host on the same stream
+        if (!h->h_sy_info) {
+            HIPCHK(hipHostMalloc((void **)&h->h_sy_info, 2 * sizeof(int32_t)));
+            h->h_sy_info[0] = 0; h->h_sy_info[1] = 0;
+        }
+        HIPCHK(hipMemcpyAsync(h->h_sy_info, info, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         return PTMI_OK;
     }
     SyLib *L = nullptr;

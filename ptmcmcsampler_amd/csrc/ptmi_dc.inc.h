@@ -68,7 +68,9 @@ __device__ __forceinline__ double hyp(double a, double b)     // sqrt(a^2 + b^2)
 }
 
 // a leaf: implicit QL with eigenvectors (the classical tql2 / tqli recurrence) in one wave, the vectors in LDS (lane r owns row r)
-__global__ __launch_bounds__(64) void leaf_kernel(const Leaf *leaves, int n, const double *d, const double *e, double *Dout, double *Qout)
+// info: set to (leaf + 1) when a leaf's QL iteration has not converged within 60 sweeps of an eigenvalue (LAPACK's dsteqr gives up at 30 n
+// in all; the merges cannot fail: their roots come from a bisection that ends when the interval cannot shrink)
+__global__ __launch_bounds__(64) void leaf_kernel(const Leaf *leaves, int n, const double *d, const double *e, double *Dout, double *Qout, int *info)
 {
     __shared__ double z[LEAF][LEAF + 1], dd[LEAF], ee[LEAF];
     const Leaf lf = leaves[blockIdx.x];
@@ -79,14 +81,17 @@ __global__ __launch_bounds__(64) void leaf_kernel(const Leaf *leaves, int n, con
         for (int c = 0; c < m0; ++c) z[r][c] = r == c ? 1.0 : 0.0;
     }
     __syncthreads();
+    bool failed = false;
     for (int l = 0; l < m0; ++l) {
-        for (int iter = 0; iter < 60; ++iter) {
+        bool conv = false;
+        for (int iter = 0; iter <= 60; ++iter) {
             int m = l;
             for (; m < m0 - 1; ++m) {
                 const double s = __builtin_fabs(dd[m]) + __builtin_fabs(dd[m + 1]);
                 if (__builtin_fabs(ee[m]) <= 2.220446049250313e-16 * s) break;
             }
-            if (m == l) break;
+            if (m == l) { conv = true; break; }
+            if (iter == 60) break;                      // 60 sweeps done and the eigenvalue has not split off
             double g = (dd[l + 1] - dd[l]) / (2.0 * ee[l]);
             double rr = hyp(g, 1.0);
             g = dd[m] - dd[l] + ee[l] / (g + (g >= 0.0 ? rr : -rr));
@@ -123,7 +128,9 @@ __global__ __launch_bounds__(64) void leaf_kernel(const Leaf *leaves, int n, con
             if (r == 0) { dd[l] -= p; ee[l] = g; ee[m] = 0.0; }
             __syncthreads();
         }
+        failed |= !conv;
     }
+    if (failed && r == 0 && info != nullptr) atomicMax(info, (int)blockIdx.x + 1);
     __syncthreads();
     if (r < m0) {
         Dout[off + r] = dd[r];

@@ -351,11 +351,11 @@ __device__ __forceinline__ bool box_inside_lds(const double *smem, int off, int 
 // and how far is x from the nearest bound (the lane's elements; padding slots hold {-inf, +inf})?
 template <int G, int EPL>
 __device__ __forceinline__ void box_test_and_margin(const double *smem, int off, int gl, const double (&x)[EPL], const double (&dq)[EPL],
-                                                    bool &inside, double &margin)
+                                                    bool &inside, double &margin, double &bmax)
 {
     const ptmi_d2 *tab = (const ptmi_d2 *)(smem + off + 2 * EPL * gl);
     bool in = true;
-    double mg = __builtin_inf();
+    double mg = __builtin_inf(), bm = 0.0;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const ptmi_d2 b = tab[e];
@@ -364,9 +364,14 @@ __device__ __forceinline__ void box_test_and_margin(const double *smem, int off,
         const double lo_gap = x[e] - b.x, hi_gap = b.y - x[e];
         const double g2 = lo_gap < hi_gap ? lo_gap : hi_gap;           // (a NaN gap -- x outside every order -- loses every comparison below: margin stays, the test decides)
         mg = g2 < mg ? g2 : mg;
+        // the largest finite |bound| of the lane's elements (padding slots hold infinities): what an element inside the box can be at most
+        const double al = __builtin_fabs(b.x), ah = __builtin_fabs(b.y);
+        bm = (al < __builtin_inf() && al > bm) ? al : bm;
+        bm = (ah < __builtin_inf() && ah > bm) ? ah : bm;
     }
     inside = in;
     margin = mg;
+    bmax = bm;
 }
 template <int G, bool STR>
 __device__ __forceinline__ double grp_min(double v)
@@ -1279,6 +1284,7 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
     const bool cold = live && tg == 0 && a.AM != nullptr;
     int am_row = a.am_row0;
     double box_margin = -1.0;                    // BOXFAST: a lower bound of the chain's distance to its nearest bound (negative: unknown)
+    double box_guard = 0.0;                      // ... and what the rounding of an accepted x + dq can add to an element: 2^-52 x the largest |bound|
 
     // Wide draw batches: a pass serves GW / 2 steps, so the steps run as an inner loop under a loop over the passes -- with the
     // refill as a rarely taken branch of ONE loop the compiler hoisted the pass's invariants (Philox key schedule, polynomial
@@ -1431,10 +1437,11 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
                 bool inside = box_reach < box_margin;
                 if (!inside) {                   // (divergent between the wave's chains; rare in a box wider than the jumps)
                     bool in1;
-                    double mg;
-                    box_test_and_margin<G, EPL>(smem, a.box_off, gl, x, dq, in1, mg);
+                    double mg, bm;
+                    box_test_and_margin<G, EPL>(smem, a.box_off, gl, x, dq, in1, mg, bm);
                     inside = grp_all<G, STR>(in1);
                     box_margin = grp_min<G, STR>(mg) * (1.0 - 0x1.0p-40);
+                    box_guard = -grp_min<G, STR>(-bm) * 0x1.0p-52;
                 }
                 nlp = inside ? 0.0 : -__builtin_inf();
             }
@@ -1466,7 +1473,9 @@ __global__ __launch_bounds__(PERS ? PERS : 256, mh_min_blocks(G, EPL, LOGL, FULL
 #pragma unroll
                 for (int j = 0; j < PTMI_J_FUSED; ++j) ja[j] += (jt == j);
             }
-            if constexpr (BOXFAST) box_margin = (box_margin - box_reach) * (1.0 - 0x1.0p-40);      // no element moved further than the reach
+            // no element moved further than the reach plus the rounding of its sum (relative to the ELEMENT, which a bound limits: the
+            // slack factors alone are relative to the margin, and a narrow box far from the origin has a margin far below |x| 2^-13)
+            if constexpr (BOXFAST) box_margin = (box_margin - box_reach - box_guard) * (1.0 - 0x1.0p-40);
         }
         // PT:327-328 (the post-swap row of a swap iteration is written by the swap).  These 25 stores of four active lanes, in ONE
         // wave of every block, are 15 % of the config-2 kernel (0.90 -> 0.77 ms without them, PTMI_MEASURE_NO_AM): the wave is its

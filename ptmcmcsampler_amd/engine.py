@@ -118,9 +118,11 @@ class PTEngine(object):
     tensor: no host round trip either; one parameter group) -- the choice for large ndim, where the host's LAPACK call is the
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
-    ``"sytrd"`` = ``ptmi_eig_sytrd`` for ONE large pooled covariance (ndim <= 1024): Householder tridiagonalization in one kernel with the
-    matrix in the LDS of 64 blocks (a quarter of the CUs), then the library's divide-and-conquer solver of the tridiagonal matrix and its
-    back-transformation -- the library's own reduction is 7000 launches of one-block kernels, two thirds of its 35 ms.
+    ``"sytrd"`` = ``ptmi_eig_sytrd`` for ONE large pooled covariance (ndim <= 1024), all of it the library's own kernels: Householder
+    tridiagonalization in one kernel with the matrix in the LDS of 64 blocks (a quarter of the CUs), the tridiagonal matrix's
+    eigenvectors by divide and conquer (csrc/ptmi_dc.inc.h), back-transformed through the reflectors -- 12.6 ms at 1000 x 1000 where the
+    ROCm library's own reduction is 7000 launches of one-block kernels, two thirds of its 35 ms.  No oracle restates its last bits; the
+    tests check every table it makes against the covariance and step the oracle's chains with it.
     ``eig_lag`` (L >= 0 launches; pooled covariance): the eigenvectors of a covariance epoch take effect L launches late --
     ``run`` queues the L launches that follow the epoch (and their swaps) with the table in force, the factorization runs
     MEANWHILE, and the launch after them uses the result (a new epoch finishes a pending one first).  The reference applies the
@@ -297,12 +299,15 @@ class PTEngine(object):
         # every block of a sharded ladder (from the configuration alone: ShardedPTEngine orders its broadcasts by it)
         self.late_finish = self.eig_lag > 0 and eig_mode in ("hipsolver", "sytrd", "ql") and not stats_async
         self.stats_async = False
-        if stats_async and self.owns_cold:                            # (a block without rank 0 has no statistics to run)
+        if stats_async:
+            # from the configuration alone, on EVERY block of a sharded ladder: a block without rank 0 has no statistics to run, but it
+            # must refuse what the owner refuses -- else the owner raises alone and the others wait in their first collective for ever
             ok = (not self.per_walker and self.eig_lag >= 1 and self.whole and eig_mode in ("lapack", "hipsolver", "sytrd")
-                  and (self.t["DE"] is None or self.burn % self.cov_update == 0))
+                  and (not has_de or self.burn % self.cov_update == 0))
             if not ok:
-                raise ValueError("stats_async needs a pooled covariance on the block that holds rank 0, eig_lag >= 1, eig_mode 'lapack', "
-                                 "'hipsolver' or 'sytrd', one parameter group, and burn a multiple of cov_update when a DE history is kept")
+                raise ValueError("stats_async needs a pooled covariance, eig_lag >= 1, eig_mode 'lapack', 'hipsolver' or 'sytrd', one "
+                                 "parameter group, and burn a multiple of cov_update when a DE history is kept")
+        if stats_async and self.owns_cold:                            # (a block without rank 0 has no statistics to run)
             self.stats_async = True
             # the second ring (and its flags): what the statistics of the period before read while this period is written
             self._alt = dict(AM=torch.zeros_like(self.t["AM"]),
@@ -703,27 +708,35 @@ class PTEngine(object):
                   eig_epochs=self.eig_epochs,
                   # eig_lag: an epoch's table that is not in force yet (its covariance is in t_cov; restore() factorizes it again)
                   eig_pending=int(self._eig_pending), eig_wait=int(self._eig_wait))
+        if self.stats_async:
+            st.update({"alt_" + k: v.cpu().numpy() for k, v in self._alt.items() if v is not None})
         return st
 
     def restore(self, st):
         torch = _torch()
-        for k, v in self.t.items():
-            if v is not None and "t_" + k in st:
-                v.copy_(torch.from_numpy(np.ascontiguousarray(st["t_" + k])).to(v.dtype))
-        self.iter, self.swap_proposed = int(st["iter"]), int(st["swap_proposed"])
-        self.eig_epochs = int(st["eig_epochs"])
-        if self.t["DE"] is not None:
-            self.set_de_head(int(st["de_head"]))
-            if int(st["de_on"]):
-                self.set_de_active(True)
-        if self._eig_pending:                                         # whatever this engine had under way is void
+        # whatever this engine has under way is void -- and is brought to an end FIRST: a factorization on the side stream (its thread
+        # joined, its result dropped), statistics still running beside the launches (stats_async: they write cov / mu / M2)
+        if self._eig_pending:
             try:
                 self._eig_finish()
             except _lib.PtmiError:
                 pass
-            for k, v in self.t.items():
-                if k in ("Ut", "S") and "t_" + k in st:
-                    v.copy_(torch.from_numpy(np.ascontiguousarray(st["t_" + k])).to(v.dtype))
+        if self.stats_async:
+            self._st.synchronize()
+            self._stats_queued = False
+        for k, v in self.t.items():
+            if v is not None and "t_" + k in st:
+                v.copy_(torch.from_numpy(np.ascontiguousarray(st["t_" + k])).to(v.dtype))
+        if self.stats_async:                                          # the ring of the period before (readers of older rows: get("AM"))
+            for k, v in self._alt.items():
+                if v is not None and "alt_" + k in st:
+                    v.copy_(torch.from_numpy(np.ascontiguousarray(st["alt_" + k])).to(v.dtype))
+        self.iter, self.swap_proposed = int(st["iter"]), int(st["swap_proposed"])
+        self.eig_epochs = int(st["eig_epochs"])                       # (behind _eig_finish, which counts the dropped table)
+        if self.t["DE"] is not None:
+            self.set_de_head(int(st["de_head"]))
+            if int(st["de_on"]):
+                self.set_de_active(True)
         if int(st.get("eig_pending", 0)):
             # the checkpoint fell between a covariance epoch and the launch its table takes effect at: the factorization is
             # issued again from the saved covariance and becomes effective after the same number of launches

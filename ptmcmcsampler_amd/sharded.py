@@ -149,6 +149,9 @@ class ShardedPTEngine(object):
         if local_factory is None:
             from .engine import PTEngine
             local_factory = PTEngine
+        if int(kw.get("eig_lag", 0)) > 0 and kw.get("eig_mode") == "ql" and kw.get("cov_mode", "per_walker") == "per_walker":
+            # (PTEngine: one GPU only -- every block would factorize its own walkers' tables late, with nothing to order the tables' arrival)
+            raise ValueError("eig_lag with eig_mode='ql' and per-walker covariances is a one-GPU mode; a sharded ladder takes it with the pooled covariance")
         self.local = local_factory(ndim, self.nt, nwalkers, cov0, ntemps_global=ntemps_global, temp0=self.temp0, **kw)
         L = self.local
         self.t, self.owns_cold, self.device = L.t, L.owns_cold, L.device

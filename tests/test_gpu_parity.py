@@ -541,3 +541,27 @@ def test_parameter_groups_with_the_device_eigensolver(mods, d, groups, cov_mode,
         assert_same(g.get("S"), o.S, "S it=%d" % g.iter)
     assert g.eig_epochs >= 6
     assert o.jstat[..., :3, 0].sum(axis=(0, 1)).min() > 0
+
+
+@pytest.mark.parametrize("d", [641, 1000])
+def test_box_prior_fast_path_in_a_narrow_box_far_from_the_origin(mods, d):
+    """The 64-lane SCAM kernel's box-prior fast path (mh_steps_kernel BOXFAST: a tracked lower bound of the chain's distance to its
+    nearest bound spares most steps the full test, PTMCMCSampler.py:605-606) where its slack is thinnest: bounds [1e6 - 0.5, 1e6 + 0.5],
+    so an accepted x + dq rounds at |x| 2^-53 = 1e-10 -- far above the relative slack of a margin of 0.3 -- and the tracked margin
+    carries an absolute guard for it (2^-52 x the largest |bound| per accepted step).  Very hot ranks, so that nearly every proposal
+    inside the box is accepted and the walls are hit: HIP == oracle bit for bit, refusals by the prior included."""
+    orc, _lib, PTEngine = mods
+    rs = np.random.RandomState(d)
+    lo, hi = 1e6 - 0.5 - 0.05 * rs.rand(d), 1e6 + 0.5 + 0.05 * rs.rand(d)
+    g, o = _pair(mods, d, 2, 3, weights=(20, 0, 0), cov_update=60, burn=1000, tskip=25, seed=d, cov_mode="pooled", ladder=[1e14, 1e15],
+                 logp=("box", lo, hi), p0=1e6 + rs.uniform(-0.3, 0.3, (3, 2, d)), cov0=np.eye(d) * 0.02)
+    for n in (130, 75, 200):
+        g.run(n)
+        o.run(n)
+        _compare(g, o, "narrow far box d=%d it=%d " % (d, g.iter))
+    flags, G, E = g.last_variant()
+    assert G == 64 and flags & _lib.VAR_UTPAD
+    js = o.jstat[..., 0, :].astype(np.int64)
+    assert (js[..., 1] > 0.3 * js[..., 0]).all() and (js[..., 1] < js[..., 0]).all()        # mostly accepted, and the walls refused some
+    X = g.get("X")
+    assert (X >= lo).all() and (X <= hi).all()
