@@ -349,6 +349,14 @@ int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL /* dev [W][T] 
  * and no DE activation at iter + 1 (the caller's schedule; PTEngine.run_callback).  qaux[.][2] then holds the next iteration's
  * accept uniform, not this one's decision (nacc / jstat count it).  Same results as the two calls, bit for bit. */
 int ptmi_accept_propose(ptmi_handle h, int64_t iter, const double *newlnL /* dev [W][T] */, const double *newlp /* dev [W][T] */);
+/* Cycles with AM entries on the split path: the increments U (cd sqrt(S) z) of the AM picks (:879-933) of iterations iter0 .. iter0 +
+ * nsteps - 1 are made AHEAD on the matrix cores (one matrix product for all picks of the piece) with the tables as they are at this call;
+ * ptmi_propose / ptmi_accept_propose then read them.  nsteps <= ptmi_split_am_piece (0 there: this handle's AM proposals come from the
+ * shape kernels and no call is needed).  A proposal for an iteration no prepared piece covers prepares that one iteration itself, so
+ * the call is an optimisation -- the caller makes it at the head of a span of iterations between which NOTHING changes the tables or
+ * the cycle (PTEngine.callback_segment). */
+int ptmi_split_am_piece(ptmi_handle h, int32_t *piece);
+int ptmi_split_am_prepare(ptmi_handle h, int64_t iter0, int32_t nsteps);
 /* The buffer that holds the current proposals: Q after ptmi_propose; after ptmi_accept_propose Q or Q2 in turn when the handle has
  * both (ptmi_buffers.Q2: X is then authoritative again only after ptmi_accept), else Q.  The callback reads THIS buffer. */
 int ptmi_proposals(ptmi_handle h, double **q);

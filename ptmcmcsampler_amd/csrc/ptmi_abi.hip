@@ -2626,17 +2626,24 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
     // -- and the gradient-jump shapes at 16 / 64 lanes per chain (the interval family, NUTS / HMC cycles at ndim > 32): their step kernels'
     // own AM product is the vector pipe's too
     // -- and per-walker covariances at 16 / 64 lanes per chain without groups (one key per walker)
-    if (e == hipSuccess && c.w_am > 0 && (c.ngroups > 1 || s.G > 4) && c.ndim <= 1024 && c.w_host == 0 &&
-        !getenv("PTMI_NO_AM_AHEAD")) {
+    // -- and the SPLIT path of every shape (ptmi_propose / ptmi_accept_propose on contiguous rows, csrc/ptmi_split.hip): an AM pick's 2 d^2
+    // flop belong on the matrix cores there too; the row kernel reads the increment as it reads a SCAM direction.  For handles the fused
+    // kernels do not take this way (4 lanes per chain, one group: their own matrix-core product) the scratch serves the split path alone.
+    const bool am_main = c.w_am > 0 && (c.ngroups > 1 || s.G > 4) && c.ndim <= 1024 && c.w_host == 0 && !getenv("PTMI_NO_AM_AHEAD");
+    const bool am_split = !am_main && buf->Q != nullptr && c.w_am > 0 && c.ndim <= 1024 && c.w_host == 0 && !getenv("PTMI_NO_SPLIT_AM");
+    if (e == hipSuccess && (am_main || am_split)) {
         const long long nch = (long long)c.nwalkers * c.ntemps;
-        const char *mb = getenv("PTMI_AM_BUDGET_MB");                    // scratch for the increments of one piece of a launch (default 6 GB)
-        const double budget = (mb ? atof(mb) : 6144.0) * 1048576.0;
+        const char *mb = getenv(am_main ? "PTMI_AM_BUDGET_MB" : "PTMI_SPLIT_AM_BUDGET_MB");     // scratch for the increments of one piece (default 6 GB; 2 GB for the split path alone)
+        const double budget = (mb ? atof(mb) : (am_main ? 6144.0 : 2048.0)) * 1048576.0;
         long long piece = (long long)(budget / ((double)c.ndim * 8.0 * (double)nch));
         piece = piece < 1 ? 1 : (piece > 64 ? 64 : piece);
         if ((c.ngroups > 1 || c.cov_per_walker) && nch * piece > 0x7FFFFFFFLL) piece = 0x7FFFFFFFLL / nch;      // (the group lists index the events with 32 bits; nch itself is below 2^32 / ntemps)
         if (piece < 1) piece = 1;
-        h->am_piece = (int)piece;
+        h->am_piece = am_main ? (int)piece : 0;
+        h->split_am_piece = (int)piece;
         h->am_cap = nch * piece;
+        if (buf->Q != nullptr) e = hipMalloc((void **)&h->d_am_next, sizeof(long long) * (size_t)(nch + 1));
+        if (e == hipSuccess)
         e = hipMalloc((void **)&h->d_am_ev, sizeof(AmEvent) * (size_t)h->am_cap);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_count, sizeof(int32_t) * (size_t)(nch + (nch + 1023) / 1024));      // counts | the scan's block sums
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_am_base, sizeof(long long) * (size_t)(nch + 1));
@@ -2656,7 +2663,8 @@ int ptmi_create(const ptmi_config *cfg, const ptmi_buffers *buf, ptmi_handle *ou
             (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm); (void)hipFree(h->d_am_kbase);
             h->d_am_ev = nullptr; h->d_am_count = nullptr; h->d_am_base = nullptr; h->d_am_inc = nullptr;
             h->d_am_grp = nullptr; h->d_am_perm = nullptr; h->d_am_kbase = nullptr;
-            h->am_piece = 0; h->am_cap = 0;
+            (void)hipFree(h->d_am_next); h->d_am_next = nullptr;
+            h->am_piece = 0; h->am_cap = 0; h->split_am_piece = 0;
             e = hipSuccess;
         }
     }
@@ -2687,7 +2695,7 @@ int ptmi_destroy(ptmi_handle h)
     }
     (void)hipFree(h->d_rle_ent); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
-    (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm); (void)hipFree(h->d_am_kbase);
+    (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm); (void)hipFree(h->d_am_kbase); (void)hipFree(h->d_am_next);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->side_go); (void)hipEventDestroy(h->side_done); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2708,6 +2716,7 @@ int ptmi_set_de_active(ptmi_handle h, int on)
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
     if (on && (h->cfg.w_de <= 0 || !h->buf.DE)) return fail(PTMI_EINVAL, "DE has no weight or no buffer");
     h->de_on = on ? 1 : 0;
+    h->split_am_lo = h->split_am_hi = 0;                         // the cycle changed: increments made ahead (ptmi_split_am_prepare) are void
     return PTMI_OK;
 }
 
@@ -2758,6 +2767,40 @@ static int make_ut_pad(ptmi_engine *h, KArgs *a)
     return PTMI_OK;
 }
 
+// The AM picks of iterations iter0 .. iter0 + ns - 1 listed (am_count / am_scan / am_fill) and their increments computed on the matrix
+// cores (am_gemm_kernel) into h->d_am_inc: increment j of a chain's picks in the piece is row h->d_am_base[chain] + j.
+static int am_prepare(ptmi_engine *h, long long iter0, int ns)
+{
+    const ptmi_config &c = h->cfg;
+    const long long nch = (long long)c.nwalkers * c.ntemps;
+    AmArgs p;
+    p.seed = c.seed; p.iter0 = iter0; p.nch = nch; p.nsteps = ns; p.nt = c.ntemps; p.ntg = c.ntemps_global; p.temp0 = c.temp0;
+    p.walker0 = c.walker0; p.w_host = c.w_host; p.w_scam = c.w_scam; p.w_am = c.w_am; p.w_de = h->de_on ? c.w_de : 0;
+    p.w_gj = c.w_nuts + c.w_hmc;
+    p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.ngroups = c.ngroups > 1 ? c.ngroups : 1; p.gcn = h->d_gcn;
+    p.per_walker = c.cov_per_walker ? 1 : 0;
+    p.temp_of = h->buf.temp_of; p.temps_mh = h->d_temps;
+    const unsigned gch = (unsigned)((nch + 255) / 256);
+    const int ngr = p.ngroups;
+    const long long nkeys = (long long)ngr * (c.cov_per_walker ? c.nwalkers : 1);
+    int32_t *gtot = h->d_am_perm ? h->d_am_grp : nullptr, *gcur = gtot ? gtot + nkeys : nullptr, *gpart = gtot ? gtot + 2 * nkeys : nullptr;
+    if (gtot) HIPCHK(hipMemsetAsync(gtot, 0, sizeof(int32_t) * 2 * (size_t)nkeys, h->stream));          // the keys' totals and the fill's cursors
+    hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count, gtot);
+    if (gtot) {                                                  // the lists' starts: the chains' scan over the keys' totals
+        const unsigned gk = (unsigned)((nkeys + 1023) / 1024);
+        hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gk), dim3(1024), 0, h->stream, (const int32_t *)gtot, gpart, nkeys);
+        hipLaunchKernelGGL(am_scan_kernel, dim3(gk), dim3(1024), 0, h->stream, (const int32_t *)gtot, (const int32_t *)gpart, h->d_am_kbase, nkeys);
+    }
+    const unsigned gsc = (unsigned)((nch + 1023) / 1024);
+    hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, h->d_am_count + nch, nch);
+    hipLaunchKernelGGL(am_scan_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, (const int32_t *)(h->d_am_count + nch),
+                       h->d_am_base, nch);
+    hipLaunchKernelGGL(am_fill_kernel, dim3(gch), dim3(256), 0, h->stream, p, (const long long *)h->d_am_base, (AmEvent *)h->d_am_ev,
+                       (const long long *)h->d_am_kbase, gcur, gtot ? h->d_am_perm : nullptr);
+    if (int rc = launch_am_gemm(h, nch * ns)) return rc;
+    return PTMI_OK;
+}
+
 int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
@@ -2804,31 +2847,7 @@ int ptmi_mh_steps(ptmi_handle h, int64_t iter0, int32_t nsteps)
         const long long nch = (long long)c.nwalkers * c.ntemps;
         for (int s0 = 0; s0 < nsteps; s0 += h->am_piece) {
             const int ns = nsteps - s0 < h->am_piece ? nsteps - s0 : h->am_piece;
-            AmArgs p;
-            p.seed = c.seed; p.iter0 = iter0 + s0; p.nch = nch; p.nsteps = ns; p.nt = c.ntemps; p.ntg = c.ntemps_global; p.temp0 = c.temp0;
-            p.walker0 = c.walker0; p.w_host = c.w_host; p.w_scam = c.w_scam; p.w_am = c.w_am; p.w_de = h->de_on ? c.w_de : 0;
-            p.w_gj = c.w_nuts + c.w_hmc;
-            p.pick_walker = c.pick_mode == PTMI_PICK_WALKER; p.ngroups = c.ngroups > 1 ? c.ngroups : 1; p.gcn = h->d_gcn;
-            p.per_walker = c.cov_per_walker ? 1 : 0;
-            p.temp_of = h->buf.temp_of; p.temps_mh = h->d_temps;
-            const unsigned gch = (unsigned)((nch + 255) / 256);
-            const int ngr = p.ngroups;
-            const long long nkeys = (long long)ngr * (c.cov_per_walker ? c.nwalkers : 1);
-            int32_t *gtot = h->d_am_perm ? h->d_am_grp : nullptr, *gcur = gtot ? gtot + nkeys : nullptr, *gpart = gtot ? gtot + 2 * nkeys : nullptr;
-            if (gtot) HIPCHK(hipMemsetAsync(gtot, 0, sizeof(int32_t) * 2 * (size_t)nkeys, h->stream));          // the keys' totals and the fill's cursors
-            hipLaunchKernelGGL(am_count_kernel, dim3(gch), dim3(256), 0, h->stream, p, h->d_am_count, gtot);
-            if (gtot) {                                                  // the lists' starts: the chains' scan over the keys' totals
-                const unsigned gk = (unsigned)((nkeys + 1023) / 1024);
-                hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gk), dim3(1024), 0, h->stream, (const int32_t *)gtot, gpart, nkeys);
-                hipLaunchKernelGGL(am_scan_kernel, dim3(gk), dim3(1024), 0, h->stream, (const int32_t *)gtot, (const int32_t *)gpart, h->d_am_kbase, nkeys);
-            }
-            const unsigned gsc = (unsigned)((nch + 1023) / 1024);
-            hipLaunchKernelGGL(am_scan_sums_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, h->d_am_count + nch, nch);
-            hipLaunchKernelGGL(am_scan_kernel, dim3(gsc), dim3(1024), 0, h->stream, (const int32_t *)h->d_am_count, (const int32_t *)(h->d_am_count + nch),
-                               h->d_am_base, nch);
-            hipLaunchKernelGGL(am_fill_kernel, dim3(gch), dim3(256), 0, h->stream, p, (const long long *)h->d_am_base, (AmEvent *)h->d_am_ev,
-                               (const long long *)h->d_am_kbase, gcur, gtot ? h->d_am_perm : nullptr);
-            if (int rc = launch_am_gemm(h, nch * ns)) return rc;
+            if (int rc = am_prepare(h, iter0 + s0, ns)) return rc;
             KArgs ap = make_args(h);
             ap.iter0 = iter0 + s0; ap.nsteps = ns;
             if (int rc = set_step_args(h, &ap)) return rc;
@@ -2856,6 +2875,18 @@ int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant)
     return PTMI_OK;
 }
 
+// The AM increments the split path's row kernel reads for the proposals of iteration `it`: the prepared piece when it covers `it`
+// (ptmi_split_am_prepare), else a piece of that one iteration made now (the tables as they are at this call).
+static int split_am_args(ptmi_engine *h, KArgs *a, long long it)
+{
+    if (h->cfg.w_am <= 0) return PTMI_OK;
+    if (!(it >= h->split_am_lo && it < h->split_am_hi))
+        if (int rc = ptmi_split_am_prepare(h, it, 1)) return rc;
+    a->am_inc = h->d_am_inc;
+    a->am_next = h->d_am_next;
+    return PTMI_OK;
+}
+
 int ptmi_propose(ptmi_handle h, int64_t iter)
 {
     if (!h) return fail(PTMI_EINVAL, "NULL handle");
@@ -2866,6 +2897,7 @@ int ptmi_propose(ptmi_handle h, int64_t iter)
     h->q_cur = 0;                                            // the proposals go to Q
     if (ptmi_split_rows_ok(h)) {
         if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; }
+        if (int rc = split_am_args(h, &a, iter)) return rc;
         if (int rc = ptmi_split_rows(h, a, 0)) return rc;
     } else {
         const int grid = chains_grid(h);
@@ -2909,6 +2941,7 @@ int ptmi_accept_propose(ptmi_handle h, int64_t iter, const double *newlnL, const
     if (ptmi_split_rows_ok(h)) {
         a.q_cur = a.q_tgt = h->q_cur;
         if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; a.q_tgt = 1 - h->q_cur; }
+        if (int rc = split_am_args(h, &a, iter + 1)) return rc;
         if (int rc = ptmi_split_rows(h, a, 2)) return rc;
         h->q_cur = a.q_tgt;
         HIPCHK(hipGetLastError());
@@ -2932,6 +2965,28 @@ int ptmi_rows_logl(ptmi_handle h, const double *rows, int64_t n, double *out)
     if (n == 0) return PTMI_OK;
     if (int rc = ptmi_rows_iso(h, rows, (long long)n, out)) return rc;
     HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_split_am_piece(ptmi_handle h, int32_t *piece)
+{
+    if (!h || !piece) return fail(PTMI_EINVAL, "NULL argument");
+    *piece = (h->cfg.w_am > 0 && ptmi_split_rows_ok(h)) ? h->split_am_piece : 0;
+    return PTMI_OK;
+}
+
+int ptmi_split_am_prepare(ptmi_handle h, int64_t iter0, int32_t nsteps)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    if (h->cfg.w_am <= 0) return PTMI_OK;
+    if (h->split_am_piece <= 0 || !h->d_am_next) return fail(PTMI_EUNSUPPORTED, "this handle's split path takes its AM proposals from the shape kernels");
+    if (nsteps < 1 || nsteps > h->split_am_piece) return fail(PTMI_EINVAL, "ptmi_split_am_prepare: 1 <= nsteps <= %d (ptmi_split_am_piece)", h->split_am_piece);
+    if (int rc = am_prepare(h, (long long)iter0, nsteps)) return rc;
+    const long long nch = (long long)h->cfg.nwalkers * h->cfg.ntemps;
+    HIPCHK(hipMemcpyAsync(h->d_am_next, h->d_am_base, sizeof(long long) * (size_t)(nch + 1), hipMemcpyDeviceToDevice, h->stream));      // every chain's cursor at its first increment
+    HIPCHK(hipGetLastError());
+    h->split_am_lo = iter0;
+    h->split_am_hi = iter0 + nsteps;
     return PTMI_OK;
 }
 

@@ -87,6 +87,7 @@ struct KArgs {
     // chain's AM picks of this launch is am_inc[(am_base[chain] + j) * d ...]; nullptr: the kernel computes its own
     const double *am_inc;
     const long long *am_base;
+    long long *am_next;          // split path (ptmi_split.hip): the chains' cursors into am_inc, advanced by the row kernel with every AM pick
     // 16- / 64-lane shapes, ONE table for the launch: the library's zero-padded copy of Ut with rows of ut_pad_ld = G * EPL doubles
     // (ut_pad_kernel, made ahead of the launch), so that a step reads its direction with unconditional loads; nullptr: none
     const double *UtPad;
@@ -171,6 +172,9 @@ struct ptmi_engine {
     int32_t *d_rle_cnt;          // ... and how many each slab has [nslab]
     const double *rp_swap_u;     // TEST HOOK (ptmi_test_replay): the swap's uniforms [W][ntemps_global - 1] instead of the Philox ones
     const u64 *rp_draws;         // TEST HOOK: see KArgs
+    long long *d_am_next;        // split path: the chains' cursors into d_am_inc (KArgs::am_next)
+    int split_am_piece;          // split path: iterations ptmi_split_am_prepare can cover at once (0: AM cycles go through the shape kernels)
+    long long split_am_lo, split_am_hi;   // ... and the iterations [lo, hi) the prepared increments cover
     int q_cur;                   // split path: the proposal buffer (0 = Q, 1 = Q2) that holds the current proposals (ptmi_proposals)
 };
 
@@ -180,6 +184,7 @@ struct ptmi_engine {
 bool ptmi_split_rows_ok(const ptmi_engine *h);
 int ptmi_split_rows(ptmi_engine *h, const KArgs &a, int mode);
 int ptmi_rows_iso(ptmi_engine *h, const double *rows, long long n, double *out);
+extern "C" int ptmi_split_am_prepare(ptmi_handle h, int64_t iter0, int32_t nsteps);
 
 // The per-chain kernels are templates over the shape (lanes per chain G, register slots per lane EPL).  Each shape
 // and likelihood family is compiled in its own translation unit (ptmi_shape.hip with -DPTMI_G -DPTMI_E -DPTMI_L) so

@@ -28,8 +28,11 @@
 // acceptance of the first thousand iterations from p0 = 0 that is 8 % of the rows instead of 91 %.  With one buffer (Q2 NULL) the
 // same rule makes every accepted row go to X at once: the single-buffer case is the one where the target IS the current buffer.
 //
-// Not here: cycles with AM entries (their 2 d^2 flop per pick want the matrix cores: the shape kernels' propose_kernel keeps
-// serving them) -- ptmi_split_rows_ok says whether a handle's configuration runs here.
+// AM picks (PT:879-933, 2 d^2 flop each) get their increments from the matrix cores AHEAD of the launch (am_gemm_kernel of ptmi_abi.hip:
+// ptmi_split_am_prepare lists the picks of a piece of iterations and multiplies; an increment depends on the chain's stream, the
+// iteration and the scale branch, not on its state) and the row kernel adds the chain's next one as it adds a SCAM direction.
+// Not here: host-served cycle entries together with AM entries, and handles without room for the increments -- the shape kernels'
+// propose_kernel / accept_kernel keep serving those; ptmi_split_rows_ok says whether a handle's configuration runs here.
 #include "ptmi_mh.inc.h"
 
 namespace {
@@ -198,6 +201,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const KArgs a)
                     const double *S = a.S + (wc * a.ngroups + (size_t)g) * d;
                     r.amp = z * cc.cd_scam(br) * det_sqrt(S[k]);                       // PT:873
                     r.urow = (long long)(((wc * a.ngroups + (size_t)g) * d + (size_t)k) * d);
+                } else if (jt == PTMI_J_AM) {
+                    // PT:879-933: the increment U (cd sqrt(S) z) was made on the matrix cores ahead of this launch (am_gemm_kernel, the
+                    // same k-ascending fma chain as the step kernels' own product); this pick takes the chain's next one
+                    const long long at = a.am_next[ch];
+                    a.am_next[ch] = at + 1;
+                    r.urow = at * d;
                 } else if (jt == PTMI_J_DE) {
                     const u32 Bn = (u32)a.de_size;
                     const u32 mm = h2index((u32)(Q0 >> 32), Bn);
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const KArgs a)
                 else v[j] = row_load(Q1p + p);
                 if (PROP) {
                     if (r.jt == PTMI_J_SCAM) u[j] = *reinterpret_cast<const PT *>(a.Ut + r.urow + (size_t)ip * VEC);
+                    else if (r.jt == PTMI_J_AM) u[j] = row_load(reinterpret_cast<const PT *>(a.am_inc + r.urow + (size_t)ip * VEC));
                     else if (r.jt == PTMI_J_DE) {
                         const double *rm = a.DE + r.rm, *rn = a.DE + r.rn;
                         if constexpr (VEC == 2) {
@@ -294,6 +304,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const KArgs a)
             if (PROP) {
                 PT dq;
                 if (r.jt == PTMI_J_SCAM) dq = r.amp * u[j];
+                else if (r.jt == PTMI_J_AM) dq = u[j];
                 else if (r.jt == PTMI_J_DE) {
                     dq = r.amp * u[j];
                     if (r.gm >= 0) {                             // only the group's parameters move (PT:978-983)
@@ -370,7 +381,7 @@ bool ptmi_split_rows_ok(const ptmi_engine *h)
 {
     const char *e = getenv("PTMI_SPLIT_ROWS");                   // read per call: the tests switch it
     if (e && atoi(e) == 0) return false;
-    return h->cfg.w_am == 0 && h->cfg.ndim >= 1;
+    return (h->cfg.w_am == 0 || h->split_am_piece > 0) && h->cfg.ndim >= 1;
 }
 
 // mode 0: propose(iter0); 1: accept(iter0); 2: accept(iter0) + propose(iter0 + 1)

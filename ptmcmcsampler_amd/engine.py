@@ -904,9 +904,19 @@ class PTEngine(object):
         if self.t["Q"] is None:
             raise _lib.PtmiError("the callback path needs the engine built with split=True")
         lib, h = self.lib, self.h
+        # cycles with AM entries: the picks' increments for a piece of the segment at a time, on the matrix cores ahead of the proposals
+        if getattr(self, "_am_piece", None) is None:
+            v = C.c_int32(0)
+            _lib.check(lib.ptmi_split_am_piece(h, C.byref(v)))
+            self._am_piece = v.value
+        piece = self._am_piece
+        if piece:
+            _lib.check(lib.ptmi_split_am_prepare(h, it, min(piece, end - it + 1)))
         _lib.check(lib.ptmi_propose(h, it))
         for j in range(it, end):
             ll, lp = self.eval_callback(self.proposals(), logl, logp)
+            if piece and (j + 1 - it) % piece == 0:                   # the proposal of j + 1 opens the next piece
+                _lib.check(lib.ptmi_split_am_prepare(h, j + 1, min(piece, end - j)))
             _lib.check(lib.ptmi_accept_propose(h, j, ll.data_ptr(), lp.data_ptr()))       # (between here and ptmi_accept X is not the state: sloc)
         ll, lp = self.eval_callback(self.proposals(), logl, logp)
         _lib.check(lib.ptmi_accept(h, end, ll.data_ptr(), lp.data_ptr()))

@@ -62,6 +62,13 @@ CASES = [
     (100, 4, 6, (20, 0, 20), dict(box=True)),                       # a prior that refuses (-inf) in the callback
     (20, 4, 5, (3, 0, 2), dict(w_host=2)),                          # host-served cycle entries: the state handed back unchanged
     (100, 8, 5, (20, 0, 20), dict(cov_mode="pooled", keep_lnl=True)),
+    # cycles with AM entries: the increments from the matrix cores ahead of the proposals (ptmi_split_am_prepare)
+    (100, 4, 37, (20, 20, 20), {}),
+    (100, 64, 2, (20, 20, 0), dict(cov_mode="per_walker")),         # a table -- and a list of picks -- per walker
+    (130, 3, 4, (20, 20, 20), dict(cov_mode="pooled")),             # 16 lanes per chain: the Box-Muller pairing (k, k + 16)
+    (7, 2, 9, (5, 4, 3), dict(groups=[[0, 2, 4], [1, 3, 5, 6]])),   # a list of picks per parameter group
+    (1000, 2, 2, (20, 20, 0), {}),
+    (100, 4, 6, (20, 20, 20), dict(small_pieces=True)),             # room for two iterations' increments: several pieces per segment
 ]
 
 
@@ -75,6 +82,8 @@ def test_row_kernels_equal_the_shape_kernels_and_one_launch_equals_two(mods, d, 
     orc, _lib, PTEngine = mods
     extra = dict(extra)
     box = extra.pop("box", False)
+    if extra.pop("small_pieces", False):
+        monkeypatch.setenv("PTMI_SPLIT_AM_BUDGET_MB", "%.6f" % (2.5 * d * 8 * nt * W / 1048576.0))
     rs = np.random.RandomState(d + nt)
     lo, hi = (-0.4 - 0.1 * rs.rand(d), 0.4 + 0.1 * rs.rand(d)) if box else (None, None)
     logl, logp = _callbacks(torch, lo, hi)
@@ -118,7 +127,9 @@ def test_row_kernels_equal_the_shape_kernels_and_one_launch_equals_two(mods, d, 
 
 
 @pytest.mark.parametrize("d,nt,W,weights,cov_mode", [(100, 4, 5, (20, 0, 20), "per_walker"), (100, 3, 4, (20, 0, 0), "pooled"),
-                                                     (37, 5, 3, (20, 0, 20), "pooled"), (6, 2, 3, (1, 0, 1), "per_walker")])
+                                                     (37, 5, 3, (20, 0, 20), "pooled"), (6, 2, 3, (1, 0, 1), "per_walker"),
+                                                     (100, 4, 5, (20, 20, 20), "per_walker"), (37, 5, 3, (20, 20, 20), "pooled"),
+                                                     (300, 2, 3, (5, 20, 5), "pooled")])
 def test_row_kernels_against_the_oracle(mods, d, nt, W, weights, cov_mode):
     """The whole callback path on the row kernels against the oracle's run (PTMCMCSampler.py:601-622, 820-876, 936-985, 631-697,
     545-585): the callback hands back the ORACLE's likelihood of every proposal (orc_logl on the host: a torch reduction sums in
@@ -145,6 +156,11 @@ def test_row_kernels_against_the_oracle(mods, d, nt, W, weights, cov_mode):
     assert calls[0] == 131 and o.nswap.sum() > 0
     if weights[2]:
         assert o.jstat[..., 2, 0].sum() > 0
+    if weights[1]:
+        assert o.jstat[..., 1, 1].sum() > 0                       # AM proposals were made and accepted
+        piece = C.c_int32(0)
+        _lib.check(g.lib.ptmi_split_am_piece(g.h, C.byref(piece)))
+        assert piece.value >= 1                                   # ... on the row kernels, their increments from the matrix cores
 
 
 def test_accept_propose_refuses_a_swap_iteration(mods):
