@@ -548,6 +548,7 @@ ALSO = (
     # (the reference's logl / logp boundary, PTMCMCSampler.py:605-611, 1072-1086)
     ("config2_batched_callback", dict(callback=True, callback_kind="hip"), 20, 5),                 # the callback is a HIP kernel behind the C ABI
     ("config2_batched_callback_torch", dict(callback=True, callback_kind="norm"), 20, 5),         # the callback is a torch expression
+    ("config2_batched_callback_default_mix", dict(callback=True, callback_kind="hip", mix="default"), 10, 105),   # AM increments from the matrix cores ahead of the proposals
 )
 L2_PEAK_TBS = 34.5             # MI355X_MICROARCH.md: aggregate L2 bandwidth (4 MiB per XCD); profiles/r05_row_gather.txt: random 8 KB rows of a
                                # 7.8 MB table (it does not fit one XCD's L2: half the rows come from the MALL) arrive at 16.1 TB/s
