@@ -261,3 +261,29 @@ def test_full_size_callback_path_equals_the_fused_kernels_run(mods):
     assert g.eig_epochs == 2 and g.get("nswap").sum() > 0 and not g.t["sloc"].any()
     acc = g.get("nacc").astype(np.float64).mean() / 230
     assert 0.5 < acc < 1.0
+
+
+@pytest.mark.parametrize("d,nt,W", [(200, 4, 6), (1000, 3, 5)])
+def test_dense_gaussian_as_a_gemm_callback(mods, d, nt, W):
+    """PTEngine.dense_logl_callback: the dense Gaussian beyond the 104 parameters the built-in family keeps in LDS, as ONE matrix
+    product per iteration for the whole batch on the split path (tests/test_simple.py:14-41 at larger ndim).  A callback's sums are
+    its own: checked against NumPy's quadratic form, the chains against the accept rule (PTMCMCSampler.py:605-622) on those values."""
+    import torch
+    orc, _lib, PTEngine = mods
+    rs = np.random.RandomState(d)
+    A = rs.randn(d, d)
+    C_ = A @ A.T / d + 0.5 * np.eye(d)
+    P, mu = np.linalg.inv(C_), rs.randn(d) * 0.1
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 20, 20), cov_update=30, burn=60, tskip=10, seed=4, split=True, cov_mode="pooled")
+    cb = g.dense_logl_callback(mu, P)
+    g.init_state_callback(mu + rs.randn(W, nt, d) * 0.05, cb, None)
+    g.run_callback(150, cb, None)
+    g.sync()
+    X, lnL = g.get("X"), g.get("lnL")
+    R = X - mu
+    want = -0.5 * np.einsum("wti,ij,wtj->wt", R, P, R)
+    assert np.allclose(lnL, want, rtol=1e-10, atol=1e-10)
+    assert torch.equal(g.t["lnL"].view(-1), cb(g.t["X"].view(-1, d)))         # the callback's own value of the row every chain holds
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., :3, 0].sum(-1) == 150).all() and js[..., 1, 1].sum() > 0 and js[..., 2, 0].sum() > 0
+    assert 0 < g.get("nacc").sum() < 150 * nt * W and g.get("nswap").sum() > 0 and g.eig_epochs >= 4
