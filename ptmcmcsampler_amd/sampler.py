@@ -288,18 +288,26 @@ class PTSampler(object):
             for r in range(1, self.nchain):
                 last_hot = hotChain and r == self.nchain - 1
                 rank_files.append(self.outDir + ("/chain_hot.txt" if last_hot else "/chain_{0}.txt".format(self.ladder[r])))
+            # several walkers of ONE temperature: every walker is a run of its own with its own file (chain_1.txt, chain_1_w<k>.txt,
+            # written when keep_walkers == nwalkers), replayed side by side
+            walker_files = [self.fname if k == 0 else self.fname[:-4] + "_w%d.txt" % k for k in range(self.nwalkers)]
+            batch_ok = self.nwalkers > 1 and self.nchain == 1 and self.keep_walkers == self.nwalkers
+            if batch_ok:
+                rank_files = walker_files
             missing = [f for f in rank_files if not os.path.isfile(f)]
-            if self.nwalkers != 1 or missing:
+            if (self.nwalkers != 1 and not batch_ok) or missing:
                 raise Exception("Couldn't resume: {0} exists but the device checkpoint {1} does not, and chain files alone can only be "
-                                "replayed for one walker with the file of every temperature present ({2}): runs of several "
-                                "walkers are resumable when they were started with checkpoint=True (or resume=True).  Refusing to "
+                                "replayed for one walker with the file of every temperature present, or for the walkers of one "
+                                "temperature with a file each (keep_walkers = nwalkers) ({2}): other batches are resumable when "
+                                "they were started with checkpoint=True (or resume=True).  Refusing to "
                                 "overwrite it.".format(self.fname, self._ckpt, "missing: " + ", ".join(missing) if missing else
-                                                       "nwalkers = %d" % self.nwalkers))
+                                                       "nwalkers = %d, ntemps = %d, keep_walkers = %d" % (self.nwalkers, self.nchain, self.keep_walkers)))
             try:
                 self._resume_rows = [np.loadtxt(f, ndmin=2) for f in rank_files]
             except ValueError as error:
                 print("Reading old chain files failed with error", error)
                 raise Exception("Couldn't read old chain to resume")
+            self._resume_by_walker = batch_ok
             self.resumechain = self._resume_rows[0]
             self.resumeLength = self.resumechain.shape[0]
             for f, rows in zip(rank_files, self._resume_rows):
@@ -539,6 +547,8 @@ class PTSampler(object):
         eng, thin, cu = self.engine, self.thin, self.covUpdate
         d, n = self.ndim, self.nchain
         last = self.resumeLength * thin - 1                         # iterations 1 .. last are replayed
+        if getattr(self, "_resume_by_walker", False):
+            return self._replay_walker_files(last)
         betas = 1.0 / eng.temps_mh
         Xs = [rows[:, :d] for rows in self._resume_rows]
         lnls = [rows[:, -3] for rows in self._resume_rows]
@@ -596,6 +606,55 @@ class PTSampler(object):
         nacc = eng.get("nacc")
         for r in range(n):
             nacc[0, r] = int(round(last * self._resume_rows[r][k, -2]))
+        eng.put("nacc", nacc.astype(np.int64))
+        self.ind_next_write = self.resumeLength
+        eng.iter = last
+        return last
+
+    def _replay_walker_files(self, last):
+        """_replay_chain_file for the walkers of ONE temperature: walker w replays its own file (a reference run each,
+        PTMCMCSampler.py:591-599) -- its rows are its AM buffer, the covariance epochs (:545-560; per walker, or pooled over all
+        walkers' rows) and the DE history (:563-571) are rebuilt from them -- and all walkers continue together."""
+        import torch
+        eng, thin, cu, d, W = self.engine, self.thin, self.covUpdate, self.ndim, self.nwalkers
+        rows = self._resume_rows
+        X = np.stack([r[:, :d] for r in rows])                      # [W][rows][d]
+        lnl = np.stack([r[:, -3] for r in rows])
+        lnp = np.stack([r[:, -4] for r in rows])
+        beta0 = 1.0 / eng.temps_mh[0]
+        with np.errstate(invalid="ignore"):
+            lpr = np.where(np.isneginf(lnp), -np.inf, lnp - beta0 * lnl)
+        dev = eng.device
+        eng.t["AM"][:, 0] = torch.from_numpy(np.ascontiguousarray(eng.am_rows(X[:, 0]))).to(dev)
+        if eng.am_rle:
+            eng.t["AMflag"].fill_(_lib.AMROW_KEY)
+        eng.t["AMaux"][:, 0, 0], eng.t["AMaux"][:, 0, 1] = torch.from_numpy(lnl[:, 0]).to(dev), torch.from_numpy(lpr[:, 0]).to(dev)
+        self._chains[:, 0], self._lnlikes[:, 0], self._lnprobs[:, 0] = X[:, 0], lnl[:, 0], lnp[:, 0]
+        it = 1
+        while it <= last:
+            before = eng.eig_epochs
+            eng._epochs(it)
+            if eng.eig_epochs != before:
+                self._mirror_cov()
+            if (it - 1) == self.burn and self.DEweight and self.DEJump not in self.propCycle:
+                self.addProposalToCycle(self.DEJump, self.DEweight)
+                self.randomizeProposalCycle()
+            end = min(eng._segment_end(it, last), last)
+            its = np.arange(it, end + 1)
+            src = its // thin
+            ring = torch.from_numpy(its % cu).to(dev)
+            eng.t["AM"][:, ring] = torch.from_numpy(np.ascontiguousarray(eng.am_rows(X[:, src]))).to(dev)
+            eng.t["AMaux"][:, ring] = torch.from_numpy(np.stack([lnl[:, src], lpr[:, src]], 2)).to(dev)
+            keep = its[its % thin == 0] // thin
+            self._chains[:, keep], self._lnlikes[:, keep], self._lnprobs[:, keep] = X[:, keep], lnl[:, keep], lnp[:, keep]
+            it = end + 1
+        k = last // thin
+        eng.t["X"].copy_(torch.from_numpy(np.ascontiguousarray(X[:, k][:, None, :])))
+        eng.put("lnL", lnl[:, k][:, None])
+        eng.put("lp", lpr[:, k][:, None])
+        nacc = eng.get("nacc")
+        for w in range(W):
+            nacc[w, 0] = int(round(last * rows[w][k, -2]))           # :597-599
         eng.put("nacc", nacc.astype(np.int64))
         self.ind_next_write = self.resumeLength
         eng.iter = last

@@ -598,3 +598,79 @@ def test_engine_modes_sample_the_same_posterior(tmp_path):
     assert s.engine.eig_epochs == 19 and s.nswap_accepted > 0
     # the adapted pooled covariance is the target's, up to the 2.4^2/d scaling being applied at proposal time, not here
     assert np.max(np.abs(s.cov - C)) / np.max(np.abs(C)) < 0.1
+
+
+@pytest.mark.parametrize("cov_mode", ["per_walker", "pooled"])
+def test_resume_a_batch_of_walkers_from_their_chain_files(tmp_path, capsys, cov_mode):
+    """PTMCMCSampler.py:290-319, 591-599 for a BATCH of walkers at one temperature: every walker is a run of its own with a chain file
+    of its own (chain_1.txt, chain_1_w<k>.txt with keep_walkers = nwalkers), and resume=True without a device checkpoint replays them
+    side by side: the AM rings are the files' rows, the covariance epochs the oracle's Welford over each walker's rows (or the
+    oracle's pooled statistics over all of them), the states the files' last rows; then sampling continues and every file grows."""
+    from oracle import oracle as orc
+    from ptmcmcsampler_amd import PTSampler
+    d, W = 4, 3
+    kw = dict(burn=200, thin=2, covUpdate=50, isave=100)
+    p0 = np.full(d, 0.1)
+
+    def make(resume):
+        return PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path), verbose=False, seed=33, nwalkers=W, keep_walkers=W,
+                         resume=resume, checkpoint=False, cov_mode=cov_mode)
+    a = make(False)
+    a.sample(p0, 400, **kw)
+    assert not os.path.exists(tmp_path / "ptmi_checkpoint.npz")
+    names = ["chain_1.txt"] + ["chain_1_w%d.txt" % k for k in range(1, W)]
+    old = {f: open(tmp_path / f).read() for f in names}
+    rows = [np.loadtxt(tmp_path / f) for f in names]
+    assert all(r.shape == (201, d + 4) for r in rows) and not np.array_equal(rows[0], rows[1])
+    b = make(True)
+    snaps, end = [], {}
+    replay = b._replay_chain_file
+
+    def watched():
+        eng = b.engine
+        upd = eng.update_cov
+
+        def update_cov(it_done):
+            upd(it_done)
+            snaps.append((it_done, eng.get("mu").copy(), eng.get("M2").copy(), eng.get("cov").copy()))
+
+        eng.update_cov = update_cov
+        last = replay()
+        eng.update_cov = upd
+        eng.sync()
+        end.update(last=last, AM=eng.get("AM").copy(), X=eng.get("X").copy(), nacc=eng.get("nacc").astype(np.int64).copy())
+        return last
+
+    b._replay_chain_file = watched
+    b.sample(p0, 600, **kw)
+    assert "Resuming with 201 samples from file representing 401 original samples" in capsys.readouterr().out
+    thin, cu, last = kw["thin"], kw["covUpdate"], 201 * kw["thin"] - 1
+    Wc = W if cov_mode == "per_walker" else 1
+    mu, M2, AM = np.zeros((Wc, d)), np.zeros((Wc, d, d)), np.zeros((W, cu, d))
+    AM[:, 0] = [r[0, :d] for r in rows]
+    want = []
+    for it in range(1, last + 1):
+        if (it - 1) % cu == 0 and it - 1 != 0:
+            if cov_mode == "per_walker":
+                cov = np.stack([orc.welford(AM[w], mu[w], M2[w], it - 1) for w in range(W)])
+            elif b.engine.am_rle:                                    # replayed rows are stored rows (KEY flags): run lengths of one
+                cov = orc.pool_update_rle(AM, np.full((W, cu), 2, dtype=np.uint64), mu[0], M2[0], it - 1)[None]
+            else:
+                cov = orc.pool_update(AM, mu[0], M2[0], it - 1)[None]
+            want.append((it - 1, mu.copy(), M2.copy(), cov.copy()))
+        AM[:, it % cu] = [r[it // thin, :d] for r in rows]
+    assert end["last"] == last == 401 and len(snaps) == len(want) == 8
+    for (i0, m0, q0, c0), (i1, m1, q1, c1) in zip(snaps, want):
+        assert i0 == i1 and np.array_equal(m0, m1) and np.array_equal(q0, q1) and np.array_equal(c0, c1), i0
+    assert np.array_equal(end["AM"], AM)
+    assert np.array_equal(end["X"][:, 0], np.stack([r[200, :d] for r in rows]))
+    assert np.array_equal(end["nacc"][:, 0], [int(round(last * r[200, -2])) for r in rows])
+    for f in names:                                                  # the old rows stand, the new ones follow
+        now = open(tmp_path / f).read()
+        assert now.startswith(old[f]) and len(now.splitlines()) == 301
+    # a ladder of several walkers still needs the checkpoint
+    c = PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path / "c"), verbose=False, seed=1, nwalkers=2, keep_walkers=2, ntemps=2)
+    c.sample(p0, 200, Tskip=10, **kw)
+    c2 = PTSampler(d, ("iso",), ("flat",), np.eye(d) * 0.05, outDir=str(tmp_path / "c"), verbose=False, seed=1, nwalkers=2, keep_walkers=2, ntemps=2, resume=True)
+    with pytest.raises(Exception, match="Couldn't resume"):
+        c2.sample(p0, 400, Tskip=10, **kw)
