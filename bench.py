@@ -82,6 +82,9 @@ def make_parser():
                     help="the callback: norm = torch, -0.5 * vector_norm(X)^2 (one pass over the proposals); naive = torch, "
                          "-0.5 * (X * X).sum(-1) (writes and re-reads a temporary of the proposals' size); hip = a device kernel behind the C "
                          "ABI (ptmi_rows_logl: the fused kernels' likelihood bits)")
+    ap.add_argument("--callback-graph", action="store_true",
+                    help="--callback: every segment (one proposal launch, then per iteration the callback and ptmi_accept_propose) captured "
+                         "once in a hipGraph and replayed -- for small, launch-bound batches (PTEngine.callback_segment_graph)")
     ap.add_argument("--callback-launches", default="one", choices=["one", "two"],
                     help="one: ptmi_accept_propose (the accept test and the next proposal in one launch); two: ptmi_propose + ptmi_accept")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -246,7 +249,7 @@ def measure(a, rank, world, local, dist, backend):
             cb_l = lambda X: torch.linalg.vector_norm(X, dim=-1).square_().mul_(-0.5)     # noqa: E731 -- one pass over the proposals
         cb_p = None                                                  # the flat prior: no launch
         eng.init_state_callback(p0, cb_l, cb_p)
-        eng.run = lambda n: eng.run_callback(n, cb_l, cb_p, fused=a.callback_launches == "one")
+        eng.run = lambda n: eng.run_callback(n, cb_l, cb_p, fused=a.callback_launches == "one", graph=a.callback_graph)
     else:
         eng.init_state(p0)
     log("engine ready")
@@ -278,15 +281,17 @@ def measure(a, rank, world, local, dist, backend):
     events = []
     # (callback path: a segment = one proposal launch, then per iteration the torch callback and ptmi_accept_propose; or split_step's
     # launch pair with --callback-launches two)
-    hot = ("callback_segment" if a.callback_launches == "one" else "split_step") if a.callback else "mh_steps"
+    hot = (("callback_segment_graph" if a.callback_graph else "callback_segment") if a.callback_launches == "one" else "split_step") if a.callback else "mh_steps"
     orig = getattr(eng, hot)
 
     def timed_mh(iter0, *rest):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(eng.stream)
-        orig(iter0, *rest)
+        ret = orig(iter0, *rest)
         e1.record(eng.stream)
-        events.append((e0, e1, (rest[0] - iter0 + 1 if hot == "callback_segment" else 1) if a.callback else rest[0]))
+        if not (hot == "callback_segment_graph" and ret is False):
+            events.append((e0, e1, (rest[0] - iter0 + 1 if hot.startswith("callback_segment") else 1) if a.callback else rest[0]))
+        return ret
 
     setattr(eng, hot, timed_mh)
     orig_cov = eng.update_cov
@@ -444,7 +449,7 @@ def measure(a, rank, world, local, dist, backend):
     if a.callback:
         out["config"]["workload"] += ("; the likelihood OUTSIDE the library: a batched torch callback (%s) on the device tensor of proposals, %s per iteration"
                                       % ({"norm": "torch: -0.5 * vector_norm(Q)^2, one pass", "naive": "torch: -0.5 * (Q * Q).sum(-1)", "hip": "a HIP kernel behind the C ABI: ptmi_rows_logl"}[a.callback_kind],
-                                         "ptmi_accept_propose (one launch)" if a.callback_launches == "one" else "ptmi_propose + ptmi_accept (two launches)"))
+                                         ("ptmi_accept_propose (one launch)" + (", every segment one hipGraph launch" if a.callback_graph else "")) if a.callback_launches == "one" else "ptmi_propose + ptmi_accept (two launches)"))
         # The split path IS bound by HBM: SURVEY 8(d)'s 16 d + 32 bytes per update are real traffic here (state in, proposal out;
         # the callback's own read of the proposals and the accepted rows written back come on top: the split design's byte model)
         acc_t = None
@@ -666,7 +671,7 @@ def main():
     if a.also == "auto":
         dflt = parse_defaults()
         a.also = all(getattr(a, k) == getattr(dflt, k) for k in ("ndim", "ntemps", "nwalkers", "mix", "weights", "pick", "logl", "prior", "cov_mode",
-                                                                 "swap_mode", "partition", "sharded", "callback", "callback_kind", "callback_launches", "am_mode", "eig_lag", "stats_async")) and a.gpus == 1
+                                                                 "swap_mode", "partition", "sharded", "callback", "callback_kind", "callback_launches", "callback_graph", "am_mode", "eig_lag", "stats_async")) and a.gpus == 1
     else:
         a.also = a.also == "on"
     if a.gpus > 1 and "LOCAL_RANK" not in os.environ:

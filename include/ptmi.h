@@ -357,6 +357,20 @@ int ptmi_accept_propose(ptmi_handle h, int64_t iter, const double *newlnL /* dev
  * the cycle (PTEngine.callback_segment). */
 int ptmi_split_am_piece(ptmi_handle h, int32_t *piece);
 int ptmi_split_am_prepare(ptmi_handle h, int64_t iter0, int32_t nsteps);
+/* The split path's inner loop in a hipGraph (launch-bound at small batches: two launches of a few microseconds per iteration).
+ * ptmi_set_stream retargets the handle's stream (to the stream a graph is being captured on, and back).  With ptmi_device_iter(h, 1)
+ * the `iter` argument of ptmi_propose / ptmi_accept / ptmi_accept_propose is an OFFSET from an iteration counter in device memory that
+ * ptmi_set_device_iter writes on the stream -- so a captured span [ptmi_propose(0), callback, ptmi_accept_propose(0), ..., ptmi_accept(L - 1)]
+ * replays for any first iteration: set the counter, launch the graph (PTEngine.run_callback(graph=True)).  The kernels derive the
+ * ring row and the swap-iteration test from the counter; the host-side checks of those calls are off in this mode; cycles with AM
+ * entries are refused (their increments are listed on the host's iteration).  Whatever the captured launches bake in -- the DE
+ * ring's head, whether DE is in the cycle -- must hold at replay: the caller captures again when it changes. */
+int ptmi_set_stream(ptmi_handle h, void *stream);
+/* (a replayed graph does not move the host's record of which buffer holds the current proposals: the caller restores what the capture
+ * ended with -- 0 = Q, 1 = Q2 -- for ptmi_proposals' sake) */
+int ptmi_set_proposals(ptmi_handle h, int32_t which);
+int ptmi_device_iter(ptmi_handle h, int32_t on);
+int ptmi_set_device_iter(ptmi_handle h, int64_t value);
 /* The buffer that holds the current proposals: Q after ptmi_propose; after ptmi_accept_propose Q or Q2 in turn when the handle has
  * both (ptmi_buffers.Q2: X is then authoritative again only after ptmi_accept), else Q.  The callback reads THIS buffer. */
 int ptmi_proposals(ptmi_handle h, double **q);

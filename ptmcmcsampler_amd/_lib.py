@@ -47,7 +47,7 @@ SYMBOLS = (
     "ptmi_last_error", "ptmi_version", "ptmi_device_count", "ptmi_lanes_for", "ptmi_lanes_for_grad", "ptmi_temperature_ladder", "ptmi_de_row_stride", "ptmi_am_row_format", "ptmi_create", "ptmi_destroy",
     "ptmi_sync", "ptmi_eval_state", "ptmi_set_de_active", "ptmi_mh_steps", "ptmi_last_mh_variant", "ptmi_swap", "ptmi_swap_gather_lnl",
     "ptmi_swap_sweep", "ptmi_swap_sweep_blocks", "ptmi_exchange_pack", "ptmi_exchange_apply", "ptmi_exchange_status", "ptmi_exchange_multihop",
-    "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_update_cov_on", "ptmi_set_am_buffers", "ptmi_eig_jacobi", "ptmi_eig_ql", "ptmi_eig_ql_from", "ptmi_eig_sytrd", "ptmi_eig_sytrd_from", "ptmi_eig_sytrd_info", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept", "ptmi_accept_propose", "ptmi_proposals", "ptmi_rows_logl", "ptmi_split_am_piece", "ptmi_split_am_prepare",
+    "ptmi_swap_write_am", "ptmi_update_cov", "ptmi_update_cov_on", "ptmi_set_am_buffers", "ptmi_eig_jacobi", "ptmi_eig_ql", "ptmi_eig_ql_from", "ptmi_eig_sytrd", "ptmi_eig_sytrd_from", "ptmi_eig_sytrd_info", "ptmi_update_de", "ptmi_set_de_head", "ptmi_propose", "ptmi_accept", "ptmi_accept_propose", "ptmi_proposals", "ptmi_rows_logl", "ptmi_split_am_piece", "ptmi_split_am_prepare", "ptmi_set_stream", "ptmi_set_proposals", "ptmi_device_iter", "ptmi_set_device_iter",
     "ptmi_am_flags_ok", "ptmi_am_expand", "ptmi_test_replay",
     "ptmi_selftest_math", "ptmi_selftest_philox", "ptmi_malloc", "ptmi_free", "ptmi_memcpy_h2d", "ptmi_memcpy_d2h",
     "ptmi_memset", "ptmi_timer_start", "ptmi_timer_stop_ms",
@@ -118,6 +118,10 @@ def load():
     L.ptmi_rows_logl.argtypes = [H, C.c_void_p, C.c_int64, C.c_void_p]
     L.ptmi_split_am_piece.argtypes = [H, C.POINTER(C.c_int32)]
     L.ptmi_split_am_prepare.argtypes = [H, C.c_int64, C.c_int32]
+    L.ptmi_set_stream.argtypes = [H, C.c_void_p]
+    L.ptmi_set_proposals.argtypes = [H, C.c_int32]
+    L.ptmi_device_iter.argtypes = [H, C.c_int32]
+    L.ptmi_set_device_iter.argtypes = [H, C.c_int64]
     L.ptmi_selftest_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.ptmi_selftest_philox.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
     L.ptmi_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]

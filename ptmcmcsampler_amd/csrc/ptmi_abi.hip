@@ -2695,7 +2695,7 @@ int ptmi_destroy(ptmi_handle h)
     }
     (void)hipFree(h->d_rle_ent); (void)hipFree(h->d_rle_cnt);
     (void)hipFree(h->d_am_ev); (void)hipFree(h->d_am_count); (void)hipFree(h->d_am_base); (void)hipFree(h->d_am_inc);
-    (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm); (void)hipFree(h->d_am_kbase); (void)hipFree(h->d_am_next);
+    (void)hipFree(h->d_am_grp); (void)hipFree(h->d_am_perm); (void)hipFree(h->d_am_kbase); (void)hipFree(h->d_am_next); (void)hipFree(h->d_iter);
     (void)hipFree(h->d_gj_tab); (void)hipFree(h->d_gj_scr); (void)hipFree(h->d_gj_scal); (void)hipFree(h->d_gj_order); (void)hipFree(h->d_gj_bucket);
     if (h->side) { (void)hipStreamDestroy(h->side); (void)hipEventDestroy(h->side_go); (void)hipEventDestroy(h->side_done); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2875,6 +2875,19 @@ int ptmi_last_mh_variant(ptmi_handle h, int32_t *variant)
     return PTMI_OK;
 }
 
+// ptmi_device_iter: the split calls' `iter` is an offset from the counter in device memory (launches captured in a graph).  The row
+// kernels derive the ring row and the swap-iteration test from the counter themselves; what the host cannot know then it cannot check.
+static int split_iter_args(ptmi_engine *h, KArgs *a, int mode)
+{
+    if (!h->dev_iter) return set_step_args(h, a);
+    if (!ptmi_split_rows_ok(h) || h->cfg.w_am > 0)
+        return fail(PTMI_EUNSUPPORTED, "ptmi_device_iter serves the row kernels' cycles without AM entries (the AM increments are listed on the host's iteration)");
+    (void)mode;
+    a->iter_dev = h->d_iter;
+    a->am_row0 = 0; a->swap_last = 0;
+    return PTMI_OK;
+}
+
 // The AM increments the split path's row kernel reads for the proposals of iteration `it`: the prepared piece when it covers `it`
 // (ptmi_split_am_prepare), else a piece of that one iteration made now (the tables as they are at this call).
 static int split_am_args(ptmi_engine *h, KArgs *a, long long it)
@@ -2893,7 +2906,7 @@ int ptmi_propose(ptmi_handle h, int64_t iter)
     if (!h->buf.Q || !h->buf.qaux) return fail(PTMI_EINVAL, "split path needs the Q and qaux buffers");
     KArgs a = make_args(h);
     a.iter0 = iter; a.nsteps = 1;
-    if (int rc = set_step_args(h, &a)) return rc;
+    if (int rc = split_iter_args(h, &a, 0)) return rc;
     h->q_cur = 0;                                            // the proposals go to Q
     if (ptmi_split_rows_ok(h)) {
         if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; }
@@ -2913,7 +2926,7 @@ int ptmi_accept(ptmi_handle h, int64_t iter, const double *newlnL, const double 
     if (!h->buf.Q || !h->buf.qaux || !newlnL || !newlp) return fail(PTMI_EINVAL, "split path buffers missing");
     KArgs a = make_args(h);
     a.iter0 = iter; a.nsteps = 1; a.newlnL = newlnL; a.newlp = newlp;
-    if (int rc = set_step_args(h, &a)) return rc;
+    if (int rc = split_iter_args(h, &a, 1)) return rc;
     if (ptmi_split_rows_ok(h)) {
         if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; }
         a.q_cur = h->q_cur;
@@ -2933,11 +2946,11 @@ int ptmi_accept_propose(ptmi_handle h, int64_t iter, const double *newlnL, const
     const ptmi_config &c = h->cfg;
     // nothing may sit between the two iterations: a swap (iter a multiple of Tskip), a covariance or DE epoch (the caller's: they
     // change the tables the proposal of iter + 1 reads)
-    if (c.tskip > 0 && c.ntemps_global > 1 && iter % c.tskip == 0)
+    if (!h->dev_iter && c.tskip > 0 && c.ntemps_global > 1 && iter % c.tskip == 0)
         return fail(PTMI_EINVAL, "ptmi_accept_propose(%lld): a swap iteration (Tskip=%d) is accepted with ptmi_accept, the swap follows", (long long)iter, c.tskip);
     KArgs a = make_args(h);
     a.iter0 = iter; a.nsteps = 1; a.newlnL = newlnL; a.newlp = newlp;
-    if (int rc = set_step_args(h, &a)) return rc;
+    if (int rc = split_iter_args(h, &a, 2)) return rc;
     if (ptmi_split_rows_ok(h)) {
         a.q_cur = a.q_tgt = h->q_cur;
         if (h->buf.Q2 && h->buf.sloc) { a.Q2 = h->buf.Q2; a.sloc = h->buf.sloc; a.q_tgt = 1 - h->q_cur; }
@@ -2964,6 +2977,38 @@ int ptmi_rows_logl(ptmi_handle h, const double *rows, int64_t n, double *out)
     if (h->cfg.logl_kind != PTMI_LOGL_ISO) return fail(PTMI_EUNSUPPORTED, "ptmi_rows_logl serves the isotropic Gaussian (PTMI_LOGL_ISO)");
     if (n == 0) return PTMI_OK;
     if (int rc = ptmi_rows_iso(h, rows, (long long)n, out)) return rc;
+    HIPCHK(hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_set_proposals(ptmi_handle h, int32_t which)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    h->q_cur = (which && h->buf.Q2) ? 1 : 0;
+    return PTMI_OK;
+}
+
+int ptmi_set_stream(ptmi_handle h, void *stream)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    h->stream = (hipStream_t)stream;
+    h->cfg.stream = stream;
+    return PTMI_OK;
+}
+
+int ptmi_device_iter(ptmi_handle h, int32_t on)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    if (on && !h->d_iter) HIPCHK(hipMalloc((void **)&h->d_iter, sizeof(long long)));
+    h->dev_iter = on ? 1 : 0;
+    return PTMI_OK;
+}
+
+int ptmi_set_device_iter(ptmi_handle h, int64_t value)
+{
+    if (!h) return fail(PTMI_EINVAL, "NULL handle");
+    if (!h->d_iter) HIPCHK(hipMalloc((void **)&h->d_iter, sizeof(long long)));
+    if (int rc = ptmi_set_iter_device(h, h->d_iter, (long long)value)) return rc;
     HIPCHK(hipGetLastError());
     return PTMI_OK;
 }

@@ -69,6 +69,7 @@ struct KArgs {
     // scalars
     u64 seed;
     long long iter0;
+    const long long *iter_dev;   // split path in a captured graph: the iteration is *iter_dev + iter0 (ptmi_device_iter), else nullptr
     int nsteps;
     int d, nt, W, ntg, temp0, walker0;
     int w_host, w_scam, w_am, w_de, de_on, de_size, de_head;
@@ -175,6 +176,8 @@ struct ptmi_engine {
     long long *d_am_next;        // split path: the chains' cursors into d_am_inc (KArgs::am_next)
     int split_am_piece;          // split path: iterations ptmi_split_am_prepare can cover at once (0: AM cycles go through the shape kernels)
     long long split_am_lo, split_am_hi;   // ... and the iterations [lo, hi) the prepared increments cover
+    long long *d_iter;           // split path: the iteration counter in device memory (ptmi_set_device_iter) ...
+    int dev_iter;                // ... and whether the split calls' `iter` arguments are offsets from it (ptmi_device_iter)
     int q_cur;                   // split path: the proposal buffer (0 = Q, 1 = Q2) that holds the current proposals (ptmi_proposals)
 };
 
@@ -184,6 +187,7 @@ struct ptmi_engine {
 bool ptmi_split_rows_ok(const ptmi_engine *h);
 int ptmi_split_rows(ptmi_engine *h, const KArgs &a, int mode);
 int ptmi_rows_iso(ptmi_engine *h, const double *rows, long long n, double *out);
+int ptmi_set_iter_device(ptmi_engine *h, long long *p, long long v);
 extern "C" int ptmi_split_am_prepare(ptmi_handle h, int64_t iter0, int32_t nsteps);
 
 // The per-chain kernels are templates over the shape (lanes per chain G, register slots per lane EPL).  Each shape

@@ -95,6 +95,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const KArgs a)
     const long long c0 = (long long)blockIdx.x * TILE;
     const int ntile = (int)(nch - c0 < TILE ? nch - c0 : TILE);
     const int tid = (int)threadIdx.x;
+    // the iteration: the launch's argument, or (launches captured in a hipGraph, replayed for other iterations: ptmi_device_iter) an
+    // offset from a counter in device memory -- then the ring row and the swap-iteration test follow from it here, as set_step_args
+    // derives them on the host
+    const long long iter0 = a.iter_dev ? *a.iter_dev + a.iter0 : a.iter0;
+    const int am_row0 = a.iter_dev ? (int)(iter0 % a.cov_update) : a.am_row0;
+    const bool swap_last = a.iter_dev ? (a.tskip > 0 && a.ntg > 1 && iter0 % a.tskip == 0) : a.swap_last != 0;
 
     // ---------------------------------------------------------------- the chains' scalars: threads 2c (slot 0) and 2c + 1 (slot 1)
     if (tid < 2 * TILE) {
@@ -117,12 +123,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const KArgs a)
             const int jt = (int)q01.y;
             const bool acc = diff > q23.y;
             const bool cold = a.temp0 + t == 0 && a.AM != nullptr;
-            const bool am = cold && !a.swap_last;
+            const bool am = cold && !swap_last;
             const size_t r = (size_t)w * nt + t;
             if (jt >= 0 && jt < PTMI_J_NTYPES) a.jstat[(r * PTMI_J_NTYPES + jt) * 2 + 0] += 1;
-            if (am && a.AMflag) a.AMflag[(size_t)w * a.cov_update + (size_t)a.am_row0] = AMROW_KEY | (acc ? AMROW_NEW : 0ull);   // the split path stores every row
+            if (am && a.AMflag) a.AMflag[(size_t)w * a.cov_update + (size_t)am_row0] = AMROW_KEY | (acc ? AMROW_NEW : 0ull);   // the split path stores every row
             if (am && a.AMaux) {
-                double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)a.am_row0) * 2;
+                double *ax = a.AMaux + ((size_t)w * a.cov_update + (size_t)am_row0) * 2;
                 ax[0] = acc ? nlnL : lnL0;
                 ax[1] = acc ? nlp : lp0;
             }
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const KArgs a)
             rec[cl].src = src;
         }
         if (PROP) {
-            const long long it = a.iter0 + (ACC ? 1 : 0);
+            const long long it = iter0 + (ACC ? 1 : 0);
             const ChainConst cc = chain_const(a.temps_mh[t], beta, d);
             const u32 sid0 = (u32)((u64)(a.walker0 + w) * (u32)a.ntg);
             const u32 sid = sid0 + (u32)(a.temp0 + t);
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const KArgs a)
             if (ACC) {
                 if (r.flags & 2) {                               // PT:327-328: the rank-0 chain's row, in the buffer's row format
                     const long long ch = c0 + cls[j];
-                    double *am = a.AM + ((size_t)(ch / nt) * a.cov_update + (size_t)a.am_row0) * d;
+                    double *am = a.AM + ((size_t)(ch / nt) * a.cov_update + (size_t)am_row0) * d;
                     if constexpr (VEC == 2) {
                         am[am_pos(2 * ips[j], a.am_epl)] = v[j].x;
                         am[am_pos(2 * ips[j] + 1, a.am_epl)] = v[j].y;
@@ -409,4 +415,11 @@ int ptmi_rows_iso(ptmi_engine *h, const double *rows, long long n, double *out)
     if (G == 4) return go(rows_iso_kernel<4>);
     if (G == 16) return go(rows_iso_kernel<16>);
     return go(rows_iso_kernel<64>);
+}
+
+__global__ void set_iter_kernel(long long *p, long long v) { *p = v; }
+int ptmi_set_iter_device(ptmi_engine *h, long long *p, long long v)
+{
+    hipLaunchKernelGGL(set_iter_kernel, dim3(1), dim3(1), 0, h->stream, p, v);
+    return PTMI_OK;
 }

@@ -938,16 +938,64 @@ class PTEngine(object):
         ll, lp = self.eval_callback(self.proposals(), logl, logp)
         _lib.check(lib.ptmi_accept(h, end, ll.data_ptr(), lp.data_ptr()))
 
-    def run_callback(self, niter, logl, logp, fused=True):
+    def callback_segment_graph(self, it, end, logl, logp):
+        """``callback_segment`` as ONE hipGraph launch.  At small batches the segment is launch-bound -- two launches of a few
+        microseconds per iteration, each behind a Python call -- so its launches are captured once per segment LENGTH (torch's graph
+        capture on a side stream the library's stream is pointed at meanwhile; the iteration comes from a counter in device memory:
+        ``ptmi_device_iter``) and replayed for every later segment of that length: set the counter, launch the graph.  The callbacks
+        must be graph-safe (no host synchronisation, the same launches for every batch: any fixed torch expression or device
+        kernel is).  What the captured launches bake in -- the DE ring's head, whether DE is in the cycle -- is part of the cache
+        key.  Returns False where it does not apply (AM entries in the cycle: their increments are listed on the host's iteration;
+        configurations the row kernels do not serve): the caller then runs ``callback_segment``.  Same results, bit for bit."""
+        torch = _torch()
+        if self.t["Q2"] is None or self.weights[1] > 0:
+            return False
+        if getattr(self, "_graphs", None) is None:
+            self._graphs = {}
+        L = end - it + 1
+        key = (L, bool(self.de_on), int(self.de_head), id(logl), id(logp))
+        g = self._graphs.get(key)
+        lib, h = self.lib, self.h
+        if g is None:
+            # a warm-up pass of the callbacks outside the capture (lazy initialisations of the libraries behind them), then the capture
+            self.eval_callback(self.t["Q"], logl, logp)
+            torch.cuda.synchronize(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(self.stream)
+            g = torch.cuda.CUDAGraph()
+            _lib.check(lib.ptmi_device_iter(h, 1))
+            _lib.check(lib.ptmi_set_stream(h, C.c_void_p(side.cuda_stream)))
+            try:
+                with torch.cuda.graph(g, stream=side):
+                    _lib.check(lib.ptmi_propose(h, 0))
+                    for j in range(L - 1):
+                        ll, lp = self.eval_callback(self.proposals(), logl, logp)
+                        _lib.check(lib.ptmi_accept_propose(h, j, ll.data_ptr(), lp.data_ptr()))
+                    ll, lp = self.eval_callback(self.proposals(), logl, logp)
+                    _lib.check(lib.ptmi_accept(h, L - 1, ll.data_ptr(), lp.data_ptr()))
+            finally:
+                _lib.check(lib.ptmi_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
+                _lib.check(lib.ptmi_device_iter(h, 0))
+            g = (g, 1 if self.proposals() is self.t["Q2"] else 0)    # ... and which buffer holds the segment's last proposals
+            self._graphs[key] = g
+        _lib.check(lib.ptmi_set_device_iter(h, it))
+        g[0].replay()
+        _lib.check(lib.ptmi_set_proposals(h, g[1]))
+        return True
+
+    def run_callback(self, niter, logl, logp, fused=True, graph=False):
         """``run`` with the likelihood and the prior in batched callbacks: the same segments (epochs and swaps between them, the
         late table of ``eig_lag`` counted in segments as ``run`` counts it in launches).  ``fused=False``: propose / accept as two
-        launches per iteration (``split_step``; same results)."""
+        launches per iteration (``split_step``; same results).  ``graph=True``: every segment one hipGraph launch
+        (``callback_segment_graph``: for small, launch-bound batches with graph-safe callbacks; same results)."""
         last = self.iter + niter
         it = self.iter + 1
         while it <= last:
             self._epochs(it)
             end = self._segment_end(it, last)
-            if fused:
+            if fused and graph and self.callback_segment_graph(it, end, logl, logp):
+                pass
+            elif fused:
                 self.callback_segment(it, end, logl, logp)
             else:
                 for j in range(it, end + 1):

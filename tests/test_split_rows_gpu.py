@@ -287,3 +287,36 @@ def test_dense_gaussian_as_a_gemm_callback(mods, d, nt, W):
     js = g.get("jstat").astype(np.int64)
     assert (js[..., :3, 0].sum(-1) == 150).all() and js[..., 1, 1].sum() > 0 and js[..., 2, 0].sum() > 0
     assert 0 < g.get("nacc").sum() < 150 * nt * W and g.get("nswap").sum() > 0 and g.eig_epochs >= 4
+
+
+@pytest.mark.parametrize("kind,d,nt,W,weights,extra", [("hip", 100, 8, 5, (20, 0, 20), dict(cov_mode="pooled")),
+                                                      ("torch", 100, 4, 7, (20, 0, 0), {}),
+                                                      ("torch", 37, 5, 3, (20, 0, 20), dict(box=True)),
+                                                      ("hip", 130, 3, 4, (20, 0, 20), dict(pick_mode="walker"))])
+def test_callback_segments_as_graph_launches_change_nothing(mods, kind, d, nt, W, weights, extra):
+    """PTEngine.run_callback(graph=True): every segment's launches -- one proposal launch, then per iteration the callback and
+    ptmi_accept_propose, ptmi_accept at the end -- captured ONCE per segment length in a hipGraph (the iteration from a counter in
+    device memory: ptmi_device_iter) and replayed.  Covariance epochs, the DE epoch and activation (the captured launches bake the DE
+    ring's head in: captured again), swaps and segments of several lengths in between; every buffer equals the run without graphs."""
+    import torch
+    orc, _lib, PTEngine = mods
+    extra = dict(extra)
+    box = extra.pop("box", False)
+    rs = np.random.RandomState(d)
+    lo, hi = (-0.4 - 0.1 * rs.rand(d), 0.4 + 0.1 * rs.rand(d)) if box else (None, None)
+    p0 = rs.randn(W, nt, d) * 0.05
+    kw = dict(weights=weights, cov_update=20, burn=40, tskip=7, seed=31, split=True, **extra)
+    runs = []
+    for graph in (True, False):
+        g = PTEngine(d, nt, W, np.eye(d) * 0.01, **kw)
+        logl, logp = _callbacks(torch, lo, hi)
+        if kind == "hip":
+            logl = g.builtin_logl()
+        g.init_state_callback(p0, logl, logp)
+        for n in (25, 3, 1, 46, 30):
+            g.run_callback(n, logl, logp, graph=graph)
+        runs.append(_snapshot(g))
+        if graph:
+            assert len(g._graphs) >= 4                               # several segment lengths, DE off / on, moving ring heads
+    _same(runs[0], runs[1], "graph launches vs plain launches")
+    assert runs[0]["nacc"].sum() > 0
