@@ -43,7 +43,7 @@ def main():
         out.append("%-86s %7d %14d %14.0f %12d %12d %6.2f" % (n[:86], k, t, a, mn, mx, 100.0 * t / tot))
     try:
         meta = c.execute("select name, max(grid_x), max(workgroup_x), max(lds_size), max(scratch_size), max(vgpr_count), "
-                         "max(accum_vgpr_count), max(sgpr_count) from kernels where name not like '%at::native%' group by name").fetchall()
+                         "max(accum_vgpr_count), max(sgpr_count) from kernels where name not like '%%at::native%%'%s group by name" % where.replace(" where", " and")).fetchall()
     except sqlite3.Error:
         meta = []
     if meta:
