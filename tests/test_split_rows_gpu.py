@@ -69,6 +69,7 @@ CASES = [
     (7, 2, 9, (5, 4, 3), dict(groups=[[0, 2, 4], [1, 3, 5, 6]])),   # a list of picks per parameter group
     (1000, 2, 2, (20, 20, 0), {}),
     (100, 4, 6, (20, 20, 20), dict(small_pieces=True)),             # room for two iterations' increments: several pieces per segment
+    (20, 4, 5, (3, 2, 2), dict(w_host=2)),                          # AM entries TOGETHER with host-served ones: the shape kernels serve all three engines
 ]
 
 
