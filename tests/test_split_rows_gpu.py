@@ -70,6 +70,9 @@ CASES = [
     (1000, 2, 2, (20, 20, 0), {}),
     (100, 4, 6, (20, 20, 20), dict(small_pieces=True)),             # room for two iterations' increments: several pieces per segment
     (20, 4, 5, (3, 2, 2), dict(w_host=2)),                          # AM entries TOGETHER with host-served ones: the shape kernels serve all three engines
+    (1, 2, 3, (20, 0, 20), {}),                                     # one parameter: a row is one 8-byte piece
+    (2, 1, 1, (20, 20, 20), {}),                                    # ONE chain: a tile of one row, no ladder
+    (104, 3, 70, (20, 20, 20), {}),                                 # the 4-lane shape's largest ndim (DE rows of 104 = 8 x 13 doubles: piece order)
 ]
 
 
@@ -124,7 +127,7 @@ def test_row_kernels_equal_the_shape_kernels_and_one_launch_equals_two(mods, d, 
         assert (js[..., 0].sum(-1) > js[..., 1].sum(-1)).all()
     if nt > 1:
         assert g.get("nswap").sum() > 0
-    assert g.eig_epochs >= 4
+    assert g.eig_epochs >= 4 or d == 1
 
 
 @pytest.mark.parametrize("d,nt,W,weights,cov_mode", [(100, 4, 5, (20, 0, 20), "per_walker"), (100, 3, 4, (20, 0, 0), "pooled"),
