@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes, one JSON line per workload, into gpurun_out/sweep_<tag>/ (copy the merged file to
 # profiles/<tag>_bench.json).  usage: gpurun --timeout 2400 -- 'bash tools/bench_sweep.sh r04'
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sweep_$TAG
 mkdir -p $OUT
@@ -18,7 +18,15 @@ b scam_rows_nolag --no-cpu-baseline --am-mode rows --eig-lag 0 --ess-window 0   
 b per_walker_lapack --no-cpu-baseline --cov-mode per_walker --steps 20 --warmup 10 --ess-window 0
 b per_walker_jacobi --no-cpu-baseline --cov-mode per_walker_jacobi --steps 30 --warmup 10 --ess-window 0
 b per_walker_ql --no-cpu-baseline --cov-mode per_walker_device --steps 30 --warmup 10 --ess-window 0       # tridiagonal QL on the device
-b callback --no-cpu-baseline --callback --steps 10 --warmup 2 --ess-window 0
+b callback_hip --no-cpu-baseline --callback --callback-kind hip --steps 20 --warmup 5 --ess-window 0          # the split path on contiguous rows, the callback a device kernel
+b callback_torch --no-cpu-baseline --callback --callback-kind norm --steps 20 --warmup 5 --ess-window 0       # ... a torch expression (one pass)
+b callback_torch_naive --no-cpu-baseline --callback --callback-kind naive --steps 20 --warmup 5 --ess-window 0   # ... a torch expression with a temporary
+b callback_two_launches --no-cpu-baseline --callback --callback-kind hip --callback-launches two --steps 20 --warmup 5 --ess-window 0
+b callback_mix --no-cpu-baseline --callback --callback-kind hip --mix default --steps 20 --warmup 105 --ess-window 0   # AM increments ahead of the proposals
+b callback_long --no-cpu-baseline --callback --callback-kind hip --steps 100 --warmup 400 --ess-window 0     # at the stationary acceptance
+b callback_small_graph --no-cpu-baseline --callback --callback-kind norm --callback-graph --nwalkers 16 --steps 20 --warmup 5 --ess-window 0
+b callback_small --no-cpu-baseline --callback --callback-kind norm --nwalkers 16 --steps 20 --warmup 5 --ess-window 0
+PTMI_SPLIT_ROWS=0 b callback_shape_kernels --no-cpu-baseline --callback --callback-kind naive --callback-launches two --steps 10 --warmup 2 --ess-window 0   # round 5's path
 b c4_share --no-cpu-baseline --ndim 1000 --nwalkers 512 --steps 40 --warmup 20 --ess-window 0
 b c4_mix --no-cpu-baseline --ndim 1000 --nwalkers 512 --mix default --steps 6 --warmup 2 --ess-window 0
 b c5_share --no-cpu-baseline --logl curved --ndim 20 --ntemps 16 --mix nuts --steps 6 --warmup 4 --ess-window 0
