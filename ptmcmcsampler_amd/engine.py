@@ -957,6 +957,8 @@ class PTEngine(object):
         g = self._graphs.get(key)
         lib, h = self.lib, self.h
         if g is None:
+            if len(self._graphs) >= 64:               # (callbacks that are new objects at every call would capture for ever: keep the SAME callables)
+                self._graphs.clear()
             # a warm-up pass of the callbacks outside the capture (lazy initialisations of the libraries behind them), then the capture
             self.eval_callback(self.t["Q"], logl, logp)
             torch.cuda.synchronize(self.device)
