@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector = FP64 matrix peak
+F64_MFMA_SUSTAINED = 47.9      # what back-to-back v_mfma_f64_16x16x4 instructions reach on this part (tools/mfma_peak.hip): 0.61 of nominal
 TSKIP = 100                    # iterations per step
 
 
@@ -521,7 +522,7 @@ def measure(a, rank, world, local, dist, backend):
         flops = base + 2 * d * d * f_am
         tfd = flops * upd_per_launch / (avg_launch_ms * 1e-3) / 1e12
         out["roofline"].update({"bound": "mfma", "achieved": tfd, "frac": tfd / F64_PEAK_TFLOPS, "algorithmic_flops_per_update": flops,
-                                "am_pick_share": f_am,
+                                "am_pick_share": f_am, "frac_of_sustained_mfma": tfd / F64_MFMA_SUSTAINED,
                                 "flops_note": ("executed flops per update: %s + 2d^2 x the share of AM picks (%.3f)" % (
                                     "the quadratic form over half of the symmetric precision matrix (d^2 + 3d)" if a.logl == "dense"
                                     else "4d (proposal + isotropic likelihood)", f_am))})
@@ -591,7 +592,7 @@ def also_legs(a, rank, world, local, dist, backend):
                                                   "kernel_time_share_of_wall", "algorithmic_flops_per_update", "algorithmic_bytes_per_update",
                                                   "split_design_bytes_per_update", "split_design_gbs", "acceptance_whole_run", "traffic",
                                                   "traffic_over_model", "traffic_gbs", "f64_valu_frac", "launch_ms_min", "launch_ms_max", "leapfrogs_timed",
-                                                  "nuts_calls_timed", "leapfrogs_per_nuts_call", "flops_per_leapfrog", "flops_note") if k in r},
+                                                  "nuts_calls_timed", "leapfrogs_per_nuts_call", "flops_per_leapfrog", "flops_note", "frac_of_sustained_mfma") if k in r},
                "leg_seconds": time.perf_counter() - t0}
         if b.ndim > 416 and b.mix == "scam":
             # 64 lanes per chain: a step reads ONE table row of 8 * ndim bytes per chain from L2 / MALL (the table, 8 MB at ndim = 1000,
