@@ -716,8 +716,12 @@ def main():
         return
     check = None
     if dist is not None and a.partition == "temps" and world > 1:
-        check = sharded_selfcheck(rank, world, local, dist)
-        log("sharded selfcheck %s (%.1f s)" % ("ok" if check[0] else "FAILED", check[1]["seconds"]))
+        try:
+            check = sharded_selfcheck(rank, world, local, dist)
+            log("sharded selfcheck %s (%.1f s)" % ("ok" if check[0] else "FAILED", check[1]["seconds"]))
+        except Exception as e:              # noqa: BLE001 -- the line must still come out, and say that its proof did not
+            check = (False, {"error": repr(e)[:300]})
+            log("sharded selfcheck raised: %r" % (e,))
     out = measure(a, rank, world, local, dist, backend)
     if check is not None:
         out["sharded_selfcheck"], out["sharded_selfcheck_detail"] = check
