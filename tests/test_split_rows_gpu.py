@@ -324,3 +324,38 @@ def test_callback_segments_as_graph_launches_change_nothing(mods, kind, d, nt, W
             assert len(g._graphs) >= 4                               # several segment lengths, DE off / on, moving ring heads
     _same(runs[0], runs[1], "graph launches vs plain launches")
     assert runs[0]["nacc"].sum() > 0
+
+
+def test_full_size_callback_path_samples_the_target_at_every_temperature(mods):
+    """BASELINE configs[1] through the callback path with a TORCH callback (its own summation order, so no bit-for-bit partner), 30 000
+    iterations from p0 = 0: 300 segments, 30 covariance epochs, two proposal buffers changing roles every iteration.  Rank t of an
+    isotropic Gaussian at temperature T_t holds x ~ N(0, T_t I): <lnL> = -d T_t / 2 with standard deviation sqrt(d / 2) T_t across the
+    4096 independent walkers for every rank up to T = 100 (above, the reference does not scale its jumps with sqrt(T),
+    PTMCMCSampler.py:861-862), and the cold chains have mean 0 and variance 1 in every parameter -- the same property the fused path is
+    held to (tests/test_gpu_bench_kernels.py)."""
+    import torch
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 4096
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 0, 0), cov_update=1000, burn=10000, tskip=100, seed=17, cov_mode="pooled", split=True,
+                 eig_lag=1)
+
+    def logl(X):
+        return torch.linalg.vector_norm(X, dim=-1).square_().mul_(-0.5)
+
+    g.init_state_callback(np.zeros(d), logl, None)
+    g.run_callback(30000, logl, None)
+    g.sync()
+    assert not g.t["sloc"].any()
+    lnL, T = g.by_temp("lnL"), g.ladder
+    warm = T <= 100.0
+    z = (lnL.mean(0) + 0.5 * d * T) / (lnL.std(0) / np.sqrt(W))
+    assert np.abs(z[warm]).max() < 5.0, z[warm]
+    assert np.allclose(lnL.std(0)[warm], np.sqrt(d / 2.0) * T[warm], rtol=0.06)
+    X = g.by_temp("X")[:, 0]
+    assert np.abs(X.mean(0)).max() < 5.0 / np.sqrt(W)
+    assert np.abs(X.var(0) - 1.0).max() < 5.0 * np.sqrt(2.0 / W)
+    S = g.get("S")[0, 0]
+    assert 0.9 < S.min() and S.max() < 1.1
+    assert np.allclose(g.get("lnL"), -0.5 * (g.get("X") ** 2).sum(-1), rtol=1e-12, atol=1e-12)
+    acc = g.get("nswap").astype(np.float64)[:, :nt - 1].mean(0) / g.swap_proposed
+    assert 0.2 < acc[:30].min() and acc[:30].max() < 0.8
