@@ -359,3 +359,29 @@ def test_full_size_callback_path_samples_the_target_at_every_temperature(mods):
     assert np.allclose(g.get("lnL"), -0.5 * (g.get("X") ** 2).sum(-1), rtol=1e-12, atol=1e-12)
     acc = g.get("nswap").astype(np.float64)[:, :nt - 1].mean(0) / g.swap_proposed
     assert 0.2 < acc[:30].min() and acc[:30].max() < 0.8
+
+
+def test_full_size_callback_path_default_cycle_samples_the_target(mods):
+    """The same property with the reference's DEFAULT cycle (SCAM / AM / DE 20 / 20 / 20) on the callback path: the AM picks' increments
+    come from the matrix cores ahead of the proposals (ptmi_split_am_prepare, pieces of ten iterations), DE joins after burn = 2000 and
+    reads its history rows in the row kernel.  64 x 2048 x 100-d, 16 000 iterations."""
+    import torch
+    orc, _lib, PTEngine = mods
+    d, nt, W = 100, 64, 2048
+    g = PTEngine(d, nt, W, np.eye(d) * 0.01, weights=(20, 20, 20), cov_update=1000, burn=2000, tskip=100, seed=23, cov_mode="pooled", split=True,
+                 eig_lag=1)
+    logl = g.builtin_logl()
+    g.init_state_callback(np.zeros(d), logl, None)
+    g.run_callback(16000, logl, None)
+    g.sync()
+    assert g.de_on and not g.t["sloc"].any()
+    js = g.get("jstat").astype(np.int64)
+    assert (js[..., :3, 0].sum(-1) == 16000).all() and (js[..., :3, 1] > 0).all()              # every type proposed and accepted on every rank
+    lnL, T = g.by_temp("lnL"), g.ladder
+    warm = T <= 100.0
+    z = (lnL.mean(0) + 0.5 * d * T) / (lnL.std(0) / np.sqrt(W))
+    assert np.abs(z[warm]).max() < 5.0, z[warm]
+    assert np.allclose(lnL.std(0)[warm], np.sqrt(d / 2.0) * T[warm], rtol=0.08)
+    X = g.by_temp("X")[:, 0]
+    assert np.abs(X.mean(0)).max() < 5.0 / np.sqrt(W)
+    assert np.abs(X.var(0) - 1.0).max() < 5.0 * np.sqrt(2.0 / W)
