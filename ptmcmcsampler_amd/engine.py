@@ -548,6 +548,8 @@ class PTEngine(object):
         p0 = np.asarray(p0, dtype=np.float64)
         full = np.array(p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d)))
         self.t["X"].copy_(torch.from_numpy(full))
+        if self.t.get("sloc") is not None:
+            self.t["sloc"].zero_()                                    # every state is in X (a segment of the split path abandoned half way left it otherwise)
         _lib.check(self.lib.ptmi_eval_state(self.h))                 # :479-487
         self._store_initial(i0)
         self.iter = int(i0)
@@ -861,6 +863,7 @@ class PTEngine(object):
         p0 = np.asarray(p0, dtype=np.float64)
         full = np.array(p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d)))
         self.t["X"].copy_(torch.from_numpy(full))
+        self.t["sloc"].zero_()                                        # every state is in X
         ll, lp = self.eval_callback(self.t["X"], logl, logp)
         ll, lp = ll.reshape(self.W, self.nt), lp.reshape(self.W, self.nt)
         self.t["lnL"].copy_(torch.where(torch.isneginf(lp), lp, ll))               # :481-483
