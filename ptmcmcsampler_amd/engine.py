@@ -863,7 +863,8 @@ class PTEngine(object):
         p0 = np.asarray(p0, dtype=np.float64)
         full = np.array(p0 if p0.ndim == 3 else np.broadcast_to(p0, (self.W, self.nt, self.d)))
         self.t["X"].copy_(torch.from_numpy(full))
-        self.t["sloc"].zero_()                                        # every state is in X
+        if self.t.get("sloc") is not None:
+            self.t["sloc"].zero_()                                    # every state is in X
         ll, lp = self.eval_callback(self.t["X"], logl, logp)
         ll, lp = ll.reshape(self.W, self.nt), lp.reshape(self.W, self.nt)
         self.t["lnL"].copy_(torch.where(torch.isneginf(lp), lp, ll))               # :481-483
