@@ -115,7 +115,7 @@ class PTEngine(object):
     ``ptmi_eig_ql``, Householder tridiagonalization + implicit QL on the device (ndim <= 128; a quarter of the Jacobi kernel's time
     on nearly degenerate spectra, two matrices per CU: the choice for thousands of per-walker covariances);
     ``"hipsolver"`` = the ROCm library's symmetric eigensolver on the engine's stream (``torch.linalg.eigh`` on the device
-    tensor: no host round trip either; one parameter group) -- the choice for large ndim, where the host's LAPACK call is the
+    tensor: no host round trip either; with parameter groups one call per group's block) -- the choice for large ndim, where the host's LAPACK call is the
     epoch (1000 x 1000: 22 ms against 83 ms on 8 host threads; at ndim = 100 the host's 0.6 ms wins).  Like LAPACK's, its
     last bits are the library's: such a run is not bit-reproducible against the oracle, only its decomposition is checked.
     ``"sytrd"`` = ``ptmi_eig_sytrd`` for ONE large pooled covariance (ndim <= 1024), all of it the library's own kernels: Householder
@@ -195,8 +195,8 @@ class PTEngine(object):
         self.ngr = len(self.groups)
         # "whole": one group that IS the full parameter vector in order (a permutation of it needs put_eig's embedding)
         self.whole = self.ngr == 1 and np.array_equal(self.groups[0], np.arange(self.d))
-        if eig_mode in ("jacobi", "hipsolver", "sytrd") and not self.whole:
-            raise ValueError("eig_mode=%r factorizes the full covariance: no parameter groups (eig_mode='ql' takes them)" % eig_mode)
+        if eig_mode in ("jacobi", "sytrd") and not self.whole:
+            raise ValueError("eig_mode=%r factorizes the full covariance: no parameter groups (eig_mode='ql' and 'hipsolver' take them)" % eig_mode)
         if eig_mode == "ql" and not self.whole and any(len(np.unique(g)) != len(g) for g in self.groups):
             raise ValueError("eig_mode='ql' with parameter groups: a group may not repeat a parameter")
         self.gsize = np.ascontiguousarray([len(g) for g in self.groups], dtype=np.int32)
@@ -504,6 +504,22 @@ class PTEngine(object):
         pooled rule: eigenvalues by decreasing size and in absolute value, eigenvectors as the rows of Ut)."""
         torch = _torch()
         with torch.cuda.stream(self.stream):
+            if not self.whole:
+                # parameter groups (PTMCMCSampler.py:139-145, 797-803: one factorization per group's block of the covariance), any ndim:
+                # the block gathered on the device, the vectors embedded in the full space, one per row of the group's table
+                cov = self.t["cov"]
+                self.t["Ut"].zero_()
+                self.t["S"].zero_()
+                for gi, g in enumerate(self.groups):
+                    idx = torch.as_tensor(g, device=self.device)
+                    m = len(g)
+                    w, V = torch.linalg.eigh(cov[:, idx][:, :, idx])                           # [Wc][m], [Wc][m][m]
+                    w, order = w.abs().sort(dim=-1, descending=True, stable=True)
+                    Vt = torch.gather(V, -1, order.unsqueeze(-2).expand_as(V)).transpose(-1, -2)    # rows = eigenvectors
+                    rows = self.t["Ut"][:, gi, :m]                                             # [Wc][m][d] (a view)
+                    rows[:, :, idx] = Vt
+                    self.t["S"][:, gi, :m] = w
+                return
             w, V = torch.linalg.eigh(self.t["cov"])                  # [Wc][d], [Wc][d][d] (columns)
             # by decreasing |eigenvalue| (a covariance's are >= 0 up to rounding: a slightly negative one must not jump the queue)
             w, order = w.abs().sort(dim=-1, descending=True, stable=True)

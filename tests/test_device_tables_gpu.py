@@ -87,7 +87,12 @@ def lockstep(g, o, tap, n, what):
     def from_device(w):
         assert w == 0 and queue, "%s: the oracle's schedule puts a table into force at iteration <= %d that the device never used" % (what, o.iter + n)
         u, s = queue.pop(0)
-        check_table(u[0, 0], s[0, 0], o.cov[0], "%s, table %d" % (what, g.eig_epochs - len(queue)))
+        for gi, grp in enumerate(o.groups):         # a group's table: its vectors on its own parameters against its block of the covariance
+            m = len(grp)
+            check_table(u[0, gi][:m][:, grp], s[0, gi][:m], o.cov[0][np.ix_(grp, grp)], "%s, table %d, group %d" % (what, g.eig_epochs - len(queue), gi))
+            if len(o.groups) > 1:
+                outside = np.setdiff1d(np.arange(o.d), grp)
+                assert not u[0, gi][:, outside].any() and not u[0, gi][m:].any() and not s[0, gi][m:].any()      # embedded: zero elsewhere
         o.Ut[...], o.S[...] = u, s
         used[0] += 1
 
@@ -269,3 +274,29 @@ def test_full_size_dense_default_mix_walker_pick(mods):
     assert (js[..., :3, 0] == js[:, :1, :3, 0]).all()                    # one pick per walker: the same counts down its ladder
     X, lnL = g.get("X"), g.get("lnL")
     assert np.allclose(lnL, -0.5 * np.einsum("wti,ij,wtj->wt", X, kw["logl"][2], X), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("d,groups", [(300, [np.arange(0, 100), np.arange(100, 250), np.arange(250, 300)]),
+                                      (40, [np.array([0, 2, 4, 6, 39]), np.arange(7, 39), np.array([1, 3, 5])])])
+def test_parameter_groups_with_the_library_eigensolver_on_the_device(mods, d, groups):
+    """Parameter groups (PTMCMCSampler.py:129-145, 797-803: one factorization per group's block of the covariance) with
+    eig_mode="hipsolver" -- any ndim, where the QL kernels stop at 128: every block gathered on the device, factorized by the ROCm
+    library, its vectors embedded in the full space.  The library's last bits are its own: every group's table is checked against the
+    ORACLE's covariance block and the oracle's chains are stepped with it (AM increments ahead of the launch group by group, DE's
+    masks): bit for bit."""
+    orc, _lib, PTEngine = mods
+    nt, W, cu = 3, 5, 30
+    kw = dict(weights=(20, 20, 20), cov_update=cu, burn=2 * cu, tskip=10, seed=5, cov_mode="pooled", groups=groups)
+    cov0 = np.eye(d) * 0.01
+    p0 = np.random.RandomState(d).randn(W, nt, d) * 0.2
+    g = PTEngine(d, nt, W, cov0, eig_mode="hipsolver", **kw)
+    o = orc.OracleEngine(d, nt, W, cov0, **kw)
+    g.init_state(p0)
+    o.init_state(p0)
+    tap = TableTap(g)
+    used = 0
+    for n in (cu + 10, 2 * cu, 7, 2 * cu + 3):
+        used += lockstep(g, o, tap, n, "groups + hipsolver d=%d it=%d" % (d, g.iter + n))
+        _compare(g, o, "groups + hipsolver d=%d it=%d " % (d, g.iter))
+        assert_same(g.get("cov"), o.cov, "cov it=%d" % g.iter)
+    assert used >= 4 and o.jstat[..., :3, 0].sum(axis=(0, 1)).min() > 0 and o.jstat[..., 1, 1].sum() > 0
