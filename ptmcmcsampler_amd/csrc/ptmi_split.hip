@@ -10,11 +10,11 @@
 //   * a block takes a TILE of 64 consecutive chains = one contiguous span of X and of Q;
 //   * two threads per chain do everything that is a scalar of the chain -- the accept test of iteration `it` (PT:615-622) from the
 //     callback's values, then the draws of the next proposal: cycle pick, scale branch, parameter group, SCAM direction and
-//     amplitude or DE's two history rows and scale (PT:1048-1067, 820-876, 936-985) -- the same operations on the same Philox
-//     words as propose() of ptmi_mh.inc.h (bit-identical; the oracle is orc_propose / mh_one), and leave a 48-byte record in LDS;
+//     amplitude, DE's two history rows and scale, an AM pick's cursor (PT:1048-1067, 820-876, 936-985) -- the same operations on the same Philox
+//     words as propose() of ptmi_mh.inc.h (bit-identical; the oracle is mh_one of oracle/ptmcmc_oracle.c), and leave a 56-byte record in LDS;
 //   * all 256 threads then walk the tile's span in 16-byte pieces (dwordx4 loads and stores, a wave instruction = 1 KB of
-//     consecutive addresses): new state = the accepted proposal or the old row, written back only where accepted, next proposal
-//     = state + increment written to Q, the loads of four pieces in flight before the first is used.
+//     consecutive addresses): new state = the accepted proposal or the old row (written to X only where the rule below says), next
+//     proposal = state + increment written to the proposal buffer, the loads of four pieces in flight before the first is used.
 //
 // ACC and PROP in ONE launch (ptmi_accept_propose: accept of iteration it, proposal of it + 1) moves a row in once and out once per
 // iteration where accept + propose as two launches moved it twice: per update 8 d (state or proposal in) + 8 d (proposal out)
